@@ -1,0 +1,130 @@
+/*
+ * salnmf.h -- C ABI of the MI355X-native KL-NMF update engine.
+ *
+ * The reference (parklab/Salamander @ 2024_10_08) has no FFI: its hot path is a set
+ * of NumPy/numba functions called from Python.  This header is therefore the boundary
+ * a maintainer would bind (ctypes); each entry point names the
+ * reference function (file:line under the reference tree) whose arithmetic it
+ * replaces.  Plain pointers and sizes only; no torch / numpy types.
+ *
+ * Conventions
+ *   - All matrices are float64, row-major, in AnnData's storage layout:
+ *       X  (n_samples  x n_features)    adata.X
+ *       H  (n_samples  x n_signatures)  adata.obsm["exposures"]
+ *       W  (n_signatures x n_features)  asignatures.X
+ *     (the reference passes the .T views of exactly these buffers,
+ *      src/salamander/models/klnmf.py:97-104).
+ *   - Every function returns 0 on success, non-zero on failure; the message is
+ *     available from salnmf_last_error().  Nothing aborts.
+ *   - Host pointers are borrowed for the duration of the call only.  The engine owns
+ *     all device memory.  A handle is not re-entrant.
+ *   - One engine = one GPU = one shard of the sample axis.
+ */
+#ifndef SALNMF_H
+#define SALNMF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct salnmf_engine salnmf_engine;
+
+/* clip floor used everywhere on the path: np.finfo(np.float32).eps as a double
+ * (src/salamander/models/_utils_klnmf.py:7). */
+#define SALNMF_EPSILON 1.1920928955078125e-07
+
+/* W-tail variants */
+#define SALNMF_CLIP_ALL 0       /* update_WH: clip every column, _utils_klnmf.py:341 */
+#define SALNMF_CLIP_NON_GIVEN 1 /* update_W: clip only non-given columns, _utils_klnmf.py:215 */
+
+/* device buffers that can be exposed to a caller-side collective (salnmf_device_ptr) */
+#define SALNMF_BUF_G 0    /* (n_signatures x n_features) numerator aux@H.T, local shard */
+#define SALNMF_BUF_W 1
+#define SALNMF_BUF_H 2
+#define SALNMF_BUF_X 3
+#define SALNMF_BUF_OBJ 4  /* scalar objective partial of the local shard */
+#define SALNMF_BUF_RED 5  /* MvNMF reduction vector: [G (K*V) | rowsums_H (K) | KL (1)] */
+
+const char* salnmf_last_error(void);
+int salnmf_version(void);
+int salnmf_device_count(void);
+
+/* Create an engine for a shard of n_samples rows on HIP device `device`.
+ * Limits of this build: n_features <= 96, n_signatures <= 64. */
+int salnmf_create(int device, int n_features, int64_t n_samples, int n_signatures,
+                  salnmf_engine** out);
+void salnmf_destroy(salnmf_engine* e);
+
+/* Upload the count matrix.  clip != 0 applies X.clip(EPSILON) on the way, as
+ * SignatureNMF._setup_adata does (src/salamander/models/signature_nmf.py:281). */
+int salnmf_upload_X(salnmf_engine* e, const double* X, int clip);
+int salnmf_upload_W(salnmf_engine* e, const double* W);
+int salnmf_upload_H(salnmf_engine* e, const double* H);
+/* Per-sample weights (each n_samples long) or NULL to disable
+ * (KLNMF._setup_fitting_parameters, klnmf.py:128-153). */
+int salnmf_set_weights(salnmf_engine* e, const double* weights_kl, const double* weights_lhalf);
+int salnmf_download_W(salnmf_engine* e, double* W);
+int salnmf_download_H(salnmf_engine* e, double* H);
+
+/* n_steps joint KLNMF updates, device resident: update_WH, _utils_klnmf.py:281-361.
+ * The first n_given rows of W are never changed. */
+int salnmf_kl_step(salnmf_engine* e, int n_steps, int n_given);
+/* update_H with the current W: _utils_klnmf.py:220-278. */
+int salnmf_update_H(salnmf_engine* e);
+/* update_W (clip_mode = SALNMF_CLIP_NON_GIVEN): _utils_klnmf.py:164-217. */
+int salnmf_update_W(salnmf_engine* e, int n_given, int clip_mode);
+
+/* KLNMF.objective_function: weighted kl_divergence (+ l-half penalty if set),
+ * klnmf.py:64-80 and _utils_klnmf.py:11-55.  With a communicator attached the value
+ * is all-reduced over the shards. */
+int salnmf_objective(salnmf_engine* e, double* out);
+/* samplewise_kl_divergence, _utils_klnmf.py:58-97 (unweighted); out has n_samples. */
+int salnmf_samplewise_kl(salnmf_engine* e, double* out);
+/* H @ W (n_samples x n_features): SignatureNMF.compute_reconstruction,
+ * signature_nmf.py:221-224. */
+int salnmf_reconstruct(salnmf_engine* e, double* out);
+
+/* MvNMF (src/salamander/models/mvnmf.py).  One call = n_steps times
+ * _update_parameters (:197-210): update_H (:162-165), update_W_unconstrained (:37-66),
+ * line_search (:69-92).  gamma_inout carries MvNMF._gamma across calls. */
+int salnmf_mv_step(salnmf_engine* e, int n_steps, int n_given, double lam, double delta,
+                   double* gamma_inout);
+/* only MvNMF._update_W (:190-195) / only _update_H (= salnmf_update_H) for the
+ * reference's single-step tests (tests/test_mvnmf.py:70-76). */
+int salnmf_mv_update_W(salnmf_engine* e, int n_given, double lam, double delta,
+                       double* gamma_inout);
+/* kl_divergence_penalized, mvnmf.py:27-34. */
+int salnmf_mv_objective(salnmf_engine* e, double lam, double delta, double* out);
+
+/* Multi-GPU: one engine per process/GPU, sample axis sharded; the only exchange is an
+ * RCCL all-reduce of the (K x V) numerator per W update (+ scalars for objectives).
+ * Rank 0 obtains an id, the host layer broadcasts it, every rank calls comm_init. */
+#define SALNMF_UNIQUE_ID_BYTES 128
+int salnmf_comm_unique_id(char* out_id /* SALNMF_UNIQUE_ID_BYTES */);
+int salnmf_comm_init(salnmf_engine* e, const char* id, int n_ranks, int rank);
+
+/* The joint step split at the exchange point, for a caller-side collective
+ * (e.g. torch.distributed on a wrapped device pointer):
+ *   partial: fused pass + local reduction -> SALNMF_BUF_G, H updated in place
+ *   finish : W tail from SALNMF_BUF_G (after the caller's all-reduce) */
+int salnmf_kl_step_partial(salnmf_engine* e);
+int salnmf_kl_step_finish(salnmf_engine* e, int n_given, int clip_mode);
+void* salnmf_device_ptr(salnmf_engine* e, int which);
+void* salnmf_stream(salnmf_engine* e);
+int salnmf_sync(salnmf_engine* e);
+
+/* Measurement: run n_steps joint steps with HIP events recorded on the engine's
+ * stream around every launch of the fused kernel.  Outputs (any may be NULL):
+ * total wall ms over the n_steps, and the average duration in ms of the fused update
+ * kernel and of the W-tail kernel. */
+int salnmf_profile_kl_steps(salnmf_engine* e, int n_steps, int n_given, double* total_ms,
+                            double* fused_avg_ms, double* tail_avg_ms);
+/* Same for the forward (W@H) + objective kernel: average duration over n_calls. */
+int salnmf_profile_objective(salnmf_engine* e, int n_calls, double* avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SALNMF_H */

@@ -1,0 +1,90 @@
+"""ctypes binding of the C ABI in ``include/salnmf.h`` (the drop-in boundary).
+
+The shared library is built in-tree by ``__graft_entry__.build()`` /
+``salamander_amd/csrc/build.sh``.  There is **no** CPU fallback: if the library is
+missing or no gfx950 device is present, every compute entry point raises.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsalnmf.so")
+
+UNIQUE_ID_BYTES = 128
+CLIP_ALL = 0
+CLIP_NON_GIVEN = 1
+BUF_G, BUF_W, BUF_H, BUF_X, BUF_OBJ, BUF_RED = range(6)
+
+# every symbol include/salnmf.h declares: name -> (restype, argtypes)
+_P = c_void_p
+_D = POINTER(c_double)
+SIGNATURES = {
+    "salnmf_last_error": (c_char_p, []),
+    "salnmf_version": (c_int, []),
+    "salnmf_device_count": (c_int, []),
+    "salnmf_create": (c_int, [c_int, c_int, c_int64, c_int, POINTER(_P)]),
+    "salnmf_destroy": (None, [_P]),
+    "salnmf_upload_X": (c_int, [_P, _D, c_int]),
+    "salnmf_upload_W": (c_int, [_P, _D]),
+    "salnmf_upload_H": (c_int, [_P, _D]),
+    "salnmf_set_weights": (c_int, [_P, _D, _D]),
+    "salnmf_download_W": (c_int, [_P, _D]),
+    "salnmf_download_H": (c_int, [_P, _D]),
+    "salnmf_kl_step": (c_int, [_P, c_int, c_int]),
+    "salnmf_update_H": (c_int, [_P]),
+    "salnmf_update_W": (c_int, [_P, c_int, c_int]),
+    "salnmf_objective": (c_int, [_P, _D]),
+    "salnmf_samplewise_kl": (c_int, [_P, _D]),
+    "salnmf_reconstruct": (c_int, [_P, _D]),
+    "salnmf_mv_step": (c_int, [_P, c_int, c_int, c_double, c_double, _D]),
+    "salnmf_mv_update_W": (c_int, [_P, c_int, c_double, c_double, _D]),
+    "salnmf_mv_objective": (c_int, [_P, c_double, c_double, _D]),
+    "salnmf_comm_unique_id": (c_int, [ctypes.c_char_p]),
+    "salnmf_comm_init": (c_int, [_P, ctypes.c_char_p, c_int, c_int]),
+    "salnmf_kl_step_partial": (c_int, [_P]),
+    "salnmf_kl_step_finish": (c_int, [_P, c_int, c_int]),
+    "salnmf_device_ptr": (c_void_p, [_P, c_int]),
+    "salnmf_stream": (c_void_p, [_P]),
+    "salnmf_sync": (c_int, [_P]),
+    "salnmf_profile_kl_steps": (c_int, [_P, c_int, c_int, _D, _D, _D]),
+    "salnmf_profile_objective": (c_int, [_P, c_int, _D]),
+}
+
+_lib = None
+
+
+class EngineUnavailable(RuntimeError):
+    """The HIP extension (or a gfx950 device) is missing.  There is no fallback."""
+
+
+def load():
+    """Load ``libsalnmf.so`` and declare every prototype.  Loading needs no GPU."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineUnavailable(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  salamander_amd has no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    msg = load().salnmf_last_error()
+    return msg.decode() if msg else ""
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise RuntimeError(f"salnmf: {last_error()}")

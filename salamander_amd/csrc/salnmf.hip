@@ -1,0 +1,620 @@
+// Host-side engine and C ABI (include/salnmf.h) of the MI355X KL-NMF update path.
+// One engine = one GPU = one shard of the sample axis.  All launches go to the
+// engine's own HIP stream; nothing inside a step synchronises with the host.
+#include "../../include/salnmf.h"
+#include "salnmf_kernels.h"
+#include "salnmf_mv_kernels.h"
+
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace salnmf;
+
+static thread_local std::string g_err;
+
+static int fail(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+
+#define HIPCK(call)                                                                              \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define NCCLCK(call)                                                                             \
+    do {                                                                                         \
+        ncclResult_t r_ = (call);                                                                \
+        if (r_ != ncclSuccess) return fail("%s failed: %s (%s:%d)", #call, ncclGetErrorString(r_), __FILE__, __LINE__); \
+    } while (0)
+#define CK(call)               \
+    do {                       \
+        int rc_ = (call);      \
+        if (rc_) return rc_;   \
+    } while (0)
+
+struct salnmf_engine {
+    int device = 0;
+    int V = 0, K = 0;
+    int64_t N = 0, ntiles = 0;
+    int KS = 0;    // instantiated contraction depth (k-steps of 4) covering K
+    int grid = 0;  // workgroups of the fused / forward kernels (one per CU)
+    hipStream_t stream = nullptr;
+    double *X = nullptr, *H = nullptr, *W = nullptr, *wkl = nullptr, *wlh = nullptr;
+    double* Gpart = nullptr;     // [grid][K][V]
+    double* Hsumpart = nullptr;  // [grid][K]
+    double* KLpart = nullptr;    // [grid]
+    double* red = nullptr;       // [K*V | K | 1 | pad]  G, rowsums_H, KL of the local shard (then all-reduced)
+    double* objpart = nullptr;   // [grid]
+    double* scal = nullptr;      // device scalars: [0]=objective, [1]=f0, [2]=f1, [3]=logdet0, [4]=logdet1
+    double* Wunc = nullptr;      // MvNMF scratch [K][V]
+    double* Wtrial = nullptr;    // [K][V]
+    double* cs = nullptr;        // [K]
+    double* hpin = nullptr;      // pinned host scalars
+    ncclComm_t comm = nullptr;
+    int n_ranks = 1, rank = 0;
+    std::vector<hipEvent_t> events;
+};
+
+static const int kKS[] = {1, 2, 4, 8, 10, 13, 16};
+
+static int pick_ks(int K) {
+    int need = (K + 3) / 4;
+    for (int ks : kKS)
+        if (ks >= need) return ks;
+    return -1;
+}
+
+// ------------------------------------------------------------------------------------ launches
+
+template <bool DO_G, bool DO_U, bool DO_STATS>
+static int launch_fused(salnmf_engine* e, const FusedParams& p) {
+    dim3 g(e->grid), b(BLOCK);
+#define SALNMF_CASE(ks)                                                             \
+    case ks:                                                                        \
+        hipLaunchKernelGGL((fused_kernel<ks, DO_G, DO_U, DO_STATS>), g, b, 0, e->stream, p); \
+        break;
+    switch (e->KS) {
+        SALNMF_CASE(1)
+        SALNMF_CASE(2)
+        SALNMF_CASE(4)
+        SALNMF_CASE(8)
+        SALNMF_CASE(10)
+        SALNMF_CASE(13)
+        SALNMF_CASE(16)
+        default:
+            return fail("no kernel instantiation for KS=%d", e->KS);
+    }
+#undef SALNMF_CASE
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+template <int MODE>
+static int launch_forward(salnmf_engine* e, const FwdParams& p) {
+    dim3 g(e->grid), b(BLOCK);
+#define SALNMF_CASE(ks)                                                        \
+    case ks:                                                                   \
+        hipLaunchKernelGGL((forward_kernel<ks, MODE>), g, b, 0, e->stream, p); \
+        break;
+    switch (e->KS) {
+        SALNMF_CASE(1)
+        SALNMF_CASE(2)
+        SALNMF_CASE(4)
+        SALNMF_CASE(8)
+        SALNMF_CASE(10)
+        SALNMF_CASE(13)
+        SALNMF_CASE(16)
+        default:
+            return fail("no kernel instantiation for KS=%d", e->KS);
+    }
+#undef SALNMF_CASE
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+static FusedParams fused_params(salnmf_engine* e) {
+    FusedParams p;
+    p.X = e->X;
+    p.H = e->H;
+    p.W = e->W;
+    p.wkl = e->wkl;
+    p.wlh = e->wlh;
+    p.hscale = nullptr;
+    p.Gpart = e->Gpart;
+    p.Hsumpart = e->Hsumpart;
+    p.KLpart = e->KLpart;
+    p.N = e->N;
+    p.V = e->V;
+    p.K = e->K;
+    p.ntiles = e->ntiles;
+    return p;
+}
+
+static int launch_tail(salnmf_engine* e, int nslabs, double* G, int n_given, int clip_mode, int do_tail) {
+    TailParams t;
+    t.Gpart = e->Gpart;
+    t.G = G;
+    t.W = e->W;
+    t.nslabs = nslabs;
+    t.V = e->V;
+    t.K = e->K;
+    t.n_given = n_given;
+    t.clip_mode = clip_mode;
+    t.do_tail = do_tail;
+    hipLaunchKernelGGL(tail_kernel, dim3(e->K), dim3(TAIL_BLOCK), 0, e->stream, t);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+static int allreduce(salnmf_engine* e, double* buf, size_t count) {
+    if (!e->comm) return 0;
+    NCCLCK(ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, e->comm, e->stream));
+    return 0;
+}
+
+// one joint step; ev != nullptr records {before fused, after fused, after tail}
+static int kl_step_once(salnmf_engine* e, int n_given, hipEvent_t* ev) {
+    FusedParams p = fused_params(e);
+    const bool all_given = n_given >= e->K;  // _utils_klnmf.py:330-331: W untouched
+    if (ev) HIPCK(hipEventRecord(ev[0], e->stream));
+    if (all_given)
+        CK((launch_fused<false, true, false>(e, p)));
+    else
+        CK((launch_fused<true, true, false>(e, p)));
+    if (ev) HIPCK(hipEventRecord(ev[1], e->stream));
+    if (!all_given) {
+        if (e->comm) {
+            CK(launch_tail(e, e->grid, e->red, 0, 0, 0));
+            CK(allreduce(e, e->red, (size_t)e->K * e->V));
+            CK(launch_tail(e, 0, e->red, n_given, SALNMF_CLIP_ALL, 1));
+        } else {
+            CK(launch_tail(e, e->grid, e->red, n_given, SALNMF_CLIP_ALL, 1));
+        }
+    }
+    if (ev) HIPCK(hipEventRecord(ev[2], e->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ C ABI
+
+extern "C" {
+
+const char* salnmf_last_error(void) { return g_err.c_str(); }
+int salnmf_version(void) { return 100; }
+
+int salnmf_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void salnmf_destroy(salnmf_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->comm) ncclCommDestroy(e->comm);
+    double* bufs[] = {e->X, e->H, e->W, e->wkl, e->wlh, e->Gpart, e->Hsumpart, e->KLpart, e->red,
+                      e->objpart, e->scal, e->Wunc, e->Wtrial, e->cs};
+    for (double* b : bufs)
+        if (b) (void)hipFree(b);
+    if (e->hpin) (void)hipHostFree(e->hpin);
+    for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int salnmf_create(int device, int n_features, int64_t n_samples, int n_signatures, salnmf_engine** out) {
+    if (!out) return fail("out is null");
+    *out = nullptr;
+    if (n_features < 1 || n_features > VMAX) return fail("n_features must be in [1, %d], got %d", VMAX, n_features);
+    if (n_signatures < 1 || n_signatures > 64) return fail("n_signatures must be in [1, 64], got %d", n_signatures);
+    if (n_samples < 1) return fail("n_samples must be positive");
+    int ndev = 0;
+    HIPCK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail("device %d out of range (%d visible)", device, ndev);
+    HIPCK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCK(hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail("this build targets gfx950 only; device %d is %s", device, prop.gcnArchName);
+
+    salnmf_engine* e = new salnmf_engine();
+    e->device = device;
+    e->V = n_features;
+    e->K = n_signatures;
+    e->N = n_samples;
+    e->ntiles = (n_samples + 15) / 16;
+    e->KS = pick_ks(n_signatures);
+    int64_t wg_needed = (e->ntiles + WAVES - 1) / WAVES;
+    e->grid = (int)std::min<int64_t>(prop.multiProcessorCount, wg_needed);
+    const size_t K = e->K, V = e->V, N = e->N;
+    auto cleanup = [&](int rc) {
+        salnmf_destroy(e);
+        return rc;
+    };
+#define ALLOC(ptr, n)                                                      \
+    if (hipMalloc(&(ptr), (n) * sizeof(double)) != hipSuccess) return cleanup(fail("hipMalloc of %zu doubles failed", (size_t)(n)));
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return cleanup(fail("stream create failed"));
+    ALLOC(e->X, N * V);
+    ALLOC(e->H, N * K);
+    ALLOC(e->W, K * V);
+    ALLOC(e->Gpart, (size_t)e->grid * K * V);
+    ALLOC(e->Hsumpart, (size_t)e->grid * K);
+    ALLOC(e->KLpart, (size_t)e->grid);
+    ALLOC(e->red, K * V + K + 2);
+    ALLOC(e->objpart, (size_t)e->grid);
+    ALLOC(e->scal, 8);
+    ALLOC(e->Wunc, K * V);
+    ALLOC(e->Wtrial, K * V);
+    ALLOC(e->cs, K);
+#undef ALLOC
+    if (hipHostMalloc((void**)&e->hpin, 8 * sizeof(double), hipHostMallocDefault) != hipSuccess)
+        return cleanup(fail("hipHostMalloc failed"));
+    *out = e;
+    return 0;
+}
+
+static int upload(salnmf_engine* e, double* dst, const double* src, size_t n) {
+    if (!e || !src) return fail("null argument");
+    HIPCK(hipSetDevice(e->device));
+    HIPCK(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    HIPCK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+int salnmf_upload_X(salnmf_engine* e, const double* X, int clip) {
+    CK(upload(e, e ? e->X : nullptr, X, (size_t)e->N * e->V));
+    if (clip) {
+        hipLaunchKernelGGL(clip_kernel, dim3(2048), dim3(256), 0, e->stream, e->X, (int64_t)e->N * e->V);
+        HIPCK(hipGetLastError());
+    }
+    return 0;
+}
+int salnmf_upload_W(salnmf_engine* e, const double* W) { return upload(e, e ? e->W : nullptr, W, (size_t)e->K * e->V); }
+int salnmf_upload_H(salnmf_engine* e, const double* H) { return upload(e, e ? e->H : nullptr, H, (size_t)e->N * e->K); }
+
+int salnmf_set_weights(salnmf_engine* e, const double* weights_kl, const double* weights_lhalf) {
+    if (!e) return fail("null engine");
+    HIPCK(hipSetDevice(e->device));
+    HIPCK(hipStreamSynchronize(e->stream));
+    auto set = [&](double*& dev, const double* host) -> int {
+        if (!host) {
+            if (dev) HIPCK(hipFree(dev));
+            dev = nullptr;
+            return 0;
+        }
+        if (!dev) HIPCK(hipMalloc(&dev, (size_t)e->N * sizeof(double)));
+        return upload(e, dev, host, (size_t)e->N);
+    };
+    CK(set(e->wkl, weights_kl));
+    CK(set(e->wlh, weights_lhalf));
+    return 0;
+}
+
+static int download(salnmf_engine* e, double* dst, const double* src, size_t n) {
+    if (!e || !dst) return fail("null argument");
+    HIPCK(hipSetDevice(e->device));
+    HIPCK(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIPCK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+int salnmf_download_W(salnmf_engine* e, double* W) { return download(e, W, e ? e->W : nullptr, (size_t)e->K * e->V); }
+int salnmf_download_H(salnmf_engine* e, double* H) { return download(e, H, e ? e->H : nullptr, (size_t)e->N * e->K); }
+
+int salnmf_kl_step(salnmf_engine* e, int n_steps, int n_given) {
+    if (!e) return fail("null engine");
+    if (n_given < 0 || n_given > e->K) return fail("n_given out of range");
+    HIPCK(hipSetDevice(e->device));
+    for (int i = 0; i < n_steps; ++i) CK(kl_step_once(e, n_given, nullptr));
+    return 0;
+}
+
+int salnmf_update_H(salnmf_engine* e) {
+    if (!e) return fail("null engine");
+    HIPCK(hipSetDevice(e->device));
+    FusedParams p = fused_params(e);
+    return launch_fused<false, true, false>(e, p);
+}
+
+int salnmf_kl_step_partial(salnmf_engine* e) {
+    if (!e) return fail("null engine");
+    HIPCK(hipSetDevice(e->device));
+    FusedParams p = fused_params(e);
+    CK((launch_fused<true, true, false>(e, p)));
+    return launch_tail(e, e->grid, e->red, 0, 0, 0);
+}
+
+int salnmf_kl_step_finish(salnmf_engine* e, int n_given, int clip_mode) {
+    if (!e) return fail("null engine");
+    HIPCK(hipSetDevice(e->device));
+    if (n_given >= e->K) return 0;
+    return launch_tail(e, 0, e->red, n_given, clip_mode, 1);
+}
+
+int salnmf_update_W(salnmf_engine* e, int n_given, int clip_mode) {
+    if (!e) return fail("null engine");
+    HIPCK(hipSetDevice(e->device));
+    if (n_given >= e->K) return 0;  // _utils_klnmf.py:204-205
+    FusedParams p = fused_params(e);
+    CK((launch_fused<true, false, false>(e, p)));
+    if (e->comm) {
+        CK(launch_tail(e, e->grid, e->red, 0, 0, 0));
+        CK(allreduce(e, e->red, (size_t)e->K * e->V));
+        return launch_tail(e, 0, e->red, n_given, clip_mode, 1);
+    }
+    return launch_tail(e, e->grid, e->red, n_given, clip_mode, 1);
+}
+
+static int fwd_params(salnmf_engine* e, FwdParams& p) {
+    p.X = e->X;
+    p.H = e->H;
+    p.W = e->W;
+    p.wkl = e->wkl;
+    p.wlh = e->wlh;
+    p.hscale = nullptr;
+    p.out = e->objpart;
+    p.N = e->N;
+    p.V = e->V;
+    p.K = e->K;
+    p.ntiles = e->ntiles;
+    return 0;
+}
+
+// objective of (W, H[, hscale]) -> device scalar e->scal[slot] (all-reduced), no host sync
+static int objective_to_slot(salnmf_engine* e, const double* W, const double* hscale, bool weighted, int slot) {
+    FwdParams p;
+    fwd_params(e, p);
+    p.W = W;
+    p.hscale = hscale;
+    if (!weighted) {
+        p.wkl = nullptr;
+        p.wlh = nullptr;
+    }
+    CK(launch_forward<0>(e, p));
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, e->stream, e->objpart, e->grid, 1, 1, e->scal + slot);
+    HIPCK(hipGetLastError());
+    return allreduce(e, e->scal + slot, 1);
+}
+
+static int read_scalars(salnmf_engine* e, int first, int count, double* out) {
+    HIPCK(hipMemcpyAsync(e->hpin, e->scal + first, count * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIPCK(hipStreamSynchronize(e->stream));
+    for (int i = 0; i < count; ++i) out[i] = e->hpin[i];
+    return 0;
+}
+
+int salnmf_objective(salnmf_engine* e, double* out) {
+    if (!e || !out) return fail("null argument");
+    HIPCK(hipSetDevice(e->device));
+    CK(objective_to_slot(e, e->W, nullptr, true, 0));
+    return read_scalars(e, 0, 1, out);
+}
+
+int salnmf_samplewise_kl(salnmf_engine* e, double* out) {
+    if (!e || !out) return fail("null argument");
+    HIPCK(hipSetDevice(e->device));
+    double* dev = nullptr;
+    HIPCK(hipMalloc(&dev, (size_t)e->N * sizeof(double)));
+    FwdParams p;
+    fwd_params(e, p);
+    p.out = dev;
+    int rc = launch_forward<1>(e, p);
+    if (!rc) rc = download(e, out, dev, (size_t)e->N);
+    (void)hipFree(dev);
+    return rc;
+}
+
+int salnmf_reconstruct(salnmf_engine* e, double* out) {
+    if (!e || !out) return fail("null argument");
+    HIPCK(hipSetDevice(e->device));
+    double* dev = nullptr;
+    HIPCK(hipMalloc(&dev, (size_t)e->N * e->V * sizeof(double)));
+    FwdParams p;
+    fwd_params(e, p);
+    p.out = dev;
+    int rc = launch_forward<2>(e, p);
+    if (!rc) rc = download(e, out, dev, (size_t)e->N * e->V);
+    (void)hipFree(dev);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------ MvNMF
+
+static int mv_logdet_to_slot(salnmf_engine* e, const double* W, double delta, int slot) {
+    hipLaunchKernelGGL(mv_logdet_kernel, dim3(1), dim3(MV_BLOCK), 0, e->stream, W, e->K, e->V, delta, e->scal + slot);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+int salnmf_mv_objective(salnmf_engine* e, double lam, double delta, double* out) {
+    if (!e || !out) return fail("null argument");
+    HIPCK(hipSetDevice(e->device));
+    CK(objective_to_slot(e, e->W, nullptr, false, 0));
+    CK(mv_logdet_to_slot(e, e->W, delta, 3));
+    double v[4];
+    CK(read_scalars(e, 0, 4, v));
+    *out = v[0] + lam * v[3];
+    return 0;
+}
+
+// MvNMF._update_W (mvnmf.py:190-195) on the current (W, H)
+static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double delta, double* gamma) {
+    if (n_given >= e->K) return 0;
+    const int K = e->K, V = e->V;
+    // pass over the shard: G = (X/(WH)) @ H.T partials, rowsums_H partials, KL partial
+    FusedParams p = fused_params(e);
+    p.wkl = nullptr;  // the MvNMF path is unweighted (mvnmf.py:56)
+    p.wlh = nullptr;
+    CK((launch_fused<true, false, true>(e, p)));
+    CK(launch_tail(e, e->grid, e->red, 0, 0, 0));
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, e->stream, e->Hsumpart, e->grid, K, K, e->red + K * V);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, e->stream, e->KLpart, e->grid, 1, 1, e->red + K * V + K);
+    HIPCK(hipGetLastError());
+    CK(allreduce(e, e->red, (size_t)K * V + K + 1));
+    // W_unconstrained and log det(W^T W + delta I); f0 = KL + lam * logdet -> scal[1]
+    hipLaunchKernelGGL(mv_prepare_kernel, dim3(1), dim3(MV_BLOCK), 0, e->stream, e->W, e->red, e->red + K * V,
+                       e->red + K * V + K, K, V, n_given, lam, delta, e->Wunc, e->scal + 1);
+    HIPCK(hipGetLastError());
+    double g = *gamma;
+    bool blend = false;
+    for (;;) {
+        // trial W: normalise + clip, column sums for H, its logdet -> scal[4]
+        hipLaunchKernelGGL(mv_trial_kernel, dim3(1), dim3(MV_BLOCK), 0, e->stream, e->W, e->Wunc, blend ? g : 1.0,
+                           blend ? 1 : 0, K, V, delta, e->Wtrial, e->cs, e->scal + 4);
+        HIPCK(hipGetLastError());
+        CK(objective_to_slot(e, e->Wtrial, e->cs, false, 2));
+        double v[5];
+        CK(read_scalars(e, 0, 5, v));
+        const double f0 = v[1], f1 = v[2] + lam * v[4];
+        if (f1 > f0 && g > 1e-16) {  // mvnmf.py:84
+            g *= 0.8;
+            blend = true;
+            continue;
+        }
+        break;
+    }
+    *gamma = std::min(1.0, 1.2 * g);  // mvnmf.py:91
+    // accept: W <- W_trial, H <- clip(H * colsum)
+    HIPCK(hipMemcpyAsync(e->W, e->Wtrial, (size_t)K * V * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+    hipLaunchKernelGGL(scale_H_kernel, dim3(2048), dim3(256), 0, e->stream, e->H, e->cs, (int64_t)e->N * K, K);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+int salnmf_mv_update_W(salnmf_engine* e, int n_given, double lam, double delta, double* gamma_inout) {
+    if (!e || !gamma_inout) return fail("null argument");
+    HIPCK(hipSetDevice(e->device));
+    return mv_update_W_impl(e, n_given, lam, delta, gamma_inout);
+}
+
+int salnmf_mv_step(salnmf_engine* e, int n_steps, int n_given, double lam, double delta, double* gamma_inout) {
+    if (!e || !gamma_inout) return fail("null argument");
+    if (n_given < 0 || n_given > e->K) return fail("n_given out of range");
+    HIPCK(hipSetDevice(e->device));
+    for (int i = 0; i < n_steps; ++i) {
+        FusedParams p = fused_params(e);
+        p.wkl = nullptr;  // MvNMF._update_H passes no weights (mvnmf.py:162-165)
+        p.wlh = nullptr;
+        CK((launch_fused<false, true, false>(e, p)));
+        CK(mv_update_W_impl(e, n_given, lam, delta, gamma_inout));
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ multi-GPU
+
+int salnmf_comm_unique_id(char* out_id) {
+    if (!out_id) return fail("null argument");
+    static_assert(sizeof(ncclUniqueId) <= SALNMF_UNIQUE_ID_BYTES, "id size");
+    ncclUniqueId id;
+    NCCLCK(ncclGetUniqueId(&id));
+    memset(out_id, 0, SALNMF_UNIQUE_ID_BYTES);
+    memcpy(out_id, &id, sizeof id);
+    return 0;
+}
+
+int salnmf_comm_init(salnmf_engine* e, const char* id_bytes, int n_ranks, int rank) {
+    if (!e || !id_bytes) return fail("null argument");
+    if (e->comm) return fail("communicator already attached");
+    HIPCK(hipSetDevice(e->device));
+    ncclUniqueId id;
+    memcpy(&id, id_bytes, sizeof id);
+    NCCLCK(ncclCommInitRank(&e->comm, n_ranks, id, rank));
+    e->n_ranks = n_ranks;
+    e->rank = rank;
+    return 0;
+}
+
+void* salnmf_device_ptr(salnmf_engine* e, int which) {
+    if (!e) return nullptr;
+    switch (which) {
+        case SALNMF_BUF_G: return e->red;
+        case SALNMF_BUF_W: return e->W;
+        case SALNMF_BUF_H: return e->H;
+        case SALNMF_BUF_X: return e->X;
+        case SALNMF_BUF_OBJ: return e->scal;
+        case SALNMF_BUF_RED: return e->red;
+        default: return nullptr;
+    }
+}
+
+void* salnmf_stream(salnmf_engine* e) { return e ? (void*)e->stream : nullptr; }
+
+int salnmf_sync(salnmf_engine* e) {
+    if (!e) return fail("null engine");
+    HIPCK(hipSetDevice(e->device));
+    HIPCK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ measurement
+
+static int ensure_events(salnmf_engine* e, size_t n) {
+    while (e->events.size() < n) {
+        hipEvent_t ev;
+        HIPCK(hipEventCreate(&ev));
+        e->events.push_back(ev);
+    }
+    return 0;
+}
+
+int salnmf_profile_kl_steps(salnmf_engine* e, int n_steps, int n_given, double* total_ms, double* fused_avg_ms,
+                            double* tail_avg_ms) {
+    if (!e) return fail("null engine");
+    if (n_steps < 1 || n_steps > 100000) return fail("n_steps out of range");
+    HIPCK(hipSetDevice(e->device));
+    CK(ensure_events(e, (size_t)3 * n_steps));
+    for (int i = 0; i < n_steps; ++i) CK(kl_step_once(e, n_given, &e->events[3 * (size_t)i]));
+    HIPCK(hipStreamSynchronize(e->stream));
+    double fused = 0, tail = 0;
+    for (int i = 0; i < n_steps; ++i) {
+        float a = 0, b = 0;
+        HIPCK(hipEventElapsedTime(&a, e->events[3 * (size_t)i], e->events[3 * (size_t)i + 1]));
+        HIPCK(hipEventElapsedTime(&b, e->events[3 * (size_t)i + 1], e->events[3 * (size_t)i + 2]));
+        fused += a;
+        tail += b;
+    }
+    float tot = 0;
+    HIPCK(hipEventElapsedTime(&tot, e->events[0], e->events[3 * (size_t)n_steps - 1]));
+    if (total_ms) *total_ms = tot;
+    if (fused_avg_ms) *fused_avg_ms = fused / n_steps;
+    if (tail_avg_ms) *tail_avg_ms = tail / n_steps;
+    return 0;
+}
+
+int salnmf_profile_objective(salnmf_engine* e, int n_calls, double* avg_ms) {
+    if (!e) return fail("null engine");
+    if (n_calls < 1 || n_calls > 100000) return fail("n_calls out of range");
+    HIPCK(hipSetDevice(e->device));
+    CK(ensure_events(e, (size_t)2 * n_calls));
+    FwdParams p;
+    fwd_params(e, p);
+    for (int i = 0; i < n_calls; ++i) {
+        HIPCK(hipEventRecord(e->events[2 * (size_t)i], e->stream));
+        CK(launch_forward<0>(e, p));
+        HIPCK(hipEventRecord(e->events[2 * (size_t)i + 1], e->stream));
+    }
+    HIPCK(hipStreamSynchronize(e->stream));
+    double s = 0;
+    for (int i = 0; i < n_calls; ++i) {
+        float a = 0;
+        HIPCK(hipEventElapsedTime(&a, e->events[2 * (size_t)i], e->events[2 * (size_t)i + 1]));
+        s += a;
+    }
+    if (avg_ms) *avg_ms = s / n_calls;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,554 @@
+// CDNA4 (gfx950) kernels of the KL-NMF update path.  fp64 throughout.
+//
+// Data layout in HBM (AnnData storage order, sample-major; one engine = one shard):
+//   X [N][V]  counts            H [N][K]  exposures           W [K][V]  signatures
+// One *tile* = 16 consecutive samples.  One wave64 owns a tile end to end; the four
+// waves of a workgroup (one per SIMD) run independent tile streams and share only the
+// LDS copy of W.  Per tile (reference arithmetic: _utils_klnmf.py:328-347):
+//   P = Ht . W          16 x V      v_mfma_f64_16x16x4, contraction over K
+//   R = X / P           in the accumulator registers (never stored to HBM)
+//   G += Ht^T . R       K x V       contraction over the tile's samples; the accumulator
+//                                   tile R is consumed directly as the B operand
+//   U = R . W^T         16 x K      contraction over V; R goes through a wave-private
+//                                   LDS transpose to become the A operand
+//   H <- clip(H * U)    written back in place
+// f64 MFMA lane maps (checked on hardware by tools/mfma_f64_probe.hip):
+//   A[i = lane&15][k = lane>>4]   B[k = lane>>4][j = lane&15]
+//   D[row = (lane>>4) + 4*reg][col = lane&15],  reg = 0..3
+// so register `reg` of a D tile is the B operand of k-step `reg` of a product that
+// contracts over D's row index.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace salnmf {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+constexpr double kEps = 1.1920928955078125e-07;  // float32 eps, _utils_klnmf.py:7
+constexpr int VT = 6;                 // feature tiles of 16  -> V <= 96
+constexpr int VMAX = 16 * VT;
+constexpr int VSTEPS = VMAX / 4;      // feature k-steps of 4
+constexpr int WS = 98;                // LDS row stride (doubles) of W   : 2*odd -> conflict-free column-slab reads
+constexpr int RS = 98;                // LDS row stride (doubles) of the ratio tile
+constexpr int WAVES = 4;              // one wave per SIMD
+constexpr int BLOCK = 64 * WAVES;
+
+__device__ __forceinline__ d4 mfma(double a, double b, d4 c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+struct FusedParams {
+    const double* __restrict__ X;    // [N][V]
+    double* __restrict__ H;          // [N][K]  updated in place when DO_U
+    const double* __restrict__ W;    // [K][V]
+    const double* __restrict__ wkl;  // [N] or null
+    const double* __restrict__ wlh;  // [N] or null
+    const double* __restrict__ hscale;  // [K] or null: H is read as clip(H*hscale) (MvNMF trial)
+    double* __restrict__ Gpart;      // [gridDim.x][K][V]        (DO_G)
+    double* __restrict__ Hsumpart;   // [gridDim.x][K]           (DO_STATS) row sums of H
+    double* __restrict__ KLpart;     // [gridDim.x]              (DO_STATS) unweighted KL partial
+    int64_t N;
+    int V;
+    int K;
+    int64_t ntiles;
+};
+
+template <int KS>
+struct Geo {
+    static constexpr int KT = (KS + 3) / 4;        // signature tiles of 16
+    static constexpr int WROWS = 16 * KT;          // rows of the LDS copy of W (zero padded)
+    static constexpr int HL = 16 * 4 * KS + 64;    // doubles per wave for the raw H tile (+ finite pad)
+    static constexpr int RL = 16 * RS;             // doubles per wave for the ratio tile
+    static constexpr int LDS_DOUBLES = WROWS * WS + WAVES * (HL + RL);
+};
+
+// natural log for the objective terms
+__device__ __forceinline__ double kl_term(double x, double p) {
+    // _utils_klnmf.py:47-50: entries with X == 0 contribute only WH
+    double t = p;
+    if (x != 0.0) t += x * log(x / p) - x;
+    return t;
+}
+
+// ----------------------------------------------------------------------------------------------
+// Fused update pass.
+//   DO_G     accumulate G = (w_kl * R)^T-contracted numerator for the W update
+//   DO_U     update H in place
+//   DO_STATS also emit row sums of H (as read) and the unweighted KL(X || WH) partial
+//            (MvNMF: update_W_unconstrained + the f0 of its line search, mvnmf.py:54,79)
+template <int KS, bool DO_G, bool DO_U, bool DO_STATS>
+__global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
+    using G_ = Geo<KS>;
+    constexpr int KT = G_::KT;
+    __shared__ __attribute__((aligned(16))) double lds[G_::LDS_DOUBLES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int c16 = lane & 15;
+    const int q = lane >> 4;
+    const int V = p.V, K = p.K;
+    const int64_t N = p.N;
+
+    double* Wl = lds;
+    double* Hl = lds + G_::WROWS * WS + wave * (G_::HL + G_::RL);
+    double* Rl = Hl + G_::HL;
+
+    // ---- W -> LDS (zero padded rows >= K and columns >= V); finite pad behind the H tile
+    for (int i = tid; i < G_::WROWS * WS; i += BLOCK) {
+        int k = i / WS, v = i - k * WS;
+        Wl[i] = (k < K && v < V) ? p.W[k * V + v] : 0.0;
+    }
+    for (int i = lane; i < G_::HL; i += 64) Hl[i] = 0.0;
+    __syncthreads();
+
+    d4 g[KT][VT];
+    if (DO_G) {
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int vt = 0; vt < VT; ++vt) g[kt][vt] = (d4){0, 0, 0, 0};
+    }
+    double hsum[KS];
+    double klacc = 0.0;
+    if (DO_STATS) {
+#pragma unroll
+        for (int j = 0; j < KS; ++j) hsum[j] = 0.0;
+    }
+
+    const int64_t tstride = (int64_t)gridDim.x * WAVES;
+    int64_t tile = (int64_t)blockIdx.x * WAVES + wave;
+
+    // prefetch registers: H tile (raw, contiguous 16*K doubles) and X tile (accumulator layout)
+    double hpre[KS];
+    double x[VT][4];
+    const int tileH = 16 * K;
+    auto load_tile = [&](int64_t t) {
+        const int64_t n0 = t * 16;
+        const int64_t hbase = n0 * K;
+        const int64_t hend = N * K;
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            int idx = lane + 64 * j;
+            double h = 0.0;
+            if (idx < tileH && hbase + idx < hend) {
+                h = p.H[hbase + idx];
+                if (p.hscale) h = fmax(h * p.hscale[idx % K], kEps);
+            }
+            hpre[j] = h;
+        }
+#pragma unroll
+        for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int64_t n = n0 + q + 4 * r;
+                int v = 16 * vt + c16;
+                x[vt][r] = (n < N && v < V) ? p.X[n * V + v] : 0.0;
+            }
+    };
+    if (tile < p.ntiles) load_tile(tile);
+
+    for (; tile < p.ntiles; tile += tstride) {
+        const int64_t n0 = tile * 16;
+        // ---- stage the H tile (wave private; LDS ops of one wave are executed in order)
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            int idx = lane + 64 * j;
+            if (idx < tileH) Hl[idx] = hpre[j];
+            if (DO_STATS) hsum[j] += hpre[j];
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- P = Ht . W   (A = H[n=c16][k=4s+q], B = W[k=4s+q][v=16vt+c16])
+        d4 pr[VT];
+#pragma unroll
+        for (int vt = 0; vt < VT; ++vt) pr[vt] = (d4){0, 0, 0, 0};
+        {
+            const double* ha = Hl + c16 * K + q;
+            const double* wb = Wl + q * WS + c16;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                double a = ha[4 * s];
+#pragma unroll
+                for (int vt = 0; vt < VT; ++vt) pr[vt] = mfma(a, wb[4 * s * WS + 16 * vt], pr[vt]);
+            }
+        }
+
+        // ---- R = X / P in place (rows n = q + 4r, columns v = 16vt + c16); invalid entries -> 0
+#pragma unroll
+        for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                bool valid = (n0 + q + 4 * r < N) && (16 * vt + c16 < V);
+                double xv = x[vt][r], pv = pr[vt][r];
+                if (DO_STATS) {
+                    if (valid) klacc += kl_term(xv, pv);
+                }
+                pr[vt][r] = valid ? xv / pv : 0.0;
+            }
+
+        // ---- G += (w_kl . Ht)^T . R   (A = H[n=4r+q][k=16kt+c16], B = register r of R)
+        if (DO_G) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double wk = 1.0;
+                if (p.wkl) {
+                    int64_t n = n0 + 4 * r + q;
+                    wk = (n < N) ? p.wkl[n] : 0.0;
+                }
+                const double* ha = Hl + (4 * r + q) * K + c16;
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    double a = ha[16 * kt];
+                    if (p.wkl) a *= wk;
+#pragma unroll
+                    for (int vt = 0; vt < VT; ++vt) g[kt][vt] = mfma(a, pr[vt][r], g[kt][vt]);
+                }
+            }
+        }
+
+        if (DO_U) {
+            // ---- transpose R through LDS: write accumulator layout, read A-operand layout
+#pragma unroll
+            for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Rl[(q + 4 * r) * RS + 16 * vt + c16] = pr[vt][r];
+            __builtin_amdgcn_wave_barrier();
+        }
+
+        // prefetch the next tile (X registers and the staging registers are free now)
+        if (tile + tstride < p.ntiles) load_tile(tile + tstride);
+
+        if (DO_U) {
+            // ---- U = R . W^T   (A = R[n=c16][v=4s+q], B = W[k=16kt+c16][v=4s+q])
+            d4 u[KT];
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) u[kt] = (d4){0, 0, 0, 0};
+            const double* ra = Rl + c16 * RS + q;
+            const double* wb = Wl + c16 * WS + q;
+#pragma unroll
+            for (int s = 0; s < VSTEPS; ++s) {
+                double a = ra[4 * s];
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) u[kt] = mfma(a, wb[16 * kt * WS + 4 * s], u[kt]);
+            }
+            // ---- H update (_utils_klnmf.py:343-361), rows n = q+4r, columns k = 16kt+c16
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int64_t n = n0 + q + 4 * r;
+                if (n < N) {
+                    double wl = 0.0, wk2 = 1.0;
+                    const bool lhalf = p.wlh != nullptr;
+                    if (lhalf) {
+                        wl = p.wlh[n];
+                        if (p.wkl) { double w = p.wkl[n]; wk2 = w * w; }
+                    }
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt) {
+                        int k = 16 * kt + c16;
+                        if (k < K) {
+                            double h = Hl[(q + 4 * r) * K + k], f = u[kt][r], hn;
+                            if (!lhalf) {
+                                hn = h * f;
+                            } else {
+                                double inter = 4.0 * h * f;
+                                if (p.wkl) inter *= wk2;
+                                double disc = 0.25 * wl * wl + inter;
+                                double t = wl / 2 - sqrt(disc);
+                                hn = 0.25 * (t * t);
+                                if (p.wkl) hn /= wk2;
+                            }
+                            p.H[n * K + k] = fmax(hn, kEps);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- workgroup reductions, fixed order (deterministic)
+    __syncthreads();  // every wave is done with the LDS copy of W
+    if (DO_G) {
+        double* Gs = lds;  // [K][VMAX], aliases W
+        for (int w = 0; w < WAVES; ++w) {
+            if (wave == w) {
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                    for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            int k = 16 * kt + q + 4 * r, v = 16 * vt + c16;
+                            if (k < K) {
+                                double prev = (w == 0) ? 0.0 : Gs[k * VMAX + v];
+                                Gs[k * VMAX + v] = prev + g[kt][vt][r];
+                            }
+                        }
+            }
+            __syncthreads();
+        }
+        double* out = p.Gpart + (int64_t)blockIdx.x * K * V;
+        for (int i = tid; i < K * V; i += BLOCK) {
+            int k = i / V, v = i - k * V;
+            out[i] = Gs[k * VMAX + v];
+        }
+    }
+    if (DO_STATS) {
+        __syncthreads();
+        // row sums of H: lane-private sums hsum[j] belong to column (lane + 64 j) % K
+        double* S = lds;  // [WAVES][64*KS]
+#pragma unroll
+        for (int j = 0; j < KS; ++j) S[wave * 64 * KS + lane + 64 * j] = hsum[j];
+        // KL partial: lane values
+        double* Ks = lds + WAVES * 64 * KS;  // [BLOCK]
+        Ks[tid] = klacc;
+        __syncthreads();
+        if (tid < K) {
+            double s = 0.0;
+            for (int w = 0; w < WAVES; ++w)
+                for (int idx = tid; idx < tileH; idx += K) s += S[w * 64 * KS + idx];
+            p.Hsumpart[(int64_t)blockIdx.x * K + tid] = s;
+        }
+        if (tid == 0) {
+            double s = 0.0;
+            for (int i = 0; i < BLOCK; ++i) s += Ks[i];
+            p.KLpart[blockIdx.x] = s;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Forward pass + objective: the "W@H step" of the north star.  P = Ht . W on MFMA, then
+//   mode 0: weighted KL partial per workgroup (+ l-half penalty)        klnmf.py:64-80
+//   mode 1: per-sample KL, zeros replaced by EPS in X and WH            _utils_klnmf.py:58-97
+//   mode 2: the reconstruction H @ W                                    signature_nmf.py:221-224
+struct FwdParams {
+    const double* __restrict__ X;
+    const double* __restrict__ H;
+    const double* __restrict__ W;
+    const double* __restrict__ wkl;
+    const double* __restrict__ wlh;
+    const double* __restrict__ hscale;  // [K] or null: H read as clip(H*hscale)
+    double* __restrict__ out;           // mode 0: [gridDim.x]; mode 1: [N]; mode 2: [N][V]
+    int64_t N;
+    int V;
+    int K;
+    int64_t ntiles;
+};
+
+template <int KS, int MODE>
+__global__ void __launch_bounds__(BLOCK, 1) forward_kernel(FwdParams p) {
+    using G_ = Geo<KS>;
+    __shared__ __attribute__((aligned(16))) double lds[G_::WROWS * WS + WAVES * G_::HL + BLOCK];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int c16 = lane & 15;
+    const int q = lane >> 4;
+    const int V = p.V, K = p.K;
+    const int64_t N = p.N;
+
+    double* Wl = lds;
+    double* Hl = lds + G_::WROWS * WS + wave * G_::HL;
+    double* red = lds + G_::WROWS * WS + WAVES * G_::HL;
+
+    for (int i = tid; i < G_::WROWS * WS; i += BLOCK) {
+        int k = i / WS, v = i - k * WS;
+        Wl[i] = (k < K && v < V) ? p.W[k * V + v] : 0.0;
+    }
+    for (int i = lane; i < G_::HL; i += 64) Hl[i] = 0.0;
+    __syncthreads();
+
+    const int tileH = 16 * K;
+    const int64_t tstride = (int64_t)gridDim.x * WAVES;
+    double total = 0.0;
+
+    for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < p.ntiles; tile += tstride) {
+        const int64_t n0 = tile * 16;
+        const int64_t hbase = n0 * K, hend = N * K;
+        double pen = 0.0;
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            int idx = lane + 64 * j;
+            double h = 0.0;
+            bool ok = idx < tileH && hbase + idx < hend;
+            if (ok) {
+                h = p.H[hbase + idx];
+                if (p.hscale) h = fmax(h * p.hscale[idx % K], kEps);
+                if (MODE == 0 && p.wlh) pen += p.wlh[n0 + idx / K] * sqrt(h);  // klnmf.py:75-79
+            }
+            if (idx < tileH) Hl[idx] = h;
+        }
+        double x[VT][4];
+#pragma unroll
+        for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int64_t n = n0 + q + 4 * r;
+                int v = 16 * vt + c16;
+                x[vt][r] = (MODE != 2 && n < N && v < V) ? p.X[n * V + v] : 0.0;
+            }
+        __builtin_amdgcn_wave_barrier();
+
+        d4 pr[VT];
+#pragma unroll
+        for (int vt = 0; vt < VT; ++vt) pr[vt] = (d4){0, 0, 0, 0};
+        const double* ha = Hl + c16 * K + q;
+        const double* wb = Wl + q * WS + c16;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            double a = ha[4 * s];
+#pragma unroll
+            for (int vt = 0; vt < VT; ++vt) pr[vt] = mfma(a, wb[4 * s * WS + 16 * vt], pr[vt]);
+        }
+
+        if (MODE == 0) {
+            double tsum = pen;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int64_t n = n0 + q + 4 * r;
+                double acc = 0.0;
+#pragma unroll
+                for (int vt = 0; vt < VT; ++vt)
+                    if (n < N && 16 * vt + c16 < V) acc += kl_term(x[vt][r], pr[vt][r]);
+                if (p.wkl && n < N) acc *= p.wkl[n];
+                tsum += acc;
+            }
+            total += tsum;
+        } else if (MODE == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int64_t n = n0 + q + 4 * r;
+                double acc = 0.0;
+#pragma unroll
+                for (int vt = 0; vt < VT; ++vt)
+                    if (n < N && 16 * vt + c16 < V) {
+                        double xv = x[vt][r], pv = pr[vt][r];
+                        double xe = (xv == 0.0) ? kEps : xv, pe = (xv == 0.0) ? kEps : pv;
+                        acc += xe * log(xe / pe) - xv + pv;
+                    }
+                // reduce over the 16 lanes that share this sample row (same q)
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) acc += __shfl_xor(acc, m, 64);
+                if (c16 == 0 && n < N) p.out[n] = acc;
+            }
+        } else {
+#pragma unroll
+            for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int64_t n = n0 + q + 4 * r;
+                    int v = 16 * vt + c16;
+                    if (n < N && v < V) p.out[n * V + v] = pr[vt][r];
+                }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    if (MODE == 0) {
+        red[tid] = total;
+        __syncthreads();
+        if (tid == 0) {
+            double s = 0.0;
+            for (int i = 0; i < BLOCK; ++i) s += red[i];
+            p.out[blockIdx.x] = s;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// W tail (_utils_klnmf.py:338-341 / :208-215): one workgroup per signature k.
+//   stage 1 (nslabs > 0): G[k][:] = sum over the per-workgroup slabs, fixed order
+//   stage 2 (do_tail)   : W' = W*G ; W' /= sum_v W' ; keep given rows ; clip
+struct TailParams {
+    const double* __restrict__ Gpart;  // [nslabs][K][V]
+    double* __restrict__ G;            // [K][V]
+    double* __restrict__ W;            // [K][V] in/out
+    int nslabs;
+    int V;
+    int K;
+    int n_given;
+    int clip_mode;
+    int do_tail;
+};
+
+constexpr int TAIL_PARTS = 8;
+constexpr int TAIL_BLOCK = VMAX * TAIL_PARTS;
+
+__global__ void __launch_bounds__(TAIL_BLOCK) tail_kernel(TailParams p) {
+    __shared__ double red[TAIL_PARTS][VMAX];
+    __shared__ double wn[VMAX];
+    __shared__ double rowsum;
+    const int k = blockIdx.x;
+    const int v = threadIdx.x % VMAX;
+    const int part = threadIdx.x / VMAX;
+    const int V = p.V, K = p.K;
+    if (p.nslabs > 0) {
+        double s = 0.0;
+        if (v < V)
+            for (int sl = part; sl < p.nslabs; sl += TAIL_PARTS) s += p.Gpart[((int64_t)sl * K + k) * V + v];
+        red[part][v] = s;
+        __syncthreads();
+        if (part == 0 && v < V) {
+            double t = 0.0;
+            for (int i = 0; i < TAIL_PARTS; ++i) t += red[i][v];
+            p.G[k * V + v] = t;
+            red[0][v] = t;
+        }
+        __syncthreads();
+    } else {
+        if (part == 0 && v < V) red[0][v] = p.G[k * V + v];
+        __syncthreads();
+    }
+    if (!p.do_tail) return;
+    double wold = 0.0;
+    if (part == 0) {
+        wold = (v < V) ? p.W[k * V + v] : 0.0;
+        wn[v] = (v < V) ? wold * red[0][v] : 0.0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < V; ++i) s += wn[i];
+        rowsum = s;
+    }
+    __syncthreads();
+    if (part == 0 && v < V) {
+        double w = wn[v] / rowsum;
+        if (k < p.n_given) {
+            w = wold;
+            if (p.clip_mode == 0) w = fmax(w, kEps);
+        } else {
+            w = fmax(w, kEps);
+        }
+        p.W[k * V + v] = w;
+    }
+}
+
+// sum a vector of partials in fixed order: out[j] = sum_i part[i*stride + j], j < width
+__global__ void sum_partials_kernel(const double* __restrict__ part, int n, int stride, int width,
+                                    double* __restrict__ out) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= width) return;
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += part[(int64_t)i * stride + j];
+    out[j] = s;
+}
+
+// H <- clip(H * scale[k]) (normalize_WH + clip of an accepted MvNMF trial, mvnmf.py:80-81)
+__global__ void scale_H_kernel(double* __restrict__ H, const double* __restrict__ scale, int64_t total, int K) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) H[i] = fmax(H[i] * scale[i % K], kEps);
+}
+
+// X <- clip(X, EPS)  (signature_nmf.py:281)
+__global__ void clip_kernel(double* __restrict__ X, int64_t total) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) X[i] = fmax(X[i], kEps);
+}
+
+}  // namespace salnmf

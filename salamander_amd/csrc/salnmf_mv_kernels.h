@@ -1,0 +1,152 @@
+// Small dense (K x K, K <= 64) algebra of the MvNMF W step, one workgroup, fp64, all in LDS.
+// Reference arithmetic: src/salamander/models/mvnmf.py:19-24 (volume_logdet), :37-66
+// (update_W_unconstrained), :80-81,86-88 (normalize + clip of a line-search trial).
+// S = W W^T + delta I is symmetric positive definite (delta > 0), so the reference's
+// LU-based inv/det are replaced by a Cholesky factorisation (same values to rounding).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace salnmf {
+
+constexpr int MV_BLOCK = 256;
+constexpr int MV_KMAX = 64;
+constexpr int MV_LD = MV_KMAX + 1;  // padded leading dimension in LDS
+constexpr int MV_VMAX = 96;
+
+// S (LDS, [K][MV_LD]) <- Wl Wl^T + delta I, with Wl (LDS, [K][MV_VMAX]) rows = signatures
+__device__ inline void mv_gram(const double* Wl, double* S, int K, int V, double delta) {
+    for (int idx = threadIdx.x; idx < K * K; idx += MV_BLOCK) {
+        int a = idx / K, b = idx - a * K;
+        double s = 0.0;
+        for (int v = 0; v < V; ++v) s += Wl[a * MV_VMAX + v] * Wl[b * MV_VMAX + v];
+        if (a == b) s += delta;
+        S[a * MV_LD + b] = s;
+    }
+    __syncthreads();
+}
+
+// in-place lower Cholesky of S; returns log det = 2 sum log L_ii (same value in every thread)
+__device__ inline double mv_cholesky_logdet(double* S, int K) {
+    for (int j = 0; j < K; ++j) {
+        if (threadIdx.x == 0) S[j * MV_LD + j] = sqrt(S[j * MV_LD + j]);
+        __syncthreads();
+        double d = S[j * MV_LD + j];
+        for (int i = j + 1 + threadIdx.x; i < K; i += MV_BLOCK) S[i * MV_LD + j] /= d;
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < K * K; idx += MV_BLOCK) {
+            int i = idx / K, c = idx - i * K;
+            if (c > j && i >= c) S[i * MV_LD + c] -= S[i * MV_LD + j] * S[c * MV_LD + j];
+        }
+        __syncthreads();
+    }
+    double ld = 0.0;
+    for (int j = 0; j < K; ++j) ld += log(S[j * MV_LD + j]);
+    return 2.0 * ld;
+}
+
+__device__ inline void mv_load_W(const double* __restrict__ W, double* Wl, int K, int V) {
+    for (int idx = threadIdx.x; idx < K * V; idx += MV_BLOCK) {
+        int k = idx / V, v = idx - k * V;
+        Wl[k * MV_VMAX + v] = W[idx];
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(MV_BLOCK) mv_logdet_kernel(const double* __restrict__ W, int K, int V, double delta,
+                                                             double* __restrict__ out) {
+    __shared__ double Wl[MV_KMAX * MV_VMAX];
+    __shared__ double S[MV_KMAX * MV_LD];
+    mv_load_W(W, Wl, K, V);
+    mv_gram(Wl, S, K, V, delta);
+    double ld = mv_cholesky_logdet(S, K);
+    if (threadIdx.x == 0) *out = ld;
+}
+
+// W_unconstrained (mvnmf.py:37-66) from the reduced G = (X/(WH)) @ H.T, rowsums of H, and W;
+// also f0 = KL + lam * log det(W W^T + delta I) (mvnmf.py:79).
+__global__ void __launch_bounds__(MV_BLOCK)
+    mv_prepare_kernel(const double* __restrict__ W, const double* __restrict__ G, const double* __restrict__ hsum,
+                      const double* __restrict__ kl, int K, int V, int n_given, double lam, double delta,
+                      double* __restrict__ Wunc, double* __restrict__ f0_out) {
+    __shared__ double Wl[MV_KMAX * MV_VMAX];
+    __shared__ double S[MV_KMAX * MV_LD];   // Gram -> Cholesky factor L -> Y = S^-1
+    __shared__ double Li[MV_KMAX * MV_LD];  // L^-1
+    mv_load_W(W, Wl, K, V);
+    mv_gram(Wl, S, K, V, delta);
+    double ld = mv_cholesky_logdet(S, K);
+    if (threadIdx.x == 0) *f0_out = *kl + lam * ld;
+
+    // L^-1 by forward substitution, one column per thread
+    for (int c = threadIdx.x; c < K; c += MV_BLOCK) {
+        for (int i = 0; i < c; ++i) Li[i * MV_LD + c] = 0.0;
+        Li[c * MV_LD + c] = 1.0 / S[c * MV_LD + c];
+        for (int i = c + 1; i < K; ++i) {
+            double s = 0.0;
+            for (int m = c; m < i; ++m) s += S[i * MV_LD + m] * Li[m * MV_LD + c];
+            Li[i * MV_LD + c] = -s / S[i * MV_LD + i];
+        }
+    }
+    __syncthreads();
+    // Y = L^-T L^-1 (overwrites S)
+    for (int idx = threadIdx.x; idx < K * K; idx += MV_BLOCK) {
+        int a = idx / K, b = idx - a * K;
+        int m0 = a > b ? a : b;
+        double s = 0.0;
+        for (int m = m0; m < K; ++m) s += Li[m * MV_LD + a] * Li[m * MV_LD + b];
+        S[a * MV_LD + b] = s;
+    }
+    __syncthreads();
+    // per entry (k, v): A = (W @ Y_minus)[v,k], B = (W @ |Y|)[v,k]; closed-form root
+    for (int idx = threadIdx.x; idx < K * V; idx += MV_BLOCK) {
+        int k = idx / V, v = idx - k * V;
+        double A = 0.0, B = 0.0;
+        for (int m = 0; m < K; ++m) {
+            double y = S[m * MV_LD + k], w = Wl[m * MV_VMAX + v];
+            A += w * fmax(0.0, -y);
+            B += w * fabs(y);
+        }
+        double w = Wl[k * MV_VMAX + v];
+        double b = hsum[k] - 4.0 * lam * A;
+        double root = sqrt(b * b + 8.0 * lam * B * G[idx]);
+        double wu = w * (root - b) / (4.0 * lam * B);
+        Wunc[idx] = (k < n_given) ? w : fmax(wu, 1.1920928955078125e-07);
+    }
+}
+
+// One line-search trial (mvnmf.py:80-81, 85-88): Wt = blend ? (1-g) W + g Wunc : Wunc;
+// cs = row sums; Wtrial = clip(Wt / cs); logdet of the trial.  H's counterpart
+// clip(H * cs) is applied on the fly by the forward pass (hscale) and on acceptance.
+__global__ void __launch_bounds__(MV_BLOCK)
+    mv_trial_kernel(const double* __restrict__ W, const double* __restrict__ Wunc, double gamma, int blend, int K, int V,
+                    double delta, double* __restrict__ Wtrial, double* __restrict__ cs, double* __restrict__ logdet_out) {
+    __shared__ double Wl[MV_KMAX * MV_VMAX];
+    __shared__ double S[MV_KMAX * MV_LD];
+    __shared__ double rs[MV_KMAX];
+    for (int idx = threadIdx.x; idx < K * V; idx += MV_BLOCK) {
+        int k = idx / V, v = idx - k * V;
+        double wt = Wunc[idx];
+        if (blend) wt = (1 - gamma) * W[idx] + gamma * wt;
+        Wl[k * MV_VMAX + v] = wt;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += MV_BLOCK) {
+        double s = 0.0;
+        for (int v = 0; v < V; ++v) s += Wl[k * MV_VMAX + v];
+        rs[k] = s;
+        cs[k] = s;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < K * V; idx += MV_BLOCK) {
+        int k = idx / V, v = idx - k * V;
+        double w = fmax(Wl[k * MV_VMAX + v] / rs[k], 1.1920928955078125e-07);
+        Wl[k * MV_VMAX + v] = w;
+        Wtrial[idx] = w;
+    }
+    __syncthreads();
+    mv_gram(Wl, S, K, V, delta);
+    double ld = mv_cholesky_logdet(S, K);
+    if (threadIdx.x == 0) *logdet_out = ld;
+}
+
+}  // namespace salnmf

@@ -1,0 +1,167 @@
+"""Python handle of one device engine (one GPU, one shard of the sample axis).
+
+Thin: validates shapes/dtypes, hands plain pointers to the C ABI
+(``include/salnmf.h``) and converts status codes into exceptions.  Arrays are in
+AnnData's storage layout: ``X (N, V)``, ``H (N, K)``, ``W (K, V)``, float64, C order.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from ctypes import POINTER, c_double
+
+import numpy as np
+
+from . import _lib
+
+_D = POINTER(c_double)
+
+
+def _as_c(a, shape, name):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if a.shape != tuple(shape):
+        raise ValueError(f"The shape of '{name}' has to be {tuple(shape)}.")
+    return a
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_D)
+
+
+class Engine:
+    """Device-resident state of one KL-NMF problem shard: X, W, H (+ weights)."""
+
+    def __init__(self, n_samples: int, n_features: int, n_signatures: int, device: int = 0):
+        self._lib = _lib.load()
+        if self._lib.salnmf_device_count() < 1:
+            raise _lib.EngineUnavailable(
+                "no HIP device visible: salamander_amd runs on MI355X (gfx950) only and has no CPU fallback."
+            )
+        self.N, self.V, self.K = int(n_samples), int(n_features), int(n_signatures)
+        self.device = int(device)
+        handle = ctypes.c_void_p()
+        _lib.check(self._lib.salnmf_create(self.device, self.V, self.N, self.K, ctypes.byref(handle)))
+        self._h = handle
+
+    # -- lifetime
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.salnmf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- transfers
+    def upload_X(self, X, clip: bool = False):
+        X = _as_c(X, (self.N, self.V), "X")
+        _lib.check(self._lib.salnmf_upload_X(self._h, _ptr(X), int(bool(clip))))
+
+    def upload_W(self, W):
+        W = _as_c(W, (self.K, self.V), "W")
+        _lib.check(self._lib.salnmf_upload_W(self._h, _ptr(W)))
+
+    def upload_H(self, H):
+        H = _as_c(H, (self.N, self.K), "H")
+        _lib.check(self._lib.salnmf_upload_H(self._h, _ptr(H)))
+
+    def set_weights(self, weights_kl=None, weights_lhalf=None):
+        wk = None if weights_kl is None else _as_c(weights_kl, (self.N,), "weights_kl")
+        wl = None if weights_lhalf is None else _as_c(weights_lhalf, (self.N,), "weights_lhalf")
+        _lib.check(
+            self._lib.salnmf_set_weights(self._h, None if wk is None else _ptr(wk), None if wl is None else _ptr(wl))
+        )
+
+    def download_W(self) -> np.ndarray:
+        W = np.empty((self.K, self.V), dtype=np.float64)
+        _lib.check(self._lib.salnmf_download_W(self._h, _ptr(W)))
+        return W
+
+    def download_H(self) -> np.ndarray:
+        H = np.empty((self.N, self.K), dtype=np.float64)
+        _lib.check(self._lib.salnmf_download_H(self._h, _ptr(H)))
+        return H
+
+    # -- KLNMF
+    def kl_step(self, n_steps: int = 1, n_given: int = 0):
+        _lib.check(self._lib.salnmf_kl_step(self._h, int(n_steps), int(n_given)))
+
+    def update_H(self):
+        _lib.check(self._lib.salnmf_update_H(self._h))
+
+    def update_W(self, n_given: int = 0, clip_mode: int = _lib.CLIP_NON_GIVEN):
+        _lib.check(self._lib.salnmf_update_W(self._h, int(n_given), int(clip_mode)))
+
+    def objective(self) -> float:
+        out = c_double()
+        _lib.check(self._lib.salnmf_objective(self._h, ctypes.byref(out)))
+        return out.value
+
+    def samplewise_kl(self) -> np.ndarray:
+        out = np.empty(self.N, dtype=np.float64)
+        _lib.check(self._lib.salnmf_samplewise_kl(self._h, _ptr(out)))
+        return out
+
+    def reconstruct(self) -> np.ndarray:
+        out = np.empty((self.N, self.V), dtype=np.float64)
+        _lib.check(self._lib.salnmf_reconstruct(self._h, _ptr(out)))
+        return out
+
+    # -- MvNMF
+    def mv_step(self, n_steps: int, n_given: int, lam: float, delta: float, gamma: float) -> float:
+        g = c_double(gamma)
+        _lib.check(self._lib.salnmf_mv_step(self._h, int(n_steps), int(n_given), float(lam), float(delta), ctypes.byref(g)))
+        return g.value
+
+    def mv_update_W(self, n_given: int, lam: float, delta: float, gamma: float) -> float:
+        g = c_double(gamma)
+        _lib.check(self._lib.salnmf_mv_update_W(self._h, int(n_given), float(lam), float(delta), ctypes.byref(g)))
+        return g.value
+
+    def mv_objective(self, lam: float, delta: float) -> float:
+        out = c_double()
+        _lib.check(self._lib.salnmf_mv_objective(self._h, float(lam), float(delta), ctypes.byref(out)))
+        return out.value
+
+    # -- multi-GPU
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = ctypes.create_string_buffer(_lib.UNIQUE_ID_BYTES)
+        _lib.check(_lib.load().salnmf_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, n_ranks: int, rank: int):
+        if len(unique_id) != _lib.UNIQUE_ID_BYTES:
+            raise ValueError("unique_id has the wrong length")
+        _lib.check(self._lib.salnmf_comm_init(self._h, unique_id, int(n_ranks), int(rank)))
+
+    def kl_step_partial(self):
+        _lib.check(self._lib.salnmf_kl_step_partial(self._h))
+
+    def kl_step_finish(self, n_given: int = 0, clip_mode: int = _lib.CLIP_ALL):
+        _lib.check(self._lib.salnmf_kl_step_finish(self._h, int(n_given), int(clip_mode)))
+
+    def device_ptr(self, which: int) -> int:
+        return int(self._lib.salnmf_device_ptr(self._h, int(which)) or 0)
+
+    def sync(self):
+        _lib.check(self._lib.salnmf_sync(self._h))
+
+    # -- measurement
+    def profile_kl_steps(self, n_steps: int, n_given: int = 0):
+        """Run ``n_steps`` joint steps; returns (total_ms, fused_kernel_avg_ms, tail_avg_ms) from HIP events."""
+        t, f, w = c_double(), c_double(), c_double()
+        _lib.check(
+            self._lib.salnmf_profile_kl_steps(
+                self._h, int(n_steps), int(n_given), ctypes.byref(t), ctypes.byref(f), ctypes.byref(w)
+            )
+        )
+        return t.value, f.value, w.value
+
+    def profile_objective(self, n_calls: int) -> float:
+        a = c_double()
+        _lib.check(self._lib.salnmf_profile_objective(self._h, int(n_calls), ctypes.byref(a)))
+        return a.value
