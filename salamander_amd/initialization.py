@@ -1,0 +1,139 @@
+"""Initialisation of ``(W, H)`` for the standard NMF models -- the step before the hot path.
+
+A one-time host computation; it mirrors the reference's
+behaviour so that ``fit(adata, init_kwargs=...)`` is a drop-in:
+``src/salamander/initialization/methods.py:15-135`` (the seven methods) and
+``initialize.py:44-119,122-255`` (post-processing, given signatures, AnnData packaging).
+Parity runs inject identical ``W0, H0`` through ``init_method="custom"``.
+"""
+
+from __future__ import annotations
+
+from typing import Any
+
+import numpy as np
+
+from .anndata_compat import ANNDATA_TYPES, AnnData, concat_rows
+from .utils import EPSILON, dict_checker, normalize_WH, shape_checker, type_checker, value_checker
+
+INIT_METHODS = ("custom", "flat", "nndsvd", "nndsvda", "nndsvdar", "random", "separableNMF")
+GIVEN_PARAMETERS_STANDARD_NMF = ["asignatures"]
+
+
+def init_custom(data_mat, n_signatures, signatures_mat, exposures_mat):
+    """User-supplied matrices, type- and shape-checked (methods.py:27-55)."""
+    n_samples, n_features = data_mat.shape
+    type_checker("signatures_mat", signatures_mat, np.ndarray)
+    type_checker("exposures_mat", exposures_mat, np.ndarray)
+    shape_checker("signatures_mat", signatures_mat, (n_signatures, n_features))
+    shape_checker("exposures_mat", exposures_mat, (n_samples, n_signatures))
+    return signatures_mat, exposures_mat
+
+
+def init_flat(data_mat, n_signatures):
+    """Uniform signatures; each sample's mass split evenly (methods.py:58-66)."""
+    n_samples, n_features = data_mat.shape
+    S = np.full((n_signatures, n_features), 1.0 / n_features)
+    E = np.repeat((data_mat.sum(axis=1) / n_signatures)[:, None], n_signatures, axis=1)
+    return S, E
+
+
+def init_random(data_mat, n_signatures, seed=None):
+    """Dirichlet signatures and scaled Dirichlet exposures from the global RNG (methods.py:89-109)."""
+    if seed is not None:
+        np.random.seed(seed)
+    n_samples, n_features = data_mat.shape
+    S = np.random.dirichlet(np.ones(n_features), size=n_signatures)
+    E = data_mat.sum(axis=1)[:, None] * np.random.dirichlet(np.ones(n_signatures), size=n_samples)
+    return S, E
+
+
+def init_nndsvd(data_mat, n_signatures, method="nndsvd", seed=None):
+    """scikit-learn's NNDSVD family, as the reference wraps it (methods.py:69-86)."""
+    try:
+        from sklearn.decomposition import _nmf as sknmf
+    except Exception as exc:  # pragma: no cover
+        raise ImportError("init_method='nndsvd*' needs scikit-learn.") from exc
+    if seed is not None:
+        np.random.seed(seed)
+    E, S = sknmf._initialize_nmf(data_mat, n_signatures, init=method)  # pylint: disable=protected-access
+    return S, E
+
+
+def init_separableNMF(data_mat, n_signatures, seed=None):
+    """Successive projection (Gillis & Vavasis 2013) for signatures + random exposures (methods.py:112-135)."""
+    R = data_mat.T / data_mat.T.sum(axis=0)
+    chosen = np.empty(n_signatures, dtype=int)
+    for k in range(n_signatures):
+        norms = (R**2).sum(axis=0)
+        j = int(np.argmax(norms))
+        u = R[:, j]
+        R = R - np.outer(u, u @ R) / norms[j]
+        chosen[k] = j
+    S = data_mat[chosen, :].astype(float)
+    S /= S.sum(axis=1, keepdims=True)
+    _, E = init_random(data_mat, n_signatures, seed=seed)
+    return S, E
+
+
+def initialize_mat(data_mat, n_signatures, method="nndsvd", given_signatures_mat=None, **kwargs):
+    """``(signatures (K, V), exposures (N, K))``: raw init, given rows, normalise, clip (initialize.py:44-119)."""
+    value_checker("method", method, INIT_METHODS)
+    if method == "custom":
+        S, E = init_custom(data_mat, n_signatures, **kwargs)
+    elif method == "flat":
+        S, E = init_flat(data_mat, n_signatures)
+    elif method in ("nndsvd", "nndsvda", "nndsvdar"):
+        S, E = init_nndsvd(data_mat, n_signatures, method=method, **kwargs)
+    elif method == "random":
+        S, E = init_random(data_mat, n_signatures, **kwargs)
+    else:
+        S, E = init_separableNMF(data_mat, n_signatures, **kwargs)
+
+    if given_signatures_mat is not None:
+        type_checker("given_signatures_mat", given_signatures_mat, np.ndarray)
+        g, vg = given_signatures_mat.shape
+        if vg != data_mat.shape[1]:
+            raise ValueError("The given signature matrix has a different number of features than the data.")
+        if g > n_signatures:
+            raise ValueError("The given signature matrix contains too many signatures.")
+        S[:g, :] = given_signatures_mat.copy()
+
+    W, H = normalize_WH(S.T, E.T)
+    W, H = W.clip(EPSILON), H.clip(EPSILON)
+    return W.T, H.T
+
+
+def check_given_asignatures(given_asignatures, adata, n_signatures) -> None:
+    """initialize.py:122-155."""
+    type_checker("given_asignatures", given_asignatures, ANNDATA_TYPES)
+    if given_asignatures.n_vars != adata.n_vars:
+        raise ValueError("The given signatures have a different number of features than the data.")
+    if not all(given_asignatures.var_names == adata.var_names):
+        raise ValueError("The features of the given signatures and the data are not identical.")
+    if given_asignatures.n_obs > n_signatures:
+        raise ValueError("The number of given signatures exceeds the number of signatures to initialize.")
+
+
+def initialize_standard_nmf(adata, n_signatures, method="nndsvd", given_parameters: dict[str, Any] | None = None, **kwargs):
+    """Builds ``asignatures`` and writes ``adata.obsm['exposures']`` (initialize.py:158-255)."""
+    given_parameters = {} if given_parameters is None else given_parameters.copy()
+    dict_checker("given_parameters", given_parameters, GIVEN_PARAMETERS_STANDARD_NMF)
+    given = given_parameters.get("asignatures")
+    given_mat = None
+    if given is not None:
+        check_given_asignatures(given, adata, n_signatures)
+        given_mat = np.asarray(given.X)
+
+    S, E = initialize_mat(np.asarray(adata.X), n_signatures, method, given_mat, **kwargs)
+    asignatures = AnnData(S)
+    asignatures.var_names = adata.var_names
+    names = [f"Sig{k + 1}" for k in range(n_signatures)]
+    asignatures.obs_names = names
+    if given is not None:
+        # given signatures keep their own annotations; the rest are Sig1..Sig(K-g) (initialize.py:211-216)
+        g = given.n_obs
+        asignatures.obs_names = list(np.roll(names, g))
+        asignatures = concat_rows(given, asignatures[g:, :])
+    adata.obsm["exposures"] = E
+    return asignatures

@@ -1,0 +1,77 @@
+"""``MvNMF``: minimum-volume KL NMF on the MI355X engine.
+
+Drop-in for ``src/salamander/models/mvnmf.py`` (constructor ``:116-137``, objective
+``:149-156``, ``_update_H``/``_update_W`` ``:162-195``, ``_update_parameters`` ``:197-210``,
+``_setup_fitting_parameters`` ``:212-218``).  The (K x K) inverse / log-determinant, the
+closed-form W root and the backtracking line search run on the device; ``_gamma`` persists
+across iterations exactly as in the reference.
+"""
+
+from __future__ import annotations
+
+from typing import Any, Literal
+
+from .standard_nmf import StandardNMF
+
+
+class MvNMF(StandardNMF):
+    def __init__(
+        self,
+        n_signatures: int = 1,
+        init_method: str = "nndsvd",
+        lam: float = 1.0,
+        delta: float = 1.0,
+        min_iterations: int = 500,
+        max_iterations: int = 10000,
+        conv_test_freq: int = 10,
+        tol: float = 1e-7,
+        **engine_kwargs,
+    ):
+        super().__init__(
+            n_signatures, init_method, min_iterations, max_iterations, conv_test_freq, tol, **engine_kwargs
+        )
+        self.lam = lam
+        self.delta = delta
+        self._gamma = 1.0
+
+    @property
+    def objective(self) -> Literal["minimize", "maximize"]:
+        return "minimize"
+
+    def compute_reconstruction_errors(self) -> None:
+        self._sync_to_device()
+        self.adata.obs["reconstruction_error"] = self._engine.samplewise_kl()
+
+    def objective_function(self) -> float:
+        self._sync_to_device()
+        return self._device_objective()
+
+    # -- the reference's single-step hooks (tests/test_mvnmf.py:70-76)
+    def _update_H(self) -> None:
+        self._sync_to_device()
+        self._engine.update_H()
+        self.adata.obsm["exposures"] = self._engine.download_H()
+
+    def _update_W(self, n_given_signatures: int = 0) -> None:
+        if n_given_signatures == self.n_signatures:
+            return
+        self._sync_to_device()
+        self._gamma = self._engine.mv_update_W(n_given_signatures, self.lam, self.delta, self._gamma)
+        self._sync_from_device()
+
+    def _update_parameters(self, given_parameters: dict[str, Any] | None = None) -> None:
+        self._sync_to_device()
+        self._device_steps(1, given_parameters)
+        self._sync_from_device()
+
+    # -- device-resident pieces used by fit()
+    def _device_steps(self, n_steps: int, given_parameters) -> None:
+        self._gamma = self._engine.mv_step(
+            n_steps, self._n_given(given_parameters), self.lam, self.delta, self._gamma
+        )
+
+    def _device_objective(self) -> float:
+        return self._engine.mv_objective(self.lam, self.delta)
+
+    def _setup_fitting_parameters(self, fitting_kwargs: dict[str, Any] | None = None) -> None:
+        self._gamma = 1.0

@@ -1,0 +1,239 @@
+"""``SignatureNMF``: the model shell of the KL-NMF fit path, device resident.
+
+Same constructor, hooks, ``fit`` signature, convergence rule and ``history`` cadence as
+the reference's abstract base (``src/salamander/models/signature_nmf.py:138-146,
+237-310, 315-385``).  The difference is *where the loop runs*: ``fit`` uploads
+``X, W, H`` once, runs ``conv_test_freq`` update steps per host round trip on the
+MI355X engine (only the objective scalar comes back) and writes ``W, H`` into the
+AnnData objects once at the end.  The single-step hooks ``_update_parameters()`` and
+``objective_function()`` still work on hand-populated models (they sync host state to
+the device, do exactly one step, and sync back), as the reference's tests drive them
+(``tests/test_klnmf.py:44-75``).
+
+Out of scope here: plotting wrappers, ``reorder``, correlation and
+dimensionality-reduction helpers.
+"""
+
+from __future__ import annotations
+
+from abc import ABC, abstractmethod
+from typing import Any, Literal
+
+import numpy as np
+import pandas as pd
+
+from ..anndata_compat import ANNDATA_TYPES, AnnData
+from ..engine import Engine
+from ..initialization import INIT_METHODS
+from ..utils import EPSILON, type_checker, value_checker
+
+
+class SignatureNMF(ABC):
+    def __init__(
+        self,
+        n_signatures: int = 1,
+        init_method: str = "nndsvd",
+        min_iterations: int = 500,
+        max_iterations: int = 10000,
+        conv_test_freq: int = 10,
+        tol: float = 1e-7,
+        *,
+        device: int = 0,
+        distributed: bool = False,
+    ):
+        value_checker("init_method", init_method, INIT_METHODS)
+        self.n_signatures = n_signatures
+        self.init_method = init_method
+        self.min_iterations = min_iterations
+        self.max_iterations = max_iterations
+        self.conv_test_freq = conv_test_freq
+        self.tol = tol
+        # ours: which GPU, and whether adata is this rank's shard of the sample axis
+        self.device = device
+        self.distributed = distributed
+
+        self.adata = AnnData()
+        self.asignatures = AnnData()
+        self.history: dict[str, Any] = {}
+        self._engine: Engine | None = None
+        self._comm_attached = False
+
+    # ------------------------------------------------------------------ accessors (signature_nmf.py:187-253)
+    @property
+    def mutation_types(self) -> list[str]:
+        return list(self.adata.var_names)
+
+    @property
+    def signature_names(self) -> list[str]:
+        return list(self.asignatures.obs_names)
+
+    @property
+    def sample_names(self) -> list[str]:
+        return list(self.adata.obs_names)
+
+    @property
+    def signatures(self) -> pd.DataFrame:
+        return self.asignatures.to_df()
+
+    @property
+    def exposures(self) -> pd.DataFrame:
+        assert "exposures" in self.adata.obsm, "Learning the sample exposures requires fitting the NMF model."
+        return pd.DataFrame(self.adata.obsm["exposures"], index=self.sample_names, columns=self.signature_names)
+
+    def compute_reconstruction(self) -> None:
+        """``exposures @ signatures`` on the device (signature_nmf.py:221-224)."""
+        self._sync_to_device()
+        self.adata.obsm["X_reconstructed"] = self._engine.reconstruct()
+
+    @property
+    def data_reconstructed(self) -> pd.DataFrame:
+        if "X_reconstructed" not in self.adata.obsm:
+            self.compute_reconstruction()
+        return pd.DataFrame(self.adata.obsm["X_reconstructed"], index=self.sample_names, columns=self.mutation_types)
+
+    @abstractmethod
+    def compute_reconstruction_errors(self) -> None:
+        """Adds samplewise errors as ``adata.obs['reconstruction_error']``."""
+
+    @property
+    def reconstruction_error(self) -> float:
+        if "reconstruction_error" not in self.adata.obs:
+            self.compute_reconstruction_errors()
+        return float(np.sum(self.adata.obs["reconstruction_error"]))
+
+    @property
+    @abstractmethod
+    def objective(self) -> Literal["minimize", "maximize"]:
+        ...
+
+    @abstractmethod
+    def objective_function(self) -> float:
+        ...
+
+    # ------------------------------------------------------------------ hooks
+    def _setup_adata(self, adata) -> None:
+        """Type check, keep a reference (no copy), clip the caller's X (signature_nmf.py:269-281)."""
+        type_checker("adata", adata, ANNDATA_TYPES)
+        self.adata = adata
+        self.adata.X = np.asarray(self.adata.X).clip(EPSILON)
+
+    @abstractmethod
+    def _initialize(self, given_parameters=None, init_kwargs=None) -> None:
+        ...
+
+    @abstractmethod
+    def _setup_fitting_parameters(self, fitting_kwargs=None) -> None:
+        ...
+
+    @abstractmethod
+    def _update_parameters(self, given_parameters=None) -> None:
+        ...
+
+    # device-side counterparts used by the resident loop
+    @abstractmethod
+    def _device_steps(self, n_steps: int, given_parameters) -> None:
+        ...
+
+    @abstractmethod
+    def _device_objective(self) -> float:
+        ...
+
+    def _device_weights(self):
+        return None, None
+
+    # ------------------------------------------------------------------ host <-> device state
+    def _host_state(self):
+        X = np.ascontiguousarray(self.adata.X, dtype=np.float64)
+        W = np.ascontiguousarray(self.asignatures.X, dtype=np.float64)
+        H = np.ascontiguousarray(self.adata.obsm["exposures"], dtype=np.float64)
+        return X, W, H
+
+    def _sync_to_device(self) -> None:
+        X, W, H = self._host_state()
+        N, V = X.shape
+        K = W.shape[0]
+        e = self._engine
+        if e is None or (e.N, e.V, e.K, e.device) != (N, V, K, self.device):
+            if e is not None:
+                e.close()
+            e = self._engine = Engine(N, V, K, device=self.device)
+            self._comm_attached = False
+        if self.distributed and not self._comm_attached:
+            from ..distributed import attach_communicator, broadcast_from_rank0
+
+            attach_communicator(e)
+            self._comm_attached = True
+            W = broadcast_from_rank0(W)  # every rank must start from bit-identical signatures
+        e.upload_X(X)
+        e.upload_W(W)
+        e.upload_H(H)
+        e.set_weights(*self._device_weights())
+
+    def _sync_from_device(self) -> None:
+        self.asignatures.X = self._engine.download_W()
+        self.adata.obsm["exposures"] = self._engine.download_H()
+
+    @staticmethod
+    def _n_given(given_parameters) -> int:
+        if given_parameters and "asignatures" in given_parameters:
+            return given_parameters["asignatures"].n_obs
+        return 0
+
+    # ------------------------------------------------------------------ fit (signature_nmf.py:315-385)
+    def fit(
+        self,
+        adata,
+        given_parameters: dict[str, Any] | None = None,
+        init_kwargs: dict[str, Any] | None = None,
+        fitting_kwargs: dict[str, Any] | None = None,
+        history: bool = True,
+        verbose: Literal[0, 1] = 0,
+        verbosity_freq: int = 1000,
+    ) -> "SignatureNMF":
+        self._setup_adata(adata)
+        self._initialize(given_parameters, init_kwargs)
+        self._setup_fitting_parameters(fitting_kwargs)
+        self._sync_to_device()
+
+        of_values = [self._device_objective()]
+        n_iteration = 0
+        converged = False
+        freq = self.conv_test_freq
+        while not converged:
+            # run up to the next iteration at which the reference would look at the model:
+            # a convergence test, the iteration cap, or a verbosity print
+            if verbose and (n_iteration + 1) % verbosity_freq == 0:
+                # printed before the update of that iteration, with the latest known objective
+                print(f"iteration: {n_iteration + 1}; objective: {of_values[-1]:.2f}")
+            stop = (n_iteration // freq + 1) * freq
+            if self.max_iterations > n_iteration:
+                stop = min(stop, self.max_iterations)
+            if verbose:
+                next_print = ((n_iteration + 1) // verbosity_freq + 1) * verbosity_freq
+                stop = min(stop, next_print - 1)
+            stop = max(stop, n_iteration + 1)
+            self._device_steps(stop - n_iteration, given_parameters)
+            n_iteration = stop
+
+            if n_iteration % freq == 0:
+                prev = of_values[-1]
+                of_values.append(self._device_objective())
+                rel_change = np.abs(prev - of_values[-1]) / np.abs(prev)
+                converged = bool(rel_change < self.tol and n_iteration >= self.min_iterations)
+            converged |= n_iteration >= self.max_iterations
+
+        self._sync_from_device()
+        self.n_iterations_ = n_iteration
+        if history:
+            self.history["objective_function"] = of_values[1:]
+        return self
+
+    # ------------------------------------------------------------------ out of scope
+    def _out_of_scope(self, *args, **kwargs):
+        raise NotImplementedError(
+            "plotting / post-hoc analysis helpers are outside the scope of salamander_amd "
+            "(SURVEY.md section 2); use the reference package on the fitted AnnData objects."
+        )
+
+    reorder = plot_history = plot_signatures = plot_exposures = _out_of_scope
+    plot_correlation = plot_embeddings = compute_correlation = correlation = _out_of_scope

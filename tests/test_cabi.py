@@ -1,0 +1,55 @@
+"""The C-ABI library loads without a GPU and exports exactly what include/salnmf.h declares."""
+
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+from salamander_amd import _lib
+
+
+def _header_functions():
+    text = open(os.path.join(ROOT, "include", "salnmf.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return set(re.findall(r"\b(salnmf_[a-z_A-Z0-9]+)\s*\(", text))
+
+
+def test_library_exists():
+    assert os.path.exists(_lib.LIB_PATH), "build the extension first: python -c 'import __graft_entry__ as g; g.build()'"
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    declared = _header_functions()
+    assert declared, "no functions parsed from the header"
+    lib = _lib.load()  # getattr on each bound symbol happens inside load()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in salnmf.h but not exported"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+
+
+def test_version_and_error_channel():
+    lib = _lib.load()
+    assert lib.salnmf_version() >= 100
+    assert isinstance(_lib.last_error(), str)
+
+
+def test_no_compute_without_device():
+    """Without a HIP device the engine refuses loudly instead of falling back to the CPU."""
+    lib = _lib.load()
+    if lib.salnmf_device_count() > 0:
+        pytest.skip("a device is present")
+    from salamander_amd import Engine, EngineUnavailable
+
+    with pytest.raises(EngineUnavailable):
+        Engine(16, 96, 2)
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under salamander_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "salamander_amd")
+    for base, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(base, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"

@@ -1,0 +1,302 @@
+"""HIP path vs oracle / golden vectors through the C ABI, on an MI355X.
+
+Tolerance: the north star asks for W, H within 1e-4 rel-L2 of the reference CPU path after
+equal iteration counts.  The engine computes in fp64 with the reference's operation order
+inside each element (only GEMM summation order differs), so the tests assert the much
+tighter ``TOL`` below; the 1e-4 contract is therefore met with eight orders of margin.
+"""
+
+import numpy as np
+import pytest
+
+import salamander_amd as sal
+from conftest import rel_l2
+from oracle import klnmf_oracle as orc
+from salamander_amd import Engine, _lib
+from salamander_amd.models import _utils_klnmf
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-10       # rel-L2 on W, H after up to 100 steps
+TOL_LONG = 1e-8   # after 500 steps
+EPS = orc.EPSILON
+
+
+def make_engine(X, W, H, wkl=None, wlh=None):
+    """X (V,N), W (V,K), H (K,N) in reference shapes -> engine holding the sample-major copies."""
+    e = Engine(X.shape[1], X.shape[0], W.shape[1])
+    e.upload_X(X.T)
+    e.upload_W(W.T)
+    e.upload_H(H.T)
+    e.set_weights(wkl, wlh)
+    return e
+
+
+# ------------------------------------------------------------------ golden trajectories (generated from the reference)
+@pytest.mark.parametrize(
+    "tag,use_wkl,use_wlh,n_given,marks",
+    [
+        ("plain", False, False, 0, (1, 10, 100)),
+        ("wkl", True, False, 0, (1, 10)),
+        ("lhalf", True, True, 0, (1, 10)),
+        ("given7", False, False, 7, (1, 10)),
+        ("given50", False, True, 50, (1, 10)),
+    ],
+)
+def test_golden_trajectories(golden, tag, use_wkl, use_wlh, n_given, marks):
+    g = golden.synth
+    wk = g["wkl"] if use_wkl else None
+    wl = g["wlh"] if use_wlh else None
+    e = make_engine(g["X"], g["W0"], g["H0"], wk, wl)
+    objs, t = [e.objective()], 0
+    for mark in sorted(set(marks) | set(range(10, max(marks) + 1, 10))):
+        e.kl_step(mark - t, n_given)
+        t = mark
+        if t in marks:
+            assert rel_l2(e.download_W(), g[f"{tag}_W{t}"].T) < TOL
+            assert rel_l2(e.download_H(), g[f"{tag}_H{t}"].T) < TOL
+        if t % 10 == 0:
+            objs.append(e.objective())
+    assert np.allclose(objs, g[f"{tag}_obj"], rtol=1e-11)
+    if n_given:
+        assert np.array_equal(e.download_W()[:n_given], g["W0"].T[:n_given].clip(EPS) if n_given < 50 else g["W0"].T)
+    e.close()
+
+
+def test_golden_pcawg_c1_engine(golden):
+    """Config c1 data (data/pcawg_breast_sbs.csv, K=5): 500 steps against the reference-generated trajectory."""
+    g = golden.pcawg
+    e = make_engine(g["X"], g["W0"], g["H0"])
+    t, objs = 0, []
+    for mark in range(10, 501, 10):
+        e.kl_step(mark - t)
+        t = mark
+        objs.append(e.objective())
+        if t in (10, 100, 500):
+            assert rel_l2(e.download_W(), g[f"W{t}"].T) < TOL and rel_l2(e.download_H(), g[f"H{t}"].T) < TOL
+    assert np.allclose(objs, g["obj"][1:], rtol=1e-12)
+    e.close()
+
+
+def test_pcawg_c1_model_fit(golden):
+    """Config c1 through the model API: KLNMF(n_signatures=5).fit(adata) with a custom init.
+
+    ``fit`` post-processes the custom init exactly as the reference does (normalise, clip:
+    initialize.py:116-118), so the expected trajectory is the oracle's fit from that init."""
+    from salamander_amd.initialization import initialize_mat
+
+    g = golden.pcawg
+    adata = sal.AnnData(g["X"].T.copy())
+    m = sal.models.KLNMF(5, "custom", min_iterations=500, max_iterations=500)
+    m.fit(adata, init_kwargs={"signatures_mat": g["W0"].T.copy(), "exposures_mat": g["H0"].T.copy()})
+    S0, E0 = initialize_mat(g["X"].T, 5, "custom", signatures_mat=g["W0"].T.copy(), exposures_mat=g["H0"].T.copy())
+    W, H, it, hist = orc.fit_klnmf(g["X"], S0.T, E0.T, min_iterations=500, max_iterations=500)
+    assert m.n_iterations_ == it == 500
+    assert np.allclose(m.history["objective_function"], hist, rtol=1e-11)
+    assert rel_l2(m.asignatures.X, W.T) < TOL_LONG and rel_l2(adata.obsm["exposures"], H.T) < TOL_LONG
+
+
+def test_golden_objectives_with_zeros(golden):
+    """X == 0 branches of kl_divergence (:47-50) and samplewise_kl_divergence (:82-86)."""
+    g = golden.synth
+    assert np.allclose(_utils_klnmf.kl_divergence(g["Xz"], g["W0"], g["H0"]), g["kl_z"], rtol=1e-12)
+    assert np.allclose(_utils_klnmf.samplewise_kl_divergence(g["Xz"], g["W0"], g["H0"]), g["skl_z"], rtol=1e-11)
+    assert np.allclose(_utils_klnmf.samplewise_kl_divergence(g["X"], g["W0"], g["H0"]), g["skl0"], rtol=1e-11)
+    assert np.allclose(_utils_klnmf.update_H(g["X"], g["W0"], g["H0"]), g["H_upd"], rtol=1e-11)
+    assert np.allclose(_utils_klnmf.update_W(g["X"], g["W0"], g["H0"], g["wkl"], 7), g["W_upd_g7"], rtol=1e-11)
+
+
+def test_golden_small_every_function(golden):
+    import os
+
+    from conftest import REF_FIX
+
+    g = golden.small
+    X, wkl, wlh = g["X"], g["wkl"], g["wlh"]
+    for K in (1, 2):
+        t = f"k{K}_"
+        W = np.load(os.path.join(REF_FIX, "utils_klnmf", f"W_nsigs{K}.npy"))
+        H = np.load(os.path.join(REF_FIX, "utils_klnmf", f"H_nsigs{K}.npy"))
+        tight = dict(rtol=1e-11, atol=1e-14)
+        assert np.allclose(_utils_klnmf.kl_divergence(X, W, H, wkl), g[t + "kl_w"], **tight)
+        assert np.allclose(_utils_klnmf.samplewise_kl_divergence(X, W, H, wkl), g[t + "skl_w"], **tight)
+        assert np.allclose(_utils_klnmf.update_W(X, W, H, wkl), g[t + "W_upd_w"], **tight)
+        assert np.allclose(_utils_klnmf.update_W(X, W, H, None, 1), g[t + "W_upd_g1"], **tight)
+        assert np.allclose(_utils_klnmf.update_H(X, W, H, wkl, wlh), g[t + "H_upd_lh"], **tight)
+        assert np.allclose(_utils_klnmf.update_H(X, W, H, None, wlh), g[t + "H_upd_lh_nokl"], **tight)
+        Wj, Hj = _utils_klnmf.update_WH(X, W, H, wkl, wlh, 1)
+        assert np.allclose(Wj, g[t + "Wj_all"], **tight) and np.allclose(Hj, g[t + "Hj_all"], **tight)
+
+
+# ------------------------------------------------------------------ MvNMF incl. the backtracking branch
+@pytest.mark.parametrize("tag", ["a", "g", "bt1", "bt2"])
+def test_golden_mvnmf(golden, tag):
+    g = golden.mv
+    lam, delta, steps, ng = g[f"{tag}_par"]
+    e = make_engine(g[f"{tag}_X"], g[f"{tag}_W0"], g[f"{tag}_H0"])
+    assert np.isclose(e.mv_objective(lam, delta), g[f"{tag}_obj0"], rtol=1e-11)
+    gamma, gammas = 1.0, []
+    for _ in range(int(steps)):
+        gamma = e.mv_step(1, int(ng), lam, delta, gamma)
+        gammas.append(gamma)
+    assert np.allclose(gammas, g[f"{tag}_gammas"], rtol=1e-12), (gammas, g[f"{tag}_gammas"])
+    assert rel_l2(e.download_W(), g[f"{tag}_W"].T) < 1e-7 and rel_l2(e.download_H(), g[f"{tag}_H"].T) < 1e-7
+    assert np.isclose(e.mv_objective(lam, delta), g[f"{tag}_obj"], rtol=1e-9)
+    e.close()
+
+
+# ------------------------------------------------------------------ shapes: ragged N, V < 96, every K bucket
+@pytest.mark.parametrize(
+    "V,N,K",
+    [(96, 1, 1), (96, 15, 3), (96, 16, 4), (96, 17, 5), (96, 63, 8), (96, 64, 9), (96, 250, 16), (96, 1000, 17),
+     (96, 999, 30), (96, 333, 33), (96, 1025, 40), (96, 777, 41), (96, 4099, 50), (96, 300, 52), (96, 301, 53),
+     (96, 500, 64), (83, 777, 30), (83, 200, 40), (7, 100, 2), (16, 40, 5)],
+)
+def test_shapes_one_and_five_steps(V, N, K):
+    X, W0, H0 = orc.synthetic_problem(V, N, K, seed=V + N + K)
+    rng = np.random.default_rng(1)
+    wkl, wlh = rng.uniform(0.5, 2, N), rng.uniform(0, 3, N)
+    for wk, wl, ng in ((None, None, 0), (wkl, wlh, min(2, K))):
+        e = Engine(N, V, K)
+        e.upload_X(X)
+        e.upload_W(W0)
+        e.upload_H(H0)
+        e.set_weights(wk, wl)
+        assert np.isclose(e.objective(), orc.klnmf_objective(X.T, W0.T, H0.T, wk, wl), rtol=1e-12)
+        W, H = W0.T, H0.T
+        for steps in (1, 4):
+            for _ in range(steps):
+                W, H = orc.update_WH(X.T, W, H, wk, wl, ng)
+            e.kl_step(steps, ng)
+            assert rel_l2(e.download_W(), W.T) < TOL and rel_l2(e.download_H(), H.T) < TOL
+        assert np.allclose(e.samplewise_kl(), orc.samplewise_kl_divergence(X.T, W, H), rtol=1e-10)
+        assert np.allclose(e.reconstruct(), H.T @ W.T, rtol=1e-13)
+        e.close()
+
+
+def test_unnormalised_inputs_and_function_level_semantics():
+    """Function-level calls take any non-negative W, H (not only normalised ones)."""
+    rng = np.random.default_rng(3)
+    V, N, K = 96, 130, 6
+    X = rng.poisson(30, size=(V, N)).astype(float)
+    W, H = rng.random((V, K)) * 3, rng.random((K, N)) * 5
+    Wj, Hj = _utils_klnmf.update_WH(X, W, H, n_given_signatures=2)
+    Wo, Ho = orc.update_WH(X, W, H, n_given_signatures=2)
+    assert rel_l2(Wj, Wo) < TOL and rel_l2(Hj, Ho) < TOL
+    assert rel_l2(_utils_klnmf.update_W(X, W, H, None, 2), orc.update_W(X, W, H, None, 2)) < TOL
+    assert rel_l2(_utils_klnmf.update_H(X, W, H), orc.update_H(X, W, H)) < TOL
+    assert np.isclose(_utils_klnmf.kl_divergence(X, W, H), orc.kl_divergence(X, W, H), rtol=1e-12)
+    # all signatures given: W comes back untouched (not even clipped), H still updates
+    Wg, Hg = _utils_klnmf.update_WH(X, W, H, n_given_signatures=K)
+    assert np.array_equal(Wg, W) and rel_l2(Hg, Ho) < TOL
+    with pytest.raises(ValueError):
+        _utils_klnmf.update_WH(X, W[:, :3], H)
+
+
+def test_errors_are_exceptions_not_aborts():
+    with pytest.raises(RuntimeError):
+        Engine(10, 97, 2)
+    with pytest.raises(RuntimeError):
+        Engine(10, 96, 65)
+    with pytest.raises(RuntimeError):
+        Engine(0, 96, 2)
+    e = Engine(10, 96, 2)
+    with pytest.raises(ValueError):
+        e.upload_X(np.zeros((10, 95)))
+    with pytest.raises(RuntimeError):
+        e.kl_step(1, 3)
+    e.close()
+
+
+def test_upload_clip_matches_setup_adata():
+    X, W0, H0 = orc.synthetic_problem(96, 100, 4, seed=9)
+    X[X <= EPS] = 0.0
+    e = Engine(100, 96, 4)
+    e.upload_X(X, clip=True)
+    e.upload_W(W0)
+    e.upload_H(H0)
+    assert np.isclose(e.objective(), orc.kl_divergence(X.T.clip(EPS), W0.T, H0.T), rtol=1e-12)
+    e.close()
+
+
+# ------------------------------------------------------------------ determinism and split-step (multi-GPU semantics on one GPU)
+def test_bitwise_reproducible():
+    X, W0, H0 = orc.synthetic_problem(96, 20000, 50, seed=4)
+    outs = []
+    for _ in range(2):
+        e = Engine(20000, 96, 50)
+        e.upload_X(X), e.upload_W(W0), e.upload_H(H0)
+        e.kl_step(7)
+        outs.append((e.download_W(), e.download_H(), e.objective()))
+        e.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
+
+
+def test_two_shards_on_one_gpu_equal_unsharded():
+    """Two engines hold the two halves of the sample axis; their numerators are summed by hand
+    (the all-reduce), both run the W tail: W identical on both and equal to the unsharded run."""
+    import torch
+
+    from salamander_amd.distributed import numerator_tensor, shard_bounds
+
+    V, N, K = 96, 5000, 50
+    X, W0, H0 = orc.synthetic_problem(V, N, K, seed=6)
+    rng = np.random.default_rng(2)
+    wkl = rng.uniform(0.5, 2, N)
+    shards = []
+    for r in range(2):
+        a, b = shard_bounds(N, 2, r)
+        e = Engine(b - a, V, K)
+        e.upload_X(X[a:b]), e.upload_W(W0), e.upload_H(H0[a:b])
+        e.set_weights(wkl[a:b], None)
+        shards.append(e)
+    for _ in range(3):
+        for e in shards:
+            e.kl_step_partial()
+            e.sync()
+        g0, g1 = numerator_tensor(shards[0]), numerator_tensor(shards[1])
+        total = g0 + g1
+        g0.copy_(total), g1.copy_(total)
+        torch.cuda.synchronize()
+        for e in shards:
+            e.kl_step_finish(3, _lib.CLIP_ALL)
+    W, H = W0.T, H0.T
+    for _ in range(3):
+        W, H = orc.update_WH(X.T, W, H, wkl, None, 3)
+    Ws = [e.download_W() for e in shards]
+    assert np.array_equal(Ws[0], Ws[1])
+    assert rel_l2(Ws[0], W.T) < TOL
+    assert rel_l2(np.concatenate([e.download_H() for e in shards]), H.T) < TOL
+    for e in shards:
+        e.close()
+
+
+def test_rccl_communicator_single_rank_path():
+    """World size 1 through the in-engine RCCL path (kernel -> ncclAllReduce -> tail) equals the plain path."""
+    import os
+
+    import torch.distributed as dist
+
+    from salamander_amd.distributed import attach_communicator
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        X, W0, H0 = orc.synthetic_problem(96, 3000, 50, seed=8)
+        res = []
+        for with_comm in (False, True):
+            e = Engine(3000, 96, 50)
+            if with_comm:
+                attach_communicator(e)
+            e.upload_X(X), e.upload_W(W0), e.upload_H(H0)
+            e.kl_step(5, 2)
+            res.append((e.download_W(), e.download_H(), e.objective()))
+            e.close()
+        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+        assert res[0][2] == res[1][2]
+    finally:
+        if created:
+            dist.destroy_process_group()

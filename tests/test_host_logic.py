@@ -1,0 +1,255 @@
+"""Host-side logic on CPU: checkers, AnnData shim, initialisation, fit-loop cadence, hooks.
+
+The device is replaced by the oracle-backed ``FakeEngine`` (tests only), so what is tested
+here is the Python mirror of the reference's operator interface, not the kernels.
+"""
+
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+import salamander_amd as sal
+from _fake_engine import FakeEngine
+from conftest import REF_FIX, read_counts, rel_l2
+from oracle import klnmf_oracle as orc
+from salamander_amd import initialization as init
+from salamander_amd import utils
+from salamander_amd.anndata_compat import MiniAnnData
+from salamander_amd.models import signature_nmf
+
+
+@pytest.fixture
+def fake_engine(monkeypatch):
+    monkeypatch.setattr(signature_nmf, "Engine", FakeEngine)
+    return FakeEngine
+
+
+@pytest.fixture
+def counts():
+    return read_counts(os.path.join(REF_FIX, "klnmf", "counts.csv"))
+
+
+def make_adata(counts):
+    return sal.AnnData(counts.T)
+
+
+# ---------------------------------------------------------------- checkers (utils.py:16-99)
+def test_checkers_raise_like_the_reference():
+    with pytest.raises(TypeError):
+        utils.type_checker("x", 1.0, int)
+    utils.type_checker("x", 1, [int, float])
+    with pytest.raises(TypeError):
+        utils.type_checker("x", np.float64(1.0), [float])  # exact type, not isinstance
+    with pytest.raises(ValueError):
+        utils.shape_checker("a", np.zeros((2, 3)), (3, 2))
+    with pytest.raises(TypeError):
+        utils.shape_checker("a", [[1]], (1, 1))
+    with pytest.raises(ValueError):
+        utils.value_checker("m", "foo", ["a", "b"])
+    with pytest.raises(ValueError):
+        utils.dict_checker("d", {"z": 1}, ["a"])
+    with pytest.raises(TypeError):
+        utils.dict_checker("d", [("a", 1)], ["a"])
+
+
+def test_normalize_WH():
+    rng = np.random.default_rng(0)
+    W, H = rng.random((96, 4)), rng.random((4, 7))
+    Wn, Hn = utils.normalize_WH(W, H)
+    assert np.allclose(Wn.sum(0), 1) and np.allclose(Wn @ Hn, W @ H)
+    Wo, Ho = orc.normalize_WH(W, H)
+    assert np.array_equal(Wn, Wo) and np.array_equal(Hn, Ho)
+
+
+# ---------------------------------------------------------------- AnnData shim
+def test_mini_anndata_surface(counts):
+    a = MiniAnnData(counts.T)
+    assert (a.n_obs, a.n_vars) == (10, 96)
+    assert list(a.obs_names) == list(counts.columns) and list(a.var_names) == list(counts.index)
+    a.obsm["exposures"] = np.ones((10, 2))
+    a.obs["reconstruction_error"] = np.arange(10.0)
+    b = a.copy()
+    b.X[0, 0] = -1
+    assert a.X[0, 0] != -1
+    sub = a[:3, :]
+    assert sub.n_obs == 3 and sub.obsm["exposures"].shape == (3, 2) and list(sub.obs_names) == list(counts.columns[:3])
+    assert a.to_df().shape == (10, 96)
+    with pytest.raises(ValueError):
+        a.X = np.zeros((3, 3))
+
+
+# ---------------------------------------------------------------- initialisation (methods.py, initialize.py)
+def test_init_methods_shapes_and_postprocessing(counts):
+    X = counts.T.values.astype(float)
+    for method, kw in (("flat", {}), ("random", {"seed": 1}), ("separableNMF", {"seed": 1}), ("nndsvda", {"seed": 1})):
+        S, E = init.initialize_mat(X, 3, method, **kw)
+        assert S.shape == (3, 96) and E.shape == (10, 3)
+        assert (S >= utils.EPSILON).all() and (E >= utils.EPSILON).all()
+        assert np.allclose(S.sum(1), 1, atol=1e-4)
+    S1, E1 = init.initialize_mat(X, 3, "random", seed=5)
+    S2, E2 = init.initialize_mat(X, 3, "random", seed=5)
+    assert np.array_equal(S1, S2) and np.array_equal(E1, E2)
+
+
+def test_init_random_matches_oracle_restatement(counts):
+    """init_random + normalise + clip equals what the reference computes from the same global RNG stream."""
+    X = counts.T.values.astype(float)
+    S, E = init.initialize_mat(X, 2, "random", seed=3)
+    np.random.seed(3)
+    S0 = np.random.dirichlet(np.ones(96), size=2)
+    E0 = X.sum(1)[:, None] * np.random.dirichlet(np.ones(2), size=10)
+    W, H = orc.normalize_WH(S0.T, E0.T)
+    assert np.allclose(S, W.T.clip(orc.EPSILON)) and np.allclose(E, H.T.clip(orc.EPSILON))
+
+
+def test_init_custom_and_errors(counts):
+    X = counts.T.values.astype(float)
+    S0, E0 = np.full((2, 96), 1 / 96), np.ones((10, 2))
+    S, E = init.initialize_mat(X, 2, "custom", signatures_mat=S0.copy(), exposures_mat=E0.copy())
+    assert np.allclose(S, S0) and np.allclose(E, E0)
+    with pytest.raises(ValueError):
+        init.initialize_mat(X, 2, "custom", signatures_mat=S0[:, :5], exposures_mat=E0)
+    with pytest.raises(TypeError):
+        init.initialize_mat(X, 2, "custom", signatures_mat=S0.tolist(), exposures_mat=E0)
+    with pytest.raises(ValueError):
+        init.initialize_mat(X, 2, "bogus")
+    with pytest.raises(ValueError):
+        init.initialize_mat(X, 1, "flat", given_signatures_mat=np.ones((2, 96)))
+
+
+def test_given_signatures_keep_names_and_values(counts):
+    adata = make_adata(counts)
+    given = adata[:1, :].copy()
+    given.X = given.X / given.X.sum(axis=1, keepdims=True)
+    asig = init.initialize_standard_nmf(adata, 3, "flat", {"asignatures": given})
+    assert list(asig.obs_names) == [given.obs_names[0], "Sig1", "Sig2"]
+    assert np.allclose(np.asarray(asig.X)[0], given.X[0])
+    assert adata.obsm["exposures"].shape == (10, 3)
+    with pytest.raises(ValueError):
+        init.initialize_standard_nmf(adata, 3, "flat", {"bogus": 1})
+    bad = given.copy()
+    bad.var_names = [f"f{i}" for i in range(96)]
+    with pytest.raises(ValueError):
+        init.initialize_standard_nmf(adata, 3, "flat", {"asignatures": bad})
+
+
+# ---------------------------------------------------------------- model API surface
+def test_constructor_defaults_match_reference():
+    m = sal.models.KLNMF()
+    assert (m.n_signatures, m.init_method, m.min_iterations, m.max_iterations, m.conv_test_freq, m.tol) == (
+        1, "nndsvd", 500, 10000, 10, 1e-7)
+    mv = sal.models.MvNMF(3, "random", 2.0, 0.5)
+    assert (mv.lam, mv.delta, mv._gamma, mv.objective) == (2.0, 0.5, 1.0, "minimize")
+    with pytest.raises(ValueError):
+        sal.models.KLNMF(init_method="nope")
+
+
+def test_fit_rejects_non_anndata(fake_engine):
+    with pytest.raises(TypeError):
+        sal.models.KLNMF(2).fit(np.ones((10, 96)))
+
+
+def test_fitting_kwargs_validation(fake_engine, counts):
+    adata = make_adata(counts)
+    m = sal.models.KLNMF(2, "flat", min_iterations=1, max_iterations=1)
+    with pytest.raises(ValueError):
+        m.fit(adata.copy(), fitting_kwargs={"weights": 1.0})
+    with pytest.raises(ValueError):
+        m.fit(adata.copy(), fitting_kwargs={"weights_kl": -1.0})
+    with pytest.raises(ValueError):
+        m.fit(adata.copy(), fitting_kwargs={"weights_kl": np.ones(3)})
+    with pytest.raises(TypeError):
+        m.fit(adata.copy(), fitting_kwargs={"weights_kl": "heavy"})
+    m.fit(adata.copy(), fitting_kwargs={"weights_kl": 2.0, "weights_lhalf": [0.5] * 10})
+    assert np.array_equal(m.weights_kl, 2 * np.ones(10)) and np.array_equal(m.weights_lhalf, 0.5 * np.ones(10))
+
+
+def test_fit_clips_callers_adata_and_writes_results(fake_engine, counts):
+    adata = make_adata(counts)
+    adata.X = adata.X.astype(float)
+    adata.X[0, 0] = 0.0
+    m = sal.models.KLNMF(2, "random", min_iterations=20, max_iterations=20)
+    out = m.fit(adata, init_kwargs={"seed": 1})
+    assert out is m
+    assert adata.X[0, 0] == utils.EPSILON  # the caller's object is mutated (signature_nmf.py:281)
+    assert m.asignatures.X.shape == (2, 96) and adata.obsm["exposures"].shape == (10, 2)
+    assert list(m.asignatures.obs_names) == ["Sig1", "Sig2"]
+    assert m.signatures.shape == (2, 96) and m.exposures.shape == (10, 2)
+    assert len(m.history["objective_function"]) == 2
+    assert m.data_reconstructed.shape == (10, 96)
+    assert m.reconstruction_error > 0 and "reconstruction_error" in adata.obs
+
+
+@pytest.mark.parametrize(
+    "min_it,max_it,freq,expect_chunks",
+    [(30, 30, 10, [10, 10, 10]), (25, 25, 10, [10, 10, 5]), (3, 3, 10, [3]), (12, 12, 5, [5, 5, 2])],
+)
+def test_fit_loop_chunks_and_history_cadence(fake_engine, counts, min_it, max_it, freq, expect_chunks):
+    adata = make_adata(counts)
+    m = sal.models.KLNMF(2, "flat", min_iterations=min_it, max_iterations=max_it, conv_test_freq=freq)
+    m.fit(adata)
+    assert m._engine.steps_log == expect_chunks
+    assert m.n_iterations_ == max_it
+    assert len(m.history["objective_function"]) == max_it // freq
+
+
+def test_fit_equals_oracle_fit_including_convergence_stop(fake_engine, counts):
+    """Same stop iteration, W, H and history as the restated reference loop (tolerance-triggered stop)."""
+    X = counts.T.values.astype(float)
+    S0, E0 = init.initialize_mat(X.clip(utils.EPSILON), 2, "random", seed=2)
+    kw = dict(min_iterations=20, max_iterations=400, conv_test_freq=10, tol=1e-4)
+    W, H, it, hist = orc.fit_klnmf(X.T, S0.T, E0.T, **kw)
+    assert it < 400  # really stopped by the tolerance
+    m = sal.models.KLNMF(2, "custom", **kw)
+    m.fit(make_adata(counts), init_kwargs={"signatures_mat": S0.copy(), "exposures_mat": E0.copy()})
+    assert m.n_iterations_ == it
+    assert np.allclose(m.history["objective_function"], hist, rtol=1e-13)
+    assert rel_l2(m.asignatures.X, W.T) < 1e-13 and rel_l2(m.adata.obsm["exposures"], H.T) < 1e-13
+
+
+def test_verbose_prints_at_the_reference_iterations(fake_engine, counts, capsys):
+    m = sal.models.KLNMF(2, "flat", min_iterations=25, max_iterations=25)
+    m.fit(make_adata(counts), verbose=1, verbosity_freq=7)
+    lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith("iteration")]
+    assert [int(l.split(";")[0].split(":")[1]) for l in lines] == [7, 14, 21]
+    assert sum(m._engine.steps_log) == 25
+
+
+def test_single_step_hooks_on_hand_populated_model(fake_engine, counts):
+    """tests/test_klnmf.py:44-75 drives _update_parameters()/objective_function() without fit()."""
+    d = os.path.join(REF_FIX, "klnmf")
+    W0, H0 = np.load(f"{d}/W_init_nsigs2.npy"), np.load(f"{d}/H_init_nsigs2.npy")
+    m = sal.models.KLNMF(n_signatures=2)
+    m.adata = make_adata(counts)
+    m.asignatures = sal.AnnData(W0.T)
+    m.adata.obsm["exposures"] = H0.T
+    assert np.allclose(m.objective_function(), np.load(f"{d}/objective_init_nsigs2.npy"))
+    m._update_parameters()
+    W1, H1 = orc.update_WH(counts.values.astype(float), W0, H0)
+    assert np.allclose(m.asignatures.X, W1.T) and np.allclose(m.adata.obsm["exposures"], H1.T)
+
+
+def test_mvnmf_gamma_persists_and_resets(fake_engine, counts, golden):
+    # a configuration whose line search backtracks (tests/golden/make_golden.py, case bt1)
+    g = golden.mv
+    lam, delta, steps, _ = g["bt1_par"]
+    X, W0, H0 = g["bt1_X"], g["bt1_W0"], g["bt1_H0"]
+    adata = sal.AnnData(X.T.copy())
+    m = sal.models.MvNMF(W0.shape[1], "custom", lam, delta, min_iterations=int(steps), max_iterations=int(steps))
+    m._gamma = 0.3  # stale state from an earlier fit must be reset (mvnmf.py:218)
+    m.fit(adata, init_kwargs={"signatures_mat": W0.T.copy(), "exposures_mat": H0.T.copy()})
+    assert np.isclose(m._gamma, g["bt1_gammas"][-1], rtol=1e-12) and m._gamma < 1.0
+    assert rel_l2(m.asignatures.X, g["bt1_W"].T) < 1e-8
+    # all signatures given: W is never touched and gamma stays at its reset value
+    given = make_adata(counts)[:2, :].copy()
+    given.X = given.X / given.X.sum(axis=1, keepdims=True)
+    m2 = sal.models.MvNMF(2, "flat", min_iterations=3, max_iterations=3)
+    m2.fit(make_adata(counts), given_parameters={"asignatures": given})
+    assert np.allclose(m2.asignatures.X, given.X) and m2._gamma == 1.0
+
+
+def test_out_of_scope_helpers_say_so():
+    with pytest.raises(NotImplementedError):
+        sal.models.KLNMF().plot_signatures()
