@@ -81,9 +81,12 @@ static int pick_ks(int K) {
 template <bool DO_G, bool DO_U, bool DO_STATS>
 static int launch_fused(salnmf_engine* e, const FusedParams& p) {
     dim3 g(e->grid), b(BLOCK);
-#define SALNMF_CASE(ks)                                                             \
-    case ks:                                                                        \
-        hipLaunchKernelGGL((fused_kernel<ks, DO_G, DO_U, DO_STATS>), g, b, 0, e->stream, p); \
+#define SALNMF_CASE(ks)                                                                          \
+    case ks:                                                                                     \
+        if (e->V == VMAX)                                                                        \
+            hipLaunchKernelGGL((fused_kernel<ks, DO_G, DO_U, DO_STATS, true>), g, b, 0, e->stream, p);  \
+        else                                                                                     \
+            hipLaunchKernelGGL((fused_kernel<ks, DO_G, DO_U, DO_STATS, false>), g, b, 0, e->stream, p); \
         break;
     switch (e->KS) {
         SALNMF_CASE(1)

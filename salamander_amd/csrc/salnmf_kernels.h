@@ -77,7 +77,19 @@ __device__ __forceinline__ double kl_term(double x, double p) {
 //   DO_U     update H in place
 //   DO_STATS also emit row sums of H (as read) and the unweighted KL(X || WH) partial
 //            (MvNMF: update_W_unconstrained + the f0 of its line search, mvnmf.py:54,79)
-template <int KS, bool DO_G, bool DO_U, bool DO_STATS>
+//
+// Register plan (one wave per SIMD, 512 registers): the K x V accumulator G lives in AGPRs for
+// the whole kernel (inline-asm MFMA with "a" operands), everything else in <= 256 VGPRs.
+// LDS operand reads are software-pipelined one k-step ahead of the MFMAs that consume them;
+// sched_barrier(0) pins that order.  Full tiles run a mask-free body; only the ragged last
+// tile (or V < 96) takes the masked one.
+
+// G accumulate step on an AGPR-resident accumulator.  The s_nop covers the VALU-write ->
+// MFMA-operand-read wait states, which hipcc does not insert inside an asm statement.
+__device__ __forceinline__ void mfma_agpr(d4& c, double a, double b) {
+    asm("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+template <int KS, bool DO_G, bool DO_U, bool DO_STATS, bool VFULL>
 __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
     using G_ = Geo<KS>;
     constexpr int KT = G_::KT;
@@ -95,12 +107,15 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
     double* Hl = lds + G_::WROWS * WS + wave * (G_::HL + G_::RL);
     double* Rl = Hl + G_::HL;
 
-    // ---- W -> LDS (zero padded rows >= K and columns >= V); finite pad behind the H tile
+    // ---- W -> LDS.  Padding is chosen so that the compute body needs no masks:
+    //   rows k >= K are 0 (they add nothing to P; their U columns / G rows are never stored);
+    //   columns v >= V of the real rows are 1, so P > 0 there and R = X/P = 0/P = 0 exactly
+    //   (X is loaded as 0), which then adds nothing to U or to the stored part of G.
     for (int i = tid; i < G_::WROWS * WS; i += BLOCK) {
         int k = i / WS, v = i - k * WS;
-        Wl[i] = (k < K && v < V) ? p.W[k * V + v] : 0.0;
+        Wl[i] = (k < K) ? ((v < V) ? p.W[k * V + v] : 1.0) : 0.0;
     }
-    for (int i = lane; i < G_::HL; i += 64) Hl[i] = 0.0;
+    for (int i = lane; i < G_::HL; i += 64) Hl[i] = 0.0;  // finite pad behind the H tile
     __syncthreads();
 
     d4 g[KT][VT];
@@ -119,44 +134,61 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
 
     const int64_t tstride = (int64_t)gridDim.x * WAVES;
     int64_t tile = (int64_t)blockIdx.x * WAVES + wave;
+    const int tileH = 16 * K;
 
     // prefetch registers: H tile (raw, contiguous 16*K doubles) and X tile (accumulator layout)
     double hpre[KS];
     double x[VT][4];
-    const int tileH = 16 * K;
-    auto load_tile = [&](int64_t t) {
-        const int64_t n0 = t * 16;
-        const int64_t hbase = n0 * K;
-        const int64_t hend = N * K;
-#pragma unroll
-        for (int j = 0; j < KS; ++j) {
-            int idx = lane + 64 * j;
-            double h = 0.0;
-            if (idx < tileH && hbase + idx < hend) {
-                h = p.H[hbase + idx];
-                if (p.hscale) h = fmax(h * p.hscale[idx % K], kEps);
-            }
-            hpre[j] = h;
-        }
-#pragma unroll
-        for (int vt = 0; vt < VT; ++vt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int64_t n = n0 + q + 4 * r;
-                int v = 16 * vt + c16;
-                x[vt][r] = (n < N && v < V) ? p.X[n * V + v] : 0.0;
-            }
-    };
-    if (tile < p.ntiles) load_tile(tile);
 
-    for (; tile < p.ntiles; tile += tstride) {
+    // Loads of one tile.  Rows n >= N (the ragged last tile) read as X = 0, H = 1: P > 0, R = 0.
+    auto load_tile = [&](int64_t t) __attribute__((always_inline)) {
+        const int64_t n0 = t * 16;
+        const double* hsrc = p.H + n0 * K;
+        const double* xsrc = p.X + (n0 + q) * V + c16;
+        const bool full = n0 + 16 <= N;  // wave-uniform
+        if (full) {
+#pragma unroll
+            for (int j = 0; j < KS; ++j) {
+                int idx = lane + 64 * j;
+                hpre[j] = (idx < tileH) ? hsrc[idx] : 0.0;
+            }
+#pragma unroll
+            for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (VFULL) x[vt][r] = xsrc[4 * r * VMAX + 16 * vt];
+                    else x[vt][r] = (16 * vt + c16 < V) ? xsrc[4 * r * V + 16 * vt] : 0.0;
+                }
+        } else {
+            const int64_t hleft = (N - n0) * K;
+#pragma unroll
+            for (int j = 0; j < KS; ++j) {
+                int idx = lane + 64 * j;
+                hpre[j] = (idx < tileH) ? ((idx < hleft) ? hsrc[idx] : 1.0) : 0.0;
+            }
+#pragma unroll
+            for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    x[vt][r] = (n0 + q + 4 * r < N && 16 * vt + c16 < V) ? xsrc[4 * r * V + 16 * vt] : 0.0;
+        }
+        if (p.hscale) {  // MvNMF line-search trial: H is read as clip(H * colsum(W_trial))
+#pragma unroll
+            for (int j = 0; j < KS; ++j) {
+                int idx = lane + 64 * j;
+                if (idx < tileH) hpre[j] = fmax(hpre[j] * p.hscale[idx % K], kEps);
+            }
+        }
+    };
+
+    auto process_tile = [&](int64_t tile) __attribute__((always_inline)) {
         const int64_t n0 = tile * 16;
         // ---- stage the H tile (wave private; LDS ops of one wave are executed in order)
 #pragma unroll
         for (int j = 0; j < KS; ++j) {
             int idx = lane + 64 * j;
             if (idx < tileH) Hl[idx] = hpre[j];
-            if (DO_STATS) hsum[j] += hpre[j];
+            if (DO_STATS) hsum[j] += (idx < (N - n0) * K) ? hpre[j] : 0.0;
         }
         __builtin_amdgcn_wave_barrier();
 
@@ -167,46 +199,48 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         {
             const double* ha = Hl + c16 * K + q;
             const double* wb = Wl + q * WS + c16;
+            double a[KS];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) a[s] = ha[4 * s];
+            double b[2][VT];
+#pragma unroll
+            for (int vt = 0; vt < VT; ++vt) b[0][vt] = wb[16 * vt];
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                double a = ha[4 * s];
+                if (s + 1 < KS) {
 #pragma unroll
-                for (int vt = 0; vt < VT; ++vt) pr[vt] = mfma(a, wb[4 * s * WS + 16 * vt], pr[vt]);
+                    for (int vt = 0; vt < VT; ++vt) b[(s + 1) & 1][vt] = wb[4 * (s + 1) * WS + 16 * vt];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int vt = 0; vt < VT; ++vt) pr[vt] = mfma(a[s], b[s & 1][vt], pr[vt]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
 
-        // ---- R = X / P in place (rows n = q + 4r, columns v = 16vt + c16); invalid entries -> 0
+        // G-phase A operands (H^T): issue the LDS reads now, they land under the divisions
+        double ga[4][KT];
+        if (DO_G) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double* ha = Hl + (4 * r + q) * K + c16;
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) ga[r][kt] = ha[16 * kt];
+            }
+        }
+
+        // ---- R = X / P in place (rows n = q + 4r, columns v = 16vt + c16); pads give 0 / P = 0
 #pragma unroll
         for (int vt = 0; vt < VT; ++vt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                bool valid = (n0 + q + 4 * r < N) && (16 * vt + c16 < V);
                 double xv = x[vt][r], pv = pr[vt][r];
                 if (DO_STATS) {
-                    if (valid) klacc += kl_term(xv, pv);
+                    bool valid = (n0 + q + 4 * r < N) && (VFULL || 16 * vt + c16 < V);
+                    klacc += valid ? kl_term(xv, pv) : 0.0;
                 }
-                pr[vt][r] = valid ? xv / pv : 0.0;
+                pr[vt][r] = xv / pv;
             }
-
-        // ---- G += (w_kl . Ht)^T . R   (A = H[n=4r+q][k=16kt+c16], B = register r of R)
-        if (DO_G) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double wk = 1.0;
-                if (p.wkl) {
-                    int64_t n = n0 + 4 * r + q;
-                    wk = (n < N) ? p.wkl[n] : 0.0;
-                }
-                const double* ha = Hl + (4 * r + q) * K + c16;
-#pragma unroll
-                for (int kt = 0; kt < KT; ++kt) {
-                    double a = ha[16 * kt];
-                    if (p.wkl) a *= wk;
-#pragma unroll
-                    for (int vt = 0; vt < VT; ++vt) g[kt][vt] = mfma(a, pr[vt][r], g[kt][vt]);
-                }
-            }
-        }
 
         if (DO_U) {
             // ---- transpose R through LDS: write accumulator layout, read A-operand layout
@@ -214,8 +248,27 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
             for (int vt = 0; vt < VT; ++vt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) Rl[(q + 4 * r) * RS + 16 * vt + c16] = pr[vt][r];
-            __builtin_amdgcn_wave_barrier();
         }
+
+        // ---- G += (w_kl . Ht)^T . R   (A = H[n=4r+q][k=16kt+c16], B = register r of R)
+        if (DO_G) {
+            if (p.wkl) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int64_t n = n0 + 4 * r + q;
+                    double wk = p.wkl[n < N ? n : N - 1];
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt) ga[r][kt] *= wk;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                    for (int vt = 0; vt < VT; ++vt) mfma_agpr(g[kt][vt], ga[r][kt], pr[vt][r]);
+        }
+        __builtin_amdgcn_wave_barrier();
 
         // prefetch the next tile (X registers and the staging registers are free now)
         if (tile + tstride < p.ntiles) load_tile(tile + tstride);
@@ -227,49 +280,64 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
             for (int kt = 0; kt < KT; ++kt) u[kt] = (d4){0, 0, 0, 0};
             const double* ra = Rl + c16 * RS + q;
             const double* wb = Wl + c16 * WS + q;
+            double a[2], b[2][KT];
+            a[0] = ra[0];
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) b[0][kt] = wb[16 * kt * WS];
 #pragma unroll
             for (int s = 0; s < VSTEPS; ++s) {
-                double a = ra[4 * s];
+                if (s + 1 < VSTEPS) {
+                    a[(s + 1) & 1] = ra[4 * (s + 1)];
 #pragma unroll
-                for (int kt = 0; kt < KT; ++kt) u[kt] = mfma(a, wb[16 * kt * WS + 4 * s], u[kt]);
+                    for (int kt = 0; kt < KT; ++kt) b[(s + 1) & 1][kt] = wb[16 * kt * WS + 4 * (s + 1)];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) u[kt] = mfma(a[s & 1], b[s & 1][kt], u[kt]);
+                __builtin_amdgcn_sched_barrier(0);
             }
             // ---- H update (_utils_klnmf.py:343-361), rows n = q+4r, columns k = 16kt+c16
+            const bool lhalf = p.wlh != nullptr;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                int64_t n = n0 + q + 4 * r;
-                if (n < N) {
-                    double wl = 0.0, wk2 = 1.0;
-                    const bool lhalf = p.wlh != nullptr;
-                    if (lhalf) {
-                        wl = p.wlh[n];
-                        if (p.wkl) { double w = p.wkl[n]; wk2 = w * w; }
-                    }
+                const int64_t n = n0 + q + 4 * r;
+                const bool nvalid = n < N;
+                double wl = 0.0, wk2 = 1.0;
+                if (lhalf) {
+                    wl = p.wlh[nvalid ? n : N - 1];
+                    if (p.wkl) { double w = p.wkl[nvalid ? n : N - 1]; wk2 = w * w; }
+                }
 #pragma unroll
-                    for (int kt = 0; kt < KT; ++kt) {
-                        int k = 16 * kt + c16;
-                        if (k < K) {
-                            double h = Hl[(q + 4 * r) * K + k], f = u[kt][r], hn;
-                            if (!lhalf) {
-                                hn = h * f;
-                            } else {
-                                double inter = 4.0 * h * f;
-                                if (p.wkl) inter *= wk2;
-                                double disc = 0.25 * wl * wl + inter;
-                                double t = wl / 2 - sqrt(disc);
-                                hn = 0.25 * (t * t);
-                                if (p.wkl) hn /= wk2;
-                            }
-                            p.H[n * K + k] = fmax(hn, kEps);
-                        }
+                for (int kt = 0; kt < KT; ++kt) {
+                    const int k = 16 * kt + c16;
+                    double h = Hl[(q + 4 * r) * K + k], f = u[kt][r], hn;
+                    if (!lhalf) {
+                        hn = h * f;
+                    } else {
+                        double inter = 4.0 * h * f;
+                        if (p.wkl) inter *= wk2;
+                        double disc = 0.25 * wl * wl + inter;
+                        double t = wl / 2 - sqrt(disc);
+                        hn = 0.25 * (t * t);
+                        if (p.wkl) hn /= wk2;
                     }
+                    if (nvalid && k < K) p.H[n * K + k] = fmax(hn, kEps);
                 }
             }
         }
-    }
+    };
+
+    if (tile < p.ntiles) load_tile(tile);
+    for (; tile < p.ntiles; tile += tstride) process_tile(tile);
 
     // ---- workgroup reductions, fixed order (deterministic)
     __syncthreads();  // every wave is done with the LDS copy of W
     if (DO_G) {
+        // the asm MFMAs are opaque to hipcc: drain the matrix pipe before VALU reads of g
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int vt = 0; vt < VT; ++vt) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(g[kt][vt]));
         double* Gs = lds;  // [K][VMAX], aliases W
         for (int w = 0; w < WAVES; ++w) {
             if (wave == w) {
@@ -486,9 +554,22 @@ __global__ void __launch_bounds__(TAIL_BLOCK) tail_kernel(TailParams p) {
     const int part = threadIdx.x / VMAX;
     const int V = p.V, K = p.K;
     if (p.nslabs > 0) {
+        // 16 independent loads in flight per round; the sum order is fixed (slab index ascending)
         double s = 0.0;
-        if (v < V)
-            for (int sl = part; sl < p.nslabs; sl += TAIL_PARTS) s += p.Gpart[((int64_t)sl * K + k) * V + v];
+        if (v < V) {
+            const double* src = p.Gpart + (int64_t)k * V + v;
+            const int64_t slab = (int64_t)K * V;
+            for (int base = part; base < p.nslabs; base += TAIL_PARTS * 16) {
+                double t[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    int sl = base + j * TAIL_PARTS;
+                    t[j] = (sl < p.nslabs) ? src[sl * slab] : 0.0;
+                }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) s += t[j];
+            }
+        }
         red[part][v] = s;
         __syncthreads();
         if (part == 0 && v < V) {

@@ -6,7 +6,7 @@ txt = open(sys.argv[1]).read() if len(sys.argv) > 1 else sys.stdin.read()
 KEYS = [("VGPR", r"VGPRs"), ("AGPR", r"AGPRs"), ("SGPR", r"SGPRs"), ("scratch", r"ScratchSize \[bytes/lane\]"),
         ("occ", r"Occupancy \[waves/SIMD\]"), ("sspill", r"SGPRs Spill"), ("vspill", r"VGPRs Spill"),
         ("LDS", r"LDS Size \[bytes/block\]")]
-for b in txt.split("remark: Function Name: ")[1:]:
+for b in txt.split("Function Name: ")[1:]:
     name = b.split()[0]
     vals = []
     for label, key in KEYS:
