@@ -39,7 +39,9 @@ typedef struct salnmf_engine salnmf_engine;
 #define SALNMF_CLIP_ALL 0       /* update_WH: clip every column, _utils_klnmf.py:341 */
 #define SALNMF_CLIP_NON_GIVEN 1 /* update_W: clip only non-given columns, _utils_klnmf.py:215 */
 
-/* device buffers that can be exposed to a caller-side collective (salnmf_device_ptr) */
+/* device buffers that can be exposed to a caller-side collective (salnmf_device_ptr).
+ * G, W, OBJ and RED are compact; X and H are in the engine's padded device layout
+ * (X [16*ceil(N/16)][96], H [16*ceil(N/16)][16*ceil(K/16)... see salnmf_kernels.h]). */
 #define SALNMF_BUF_G 0    /* (n_signatures x n_features) numerator aux@H.T, local shard */
 #define SALNMF_BUF_W 1
 #define SALNMF_BUF_H 2

@@ -47,8 +47,11 @@ static int fail(const char* fmt, ...) {
 struct salnmf_engine {
     int device = 0;
     int V = 0, K = 0;
-    int64_t N = 0, ntiles = 0;
+    int64_t N = 0, Np = 0, ntiles = 0;  // Np = 16 * ntiles: rows of the padded device layout
     int KS = 0;    // instantiated contraction depth (k-steps of 4) covering K
+    int KP = 0;    // leading dimension of H on the device = 16 * ceil(KS / 4)
+    double* scratch = nullptr;  // compact staging buffer for layout conversion (lazily sized)
+    size_t scratch_n = 0;
     int grid = 0;  // workgroups of the fused / forward kernels (one per CU)
     hipStream_t stream = nullptr;
     double *X = nullptr, *H = nullptr, *W = nullptr, *wkl = nullptr, *wlh = nullptr;
@@ -60,7 +63,7 @@ struct salnmf_engine {
     double* scal = nullptr;      // device scalars: [0]=objective, [1]=f0, [2]=f1, [3]=logdet0, [4]=logdet1
     double* Wunc = nullptr;      // MvNMF scratch [K][V]
     double* Wtrial = nullptr;    // [K][V]
-    double* cs = nullptr;        // [K]
+    double* cs = nullptr;        // [KP], filler 1
     double* hpin = nullptr;      // pinned host scalars
     ncclComm_t comm = nullptr;
     int n_ranks = 1, rank = 0;
@@ -81,12 +84,9 @@ static int pick_ks(int K) {
 template <bool DO_G, bool DO_U, bool DO_STATS>
 static int launch_fused(salnmf_engine* e, const FusedParams& p) {
     dim3 g(e->grid), b(BLOCK);
-#define SALNMF_CASE(ks)                                                                          \
-    case ks:                                                                                     \
-        if (e->V == VMAX)                                                                        \
-            hipLaunchKernelGGL((fused_kernel<ks, DO_G, DO_U, DO_STATS, true>), g, b, 0, e->stream, p);  \
-        else                                                                                     \
-            hipLaunchKernelGGL((fused_kernel<ks, DO_G, DO_U, DO_STATS, false>), g, b, 0, e->stream, p); \
+#define SALNMF_CASE(ks)                                                                   \
+    case ks:                                                                              \
+        hipLaunchKernelGGL((fused_kernel<ks, DO_G, DO_U, DO_STATS>), g, b, 0, e->stream, p); \
         break;
     switch (e->KS) {
         SALNMF_CASE(1)
@@ -209,7 +209,7 @@ void salnmf_destroy(salnmf_engine* e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->comm) ncclCommDestroy(e->comm);
     double* bufs[] = {e->X, e->H, e->W, e->wkl, e->wlh, e->Gpart, e->Hsumpart, e->KLpart, e->red,
-                      e->objpart, e->scal, e->Wunc, e->Wtrial, e->cs};
+                      e->objpart, e->scal, e->Wunc, e->Wtrial, e->cs, e->scratch};
     for (double* b : bufs)
         if (b) (void)hipFree(b);
     if (e->hpin) (void)hipHostFree(e->hpin);
@@ -239,10 +239,12 @@ int salnmf_create(int device, int n_features, int64_t n_samples, int n_signature
     e->K = n_signatures;
     e->N = n_samples;
     e->ntiles = (n_samples + 15) / 16;
+    e->Np = e->ntiles * 16;
     e->KS = pick_ks(n_signatures);
+    e->KP = 16 * ((e->KS + 3) / 4);
     int64_t wg_needed = (e->ntiles + WAVES - 1) / WAVES;
     e->grid = (int)std::min<int64_t>(prop.multiProcessorCount, wg_needed);
-    const size_t K = e->K, V = e->V, N = e->N;
+    const size_t K = e->K, V = e->V, Np = e->Np, KP = e->KP;
     auto cleanup = [&](int rc) {
         salnmf_destroy(e);
         return rc;
@@ -250,8 +252,8 @@ int salnmf_create(int device, int n_features, int64_t n_samples, int n_signature
 #define ALLOC(ptr, n)                                                      \
     if (hipMalloc(&(ptr), (n) * sizeof(double)) != hipSuccess) return cleanup(fail("hipMalloc of %zu doubles failed", (size_t)(n)));
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return cleanup(fail("stream create failed"));
-    ALLOC(e->X, N * V);
-    ALLOC(e->H, N * K);
+    ALLOC(e->X, Np * VMAX);
+    ALLOC(e->H, Np * KP);
     ALLOC(e->W, K * V);
     ALLOC(e->Gpart, (size_t)e->grid * K * V);
     ALLOC(e->Hsumpart, (size_t)e->grid * K);
@@ -261,8 +263,13 @@ int salnmf_create(int device, int n_features, int64_t n_samples, int n_signature
     ALLOC(e->scal, 8);
     ALLOC(e->Wunc, K * V);
     ALLOC(e->Wtrial, K * V);
-    ALLOC(e->cs, K);
+    ALLOC(e->cs, KP);
 #undef ALLOC
+    {
+        std::vector<double> ones(KP, 1.0);
+        if (hipMemcpy(e->cs, ones.data(), KP * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+            return cleanup(fail("hipMemcpy failed"));
+    }
     if (hipHostMalloc((void**)&e->hpin, 8 * sizeof(double), hipHostMallocDefault) != hipSuccess)
         return cleanup(fail("hipHostMalloc failed"));
     *out = e;
@@ -277,32 +284,66 @@ static int upload(salnmf_engine* e, double* dst, const double* src, size_t n) {
     return 0;
 }
 
-int salnmf_upload_X(salnmf_engine* e, const double* X, int clip) {
-    CK(upload(e, e ? e->X : nullptr, X, (size_t)e->N * e->V));
-    if (clip) {
-        hipLaunchKernelGGL(clip_kernel, dim3(2048), dim3(256), 0, e->stream, e->X, (int64_t)e->N * e->V);
-        HIPCK(hipGetLastError());
-    }
+static int ensure_scratch(salnmf_engine* e, size_t n) {
+    if (e->scratch_n >= n) return 0;
+    if (e->scratch) HIPCK(hipFree(e->scratch));
+    e->scratch = nullptr;
+    e->scratch_n = 0;
+    HIPCK(hipMalloc(&e->scratch, n * sizeof(double)));
+    e->scratch_n = n;
     return 0;
 }
+
+// host compact [rows][cols] -> device padded [Np][ld]
+static int upload_padded(salnmf_engine* e, double* dst, const double* src, int cols, int ld, double fill_cols,
+                         double fill_rows, double clip_lo) {
+    if (!e || !src) return fail("null argument");
+    HIPCK(hipSetDevice(e->device));
+    CK(ensure_scratch(e, (size_t)e->N * cols));
+    CK(upload(e, e->scratch, src, (size_t)e->N * cols));
+    hipLaunchKernelGGL(pad_kernel, dim3(2048), dim3(256), 0, e->stream, dst, e->scratch, e->N, cols, e->Np, ld,
+                       fill_cols, fill_rows, clip_lo);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+// device padded [.][ld] -> host compact [N][cols]
+static int download_padded(salnmf_engine* e, double* dst, const double* src, int cols, int ld) {
+    if (!e || !dst) return fail("null argument");
+    HIPCK(hipSetDevice(e->device));
+    CK(ensure_scratch(e, (size_t)e->N * cols));
+    hipLaunchKernelGGL(unpad_kernel, dim3(2048), dim3(256), 0, e->stream, e->scratch, src, e->N, cols, ld);
+    HIPCK(hipGetLastError());
+    HIPCK(hipMemcpyAsync(dst, e->scratch, (size_t)e->N * cols * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIPCK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+int salnmf_upload_X(salnmf_engine* e, const double* X, int clip) {
+    // pad rows / columns are exactly 0 (never clipped): they must contribute X/P = 0
+    return upload_padded(e, e ? e->X : nullptr, X, e ? e->V : 0, VMAX, 0.0, 0.0, clip ? kEps : 0.0);
+}
 int salnmf_upload_W(salnmf_engine* e, const double* W) { return upload(e, e ? e->W : nullptr, W, (size_t)e->K * e->V); }
-int salnmf_upload_H(salnmf_engine* e, const double* H) { return upload(e, e ? e->H : nullptr, H, (size_t)e->N * e->K); }
+int salnmf_upload_H(salnmf_engine* e, const double* H) {
+    // pad columns 0, pad rows 1: finite, and positive in the rows so that P > 0 there
+    return upload_padded(e, e ? e->H : nullptr, H, e ? e->K : 0, e ? e->KP : 0, 0.0, 1.0, 0.0);
+}
 
 int salnmf_set_weights(salnmf_engine* e, const double* weights_kl, const double* weights_lhalf) {
     if (!e) return fail("null engine");
     HIPCK(hipSetDevice(e->device));
     HIPCK(hipStreamSynchronize(e->stream));
-    auto set = [&](double*& dev, const double* host) -> int {
+    auto set = [&](double*& dev, const double* host, double filler) -> int {
         if (!host) {
             if (dev) HIPCK(hipFree(dev));
             dev = nullptr;
             return 0;
         }
-        if (!dev) HIPCK(hipMalloc(&dev, (size_t)e->N * sizeof(double)));
-        return upload(e, dev, host, (size_t)e->N);
+        if (!dev) HIPCK(hipMalloc(&dev, (size_t)e->Np * sizeof(double)));
+        return upload_padded(e, dev, host, 1, 1, filler, filler, 0.0);
     };
-    CK(set(e->wkl, weights_kl));
-    CK(set(e->wlh, weights_lhalf));
+    CK(set(e->wkl, weights_kl, 1.0));
+    CK(set(e->wlh, weights_lhalf, 0.0));
     return 0;
 }
 
@@ -314,7 +355,7 @@ static int download(salnmf_engine* e, double* dst, const double* src, size_t n) 
     return 0;
 }
 int salnmf_download_W(salnmf_engine* e, double* W) { return download(e, W, e ? e->W : nullptr, (size_t)e->K * e->V); }
-int salnmf_download_H(salnmf_engine* e, double* H) { return download(e, H, e ? e->H : nullptr, (size_t)e->N * e->K); }
+int salnmf_download_H(salnmf_engine* e, double* H) { return download_padded(e, H, e ? e->H : nullptr, e ? e->K : 0, e ? e->KP : 0); }
 
 int salnmf_kl_step(salnmf_engine* e, int n_steps, int n_given) {
     if (!e) return fail("null engine");
@@ -409,7 +450,7 @@ int salnmf_samplewise_kl(salnmf_engine* e, double* out) {
     if (!e || !out) return fail("null argument");
     HIPCK(hipSetDevice(e->device));
     double* dev = nullptr;
-    HIPCK(hipMalloc(&dev, (size_t)e->N * sizeof(double)));
+    HIPCK(hipMalloc(&dev, (size_t)e->Np * sizeof(double)));
     FwdParams p;
     fwd_params(e, p);
     p.out = dev;
@@ -423,12 +464,12 @@ int salnmf_reconstruct(salnmf_engine* e, double* out) {
     if (!e || !out) return fail("null argument");
     HIPCK(hipSetDevice(e->device));
     double* dev = nullptr;
-    HIPCK(hipMalloc(&dev, (size_t)e->N * e->V * sizeof(double)));
+    HIPCK(hipMalloc(&dev, (size_t)e->Np * VMAX * sizeof(double)));
     FwdParams p;
     fwd_params(e, p);
     p.out = dev;
     int rc = launch_forward<2>(e, p);
-    if (!rc) rc = download(e, out, dev, (size_t)e->N * e->V);
+    if (!rc) rc = download_padded(e, out, dev, e->V, VMAX);
     (void)hipFree(dev);
     return rc;
 }
@@ -491,7 +532,7 @@ static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double de
     *gamma = std::min(1.0, 1.2 * g);  // mvnmf.py:91
     // accept: W <- W_trial, H <- clip(H * colsum)
     HIPCK(hipMemcpyAsync(e->W, e->Wtrial, (size_t)K * V * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
-    hipLaunchKernelGGL(scale_H_kernel, dim3(2048), dim3(256), 0, e->stream, e->H, e->cs, (int64_t)e->N * K, K);
+    hipLaunchKernelGGL(scale_H_kernel, dim3(2048), dim3(256), 0, e->stream, e->H, e->cs, (int64_t)e->Np * e->KP, e->KP);
     HIPCK(hipGetLastError());
     return 0;
 }

@@ -1,22 +1,32 @@
 // CDNA4 (gfx950) kernels of the KL-NMF update path.  fp64 throughout.
 //
-// Data layout in HBM (AnnData storage order, sample-major; one engine = one shard):
-//   X [N][V]  counts            H [N][K]  exposures           W [K][V]  signatures
-// One *tile* = 16 consecutive samples.  One wave64 owns a tile end to end; the four
-// waves of a workgroup (one per SIMD) run independent tile streams and share only the
-// LDS copy of W.  Per tile (reference arithmetic: _utils_klnmf.py:328-347):
-//   P = Ht . W          16 x V      v_mfma_f64_16x16x4, contraction over K
+// Device layout (owned by the engine; the C ABI converts from/to AnnData's compact layout):
+//   X  [Np][96]   counts, sample-major, feature columns >= V are 0, rows >= N are 0
+//   H  [Np][KP]   exposures, KP = 16*KT >= K; columns >= K and rows >= N hold finite filler
+//   W  [K][V]     signatures, compact (38 KB; each workgroup stages it into LDS once)
+//   w_kl, w_lhalf [Np]  per-sample weights (filler 1 / 0)
+// Np = 16 * ceil(N/16).  One *tile* = 16 consecutive samples; with this padding every tile is
+// full, every row is 128-byte aligned, and the hot loop needs no masks:
+//   * pad rows have X = 0 and H > 0, so P > 0 and R = X/P = 0 exactly: nothing reaches G or U;
+//   * pad feature columns have W_lds = 1 (P > 0, R = 0);
+//   * pad signature rows of W_lds are 0, so pad columns of H never reach P, and the pad
+//     columns of U / pad rows of G are simply never read.
+//
+// One wave64 owns a tile end to end; the four waves of a workgroup (one per SIMD) run
+// independent tile streams and share only the LDS copy of W.  Per tile (reference arithmetic:
+// _utils_klnmf.py:328-347):
+//   P = Ht . W          16 x 96     v_mfma_f64_16x16x4, contraction over K
 //   R = X / P           in the accumulator registers (never stored to HBM)
-//   G += Ht^T . R       K x V       contraction over the tile's samples; the accumulator
-//                                   tile R is consumed directly as the B operand
-//   U = R . W^T         16 x K      contraction over V; R goes through a wave-private
-//                                   LDS transpose to become the A operand
+//   G += Ht^T . R       K x 96      contraction over the tile's samples; the accumulator tile R
+//                                   is consumed directly as the B operand
+//   U = R . W^T         16 x K      contraction over the features; R goes through a
+//                                   wave-private LDS transpose to become the A operand
 //   H <- clip(H * U)    written back in place
 // f64 MFMA lane maps (checked on hardware by tools/mfma_f64_probe.hip):
 //   A[i = lane&15][k = lane>>4]   B[k = lane>>4][j = lane&15]
 //   D[row = (lane>>4) + 4*reg][col = lane&15],  reg = 0..3
-// so register `reg` of a D tile is the B operand of k-step `reg` of a product that
-// contracts over D's row index.
+// so register `reg` of a D tile is the B operand of k-step `reg` of a product that contracts
+// over D's row index.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -24,12 +34,13 @@
 namespace salnmf {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
 
 constexpr double kEps = 1.1920928955078125e-07;  // float32 eps, _utils_klnmf.py:7
 constexpr int VT = 6;                 // feature tiles of 16  -> V <= 96
-constexpr int VMAX = 16 * VT;
+constexpr int VMAX = 16 * VT;         // leading dimension of X on the device
 constexpr int VSTEPS = VMAX / 4;      // feature k-steps of 4
-constexpr int WS = 98;                // LDS row stride (doubles) of W   : 2*odd -> conflict-free column-slab reads
+constexpr int WS = 98;                // LDS row stride (doubles) of W: 2*odd -> conflict-free column-slab reads
 constexpr int RS = 98;                // LDS row stride (doubles) of the ratio tile
 constexpr int WAVES = 4;              // one wave per SIMD
 constexpr int BLOCK = 64 * WAVES;
@@ -37,14 +48,31 @@ constexpr int BLOCK = 64 * WAVES;
 __device__ __forceinline__ d4 mfma(double a, double b, d4 c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
+// Accumulate step on an AGPR-resident accumulator.  The s_nop covers the VALU-write ->
+// MFMA-operand-read wait states, which hipcc does not insert inside an asm statement.
+__device__ __forceinline__ void mfma_agpr(d4& c, double a, double b) {
+    asm("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+
+template <int KS>
+struct Geo {
+    static constexpr int KT = (KS + 3) / 4;        // signature tiles of 16
+    static constexpr int KP = 16 * KT;             // leading dimension of H on the device
+    static constexpr int LS = KP + 2;              // LDS row stride of the H tile (2*odd: conflict-free A reads)
+    static constexpr int WROWS = KP;               // rows of the LDS copy of W (zero padded)
+    static constexpr int HL = 16 * LS;             // doubles per wave for the H tile
+    static constexpr int RL = 16 * RS;             // doubles per wave for the ratio tile
+    static constexpr int HV = KP / 8;              // 16-byte loads per lane that fetch one H tile
+    static constexpr int LDS_DOUBLES = WROWS * WS + WAVES * (HL + RL);
+};
 
 struct FusedParams {
-    const double* __restrict__ X;    // [N][V]
-    double* __restrict__ H;          // [N][K]  updated in place when DO_U
+    const double* __restrict__ X;    // [Np][VMAX]
+    double* __restrict__ H;          // [Np][KP]  updated in place when DO_U
     const double* __restrict__ W;    // [K][V]
-    const double* __restrict__ wkl;  // [N] or null
-    const double* __restrict__ wlh;  // [N] or null
-    const double* __restrict__ hscale;  // [K] or null: H is read as clip(H*hscale) (MvNMF trial)
+    const double* __restrict__ wkl;  // [Np] or null
+    const double* __restrict__ wlh;  // [Np] or null
+    const double* __restrict__ hscale;  // [KP] or null: H is read as clip(H*hscale) (MvNMF trial)
     double* __restrict__ Gpart;      // [gridDim.x][K][V]        (DO_G)
     double* __restrict__ Hsumpart;   // [gridDim.x][K]           (DO_STATS) row sums of H
     double* __restrict__ KLpart;     // [gridDim.x]              (DO_STATS) unweighted KL partial
@@ -54,21 +82,31 @@ struct FusedParams {
     int64_t ntiles;
 };
 
-template <int KS>
-struct Geo {
-    static constexpr int KT = (KS + 3) / 4;        // signature tiles of 16
-    static constexpr int WROWS = 16 * KT;          // rows of the LDS copy of W (zero padded)
-    static constexpr int HL = 16 * 4 * KS + 64;    // doubles per wave for the raw H tile (+ finite pad)
-    static constexpr int RL = 16 * RS;             // doubles per wave for the ratio tile
-    static constexpr int LDS_DOUBLES = WROWS * WS + WAVES * (HL + RL);
-};
-
 // natural log for the objective terms
 __device__ __forceinline__ double kl_term(double x, double p) {
     // _utils_klnmf.py:47-50: entries with X == 0 contribute only WH
     double t = p;
     if (x != 0.0) t += x * log(x / p) - x;
     return t;
+}
+
+// W -> LDS with the padding described at the top of the file.  All loads in flight together.
+template <int WROWS>
+__device__ __forceinline__ void stage_W(double* Wl, const double* __restrict__ W, int K, int V, int tid) {
+    constexpr int WPT = (WROWS * VMAX + BLOCK - 1) / BLOCK;
+    double wreg[WPT];
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) {
+        int idx = tid + BLOCK * j;
+        int k = idx / VMAX, v = idx - k * VMAX;
+        wreg[j] = (k < K) ? ((v < V) ? W[k * V + v] : 1.0) : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) {
+        int idx = tid + BLOCK * j;
+        int k = idx / VMAX, v = idx - k * VMAX;
+        if (k < WROWS) Wl[k * WS + v] = wreg[j];
+    }
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -81,18 +119,11 @@ __device__ __forceinline__ double kl_term(double x, double p) {
 // Register plan (one wave per SIMD, 512 registers): the K x V accumulator G lives in AGPRs for
 // the whole kernel (inline-asm MFMA with "a" operands), everything else in <= 256 VGPRs.
 // LDS operand reads are software-pipelined one k-step ahead of the MFMAs that consume them;
-// sched_barrier(0) pins that order.  Full tiles run a mask-free body; only the ragged last
-// tile (or V < 96) takes the masked one.
-
-// G accumulate step on an AGPR-resident accumulator.  The s_nop covers the VALU-write ->
-// MFMA-operand-read wait states, which hipcc does not insert inside an asm statement.
-__device__ __forceinline__ void mfma_agpr(d4& c, double a, double b) {
-    asm("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-}
-template <int KS, bool DO_G, bool DO_U, bool DO_STATS, bool VFULL>
+// sched_barrier(0) pins that order.
+template <int KS, bool DO_G, bool DO_U, bool DO_STATS>
 __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
     using G_ = Geo<KS>;
-    constexpr int KT = G_::KT;
+    constexpr int KT = G_::KT, KP = G_::KP, LS = G_::LS, HV = G_::HV;
     __shared__ __attribute__((aligned(16))) double lds[G_::LDS_DOUBLES];
 
     const int tid = threadIdx.x;
@@ -107,15 +138,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
     double* Hl = lds + G_::WROWS * WS + wave * (G_::HL + G_::RL);
     double* Rl = Hl + G_::HL;
 
-    // ---- W -> LDS.  Padding is chosen so that the compute body needs no masks:
-    //   rows k >= K are 0 (they add nothing to P; their U columns / G rows are never stored);
-    //   columns v >= V of the real rows are 1, so P > 0 there and R = X/P = 0/P = 0 exactly
-    //   (X is loaded as 0), which then adds nothing to U or to the stored part of G.
-    for (int i = tid; i < G_::WROWS * WS; i += BLOCK) {
-        int k = i / WS, v = i - k * WS;
-        Wl[i] = (k < K) ? ((v < V) ? p.W[k * V + v] : 1.0) : 0.0;
-    }
-    for (int i = lane; i < G_::HL; i += 64) Hl[i] = 0.0;  // finite pad behind the H tile
+    stage_W<G_::WROWS>(Wl, p.W, K, V, tid);
     __syncthreads();
 
     d4 g[KT][VT];
@@ -125,58 +148,44 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
 #pragma unroll
             for (int vt = 0; vt < VT; ++vt) g[kt][vt] = (d4){0, 0, 0, 0};
     }
-    double hsum[KS];
+    d2 hsum[HV];
     double klacc = 0.0;
     if (DO_STATS) {
 #pragma unroll
-        for (int j = 0; j < KS; ++j) hsum[j] = 0.0;
+        for (int j = 0; j < HV; ++j) hsum[j] = (d2){0, 0};
     }
 
     const int64_t tstride = (int64_t)gridDim.x * WAVES;
     int64_t tile = (int64_t)blockIdx.x * WAVES + wave;
-    const int tileH = 16 * K;
 
-    // prefetch registers: H tile (raw, contiguous 16*K doubles) and X tile (accumulator layout)
-    double hpre[KS];
+    // lane's slice of an H tile: element pair e = 2*lane + 128*j of the contiguous [16][KP] block
+    int hrow[HV], hcol[HV];
+#pragma unroll
+    for (int j = 0; j < HV; ++j) {
+        int e = 2 * lane + 128 * j;
+        hrow[j] = e / KP;
+        hcol[j] = e - hrow[j] * KP;
+    }
+
+    // prefetch registers: H tile (16-byte pieces of the contiguous block) and X tile (accumulator layout)
+    d2 hpre[HV];
     double x[VT][4];
 
-    // Loads of one tile.  Rows n >= N (the ragged last tile) read as X = 0, H = 1: P > 0, R = 0.
     auto load_tile = [&](int64_t t) __attribute__((always_inline)) {
         const int64_t n0 = t * 16;
-        const double* hsrc = p.H + n0 * K;
-        const double* xsrc = p.X + (n0 + q) * V + c16;
-        const bool full = n0 + 16 <= N;  // wave-uniform
-        if (full) {
+        const d2* hsrc = reinterpret_cast<const d2*>(p.H + n0 * KP) + lane;
 #pragma unroll
-            for (int j = 0; j < KS; ++j) {
-                int idx = lane + 64 * j;
-                hpre[j] = (idx < tileH) ? hsrc[idx] : 0.0;
-            }
+        for (int j = 0; j < HV; ++j) hpre[j] = hsrc[64 * j];
+        const double* xsrc = p.X + (n0 + q) * VMAX + c16;
 #pragma unroll
-            for (int vt = 0; vt < VT; ++vt)
+        for (int vt = 0; vt < VT; ++vt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (VFULL) x[vt][r] = xsrc[4 * r * VMAX + 16 * vt];
-                    else x[vt][r] = (16 * vt + c16 < V) ? xsrc[4 * r * V + 16 * vt] : 0.0;
-                }
-        } else {
-            const int64_t hleft = (N - n0) * K;
-#pragma unroll
-            for (int j = 0; j < KS; ++j) {
-                int idx = lane + 64 * j;
-                hpre[j] = (idx < tileH) ? ((idx < hleft) ? hsrc[idx] : 1.0) : 0.0;
-            }
-#pragma unroll
-            for (int vt = 0; vt < VT; ++vt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    x[vt][r] = (n0 + q + 4 * r < N && 16 * vt + c16 < V) ? xsrc[4 * r * V + 16 * vt] : 0.0;
-        }
+            for (int r = 0; r < 4; ++r) x[vt][r] = xsrc[4 * r * VMAX + 16 * vt];
         if (p.hscale) {  // MvNMF line-search trial: H is read as clip(H * colsum(W_trial))
 #pragma unroll
-            for (int j = 0; j < KS; ++j) {
-                int idx = lane + 64 * j;
-                if (idx < tileH) hpre[j] = fmax(hpre[j] * p.hscale[idx % K], kEps);
+            for (int j = 0; j < HV; ++j) {
+                hpre[j][0] = fmax(hpre[j][0] * p.hscale[hcol[j]], kEps);
+                hpre[j][1] = fmax(hpre[j][1] * p.hscale[hcol[j] + 1], kEps);
             }
         }
     };
@@ -185,10 +194,11 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         const int64_t n0 = tile * 16;
         // ---- stage the H tile (wave private; LDS ops of one wave are executed in order)
 #pragma unroll
-        for (int j = 0; j < KS; ++j) {
-            int idx = lane + 64 * j;
-            if (idx < tileH) Hl[idx] = hpre[j];
-            if (DO_STATS) hsum[j] += (idx < (N - n0) * K) ? hpre[j] : 0.0;
+        for (int j = 0; j < HV; ++j) {
+            *reinterpret_cast<d2*>(Hl + hrow[j] * LS + hcol[j]) = hpre[j];
+            if (DO_STATS) {
+                if (n0 + hrow[j] < N) hsum[j] += hpre[j];
+            }
         }
         __builtin_amdgcn_wave_barrier();
 
@@ -197,7 +207,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
 #pragma unroll
         for (int vt = 0; vt < VT; ++vt) pr[vt] = (d4){0, 0, 0, 0};
         {
-            const double* ha = Hl + c16 * K + q;
+            const double* ha = Hl + c16 * LS + q;
             const double* wb = Wl + q * WS + c16;
             double a[KS];
 #pragma unroll
@@ -223,7 +233,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         if (DO_G) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const double* ha = Hl + (4 * r + q) * K + c16;
+                const double* ha = Hl + (4 * r + q) * LS + c16;
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt) ga[r][kt] = ha[16 * kt];
             }
@@ -236,7 +246,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
             for (int r = 0; r < 4; ++r) {
                 double xv = x[vt][r], pv = pr[vt][r];
                 if (DO_STATS) {
-                    bool valid = (n0 + q + 4 * r < N) && (VFULL || 16 * vt + c16 < V);
+                    bool valid = (n0 + q + 4 * r < N) && (16 * vt + c16 < V);
                     klacc += valid ? kl_term(xv, pv) : 0.0;
                 }
                 pr[vt][r] = xv / pv;
@@ -255,8 +265,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
             if (p.wkl) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    int64_t n = n0 + 4 * r + q;
-                    double wk = p.wkl[n < N ? n : N - 1];
+                    double wk = p.wkl[n0 + 4 * r + q];
 #pragma unroll
                     for (int kt = 0; kt < KT; ++kt) ga[r][kt] *= wk;
                 }
@@ -278,6 +287,12 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
             d4 u[KT];
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) u[kt] = (d4){0, 0, 0, 0};
+            // H of this tile in the U accumulator layout; read now, consumed by the epilogue
+            double hcur[4][KT];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) hcur[r][kt] = Hl[(q + 4 * r) * LS + 16 * kt + c16];
             const double* ra = Rl + c16 * RS + q;
             const double* wb = Wl + c16 * WS + q;
             double a[2], b[2][KT];
@@ -296,32 +311,31 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
                 for (int kt = 0; kt < KT; ++kt) u[kt] = mfma(a[s & 1], b[s & 1][kt], u[kt]);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // ---- H update (_utils_klnmf.py:343-361), rows n = q+4r, columns k = 16kt+c16
-            const bool lhalf = p.wlh != nullptr;
+            // ---- H update (_utils_klnmf.py:343-361), rows n = q+4r, columns k = 16kt+c16.
+            // Unmasked: pad rows / columns just receive finite filler.
+            double* hdst = p.H + (n0 + q) * KP + c16;
+            if (p.wlh == nullptr) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t n = n0 + q + 4 * r;
-                const bool nvalid = n < N;
-                double wl = 0.0, wk2 = 1.0;
-                if (lhalf) {
-                    wl = p.wlh[nvalid ? n : N - 1];
-                    if (p.wkl) { double w = p.wkl[nvalid ? n : N - 1]; wk2 = w * w; }
-                }
+                for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int kt = 0; kt < KT; ++kt) {
-                    const int k = 16 * kt + c16;
-                    double h = Hl[(q + 4 * r) * K + k], f = u[kt][r], hn;
-                    if (!lhalf) {
-                        hn = h * f;
-                    } else {
-                        double inter = 4.0 * h * f;
+                    for (int kt = 0; kt < KT; ++kt) hdst[4 * r * KP + 16 * kt] = fmax(hcur[r][kt] * u[kt][r], kEps);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t n = n0 + q + 4 * r;
+                    const double wl = p.wlh[n];
+                    double wk2 = 1.0;
+                    if (p.wkl) { double w = p.wkl[n]; wk2 = w * w; }
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt) {
+                        double inter = 4.0 * hcur[r][kt] * u[kt][r];
                         if (p.wkl) inter *= wk2;
                         double disc = 0.25 * wl * wl + inter;
                         double t = wl / 2 - sqrt(disc);
-                        hn = 0.25 * (t * t);
+                        double hn = 0.25 * (t * t);
                         if (p.wkl) hn /= wk2;
+                        hdst[4 * r * KP + 16 * kt] = fmax(hn, kEps);
                     }
-                    if (nvalid && k < K) p.H[n * K + k] = fmax(hn, kEps);
                 }
             }
         }
@@ -333,49 +347,60 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
     // ---- workgroup reductions, fixed order (deterministic)
     __syncthreads();  // every wave is done with the LDS copy of W
     if (DO_G) {
-        // the asm MFMAs are opaque to hipcc: drain the matrix pipe before VALU reads of g
+        // the asm MFMAs are opaque to hipcc: drain the matrix pipe before any VALU read of g
+        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-            for (int vt = 0; vt < VT; ++vt) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(g[kt][vt]));
-        double* Gs = lds;  // [K][VMAX], aliases W
-        for (int w = 0; w < WAVES; ++w) {
-            if (wave == w) {
+            for (int vt = 0; vt < VT; ++vt) asm volatile("" : "+a"(g[kt][vt]));  // orders the reads below after the drain
+        // Cross-wave sum through LDS (all of it is free now), fixed order (wave 0 + 1 + 2 + 3).
+        // Two rounds of VT/2 feature tiles each, so that every wave has a private slot of
+        // [16*KT][HW] doubles: plain unmasked stores, no read-modify-write chains.
+        constexpr int HT = VT / 2, HW = 16 * HT, SLOT = 16 * KT * HW;
+        static_assert(WAVES * SLOT <= G_::LDS_DOUBLES, "reduction slots must fit in LDS");
+        double* out = p.Gpart + (int64_t)blockIdx.x * K * V;
 #pragma unroll
-                for (int kt = 0; kt < KT; ++kt)
+        for (int half = 0; half < 2; ++half) {
+            double* mine = lds + wave * SLOT;
 #pragma unroll
-                    for (int vt = 0; vt < VT; ++vt)
+            for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            int k = 16 * kt + q + 4 * r, v = 16 * vt + c16;
-                            if (k < K) {
-                                double prev = (w == 0) ? 0.0 : Gs[k * VMAX + v];
-                                Gs[k * VMAX + v] = prev + g[kt][vt][r];
-                            }
-                        }
+                for (int h = 0; h < HT; ++h)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        mine[(16 * kt + q + 4 * r) * HW + 16 * h + c16] = g[kt][half * HT + h][r];
+            __syncthreads();
+            for (int i = tid; i < K * HW; i += BLOCK) {
+                int k = i / HW, vv = i - k * HW;
+                int v = half * HW + vv;
+                double t = ((lds[i] + lds[SLOT + i]) + lds[2 * SLOT + i]) + lds[3 * SLOT + i];
+                if (v < V) out[k * V + v] = t;
             }
             __syncthreads();
-        }
-        double* out = p.Gpart + (int64_t)blockIdx.x * K * V;
-        for (int i = tid; i < K * V; i += BLOCK) {
-            int k = i / V, v = i - k * V;
-            out[i] = Gs[k * VMAX + v];
         }
     }
     if (DO_STATS) {
         __syncthreads();
-        // row sums of H: lane-private sums hsum[j] belong to column (lane + 64 j) % K
-        double* S = lds;  // [WAVES][64*KS]
+        // row sums of H: lane-private pair sums hsum[j] belong to columns hcol[j], hcol[j]+1
+        double* S = lds;  // [BLOCK][HV*2] then reduced per column by one thread each
 #pragma unroll
-        for (int j = 0; j < KS; ++j) S[wave * 64 * KS + lane + 64 * j] = hsum[j];
-        // KL partial: lane values
-        double* Ks = lds + WAVES * 64 * KS;  // [BLOCK]
+        for (int j = 0; j < HV; ++j) {
+            S[(tid * HV + j) * 2] = hsum[j][0];
+            S[(tid * HV + j) * 2 + 1] = hsum[j][1];
+        }
+        double* Ks = lds + BLOCK * HV * 2;  // [BLOCK]
         Ks[tid] = klacc;
         __syncthreads();
         if (tid < K) {
             double s = 0.0;
-            for (int w = 0; w < WAVES; ++w)
-                for (int idx = tid; idx < tileH; idx += K) s += S[w * 64 * KS + idx];
+            for (int t = 0; t < BLOCK; ++t) {
+                int l = t & 63;
+                for (int j = 0; j < HV; ++j) {
+                    int c = (2 * l + 128 * j) % KP;
+                    if (c == tid) s += S[(t * HV + j) * 2];
+                    else if (c + 1 == tid) s += S[(t * HV + j) * 2 + 1];
+                }
+            }
             p.Hsumpart[(int64_t)blockIdx.x * K + tid] = s;
         }
         if (tid == 0) {
@@ -392,13 +417,13 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
 //   mode 1: per-sample KL, zeros replaced by EPS in X and WH            _utils_klnmf.py:58-97
 //   mode 2: the reconstruction H @ W                                    signature_nmf.py:221-224
 struct FwdParams {
-    const double* __restrict__ X;
-    const double* __restrict__ H;
-    const double* __restrict__ W;
-    const double* __restrict__ wkl;
-    const double* __restrict__ wlh;
-    const double* __restrict__ hscale;  // [K] or null: H read as clip(H*hscale)
-    double* __restrict__ out;           // mode 0: [gridDim.x]; mode 1: [N]; mode 2: [N][V]
+    const double* __restrict__ X;       // [Np][VMAX]
+    const double* __restrict__ H;       // [Np][KP]
+    const double* __restrict__ W;       // [K][V]
+    const double* __restrict__ wkl;     // [Np] or null
+    const double* __restrict__ wlh;     // [Np] or null
+    const double* __restrict__ hscale;  // [KP] or null: H read as clip(H*hscale)
+    double* __restrict__ out;           // mode 0: [gridDim.x]; mode 1: [Np]; mode 2: [Np][VMAX]
     int64_t N;
     int V;
     int K;
@@ -408,6 +433,7 @@ struct FwdParams {
 template <int KS, int MODE>
 __global__ void __launch_bounds__(BLOCK, 1) forward_kernel(FwdParams p) {
     using G_ = Geo<KS>;
+    constexpr int KP = G_::KP, LS = G_::LS, HV = G_::HV;
     __shared__ __attribute__((aligned(16))) double lds[G_::WROWS * WS + WAVES * G_::HL + BLOCK];
 
     const int tid = threadIdx.x;
@@ -422,48 +448,57 @@ __global__ void __launch_bounds__(BLOCK, 1) forward_kernel(FwdParams p) {
     double* Hl = lds + G_::WROWS * WS + wave * G_::HL;
     double* red = lds + G_::WROWS * WS + WAVES * G_::HL;
 
-    for (int i = tid; i < G_::WROWS * WS; i += BLOCK) {
-        int k = i / WS, v = i - k * WS;
-        Wl[i] = (k < K && v < V) ? p.W[k * V + v] : 0.0;
-    }
-    for (int i = lane; i < G_::HL; i += 64) Hl[i] = 0.0;
+    stage_W<G_::WROWS>(Wl, p.W, K, V, tid);
     __syncthreads();
 
-    const int tileH = 16 * K;
+    int hrow[HV], hcol[HV];
+#pragma unroll
+    for (int j = 0; j < HV; ++j) {
+        int e = 2 * lane + 128 * j;
+        hrow[j] = e / KP;
+        hcol[j] = e - hrow[j] * KP;
+    }
+
     const int64_t tstride = (int64_t)gridDim.x * WAVES;
     double total = 0.0;
 
     for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < p.ntiles; tile += tstride) {
         const int64_t n0 = tile * 16;
-        const int64_t hbase = n0 * K, hend = N * K;
+        const d2* hsrc = reinterpret_cast<const d2*>(p.H + n0 * KP) + lane;
+        d2 hv[HV];
+#pragma unroll
+        for (int j = 0; j < HV; ++j) hv[j] = hsrc[64 * j];
+        double x[VT][4];
+        if (MODE != 2) {
+            const double* xsrc = p.X + (n0 + q) * VMAX + c16;
+#pragma unroll
+            for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[vt][r] = xsrc[4 * r * VMAX + 16 * vt];
+        }
         double pen = 0.0;
 #pragma unroll
-        for (int j = 0; j < KS; ++j) {
-            int idx = lane + 64 * j;
-            double h = 0.0;
-            bool ok = idx < tileH && hbase + idx < hend;
-            if (ok) {
-                h = p.H[hbase + idx];
-                if (p.hscale) h = fmax(h * p.hscale[idx % K], kEps);
-                if (MODE == 0 && p.wlh) pen += p.wlh[n0 + idx / K] * sqrt(h);  // klnmf.py:75-79
+        for (int j = 0; j < HV; ++j) {
+            if (p.hscale) {
+                hv[j][0] = fmax(hv[j][0] * p.hscale[hcol[j]], kEps);
+                hv[j][1] = fmax(hv[j][1] * p.hscale[hcol[j] + 1], kEps);
             }
-            if (idx < tileH) Hl[idx] = h;
+            if (MODE == 0 && p.wlh) {  // l-half penalty, klnmf.py:75-79
+                int64_t n = n0 + hrow[j];
+                if (n < N) {
+                    double w = p.wlh[n];
+                    if (hcol[j] < K) pen += w * sqrt(hv[j][0]);
+                    if (hcol[j] + 1 < K) pen += w * sqrt(hv[j][1]);
+                }
+            }
+            *reinterpret_cast<d2*>(Hl + hrow[j] * LS + hcol[j]) = hv[j];
         }
-        double x[VT][4];
-#pragma unroll
-        for (int vt = 0; vt < VT; ++vt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int64_t n = n0 + q + 4 * r;
-                int v = 16 * vt + c16;
-                x[vt][r] = (MODE != 2 && n < N && v < V) ? p.X[n * V + v] : 0.0;
-            }
         __builtin_amdgcn_wave_barrier();
 
         d4 pr[VT];
 #pragma unroll
         for (int vt = 0; vt < VT; ++vt) pr[vt] = (d4){0, 0, 0, 0};
-        const double* ha = Hl + c16 * K + q;
+        const double* ha = Hl + c16 * LS + q;
         const double* wb = Wl + q * WS + c16;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -481,7 +516,7 @@ __global__ void __launch_bounds__(BLOCK, 1) forward_kernel(FwdParams p) {
 #pragma unroll
                 for (int vt = 0; vt < VT; ++vt)
                     if (n < N && 16 * vt + c16 < V) acc += kl_term(x[vt][r], pr[vt][r]);
-                if (p.wkl && n < N) acc *= p.wkl[n];
+                if (p.wkl) acc *= p.wkl[n];
                 tsum += acc;
             }
             total += tsum;
@@ -500,17 +535,14 @@ __global__ void __launch_bounds__(BLOCK, 1) forward_kernel(FwdParams p) {
                 // reduce over the 16 lanes that share this sample row (same q)
 #pragma unroll
                 for (int m = 1; m < 16; m <<= 1) acc += __shfl_xor(acc, m, 64);
-                if (c16 == 0 && n < N) p.out[n] = acc;
+                if (c16 == 0) p.out[n] = acc;
             }
         } else {
+            double* dst = p.out + (n0 + q) * VMAX + c16;
 #pragma unroll
             for (int vt = 0; vt < VT; ++vt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    int64_t n = n0 + q + 4 * r;
-                    int v = 16 * vt + c16;
-                    if (n < N && v < V) p.out[n * V + v] = pr[vt][r];
-                }
+                for (int r = 0; r < 4; ++r) dst[4 * r * VMAX + 16 * vt] = pr[vt][r];
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -618,18 +650,42 @@ __global__ void sum_partials_kernel(const double* __restrict__ part, int n, int 
     out[j] = s;
 }
 
-// H <- clip(H * scale[k]) (normalize_WH + clip of an accepted MvNMF trial, mvnmf.py:80-81)
-__global__ void scale_H_kernel(double* __restrict__ H, const double* __restrict__ scale, int64_t total, int K) {
+// H <- clip(H * scale[k]) on the padded layout (normalize_WH + clip of an accepted MvNMF trial,
+// mvnmf.py:80-81); scale has ldh entries, filler 1
+__global__ void scale_H_kernel(double* __restrict__ H, const double* __restrict__ scale, int64_t total, int ldh) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < total; i += stride) H[i] = fmax(H[i] * scale[i % K], kEps);
+    for (; i < total; i += stride) H[i] = fmax(H[i] * scale[i % ldh], kEps);
 }
 
-// X <- clip(X, EPS)  (signature_nmf.py:281)
-__global__ void clip_kernel(double* __restrict__ X, int64_t total) {
+// compact [rows][cols] -> padded [prows][ld] (clip_lo > 0 clips the copied entries from below)
+__global__ void pad_kernel(double* __restrict__ dst, const double* __restrict__ src, int64_t rows, int cols,
+                           int64_t prows, int ld, double fill_cols, double fill_rows, double clip_lo) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < total; i += stride) X[i] = fmax(X[i], kEps);
+    for (; i < prows * ld; i += stride) {
+        int64_t r = i / ld;
+        int c = (int)(i - r * ld);
+        double v;
+        if (r >= rows) v = fill_rows;
+        else if (c >= cols) v = fill_cols;
+        else {
+            v = src[r * cols + c];
+            if (clip_lo > 0.0) v = fmax(v, clip_lo);
+        }
+        dst[i] = v;
+    }
+}
+
+// padded [.][ld] -> compact [rows][cols]
+__global__ void unpad_kernel(double* __restrict__ dst, const double* __restrict__ src, int64_t rows, int cols, int ld) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < rows * cols; i += stride) {
+        int64_t r = i / cols;
+        int c = (int)(i - r * cols);
+        dst[i] = src[r * ld + c];
+    }
 }
 
 }  // namespace salnmf
