@@ -2,7 +2,7 @@
 import os
 
 s = open("salamander_amd/csrc/salnmf_kernels.h").read()
-s = s.replace("    int64_t ntiles;\n};\n\ntemplate <int KS>\nstruct Geo", "    int64_t ntiles;\n    unsigned long long* dbg;\n};\n\ntemplate <int KS>\nstruct Geo", 1)
+s = s.replace("    int64_t ntiles;\n};\n\n// natural log", "    int64_t ntiles;\n    unsigned long long* dbg;\n};\n\n// natural log", 1)
 anchor = "    const int64_t N = p.N;\n\n    double* Wl = lds;"
 assert anchor in s
 s = s.replace(anchor, "    const int64_t N = p.N;\n    unsigned long long T0 = __builtin_amdgcn_s_memtime(), R0 = __builtin_amdgcn_s_memrealtime();\n\n    double* Wl = lds;", 1)

@@ -10,12 +10,12 @@ def rep(anchor, new):
     s = s.replace(anchor, new, 1)
 
 
-rep("    int64_t ntiles;\n};\n\ntemplate <int KS>\nstruct Geo", "    int64_t ntiles;\n    unsigned long long* dbg;\n};\n\ntemplate <int KS>\nstruct Geo")
+rep("    int64_t ntiles;\n};\n\n// natural log", "    int64_t ntiles;\n    unsigned long long* dbg;\n};\n\n// natural log")
 macro = '''#define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t1_; asm volatile("s_memtime %0\\n\\ts_waitcnt lgkmcnt(0)" : "=s"(t1_) :: "memory"); __builtin_amdgcn_sched_barrier(0); ph[i] += t1_ - t0_; t0_ = t1_; } while (0)
 '''
-rep("template <int KS, bool DO_G, bool DO_U, bool DO_STATS, bool VFULL>\n__global__", macro + "template <int KS, bool DO_G, bool DO_U, bool DO_STATS, bool VFULL>\n__global__")
-rep("    // prefetch registers: H tile (raw, contiguous 16*K doubles) and X tile (accumulator layout)\n    double hpre[KS];",
-    "    unsigned long long ph[8] = {0,0,0,0,0,0,0,0}; unsigned long long t0_;\n    double hpre[KS];")
+rep("template <int KS, bool DO_G, bool DO_U, bool DO_STATS>\n__global__", macro + "template <int KS, bool DO_G, bool DO_U, bool DO_STATS>\n__global__")
+rep("    d2 hpre[HV];\n    double x[VT][4];\n\n    auto load_tile",
+    "    unsigned long long ph[8] = {0,0,0,0,0,0,0,0}; unsigned long long t0_;\n    d2 hpre[HV];\n    double x[VT][4];\n\n    auto load_tile")
 rep("        const int64_t n0 = tile * 16;\n        // ---- stage the H tile", "        const int64_t n0 = tile * 16;\n        STAMP(7);\n        // ---- stage the H tile")
 rep("        // G-phase A operands (H^T): issue the LDS reads now", "        STAMP(0);\n        // G-phase A operands (H^T): issue the LDS reads now")
 rep("        if (DO_U) {\n            // ---- transpose R through LDS", "        STAMP(1);\n        if (DO_U) {\n            // ---- transpose R through LDS")
