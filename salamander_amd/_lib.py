@@ -50,7 +50,7 @@ SIGNATURES = {
     "salnmf_device_ptr": (c_void_p, [_P, c_int]),
     "salnmf_stream": (c_void_p, [_P]),
     "salnmf_sync": (c_int, [_P]),
-    "salnmf_profile_kl_steps": (c_int, [_P, c_int, c_int, _D, _D, _D]),
+    "salnmf_profile_kl_steps": (c_int, [_P, c_int, c_int, c_int, _D, _D, _D]),
     "salnmf_profile_objective": (c_int, [_P, c_int, _D]),
 }
 

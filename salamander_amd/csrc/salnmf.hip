@@ -50,6 +50,8 @@ struct salnmf_engine {
     int64_t N = 0, Np = 0, ntiles = 0;  // Np = 16 * ntiles: rows of the padded device layout
     int KS = 0;    // instantiated contraction depth (k-steps of 4) covering K
     int KP = 0;    // leading dimension of H on the device = 16 * ceil(KS / 4)
+    int KTM = 0;   // 16-wide signature tiles done on MFMA on the output side of G and U
+    int KR = 0;    // remainder columns (K - 16*KTM, <= 4) done on the VALU; 0 = none
     double* scratch = nullptr;  // compact staging buffer for layout conversion (lazily sized)
     size_t scratch_n = 0;
     int grid = 0;  // workgroups of the fused / forward kernels (one per CU)
@@ -81,25 +83,25 @@ static int pick_ks(int K) {
 
 // ------------------------------------------------------------------------------------ launches
 
+// (KS, KTM, KR) combinations that are instantiated; K -> combination in pick_geometry()
+#define SALNMF_GEOMETRIES(X) \
+    X(1, 1, 0) X(2, 1, 0) X(4, 1, 0) X(8, 2, 0) X(10, 3, 0) X(13, 3, 0) X(16, 4, 0) \
+    X(8, 1, 1) X(8, 1, 2) X(8, 1, 3) X(8, 1, 4)                                      \
+    X(10, 2, 1) X(10, 2, 2) X(10, 2, 3) X(10, 2, 4)                                  \
+    X(13, 3, 1) X(13, 3, 2) X(13, 3, 3) X(13, 3, 4)
+
 template <bool DO_G, bool DO_U, bool DO_STATS>
 static int launch_fused(salnmf_engine* e, const FusedParams& p) {
     dim3 g(e->grid), b(BLOCK);
-#define SALNMF_CASE(ks)                                                                   \
-    case ks:                                                                              \
-        hipLaunchKernelGGL((fused_kernel<ks, DO_G, DO_U, DO_STATS>), g, b, 0, e->stream, p); \
-        break;
-    switch (e->KS) {
-        SALNMF_CASE(1)
-        SALNMF_CASE(2)
-        SALNMF_CASE(4)
-        SALNMF_CASE(8)
-        SALNMF_CASE(10)
-        SALNMF_CASE(13)
-        SALNMF_CASE(16)
-        default:
-            return fail("no kernel instantiation for KS=%d", e->KS);
+    bool done = false;
+#define SALNMF_CASE(ks, ktm, kr)                                                                           \
+    if (!done && e->KS == ks && e->KTM == ktm && e->KR == kr) {                                            \
+        hipLaunchKernelGGL((fused_kernel<ks, ktm, kr, DO_G, DO_U, DO_STATS>), g, b, 0, e->stream, p);      \
+        done = true;                                                                                       \
     }
+    SALNMF_GEOMETRIES(SALNMF_CASE)
 #undef SALNMF_CASE
+    if (!done) return fail("no kernel instantiation for KS=%d KTM=%d KR=%d", e->KS, e->KTM, e->KR);
     HIPCK(hipGetLastError());
     return 0;
 }
@@ -242,6 +244,13 @@ int salnmf_create(int device, int n_features, int64_t n_samples, int n_signature
     e->Np = e->ntiles * 16;
     e->KS = pick_ks(n_signatures);
     e->KP = 16 * ((e->KS + 3) / 4);
+    // output-side split: full MFMA tiles + up to 4 remainder columns on the VALU (K >= 17 only)
+    e->KTM = (n_signatures + 15) / 16;
+    e->KR = 0;
+    if (n_signatures > 16 && n_signatures % 16 >= 1 && n_signatures % 16 <= 4) {
+        e->KTM = n_signatures / 16;
+        e->KR = n_signatures % 16;
+    }
     int64_t wg_needed = (e->ntiles + WAVES - 1) / WAVES;
     e->grid = (int)std::min<int64_t>(prop.multiProcessorCount, wg_needed);
     const size_t K = e->K, V = e->V, Np = e->Np, KP = e->KP;
@@ -614,16 +623,25 @@ static int ensure_events(salnmf_engine* e, size_t n) {
     return 0;
 }
 
-int salnmf_profile_kl_steps(salnmf_engine* e, int n_steps, int n_given, double* total_ms, double* fused_avg_ms,
-                            double* tail_avg_ms) {
+int salnmf_profile_kl_steps(salnmf_engine* e, int n_steps, int n_given, int sample_stride, double* total_ms,
+                            double* fused_avg_ms, double* tail_avg_ms) {
     if (!e) return fail("null engine");
-    if (n_steps < 1 || n_steps > 100000) return fail("n_steps out of range");
+    if (n_steps < 1 || n_steps > 1000000) return fail("n_steps out of range");
+    if (sample_stride < 1) sample_stride = 1;
     HIPCK(hipSetDevice(e->device));
-    CK(ensure_events(e, (size_t)3 * n_steps));
-    for (int i = 0; i < n_steps; ++i) CK(kl_step_once(e, n_given, &e->events[3 * (size_t)i]));
+    const int n_samples = (n_steps + sample_stride - 1) / sample_stride;
+    CK(ensure_events(e, (size_t)3 * n_samples + 2));
+    hipEvent_t first = e->events[3 * (size_t)n_samples], last = e->events[3 * (size_t)n_samples + 1];
+    HIPCK(hipEventRecord(first, e->stream));
+    for (int i = 0; i < n_steps; ++i) {
+        // events are recorded around every sample_stride-th step only: each record costs a few us on the stream
+        hipEvent_t* ev = (i % sample_stride == 0) ? &e->events[3 * (size_t)(i / sample_stride)] : nullptr;
+        CK(kl_step_once(e, n_given, ev));
+    }
+    HIPCK(hipEventRecord(last, e->stream));
     HIPCK(hipStreamSynchronize(e->stream));
     double fused = 0, tail = 0;
-    for (int i = 0; i < n_steps; ++i) {
+    for (int i = 0; i < n_samples; ++i) {
         float a = 0, b = 0;
         HIPCK(hipEventElapsedTime(&a, e->events[3 * (size_t)i], e->events[3 * (size_t)i + 1]));
         HIPCK(hipEventElapsedTime(&b, e->events[3 * (size_t)i + 1], e->events[3 * (size_t)i + 2]));
@@ -631,10 +649,10 @@ int salnmf_profile_kl_steps(salnmf_engine* e, int n_steps, int n_given, double* 
         tail += b;
     }
     float tot = 0;
-    HIPCK(hipEventElapsedTime(&tot, e->events[0], e->events[3 * (size_t)n_steps - 1]));
+    HIPCK(hipEventElapsedTime(&tot, first, last));
     if (total_ms) *total_ms = tot;
-    if (fused_avg_ms) *fused_avg_ms = fused / n_steps;
-    if (tail_avg_ms) *tail_avg_ms = tail / n_steps;
+    if (fused_avg_ms) *fused_avg_ms = fused / n_samples;
+    if (tail_avg_ms) *tail_avg_ms = tail / n_samples;
     return 0;
 }
 

@@ -31,6 +31,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace salnmf {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -52,6 +54,39 @@ __device__ __forceinline__ d4 mfma(double a, double b, d4 c) {
 // MFMA-operand-read wait states, which hipcc does not insert inside an asm statement.
 __device__ __forceinline__ void mfma_agpr(d4& c, double a, double b) {
     asm("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+
+// x / p for the path's operands.  Same FMA sequence as hipcc's IEEE fp64 divide (reciprocal, two
+// Newton steps, residual correction) without its range-scaling / fix-up instructions, which only
+// act on operands outside ~[1e-280, 1e280].  Bit-identical to `x / p` on 16.7 M probes covering
+// counts, clipped zeros, 1e-30..1e30 ratios and x = 0 (tools/div_probe.hip); the parity tests pin it.
+__device__ __forceinline__ double div_path(double x, double p) {
+    double r = __builtin_amdgcn_rcp(p);
+    double e = __builtin_fma(-p, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-p, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    double q = x * r;
+    double rem = __builtin_fma(-p, q, x);
+    return __builtin_fma(rem, r, q);
+}
+
+// Exchange with lane (c16 ^ M) inside each row of 16 lanes, M in {8, 4, 2, 1}: DPP moves only
+// (VALU, no LDS round trip).  xor 8 = row_ror:8, xor 4 = row_half_mirror then quad_perm[3,2,1,0],
+// xor 2 = quad_perm[2,3,0,1], xor 1 = quad_perm[1,0,3,2].
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int M>
+__device__ __forceinline__ double xor16(double v) {
+    if (M == 8) return dpp_f64<0x128>(v);
+    if (M == 4) return dpp_f64<0x1B>(dpp_f64<0x141>(v));
+    if (M == 2) return dpp_f64<0x4E>(v);
+    return dpp_f64<0xB1>(v);
 }
 
 template <int KS>
@@ -120,10 +155,18 @@ __device__ __forceinline__ void stage_W(double* Wl, const double* __restrict__ W
 // the whole kernel (inline-asm MFMA with "a" operands), everything else in <= 256 VGPRs.
 // LDS operand reads are software-pipelined one k-step ahead of the MFMAs that consume them;
 // sched_barrier(0) pins that order.
-template <int KS, bool DO_G, bool DO_U, bool DO_STATS>
+//
+// Output-side signature columns: KTM full 16-wide tiles go through MFMA; KR (0..4) remainder
+// columns k = 16*KTM + j are done on the VALU instead of spending a whole MFMA tile on them
+// (K = 50: KTM = 3, KR = 2 -- 222 instead of 270 MFMAs per tile).  KR = 0: KTM = ceil(K/16).
+template <int KS, int KTM, int KR, bool DO_G, bool DO_U, bool DO_STATS>
 __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
     using G_ = Geo<KS>;
-    constexpr int KT = G_::KT, KP = G_::KP, LS = G_::LS, HV = G_::HV;
+    constexpr int KT = KTM;  // MFMA tiles on the output side
+    constexpr int KP = G_::KP, LS = G_::LS, HV = G_::HV;
+    constexpr int KB = 16 * KTM;                                   // first remainder column
+    constexpr int NVP = KR == 0 ? 0 : (KR == 1 ? 4 : (KR == 2 ? 8 : 16));  // 4*KR values, padded to a power of two
+    static_assert(KR >= 0 && KR <= 4 && KB + KR <= KP, "remainder columns must fit the padded layout");
     __shared__ __attribute__((aligned(16))) double lds[G_::LDS_DOUBLES];
 
     const int tid = threadIdx.x;
@@ -147,6 +190,13 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
             for (int vt = 0; vt < VT; ++vt) g[kt][vt] = (d4){0, 0, 0, 0};
+    }
+    double grem[KR > 0 ? KR : 1][VT];  // remainder rows of G: per-lane partials over this lane's sample rows
+    if (DO_G && KR > 0) {
+#pragma unroll
+        for (int j = 0; j < KR; ++j)
+#pragma unroll
+            for (int vt = 0; vt < VT; ++vt) grem[j][vt] = 0.0;
     }
     d2 hsum[HV];
     double klacc = 0.0;
@@ -209,21 +259,20 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         {
             const double* ha = Hl + c16 * LS + q;
             const double* wb = Wl + q * WS + c16;
-            double a[KS];
-#pragma unroll
-            for (int s = 0; s < KS; ++s) a[s] = ha[4 * s];
-            double b[2][VT];
+            double a[2], b[2][VT];
+            a[0] = ha[0];
 #pragma unroll
             for (int vt = 0; vt < VT; ++vt) b[0][vt] = wb[16 * vt];
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 if (s + 1 < KS) {
+                    a[(s + 1) & 1] = ha[4 * (s + 1)];
 #pragma unroll
                     for (int vt = 0; vt < VT; ++vt) b[(s + 1) & 1][vt] = wb[4 * (s + 1) * WS + 16 * vt];
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int vt = 0; vt < VT; ++vt) pr[vt] = mfma(a[s], b[s & 1][vt], pr[vt]);
+                for (int vt = 0; vt < VT; ++vt) pr[vt] = mfma(a[s & 1], b[s & 1][vt], pr[vt]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -249,7 +298,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
                     bool valid = (n0 + q + 4 * r < N) && (16 * vt + c16 < V);
                     klacc += valid ? kl_term(xv, pv) : 0.0;
                 }
-                pr[vt][r] = xv / pv;
+                pr[vt][r] = div_path(xv, pv);
             }
 
         if (DO_U) {
@@ -276,6 +325,39 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
                 for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
                     for (int vt = 0; vt < VT; ++vt) mfma_agpr(g[kt][vt], ga[r][kt], pr[vt][r]);
+            if (KR > 0) {
+                // remainder rows: G[KB+j][v] += sum over this lane's rows n = q+4r of H[n][KB+j] * R[n][v]
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double wk = p.wkl ? p.wkl[n0 + 4 * r + q] : 1.0;
+#pragma unroll
+                    for (int j = 0; j < KR; ++j) {
+                        double hv = Hl[(4 * r + q) * LS + KB + j];
+                        if (p.wkl) hv *= wk;
+#pragma unroll
+                        for (int vt = 0; vt < VT; ++vt) grem[j][vt] = __builtin_fma(hv, pr[vt][r], grem[j][vt]);
+                    }
+                }
+            }
+        }
+        // remainder columns of U: per-lane partial dot products over this lane's 6 feature columns
+        double urem[NVP > 0 ? NVP : 1];
+        if (DO_U && KR > 0) {
+#pragma unroll
+            for (int i = 0; i < NVP; ++i) urem[i] = 0.0;
+#pragma unroll
+            for (int j = 0; j < KR; ++j) {
+                double wj[VT];
+#pragma unroll
+                for (int vt = 0; vt < VT; ++vt) wj[vt] = Wl[(KB + j) * WS + 16 * vt + c16];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int vt = 0; vt < VT; ++vt) s = __builtin_fma(pr[vt][r], wj[vt], s);
+                    urem[4 * j + r] = s;
+                }
+            }
         }
         __builtin_amdgcn_wave_barrier();
 
@@ -293,6 +375,26 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt) hcur[r][kt] = Hl[(q + 4 * r) * LS + 16 * kt + c16];
+            // Reduce-scatter of the NVP remainder partials over the 16 lanes that share q: every
+            // stage halves the live values; afterwards lane c16 holds the complete
+            // U[n = q+4r][k = KB+j] for (j, r) = (rs_idx >> 2, rs_idx & 3).
+            auto rs_stage = [&](auto mtag, auto livetag) __attribute__((always_inline)) {
+                constexpr int M = decltype(mtag)::value, LIVE = decltype(livetag)::value;
+                if (LIVE > 1) {
+                    constexpr int half = LIVE / 2;
+                    const bool upper = (c16 & M) != 0;
+#pragma unroll
+                    for (int i = 0; i < half; ++i) {
+                        double send = upper ? urem[i] : urem[i + half];
+                        double keep = upper ? urem[i + half] : urem[i];
+                        urem[i] = keep + xor16<M>(send);
+                    }
+                } else {
+                    urem[0] += xor16<M>(urem[0]);
+                }
+            };
+            // value index owned by this lane after the stages: the c16 bits consumed by halving stages
+            const int rs_idx = NVP == 16 ? c16 : (NVP == 8 ? (c16 >> 1) : (c16 >> 2));
             const double* ra = Rl + c16 * RS + q;
             const double* wb = Wl + c16 * WS + q;
             double a[2], b[2][KT];
@@ -309,6 +411,15 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt) u[kt] = mfma(a[s & 1], b[s & 1][kt], u[kt]);
+                if (KR > 0) {
+                    // one butterfly stage of the remainder reduce-scatter per marked step: its
+                    // DPP moves / selects issue in the shadow of this step's MFMAs
+                    using std::integral_constant;
+                    if (s == 2) rs_stage(integral_constant<int, 8>{}, integral_constant<int, NVP>{});
+                    if (s == 7) rs_stage(integral_constant<int, 4>{}, integral_constant<int, (NVP / 2 > 1 ? NVP / 2 : 1)>{});
+                    if (s == 12) rs_stage(integral_constant<int, 2>{}, integral_constant<int, (NVP / 4 > 1 ? NVP / 4 : 1)>{});
+                    if (s == 17) rs_stage(integral_constant<int, 1>{}, integral_constant<int, (NVP / 8 > 1 ? NVP / 8 : 1)>{});
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             // ---- H update (_utils_klnmf.py:343-361), rows n = q+4r, columns k = 16kt+c16.
@@ -338,6 +449,30 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
                     }
                 }
             }
+            if (KR > 0) {
+                const int j = rs_idx >> 2, r = rs_idx & 3;
+                // one owner lane per (j, r): the lanes whose untouched low bits of c16 are zero
+                const int lowmask = NVP == 16 ? 0 : (NVP == 8 ? 1 : 3);
+                if (j < KR && (c16 & lowmask) == 0) {
+                    const int64_t n = n0 + q + 4 * r;
+                    const double h = Hl[(q + 4 * r) * LS + KB + j];
+                    double hn;
+                    if (p.wlh == nullptr) {
+                        hn = h * urem[0];
+                    } else {
+                        const double wl = p.wlh[n];
+                        double wk2 = 1.0;
+                        if (p.wkl) { double w = p.wkl[n]; wk2 = w * w; }
+                        double inter = 4.0 * h * urem[0];
+                        if (p.wkl) inter *= wk2;
+                        double disc = 0.25 * wl * wl + inter;
+                        double t = wl / 2 - sqrt(disc);
+                        hn = 0.25 * (t * t);
+                        if (p.wkl) hn /= wk2;
+                    }
+                    p.H[n * KP + KB + j] = fmax(hn, kEps);
+                }
+            }
         }
     };
 
@@ -356,7 +491,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         // Cross-wave sum through LDS (all of it is free now), fixed order (wave 0 + 1 + 2 + 3).
         // Two rounds of VT/2 feature tiles each, so that every wave has a private slot of
         // [16*KT][HW] doubles: plain unmasked stores, no read-modify-write chains.
-        constexpr int HT = VT / 2, HW = 16 * HT, SLOT = 16 * KT * HW;
+        constexpr int HT = VT / 2, HW = 16 * HT, SLOT = (16 * KT + (KR > 0 ? 16 : 0)) * HW;
         static_assert(WAVES * SLOT <= G_::LDS_DOUBLES, "reduction slots must fit in LDS");
         double* out = p.Gpart + (int64_t)blockIdx.x * K * V;
 #pragma unroll
@@ -369,6 +504,17 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         mine[(16 * kt + q + 4 * r) * HW + 16 * h + c16] = g[kt][half * HT + h][r];
+            if (KR > 0) {
+#pragma unroll
+                for (int j = 0; j < KR; ++j)
+#pragma unroll
+                    for (int h = 0; h < HT; ++h) {
+                        double t = grem[j][half * HT + h];  // sum the four q groups (lanes l, l^16, l^32, l^48)
+                        t += __shfl_xor(t, 16, 64);
+                        t += __shfl_xor(t, 32, 64);
+                        if (q == 0) mine[(KB + j) * HW + 16 * h + c16] = t;
+                    }
+            }
             __syncthreads();
             for (int i = tid; i < K * HW; i += BLOCK) {
                 int k = i / HW, vv = i - k * HW;

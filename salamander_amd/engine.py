@@ -151,12 +151,14 @@ class Engine:
         _lib.check(self._lib.salnmf_sync(self._h))
 
     # -- measurement
-    def profile_kl_steps(self, n_steps: int, n_given: int = 0):
-        """Run ``n_steps`` joint steps; returns (total_ms, fused_kernel_avg_ms, tail_avg_ms) from HIP events."""
+    def profile_kl_steps(self, n_steps: int, n_given: int = 0, sample_stride: int = 8):
+        """Run ``n_steps`` joint steps with HIP events around every ``sample_stride``-th step's launches.
+
+        Returns (total_ms, fused_kernel_avg_ms, tail_avg_ms)."""
         t, f, w = c_double(), c_double(), c_double()
         _lib.check(
             self._lib.salnmf_profile_kl_steps(
-                self._h, int(n_steps), int(n_given), ctypes.byref(t), ctypes.byref(f), ctypes.byref(w)
+                self._h, int(n_steps), int(n_given), int(sample_stride), ctypes.byref(t), ctypes.byref(f), ctypes.byref(w)
             )
         )
         return t.value, f.value, w.value

@@ -39,8 +39,8 @@ int main(int argc, char** argv) {
         double fl = flops_per_elem * V * K * N;
         printf("%-28s avg %.1f us  best %.1f us  -> %.1f TF/s algorithmic (%.1f%% of 78.6)\n", name, sum / reps * 1e3, best * 1e3, fl / (best * 1e-3) / 1e12, fl / (best * 1e-3) / 1e12 / 78.6 * 100);
     };
-    run("fused G+U", fused_kernel<KSV, true, true, false>, 6);
-    run("fused U only", fused_kernel<KSV, false, true, false>, 4);
-    run("fused G only", fused_kernel<KSV, true, false, false>, 4);
+    run("fused G+U", fused_kernel<KSV, 3, 2, true, true, false>, 6);
+    run("fused U only", fused_kernel<KSV, 3, 2, false, true, false>, 4);
+    run("fused G only", fused_kernel<KSV, 3, 2, true, false, false>, 4);
     return 0;
 }

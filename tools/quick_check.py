@@ -58,6 +58,6 @@ V, N, K = 96, 100000, 50
 X, W0, H0 = orc.synthetic_problem(V, N, K, seed=0)
 e = Engine(N, V, K); e.upload_X(X); e.upload_W(W0); e.upload_H(H0)
 e.kl_step(5); e.sync()
-tot, fused, tail = e.profile_kl_steps(50)
+tot, fused, tail = e.profile_kl_steps(50, 0, 1)
 print(f"c2: total {tot/50*1e3:.1f} us/step, fused kernel {fused*1e3:.1f} us, tail {tail*1e3:.1f} us; fused MFMA-roofline frac = {6*V*K*N/(fused*1e-3)/78.6e12:.3f}")
 print(f"forward+objective kernel: {e.profile_objective(20)*1e3:.1f} us -> W@H frac = {2*V*K*N/(e.profile_objective(20)*1e-3)/78.6e12:.3f}")
