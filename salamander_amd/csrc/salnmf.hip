@@ -54,7 +54,8 @@ struct salnmf_engine {
     int KR = 0;    // remainder columns (K - 16*KTM, <= 4) done on the VALU; 0 = none
     double* scratch = nullptr;  // compact staging buffer for layout conversion (lazily sized)
     size_t scratch_n = 0;
-    int grid = 0;  // workgroups of the fused / forward kernels (one per CU)
+    int grid = 0;   // workgroups of the fused kernel (one per CU)
+    int fgrid = 0;  // workgroups of the forward kernels (two per CU)
     hipStream_t stream = nullptr;
     double *X = nullptr, *H = nullptr, *W = nullptr, *wkl = nullptr, *wlh = nullptr;
     double* Gpart = nullptr;     // [grid][K][V]
@@ -108,7 +109,7 @@ static int launch_fused(salnmf_engine* e, const FusedParams& p) {
 
 template <int MODE>
 static int launch_forward(salnmf_engine* e, const FwdParams& p) {
-    dim3 g(e->grid), b(BLOCK);
+    dim3 g(e->fgrid), b(BLOCK);
 #define SALNMF_CASE(ks)                                                        \
     case ks:                                                                   \
         hipLaunchKernelGGL((forward_kernel<ks, MODE>), g, b, 0, e->stream, p); \
@@ -253,6 +254,7 @@ int salnmf_create(int device, int n_features, int64_t n_samples, int n_signature
     }
     int64_t wg_needed = (e->ntiles + WAVES - 1) / WAVES;
     e->grid = (int)std::min<int64_t>(prop.multiProcessorCount, wg_needed);
+    e->fgrid = (int)std::min<int64_t>(2 * prop.multiProcessorCount, wg_needed);
     const size_t K = e->K, V = e->V, Np = e->Np, KP = e->KP;
     auto cleanup = [&](int rc) {
         salnmf_destroy(e);
@@ -268,7 +270,7 @@ int salnmf_create(int device, int n_features, int64_t n_samples, int n_signature
     ALLOC(e->Hsumpart, (size_t)e->grid * K);
     ALLOC(e->KLpart, (size_t)e->grid);
     ALLOC(e->red, K * V + K + 2);
-    ALLOC(e->objpart, (size_t)e->grid);
+    ALLOC(e->objpart, (size_t)e->fgrid);
     ALLOC(e->scal, 8);
     ALLOC(e->Wunc, K * V);
     ALLOC(e->Wtrial, K * V);
@@ -436,7 +438,7 @@ static int objective_to_slot(salnmf_engine* e, const double* W, const double* hs
         p.wlh = nullptr;
     }
     CK(launch_forward<0>(e, p));
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, e->stream, e->objpart, e->grid, 1, 1, e->scal + slot);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, e->stream, e->objpart, e->fgrid, 1, 1, e->scal + slot);
     HIPCK(hipGetLastError());
     return allreduce(e, e->scal + slot, 1);
 }

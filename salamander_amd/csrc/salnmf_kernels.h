@@ -117,13 +117,45 @@ struct FusedParams {
     int64_t ntiles;
 };
 
-// natural log for the objective terms
+// log(x / p) for positive normal x, p with ONE division and no library call (the objective
+// kernels are bound by fp64 VALU work, which shares the pipe with the MFMAs).
+//   k  = round(log2(x/p)) estimated from the exponent/mantissa bits (integer ops only)
+//   p' = p * 2^k (exponent-field add), so x/p' lies in about [0.67, 1.50]
+//   s  = (x - p') / (x + p')      x - p' is exact (Sterbenz)
+//   log(x/p) = k ln2 + log((1+s)/(1-s)) = k ln2 + 2s + s R(s^2), R fitted for this range
+// Measured against a long-double reference (tools/log_probe.hip): abs error <= 2e-14 over
+// |log| <= 460, relative error <= 1e-15 away from ratio = 1 and better than log(fl(x/p)) near it.
+// Callers guarantee the operands are in range with log_operand_ok().
+__device__ __forceinline__ bool log_operand_ok(double v) {
+    // positive, normal, and far enough from the ends of the exponent range for the p * 2^k trick
+    return (unsigned)(__double2hiint(v) - 0x03D00000) < (unsigned)(0x7C200000 - 0x03D00000);
+}
+__device__ __forceinline__ double log_ratio(double x, double p) {
+    const int hx = __double2hiint(x), hp = __double2hiint(p);
+    const int k = (hx - hp + 0x80000) >> 20;
+    const double ps = __hiloint2double(hp + (k << 20), __double2loint(p));  // p * 2^k
+    const double s = div_path(x - ps, x + ps);
+    // R(z)/z: 8-coefficient Chebyshev fit of sum 2/(2i+3) z^i on z in [0, 0.041] (|s| <= 0.2025, the
+    // range the integer estimate of k leaves); max error 3.1e-17, i.e. < 3e-19 on the logarithm
+    const double z = s * s, w = z * z;
+    const double t1 = __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, 0.1365426141372305, 0.15389174135906675), 0.22222223148322984), 0.40000000000009306);
+    const double t2 = __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, 0.1320375159044889, 0.18181729869745253), 0.2857142856666864), 0.6666666666666666);
+    const double R = z * __builtin_fma(z, t1, t2);
+    const double kd = (double)k;
+    double t = __builtin_fma(kd, 1.90821492927058770002e-10, s * R);  // kd*ln2_hi + (2s + (s*R + kd*ln2_lo))
+    t = __builtin_fma(2.0, s, t);
+    return __builtin_fma(kd, 6.93147180369123816490e-01, t);
+}
+
+// one entry of the generalised KL divergence, any operands (library log)
 __device__ __forceinline__ double kl_term(double x, double p) {
     // _utils_klnmf.py:47-50: entries with X == 0 contribute only WH
     double t = p;
     if (x != 0.0) t += x * log(x / p) - x;
     return t;
 }
+// the same for operands that passed log_operand_ok()
+__device__ __forceinline__ double kl_term_fast(double x, double p) { return __builtin_fma(x, log_ratio(x, p), p - x); }
 
 // W -> LDS with the padding described at the top of the file.  All loads in flight together.
 template <int WROWS>
@@ -142,6 +174,52 @@ __device__ __forceinline__ void stage_W(double* Wl, const double* __restrict__ W
         int k = idx / VMAX, v = idx - k * VMAX;
         if (k < WROWS) Wl[k * WS + v] = wreg[j];
     }
+}
+
+// Sum over one tile (accumulator layout: rows n = q+4r, columns v = 16vt+c16) of the per-sample
+// weighted KL terms.  Entries outside [0,N) x [0,V) are skipped.  If every valid operand of the
+// wave passes log_operand_ok() -- always the case inside fit(), where X >= EPS -- the terms go
+// through the division-fused log_ratio; otherwise (zeros in X through the function-level API,
+// denormals) the whole tile takes the library path.
+__device__ __forceinline__ double tile_kl(const double (&x)[VT][4], const d4 (&pr)[VT], const double* __restrict__ wrow,
+                                          int64_t n0, int64_t N, int V, int q, int c16) {
+    bool ok = true;
+#pragma unroll
+    for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool valid = (n0 + q + 4 * r < N) && (16 * vt + c16 < V);
+            ok &= !valid || (log_operand_ok(x[vt][r]) && log_operand_ok(pr[vt][r]));
+        }
+    double total = 0.0;
+    if (__all(ok)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool nvalid = n0 + q + 4 * r < N;
+            double acc = 0.0;
+#pragma unroll
+            for (int vt = 0; vt < VT; ++vt) {
+                const bool valid = nvalid && (16 * vt + c16 < V);
+                const double xs = valid ? x[vt][r] : 1.0, ps = valid ? pr[vt][r] : 1.0;  // pads: harmless operands
+                const double t = kl_term_fast(xs, ps);
+                acc += valid ? t : 0.0;
+            }
+            if (wrow) acc *= wrow[n0 + q + 4 * r];
+            total += acc;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool nvalid = n0 + q + 4 * r < N;
+            double acc = 0.0;
+#pragma unroll
+            for (int vt = 0; vt < VT; ++vt)
+                if (nvalid && 16 * vt + c16 < V) acc += kl_term(x[vt][r], pr[vt][r]);
+            if (wrow) acc *= wrow[n0 + q + 4 * r];
+            total += acc;
+        }
+    }
+    return total;
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -288,18 +366,12 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
             }
         }
 
+        if (DO_STATS) klacc += tile_kl(x, pr, nullptr, n0, N, V, q, c16);
         // ---- R = X / P in place (rows n = q + 4r, columns v = 16vt + c16); pads give 0 / P = 0
 #pragma unroll
         for (int vt = 0; vt < VT; ++vt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double xv = x[vt][r], pv = pr[vt][r];
-                if (DO_STATS) {
-                    bool valid = (n0 + q + 4 * r < N) && (16 * vt + c16 < V);
-                    klacc += valid ? kl_term(xv, pv) : 0.0;
-                }
-                pr[vt][r] = div_path(xv, pv);
-            }
+            for (int r = 0; r < 4; ++r) pr[vt][r] = div_path(x[vt][r], pr[vt][r]);
 
         if (DO_U) {
             // ---- transpose R through LDS: write accumulator layout, read A-operand layout
@@ -576,11 +648,18 @@ struct FwdParams {
     int64_t ntiles;
 };
 
+// Two workgroups per CU (two waves per SIMD): the objective terms are VALU-heavy and the loads
+// are not software-pipelined here, so the second wave hides the first one's memory latency.
+// Only the 4*KS rows of W that the contraction touches are staged, which keeps LDS <= 80 KB.
+template <int KS>
+constexpr int fwd_lds_doubles() { return 4 * KS * WS + WAVES * Geo<KS>::HL + BLOCK; }
+
 template <int KS, int MODE>
-__global__ void __launch_bounds__(BLOCK, 1) forward_kernel(FwdParams p) {
+__global__ void __launch_bounds__(BLOCK, (fwd_lds_doubles<KS>() * 8 <= 80 * 1024 ? 2 : 1)) forward_kernel(FwdParams p) {
     using G_ = Geo<KS>;
     constexpr int KP = G_::KP, LS = G_::LS, HV = G_::HV;
-    __shared__ __attribute__((aligned(16))) double lds[G_::WROWS * WS + WAVES * G_::HL + BLOCK];
+    constexpr int FROWS = 4 * KS;  // rows of W read by the P product
+    __shared__ __attribute__((aligned(16))) double lds[fwd_lds_doubles<KS>()];  // <= 80 KB (two per CU) up to KS = 13
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -591,10 +670,10 @@ __global__ void __launch_bounds__(BLOCK, 1) forward_kernel(FwdParams p) {
     const int64_t N = p.N;
 
     double* Wl = lds;
-    double* Hl = lds + G_::WROWS * WS + wave * G_::HL;
-    double* red = lds + G_::WROWS * WS + WAVES * G_::HL;
+    double* Hl = lds + FROWS * WS + wave * G_::HL;
+    double* red = lds + FROWS * WS + WAVES * G_::HL;
 
-    stage_W<G_::WROWS>(Wl, p.W, K, V, tid);
+    stage_W<FROWS>(Wl, p.W, K, V, tid);
     __syncthreads();
 
     int hrow[HV], hcol[HV];
@@ -654,18 +733,7 @@ __global__ void __launch_bounds__(BLOCK, 1) forward_kernel(FwdParams p) {
         }
 
         if (MODE == 0) {
-            double tsum = pen;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int64_t n = n0 + q + 4 * r;
-                double acc = 0.0;
-#pragma unroll
-                for (int vt = 0; vt < VT; ++vt)
-                    if (n < N && 16 * vt + c16 < V) acc += kl_term(x[vt][r], pr[vt][r]);
-                if (p.wkl) acc *= p.wkl[n];
-                tsum += acc;
-            }
-            total += tsum;
+            total += pen + tile_kl(x, pr, p.wkl, n0, N, V, q, c16);
         } else if (MODE == 1) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -676,7 +744,8 @@ __global__ void __launch_bounds__(BLOCK, 1) forward_kernel(FwdParams p) {
                     if (n < N && 16 * vt + c16 < V) {
                         double xv = x[vt][r], pv = pr[vt][r];
                         double xe = (xv == 0.0) ? kEps : xv, pe = (xv == 0.0) ? kEps : pv;
-                        acc += xe * log(xe / pe) - xv + pv;
+                        double l = (log_operand_ok(xe) && log_operand_ok(pe)) ? log_ratio(xe, pe) : log(xe / pe);
+                        acc += xe * l - xv + pv;
                     }
                 // reduce over the 16 lanes that share this sample row (same q)
 #pragma unroll
