@@ -438,7 +438,7 @@ static int objective_to_slot(salnmf_engine* e, const double* W, const double* hs
         p.wlh = nullptr;
     }
     CK(launch_forward<0>(e, p));
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, e->stream, e->objpart, e->fgrid, 1, 1, e->scal + slot);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, e->objpart, e->fgrid, 1, 1, e->scal + slot);
     HIPCK(hipGetLastError());
     return allreduce(e, e->scal + slot, 1);
 }
@@ -505,17 +505,23 @@ int salnmf_mv_objective(salnmf_engine* e, double lam, double delta, double* out)
 }
 
 // MvNMF._update_W (mvnmf.py:190-195) on the current (W, H)
-static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double delta, double* gamma) {
+static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double delta, double* gamma, bool have_hsum) {
     if (n_given >= e->K) return 0;
     const int K = e->K, V = e->V;
-    // pass over the shard: G = (X/(WH)) @ H.T partials, rowsums_H partials, KL partial
+    // pass over the shard: G = (X/(WH)) @ H.T partials and the KL partial; the rowsums_H partials
+    // come from the preceding update_H pass (have_hsum) or, for a stand-alone _update_W, from a
+    // column-sum kernel over the current H
     FusedParams p = fused_params(e);
     p.wkl = nullptr;  // the MvNMF path is unweighted (mvnmf.py:56)
     p.wlh = nullptr;
     CK((launch_fused<true, false, true>(e, p)));
     CK(launch_tail(e, e->grid, e->red, 0, 0, 0));
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, e->stream, e->Hsumpart, e->grid, K, K, e->red + K * V);
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, e->stream, e->KLpart, e->grid, 1, 1, e->red + K * V + K);
+    if (have_hsum) {
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(K), dim3(256), 0, e->stream, e->Hsumpart, e->grid, K, K, e->red + K * V);
+    } else {
+        hipLaunchKernelGGL(colsum_kernel, dim3(K), dim3(256), 0, e->stream, e->H, e->N, e->KP, e->red + K * V);
+    }
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, e->KLpart, e->grid, 1, 1, e->red + K * V + K);
     HIPCK(hipGetLastError());
     CK(allreduce(e, e->red, (size_t)K * V + K + 1));
     // W_unconstrained and log det(W^T W + delta I); f0 = KL + lam * logdet -> scal[1]
@@ -551,7 +557,7 @@ static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double de
 int salnmf_mv_update_W(salnmf_engine* e, int n_given, double lam, double delta, double* gamma_inout) {
     if (!e || !gamma_inout) return fail("null argument");
     HIPCK(hipSetDevice(e->device));
-    return mv_update_W_impl(e, n_given, lam, delta, gamma_inout);
+    return mv_update_W_impl(e, n_given, lam, delta, gamma_inout, false);
 }
 
 int salnmf_mv_step(salnmf_engine* e, int n_steps, int n_given, double lam, double delta, double* gamma_inout) {
@@ -562,8 +568,8 @@ int salnmf_mv_step(salnmf_engine* e, int n_steps, int n_given, double lam, doubl
         FusedParams p = fused_params(e);
         p.wkl = nullptr;  // MvNMF._update_H passes no weights (mvnmf.py:162-165)
         p.wlh = nullptr;
-        CK((launch_fused<false, true, false>(e, p)));
-        CK(mv_update_W_impl(e, n_given, lam, delta, gamma_inout));
+        CK((launch_fused<false, true, true>(e, p)));  // update_H + row sums of the new H
+        CK(mv_update_W_impl(e, n_given, lam, delta, gamma_inout, true));
     }
     return 0;
 }

@@ -226,8 +226,9 @@ __device__ __forceinline__ double tile_kl(const double (&x)[VT][4], const d4 (&p
 // Fused update pass.
 //   DO_G     accumulate G = (w_kl * R)^T-contracted numerator for the W update
 //   DO_U     update H in place
-//   DO_STATS also emit row sums of H (as read) and the unweighted KL(X || WH) partial
-//            (MvNMF: update_W_unconstrained + the f0 of its line search, mvnmf.py:54,79)
+//   DO_STATS MvNMF by-products: with DO_U the row sums of the *updated* H (rowsums_H of
+//            update_W_unconstrained, mvnmf.py:54); with DO_G the unweighted KL(X || WH) partial
+//            (the f0 of the line search, mvnmf.py:79)
 //
 // Register plan (one wave per SIMD, 512 registers): the K x V accumulator G lives in AGPRs for
 // the whole kernel (inline-asm MFMA with "a" operands), everything else in <= 256 VGPRs.
@@ -276,11 +277,12 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
 #pragma unroll
             for (int vt = 0; vt < VT; ++vt) grem[j][vt] = 0.0;
     }
-    d2 hsum[HV];
+    double hsum[KT > 0 ? KT : 1];  // column sums of the updated H over this lane's rows (columns 16kt+c16)
+    double hsum_rem = 0.0;         // same for the remainder column this lane owns
     double klacc = 0.0;
     if (DO_STATS) {
 #pragma unroll
-        for (int j = 0; j < HV; ++j) hsum[j] = (d2){0, 0};
+        for (int kt = 0; kt < KT; ++kt) hsum[kt] = 0.0;
     }
 
     const int64_t tstride = (int64_t)gridDim.x * WAVES;
@@ -324,9 +326,6 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
 #pragma unroll
         for (int j = 0; j < HV; ++j) {
             *reinterpret_cast<d2*>(Hl + hrow[j] * LS + hcol[j]) = hpre[j];
-            if (DO_STATS) {
-                if (n0 + hrow[j] < N) hsum[j] += hpre[j];
-            }
         }
         __builtin_amdgcn_wave_barrier();
 
@@ -366,7 +365,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
             }
         }
 
-        if (DO_STATS) klacc += tile_kl(x, pr, nullptr, n0, N, V, q, c16);
+        if (DO_STATS && DO_G) klacc += tile_kl(x, pr, nullptr, n0, N, V, q, c16);
         // ---- R = X / P in place (rows n = q + 4r, columns v = 16vt + c16); pads give 0 / P = 0
 #pragma unroll
         for (int vt = 0; vt < VT; ++vt)
@@ -501,7 +500,11 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int kt = 0; kt < KT; ++kt) hdst[4 * r * KP + 16 * kt] = fmax(hcur[r][kt] * u[kt][r], kEps);
+                    for (int kt = 0; kt < KT; ++kt) {
+                        const double hn = fmax(hcur[r][kt] * u[kt][r], kEps);
+                        hdst[4 * r * KP + 16 * kt] = hn;
+                        if (DO_STATS) hsum[kt] += (n0 + q + 4 * r < N) ? hn : 0.0;
+                    }
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -517,7 +520,9 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
                         double t = wl / 2 - sqrt(disc);
                         double hn = 0.25 * (t * t);
                         if (p.wkl) hn /= wk2;
-                        hdst[4 * r * KP + 16 * kt] = fmax(hn, kEps);
+                        hn = fmax(hn, kEps);
+                        hdst[4 * r * KP + 16 * kt] = hn;
+                        if (DO_STATS) hsum[kt] += (n < N) ? hn : 0.0;
                     }
                 }
             }
@@ -542,7 +547,9 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
                         hn = 0.25 * (t * t);
                         if (p.wkl) hn /= wk2;
                     }
-                    p.H[n * KP + KB + j] = fmax(hn, kEps);
+                    hn = fmax(hn, kEps);
+                    p.H[n * KP + KB + j] = hn;
+                    if (DO_STATS) hsum_rem += (n < N) ? hn : 0.0;
                 }
             }
         }
@@ -597,35 +604,41 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
             __syncthreads();
         }
     }
-    if (DO_STATS) {
+    if (DO_STATS && DO_U) {
         __syncthreads();
-        // row sums of H: lane-private pair sums hsum[j] belong to columns hcol[j], hcol[j]+1
-        double* S = lds;  // [BLOCK][HV*2] then reduced per column by one thread each
+        // column k = 16kt + c16 (or KB + j) of the updated H: sum the 4 waves x 4 q-groups in fixed order
+        double* S = lds;  // [16*KT + 16][16]: row = column index k, 16 slots = (wave, q)
 #pragma unroll
-        for (int j = 0; j < HV; ++j) {
-            S[(tid * HV + j) * 2] = hsum[j][0];
-            S[(tid * HV + j) * 2 + 1] = hsum[j][1];
+        for (int kt = 0; kt < KT; ++kt) S[(16 * kt + c16) * 16 + wave * 4 + q] = hsum[kt];
+        if (KR > 0) {
+            // owner lanes: value index idx = (j, r); sum the r's of one j inside the q-group first
+            const int idx = NVP == 16 ? c16 : (NVP == 8 ? (c16 >> 1) : (c16 >> 2));
+            const int lowmask = NVP == 16 ? 0 : (NVP == 8 ? 1 : 3);
+            const int j = idx >> 2;
+            for (int jj = 0; jj < KR; ++jj) {
+                double v = (j == jj && (c16 & lowmask) == 0) ? hsum_rem : 0.0;
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) v += __shfl_xor(v, m, 64);
+                if (c16 == 0) S[(KB + jj) * 16 + wave * 4 + q] = v;
+            }
         }
-        double* Ks = lds + BLOCK * HV * 2;  // [BLOCK]
-        Ks[tid] = klacc;
         __syncthreads();
         if (tid < K) {
-            double s = 0.0;
-            for (int t = 0; t < BLOCK; ++t) {
-                int l = t & 63;
-                for (int j = 0; j < HV; ++j) {
-                    int c = (2 * l + 128 * j) % KP;
-                    if (c == tid) s += S[(t * HV + j) * 2];
-                    else if (c + 1 == tid) s += S[(t * HV + j) * 2 + 1];
-                }
-            }
-            p.Hsumpart[(int64_t)blockIdx.x * K + tid] = s;
+            double t = 0.0;
+            for (int i = 0; i < 16; ++i) t += S[tid * 16 + i];
+            p.Hsumpart[(int64_t)blockIdx.x * K + tid] = t;
         }
-        if (tid == 0) {
-            double s = 0.0;
-            for (int i = 0; i < BLOCK; ++i) s += Ks[i];
-            p.KLpart[blockIdx.x] = s;
+    }
+    if (DO_STATS && DO_G) {
+        __syncthreads();
+        double* Ks = lds;  // [BLOCK], fixed binary tree
+        Ks[tid] = klacc;
+        __syncthreads();
+        for (int h = BLOCK / 2; h > 0; h >>= 1) {
+            if (tid < h) Ks[tid] += Ks[tid + h];
+            __syncthreads();
         }
+        if (tid == 0) p.KLpart[blockIdx.x] = Ks[0];
     }
 }
 
@@ -855,14 +868,38 @@ __global__ void __launch_bounds__(TAIL_BLOCK) tail_kernel(TailParams p) {
     }
 }
 
-// sum a vector of partials in fixed order: out[j] = sum_i part[i*stride + j], j < width
-__global__ void sum_partials_kernel(const double* __restrict__ part, int n, int stride, int width,
-                                    double* __restrict__ out) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
+// out[j] = sum_i part[i*stride + j], j < width: one workgroup per output, fixed summation order
+// (thread t adds rows t, t+256, ... in order; then a fixed binary tree over the 256 threads)
+__global__ void __launch_bounds__(256) sum_partials_kernel(const double* __restrict__ part, int n, int stride, int width,
+                                                           double* __restrict__ out) {
+    __shared__ double red[256];
+    const int j = blockIdx.x;
     if (j >= width) return;
     double s = 0.0;
-    for (int i = 0; i < n; ++i) s += part[(int64_t)i * stride + j];
-    out[j] = s;
+    for (int i = threadIdx.x; i < n; i += 256) s += part[(int64_t)i * stride + j];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[j] = red[0];
+}
+
+// out[k] = sum over rows n < N of H[n][k] (padded layout, leading dimension ldh): one workgroup per
+// column, fixed order (thread t adds rows t, t+256, ...; then a fixed binary tree)
+__global__ void __launch_bounds__(256) colsum_kernel(const double* __restrict__ H, int64_t N, int ldh, double* __restrict__ out) {
+    __shared__ double red[256];
+    const int k = blockIdx.x;
+    double s = 0.0;
+    for (int64_t n = threadIdx.x; n < N; n += 256) s += H[n * ldh + k];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[k] = red[0];
 }
 
 // H <- clip(H * scale[k]) on the padded layout (normalize_WH + clip of an accepted MvNMF trial,

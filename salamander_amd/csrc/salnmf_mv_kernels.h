@@ -26,29 +26,51 @@ __device__ inline void mv_gram(const double* Wl, double* S, int K, int V, double
     __syncthreads();
 }
 
-// in-place lower Cholesky of S; returns log det = 2 sum log L_ii (same value in every thread)
+// in-place lower Cholesky of S (K <= 64); returns log det = 2 sum log L_ii (same value in every
+// thread).  Left-looking, done by ONE wave in lockstep (lane i owns row i): at column j every lane
+// forms S[i][j] - sum_{m<j} L[i][m] L[j][m] from finished columns, lane j's value gives the pivot.
+// No workgroup barriers inside the column loop; LDS operations of one wave execute in order.
 __device__ inline double mv_cholesky_logdet(double* S, int K) {
-    for (int j = 0; j < K; ++j) {
-        if (threadIdx.x == 0) S[j * MV_LD + j] = sqrt(S[j * MV_LD + j]);
-        __syncthreads();
-        double d = S[j * MV_LD + j];
-        for (int i = j + 1 + threadIdx.x; i < K; i += MV_BLOCK) S[i * MV_LD + j] /= d;
-        __syncthreads();
-        for (int idx = threadIdx.x; idx < K * K; idx += MV_BLOCK) {
-            int i = idx / K, c = idx - i * K;
-            if (c > j && i >= c) S[i * MV_LD + c] -= S[i * MV_LD + j] * S[c * MV_LD + j];
+    __shared__ double ld_shared;
+    if (threadIdx.x < 64) {
+        const int i = threadIdx.x;
+        const int row = (i < K ? i : K - 1) * MV_LD;  // idle lanes shadow the last row (results discarded)
+        for (int j = 0; j < K; ++j) {
+            double dot = 0.0;
+            for (int m = 0; m < j; ++m) dot += S[row + m] * S[j * MV_LD + m];
+            const double v = S[row + j] - dot;
+            const double piv = sqrt(__shfl(v, j, 64));
+            if (i == j) S[row + j] = piv;
+            else if (i > j && i < K) S[row + j] = v / piv;
+            __builtin_amdgcn_wave_barrier();
         }
-        __syncthreads();
+        double l = (i < K) ? log(S[i * MV_LD + i]) : 0.0;
+        // fixed-order sum over the lanes
+        double tot = 0.0;
+        for (int j = 0; j < K; ++j) tot += __shfl(l, j, 64);
+        if (i == 0) ld_shared = 2.0 * tot;
     }
-    double ld = 0.0;
-    for (int j = 0; j < K; ++j) ld += log(S[j * MV_LD + j]);
-    return 2.0 * ld;
+    __syncthreads();
+    return ld_shared;
 }
 
+// compact W[K][V] (global) -> Wl[K][MV_VMAX] (LDS); all loads of a thread are issued before any use
 __device__ inline void mv_load_W(const double* __restrict__ W, double* Wl, int K, int V) {
-    for (int idx = threadIdx.x; idx < K * V; idx += MV_BLOCK) {
-        int k = idx / V, v = idx - k * V;
-        Wl[k * MV_VMAX + v] = W[idx];
+    constexpr int PT = (MV_KMAX * MV_VMAX + MV_BLOCK - 1) / MV_BLOCK;
+    double w[PT];
+    const int total = K * V;
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+        int idx = threadIdx.x + MV_BLOCK * j;
+        w[j] = idx < total ? W[idx] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+        int idx = threadIdx.x + MV_BLOCK * j;
+        if (idx < total) {
+            int k = idx / V, v = idx - k * V;
+            Wl[k * MV_VMAX + v] = w[j];
+        }
     }
     __syncthreads();
 }
@@ -123,11 +145,26 @@ __global__ void __launch_bounds__(MV_BLOCK)
     __shared__ double Wl[MV_KMAX * MV_VMAX];
     __shared__ double S[MV_KMAX * MV_LD];
     __shared__ double rs[MV_KMAX];
-    for (int idx = threadIdx.x; idx < K * V; idx += MV_BLOCK) {
-        int k = idx / V, v = idx - k * V;
-        double wt = Wunc[idx];
-        if (blend) wt = (1 - gamma) * W[idx] + gamma * wt;
-        Wl[k * MV_VMAX + v] = wt;
+    {
+        constexpr int PT = (MV_KMAX * MV_VMAX + MV_BLOCK - 1) / MV_BLOCK;
+        double a[PT], b[PT];
+        const int total = K * V;
+#pragma unroll
+        for (int j = 0; j < PT; ++j) {
+            int idx = threadIdx.x + MV_BLOCK * j;
+            a[j] = idx < total ? Wunc[idx] : 0.0;
+            b[j] = (blend && idx < total) ? W[idx] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < PT; ++j) {
+            int idx = threadIdx.x + MV_BLOCK * j;
+            if (idx < total) {
+                int k = idx / V, v = idx - k * V;
+                double wt = a[j];
+                if (blend) wt = (1 - gamma) * b[j] + gamma * wt;
+                Wl[k * MV_VMAX + v] = wt;
+            }
+        }
     }
     __syncthreads();
     for (int k = threadIdx.x; k < K; k += MV_BLOCK) {

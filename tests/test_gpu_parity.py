@@ -150,7 +150,9 @@ def test_golden_mvnmf(golden, tag):
     "V,N,K",
     [(96, 1, 1), (96, 15, 3), (96, 16, 4), (96, 17, 5), (96, 63, 8), (96, 64, 9), (96, 250, 16), (96, 1000, 17),
      (96, 999, 30), (96, 333, 33), (96, 1025, 40), (96, 777, 41), (96, 4099, 50), (96, 300, 52), (96, 301, 53),
-     (96, 500, 64), (83, 777, 30), (83, 200, 40), (7, 100, 2), (16, 40, 5)],
+     (96, 500, 64), (83, 777, 30), (83, 200, 40), (7, 100, 2), (16, 40, 5),
+     # more tiles than waves with a short leftover round: the cooperative kernel runs
+     (96, 17190, 50), (96, 17001, 30), (83, 17100, 34), (96, 16500, 64), (96, 16390, 20)],
 )
 def test_shapes_one_and_five_steps(V, N, K):
     X, W0, H0 = orc.synthetic_problem(V, N, K, seed=V + N + K)

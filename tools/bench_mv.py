@@ -1,7 +1,7 @@
 """Development aid: time MvNMF steps (config c4) and the objective kernels on the GPU."""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from oracle import klnmf_oracle as orc
 from salamander_amd import Engine
 V, N, K = 96, 100000, 30

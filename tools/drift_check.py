@@ -1,7 +1,7 @@
 """Development aid: drift of the GPU trajectory from the reference-generated golden trajectory."""
 import sys
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from salamander_amd import Engine
 def rel(a, b): return float(np.linalg.norm(a - b) / np.linalg.norm(b))
 g = np.load("tests/golden/kl_pcawg.npz")

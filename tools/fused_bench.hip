@@ -9,6 +9,8 @@ using namespace salnmf;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 #ifndef KSV
 #define KSV 13
+#define KTMV 3
+#define KRV 2
 #endif
 int main(int argc, char** argv) {
     int64_t N = argc > 1 ? atoll(argv[1]) : 100000;
@@ -39,8 +41,11 @@ int main(int argc, char** argv) {
         double fl = flops_per_elem * V * K * N;
         printf("%-28s avg %.1f us  best %.1f us  -> %.1f TF/s algorithmic (%.1f%% of 78.6)\n", name, sum / reps * 1e3, best * 1e3, fl / (best * 1e-3) / 1e12, fl / (best * 1e-3) / 1e12 / 78.6 * 100);
     };
-    run("fused G+U", fused_kernel<KSV, 3, 2, true, true, false>, 6);
-    run("fused U only", fused_kernel<KSV, 3, 2, false, true, false>, 4);
-    run("fused G only", fused_kernel<KSV, 3, 2, true, false, false>, 4);
+    run("fused G+U", fused_kernel<KSV, KTMV, KRV, true, true, false>, 6);
+    run("fused U only", fused_kernel<KSV, KTMV, KRV, false, true, false>, 4);
+    run("fused G only", fused_kernel<KSV, KTMV, KRV, true, false, false>, 4);
+    double *dHs, *dKL; CK(hipMalloc(&dHs, (size_t)grid * K * 8)); CK(hipMalloc(&dKL, grid * 8)); p.Hsumpart = dHs; p.KLpart = dKL;
+    run("fused G + KL stats (MvNMF)", fused_kernel<KSV, KTMV, KRV, true, false, true>, 4);
+    run("fused U + rowsums (MvNMF)", fused_kernel<KSV, KTMV, KRV, false, true, true>, 4);
     return 0;
 }
