@@ -91,6 +91,12 @@ def copy_ref_fixtures():
             if f.endswith(".npy") or f.endswith(".csv"):  # data only; the .pkl files are not copied
                 shutil.copyfile(os.path.join(base, sub, f), os.path.join(dst, f))
     shutil.copyfile(os.path.join(REF, "data", "pcawg_breast_sbs.csv"), os.path.join(HERE, "pcawg_breast_sbs.csv"))
+    # the step before the path: the reference's initialisation fixtures
+    src, dst = os.path.join(REF, "tests", "test_data", "initialization"), os.path.join(HERE, "ref_fixtures", "initialization")
+    os.makedirs(dst, exist_ok=True)
+    for f in sorted(os.listdir(src)):
+        if f.endswith(".npy"):
+            shutil.copyfile(os.path.join(src, f), os.path.join(dst, f))
 
 
 def read_counts(path):

@@ -104,6 +104,27 @@ def test_init_random_matches_oracle_restatement(counts):
     assert np.allclose(S, W.T.clip(orc.EPSILON)) and np.allclose(E, H.T.clip(orc.EPSILON))
 
 
+@pytest.mark.parametrize("method", ["flat", "nndsvd", "nndsvda", "nndsvdar", "random", "separableNMF"])
+def test_init_methods_match_reference_fixtures(method):
+    """The reference's own initialisation fixtures (tests/test_initialization.py:28-53), seed 1, K = 2."""
+    d = os.path.join(REF_FIX, "initialization")
+    data = np.load(f"{d}/data_mat.npy")
+    suffix = "flat.npy" if method == "flat" else f"{method}_seed1.npy"
+    kwargs = {} if method == "flat" else {"seed": 1}
+    S, E = init.initialize_mat(data, 2, method, **kwargs)
+    assert np.allclose(S, np.load(f"{d}/signatures_mat_{suffix}"))
+    assert np.allclose(E, np.load(f"{d}/exposures_mat_{suffix}"))
+
+
+def test_init_custom_keeps_normalised_input_bitwise():
+    """tests/test_initialization.py:56-67: a normalised custom init comes back untouched."""
+    data = np.load(os.path.join(REF_FIX, "initialization", "data_mat.npy"))
+    S0 = np.array([[0.1, 0.2, 0.7], [0.6, 0.1, 0.3]])
+    E0 = np.arange(1, 9).reshape((4, 2))
+    S, E = init.initialize_mat(data, 2, "custom", signatures_mat=S0, exposures_mat=E0)
+    assert np.array_equal(S0, S) and np.array_equal(E0, E)
+
+
 def test_init_custom_and_errors(counts):
     X = counts.T.values.astype(float)
     S0, E0 = np.full((2, 96), 1 / 96), np.ones((10, 2))
