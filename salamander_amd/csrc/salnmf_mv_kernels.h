@@ -9,19 +9,49 @@
 
 namespace salnmf {
 
-constexpr int MV_BLOCK = 256;
+constexpr int MV_BLOCK = 1024;  // one workgroup, four waves per SIMD: the parallel phases are fp64-issue bound
 constexpr int MV_KMAX = 64;
 constexpr int MV_LD = MV_KMAX + 1;  // padded leading dimension in LDS
 constexpr int MV_VMAX = 96;
+constexpr int MV_WS = 97;  // LDS row stride of W: odd, so different signature rows fall into different banks
 
-// S (LDS, [K][MV_LD]) <- Wl Wl^T + delta I, with Wl (LDS, [K][MV_VMAX]) rows = signatures
+// sum_{m<n} a[m*sa] * b[m*sb] over LDS operands, reads issued in independent batches of 8 so that one
+// LDS latency is paid per batch instead of per element; fixed summation order
+__device__ __forceinline__ double mv_dot(const double* a, int sa, const double* b, int sb, int n) {
+    double s = 0.0;
+    int m = 0;
+    for (; m + 8 <= n; m += 8) {
+        double x[8], y[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { x[u] = a[(m + u) * sa]; y[u] = b[(m + u) * sb]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += x[u] * y[u];
+    }
+    if (m < n) {  // last partial batch: clamped (in-bounds) reads, contributions masked by selects
+        double x[8], y[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int mm = (m + u < n) ? m + u : n - 1;
+            x[u] = a[mm * sa];
+            y[u] = b[mm * sb];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += (m + u < n) ? x[u] * y[u] : 0.0;
+    }
+    return s;
+}
+
+// S (LDS, [K][MV_LD]) <- Wl Wl^T + delta I, with Wl (LDS, [K][MV_WS]) rows = signatures
 __device__ inline void mv_gram(const double* Wl, double* S, int K, int V, double delta) {
+    // symmetric: each pair a <= b is computed once and mirrored (the phase is LDS-bandwidth bound)
     for (int idx = threadIdx.x; idx < K * K; idx += MV_BLOCK) {
         int a = idx / K, b = idx - a * K;
-        double s = 0.0;
-        for (int v = 0; v < V; ++v) s += Wl[a * MV_VMAX + v] * Wl[b * MV_VMAX + v];
-        if (a == b) s += delta;
-        S[a * MV_LD + b] = s;
+        if (a <= b) {
+            double s = mv_dot(Wl + a * MV_WS, 1, Wl + b * MV_WS, 1, V);
+            if (a == b) s += delta;
+            S[a * MV_LD + b] = s;
+            S[b * MV_LD + a] = s;
+        }
     }
     __syncthreads();
 }
@@ -36,8 +66,7 @@ __device__ inline double mv_cholesky_logdet(double* S, int K) {
         const int i = threadIdx.x;
         const int row = (i < K ? i : K - 1) * MV_LD;  // idle lanes shadow the last row (results discarded)
         for (int j = 0; j < K; ++j) {
-            double dot = 0.0;
-            for (int m = 0; m < j; ++m) dot += S[row + m] * S[j * MV_LD + m];
+            const double dot = mv_dot(S + row, 1, S + j * MV_LD, 1, j);
             const double v = S[row + j] - dot;
             const double piv = sqrt(__shfl(v, j, 64));
             if (i == j) S[row + j] = piv;
@@ -54,7 +83,7 @@ __device__ inline double mv_cholesky_logdet(double* S, int K) {
     return ld_shared;
 }
 
-// compact W[K][V] (global) -> Wl[K][MV_VMAX] (LDS); all loads of a thread are issued before any use
+// compact W[K][V] (global) -> Wl[K][MV_WS] (LDS); all loads of a thread are issued before any use
 __device__ inline void mv_load_W(const double* __restrict__ W, double* Wl, int K, int V) {
     constexpr int PT = (MV_KMAX * MV_VMAX + MV_BLOCK - 1) / MV_BLOCK;
     double w[PT];
@@ -69,7 +98,7 @@ __device__ inline void mv_load_W(const double* __restrict__ W, double* Wl, int K
         int idx = threadIdx.x + MV_BLOCK * j;
         if (idx < total) {
             int k = idx / V, v = idx - k * V;
-            Wl[k * MV_VMAX + v] = w[j];
+            Wl[k * MV_WS + v] = w[j];
         }
     }
     __syncthreads();
@@ -77,7 +106,7 @@ __device__ inline void mv_load_W(const double* __restrict__ W, double* Wl, int K
 
 __global__ void __launch_bounds__(MV_BLOCK) mv_logdet_kernel(const double* __restrict__ W, int K, int V, double delta,
                                                              double* __restrict__ out) {
-    __shared__ double Wl[MV_KMAX * MV_VMAX];
+    __shared__ double Wl[MV_KMAX * MV_WS];
     __shared__ double S[MV_KMAX * MV_LD];
     mv_load_W(W, Wl, K, V);
     mv_gram(Wl, S, K, V, delta);
@@ -91,7 +120,7 @@ __global__ void __launch_bounds__(MV_BLOCK)
     mv_prepare_kernel(const double* __restrict__ W, const double* __restrict__ G, const double* __restrict__ hsum,
                       const double* __restrict__ kl, int K, int V, int n_given, double lam, double delta,
                       double* __restrict__ Wunc, double* __restrict__ f0_out) {
-    __shared__ double Wl[MV_KMAX * MV_VMAX];
+    __shared__ double Wl[MV_KMAX * MV_WS];
     __shared__ double S[MV_KMAX * MV_LD];   // Gram -> Cholesky factor L -> Y = S^-1
     __shared__ double Li[MV_KMAX * MV_LD];  // L^-1
     mv_load_W(W, Wl, K, V);
@@ -104,8 +133,7 @@ __global__ void __launch_bounds__(MV_BLOCK)
         for (int i = 0; i < c; ++i) Li[i * MV_LD + c] = 0.0;
         Li[c * MV_LD + c] = 1.0 / S[c * MV_LD + c];
         for (int i = c + 1; i < K; ++i) {
-            double s = 0.0;
-            for (int m = c; m < i; ++m) s += S[i * MV_LD + m] * Li[m * MV_LD + c];
+            const double s = mv_dot(S + i * MV_LD + c, 1, Li + c * MV_LD + c, MV_LD, i - c);
             Li[i * MV_LD + c] = -s / S[i * MV_LD + i];
         }
     }
@@ -114,8 +142,7 @@ __global__ void __launch_bounds__(MV_BLOCK)
     for (int idx = threadIdx.x; idx < K * K; idx += MV_BLOCK) {
         int a = idx / K, b = idx - a * K;
         int m0 = a > b ? a : b;
-        double s = 0.0;
-        for (int m = m0; m < K; ++m) s += Li[m * MV_LD + a] * Li[m * MV_LD + b];
+        const double s = mv_dot(Li + m0 * MV_LD + a, MV_LD, Li + m0 * MV_LD + b, MV_LD, K - m0);
         S[a * MV_LD + b] = s;
     }
     __syncthreads();
@@ -123,12 +150,26 @@ __global__ void __launch_bounds__(MV_BLOCK)
     for (int idx = threadIdx.x; idx < K * V; idx += MV_BLOCK) {
         int k = idx / V, v = idx - k * V;
         double A = 0.0, B = 0.0;
-        for (int m = 0; m < K; ++m) {
-            double y = S[m * MV_LD + k], w = Wl[m * MV_VMAX + v];
-            A += w * fmax(0.0, -y);
-            B += w * fabs(y);
+        int m = 0;
+        for (; m + 8 <= K; m += 8) {  // batches of 8 independent LDS reads per operand
+            double y[8], wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                y[u] = S[(m + u) * MV_LD + k];
+                wv[u] = Wl[(m + u) * MV_WS + v];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                A += wv[u] * fmax(0.0, -y[u]);
+                B += wv[u] * fabs(y[u]);
+            }
         }
-        double w = Wl[k * MV_VMAX + v];
+        for (; m < K; ++m) {
+            const double y = S[m * MV_LD + k], wv = Wl[m * MV_WS + v];
+            A += wv * fmax(0.0, -y);
+            B += wv * fabs(y);
+        }
+        double w = Wl[k * MV_WS + v];
         double b = hsum[k] - 4.0 * lam * A;
         double root = sqrt(b * b + 8.0 * lam * B * G[idx]);
         double wu = w * (root - b) / (4.0 * lam * B);
@@ -142,7 +183,7 @@ __global__ void __launch_bounds__(MV_BLOCK)
 __global__ void __launch_bounds__(MV_BLOCK)
     mv_trial_kernel(const double* __restrict__ W, const double* __restrict__ Wunc, double gamma, int blend, int K, int V,
                     double delta, double* __restrict__ Wtrial, double* __restrict__ cs, double* __restrict__ logdet_out) {
-    __shared__ double Wl[MV_KMAX * MV_VMAX];
+    __shared__ double Wl[MV_KMAX * MV_WS];
     __shared__ double S[MV_KMAX * MV_LD];
     __shared__ double rs[MV_KMAX];
     {
@@ -162,22 +203,23 @@ __global__ void __launch_bounds__(MV_BLOCK)
                 int k = idx / V, v = idx - k * V;
                 double wt = a[j];
                 if (blend) wt = (1 - gamma) * b[j] + gamma * wt;
-                Wl[k * MV_VMAX + v] = wt;
+                Wl[k * MV_WS + v] = wt;
             }
         }
     }
     __syncthreads();
     for (int k = threadIdx.x; k < K; k += MV_BLOCK) {
         double s = 0.0;
-        for (int v = 0; v < V; ++v) s += Wl[k * MV_VMAX + v];
+#pragma unroll 8
+        for (int v = 0; v < V; ++v) s += Wl[k * MV_WS + v];
         rs[k] = s;
         cs[k] = s;
     }
     __syncthreads();
     for (int idx = threadIdx.x; idx < K * V; idx += MV_BLOCK) {
         int k = idx / V, v = idx - k * V;
-        double w = fmax(Wl[k * MV_VMAX + v] / rs[k], 1.1920928955078125e-07);
-        Wl[k * MV_VMAX + v] = w;
+        double w = fmax(Wl[k * MV_WS + v] / rs[k], 1.1920928955078125e-07);
+        Wl[k * MV_WS + v] = w;
         Wtrial[idx] = w;
     }
     __syncthreads();
