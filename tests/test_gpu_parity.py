@@ -302,3 +302,42 @@ def test_rccl_communicator_single_rank_path():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_model_distributed_flag_world_size_one(golden):
+    """KLNMF(..., distributed=True).fit on a one-rank process group: communicator attach, W broadcast and
+    the kernel -> all-reduce -> tail step give the same fit as the single-GPU path."""
+    import os
+
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        g = golden.synth
+        fits = []
+        for distributed in (False, True):
+            adata = sal.AnnData(g["X"].T.copy())
+            m = sal.models.KLNMF(50, "custom", min_iterations=30, max_iterations=30, distributed=distributed)
+            m.fit(adata, init_kwargs={"signatures_mat": g["W0"].T.copy(), "exposures_mat": g["H0"].T.copy()},
+                  fitting_kwargs={"weights_kl": g["wkl"].copy()})
+            fits.append((m.asignatures.X.copy(), adata.obsm["exposures"].copy(), list(m.history["objective_function"])))
+        assert np.array_equal(fits[0][0], fits[1][0]) and np.array_equal(fits[0][1], fits[1][1])
+        assert fits[0][2] == fits[1][2]
+        W, H, _, hist = orc.fit_klnmf(g["X"], *_post_init(g), weights_kl=g["wkl"], min_iterations=30, max_iterations=30)
+        assert rel_l2(fits[1][0], W.T) < TOL and rel_l2(fits[1][1], H.T) < TOL
+        assert np.allclose(fits[1][2], hist, rtol=1e-11)
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
+def _post_init(g):
+    """The custom init after fit's post-processing (normalise, clip), in reference shapes (V,K), (K,N)."""
+    from salamander_amd.initialization import initialize_mat
+
+    S0, E0 = initialize_mat(g["X"].T, g["W0"].shape[1], "custom", signatures_mat=g["W0"].T.copy(), exposures_mat=g["H0"].T.copy())
+    return S0.T, E0.T
