@@ -494,7 +494,9 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             // ---- H update (_utils_klnmf.py:343-361), rows n = q+4r, columns k = 16kt+c16.
-            // Unmasked: pad rows / columns just receive finite filler.
+            // Unmasked: pad rows / columns just receive finite filler.  Non-temporal stores: 51 MB of H
+            // per launch would otherwise sit dirty in L2 and be flushed at the kernel boundary
+            // (-1.5 % on the fused + tail pair, tools/ab_bench.hip).
             double* hdst = p.H + (n0 + q) * KP + c16;
             if (p.wlh == nullptr) {
 #pragma unroll
@@ -502,7 +504,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
 #pragma unroll
                     for (int kt = 0; kt < KT; ++kt) {
                         const double hn = fmax(hcur[r][kt] * u[kt][r], kEps);
-                        hdst[4 * r * KP + 16 * kt] = hn;
+                        __builtin_nontemporal_store(hn, &hdst[4 * r * KP + 16 * kt]);
                         if (DO_STATS) hsum[kt] += (n0 + q + 4 * r < N) ? hn : 0.0;
                     }
             } else {
@@ -521,7 +523,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
                         double hn = 0.25 * (t * t);
                         if (p.wkl) hn /= wk2;
                         hn = fmax(hn, kEps);
-                        hdst[4 * r * KP + 16 * kt] = hn;
+                        __builtin_nontemporal_store(hn, &hdst[4 * r * KP + 16 * kt]);
                         if (DO_STATS) hsum[kt] += (n < N) ? hn : 0.0;
                     }
                 }

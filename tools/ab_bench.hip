@@ -27,12 +27,15 @@ int main(int argc, char** argv) {
     salnmf_A::FusedParams pa{}; pa.X = dX; pa.H = dH; pa.W = dW; pa.Gpart = dG; pa.N = N; pa.V = V; pa.K = K; pa.ntiles = Np / 16;
     salnmf_B::FusedParams pb{}; pb.X = dX; pb.H = dH; pb.W = dW; pb.Gpart = dG; pb.N = N; pb.V = V; pb.K = K; pb.ntiles = Np / 16;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    double *dGr, *dW2; CK(hipMalloc(&dGr, K * V * 8)); CK(hipMalloc(&dW2, K * V * 8)); CK(hipMemcpy(dW2, dW, K * V * 8, hipMemcpyDeviceToDevice));
+    salnmf_A::TailParams tp{}; tp.Gpart = dG; tp.G = dGr; tp.W = dW2; tp.nslabs = grid; tp.V = V; tp.K = K; tp.n_given = 0; tp.clip_mode = 0; tp.do_tail = 1;  // PAIR: fused + tail
     std::vector<float> ta, tb;
     auto once = [&](int which) {
         CK(hipMemcpy(dH, dH0, H.size() * 8, hipMemcpyDeviceToDevice));
         CK(hipEventRecord(e0));
         if (which == 0) hipLaunchKernelGGL((salnmf_A::fused_kernel<13, 3, 2, true, true, false>), dim3(grid), dim3(256), 0, 0, pa);
         else hipLaunchKernelGGL((salnmf_B::fused_kernel<13, 3, 2, true, true, false>), dim3(grid), dim3(256), 0, 0, pb);
+        hipLaunchKernelGGL(salnmf_A::tail_kernel, dim3(K), dim3(salnmf_A::TAIL_BLOCK), 0, 0, tp);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); return ms;
     };
