@@ -372,6 +372,10 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) pr[vt][r] = div_path(x[vt][r], pr[vt][r]);
 
+        // prefetch the next tile: X and the staging registers are free from here on, and the loads
+        // get the G and U phases to land
+        if (tile + tstride < p.ntiles) load_tile(tile + tstride);
+
         if (DO_U) {
             // ---- transpose R through LDS: write accumulator layout, read A-operand layout
 #pragma unroll
@@ -432,8 +436,6 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         }
         __builtin_amdgcn_wave_barrier();
 
-        // prefetch the next tile (X registers and the staging registers are free now)
-        if (tile + tstride < p.ntiles) load_tile(tile + tstride);
 
         if (DO_U) {
             // ---- U = R . W^T   (A = R[n=c16][v=4s+q], B = W[k=16kt+c16][v=4s+q])
@@ -482,17 +484,9 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt) u[kt] = mfma(a[s & 1], b[s & 1][kt], u[kt]);
-                if (KR > 0) {
-                    // one butterfly stage of the remainder reduce-scatter per marked step: its
-                    // DPP moves / selects issue in the shadow of this step's MFMAs
-                    using std::integral_constant;
-                    if (s == 2) rs_stage(integral_constant<int, 8>{}, integral_constant<int, NVP>{});
-                    if (s == 7) rs_stage(integral_constant<int, 4>{}, integral_constant<int, (NVP / 2 > 1 ? NVP / 2 : 1)>{});
-                    if (s == 12) rs_stage(integral_constant<int, 2>{}, integral_constant<int, (NVP / 4 > 1 ? NVP / 4 : 1)>{});
-                    if (s == 17) rs_stage(integral_constant<int, 1>{}, integral_constant<int, (NVP / 8 > 1 ? NVP / 8 : 1)>{});
-                }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (KR > 0) { using std::integral_constant; rs_stage(integral_constant<int, 8>{}, integral_constant<int, NVP>{}); rs_stage(integral_constant<int, 4>{}, integral_constant<int, (NVP / 2 > 1 ? NVP / 2 : 1)>{}); rs_stage(integral_constant<int, 2>{}, integral_constant<int, (NVP / 4 > 1 ? NVP / 4 : 1)>{}); rs_stage(integral_constant<int, 1>{}, integral_constant<int, (NVP / 8 > 1 ? NVP / 8 : 1)>{}); }
             // ---- H update (_utils_klnmf.py:343-361), rows n = q+4r, columns k = 16kt+c16.
             // Unmasked: pad rows / columns just receive finite filler.  Non-temporal stores: 51 MB of H
             // per launch would otherwise sit dirty in L2 and be flushed at the kernel boundary
