@@ -64,27 +64,36 @@ class KLNMF(StandardNMF):
     def _device_objective(self) -> float:
         return self._engine.objective()
 
-    # -- fitting kwargs (klnmf.py:108-153)
+    # -- fitting kwargs: per-sample loss weights and l-half penalty weights
+    def _weight_vector(self, name: str, value):
+        """Normalise one fitting kwarg to ``None`` or a non-negative ``ndarray (n_obs,)``.
+
+        Same acceptance rules and exception types as the reference
+        (``klnmf.py:108-126,142-151``): scalars broadcast, lists convert, anything else that is
+        not an ndarray is a ``TypeError``; wrong shape or a negative entry is a ``ValueError``.
+        """
+        if value is None:
+            return None
+        type_checker(name, value, [float, int, list, np.ndarray])
+        n_obs = self.adata.n_obs
+        if isinstance(value, (float, int)):
+            value = np.full(n_obs, float(value))
+        elif isinstance(value, list):
+            value = np.array(value)
+        self._check_weights(value, name)
+        return value
+
     def _check_weights(self, weights: np.ndarray, name: str = "weights") -> None:
         type_checker(name, weights, np.ndarray)
         shape_checker(name, weights, (self.adata.n_obs,))
-        if not all(weights >= 0):
+        if np.any(weights < 0):
             raise ValueError("Only non-negative KL-divergence and sparsity penalty weights are allowed.")
 
     def _setup_fitting_parameters(self, fitting_kwargs: dict[str, Any] | None = None) -> None:
-        if fitting_kwargs is None:
-            fitting_kwargs = {name: None for name in _FITTING_KWARGS}
-        for name in fitting_kwargs:
-            if name not in _FITTING_KWARGS:
-                raise ValueError(
-                    f"The given fitting keyword arguments include parameters outside of {_FITTING_KWARGS}."
-                )
-        for name, weights in fitting_kwargs.items():
-            if weights is not None:
-                type_checker(name, weights, [float, int, list, np.ndarray])
-                if type(weights) in (float, int):
-                    weights = weights * np.ones(self.adata.n_obs)
-                if type(weights) is list:
-                    weights = np.array(weights)
-                self._check_weights(weights, name)
-            setattr(self, name, weights)
+        """``fitting_kwargs`` may hold ``weights_kl`` and/or ``weights_lhalf`` (``klnmf.py:128-153``)."""
+        requested = dict.fromkeys(_FITTING_KWARGS) if fitting_kwargs is None else fitting_kwargs
+        unknown = [name for name in requested if name not in _FITTING_KWARGS]
+        if unknown:
+            raise ValueError(f"The given fitting keyword arguments include parameters outside of {_FITTING_KWARGS}.")
+        for name, value in requested.items():
+            setattr(self, name, self._weight_vector(name, value))

@@ -10,7 +10,7 @@ def rep(anchor, new):
     s = s.replace(anchor, new, 1)
 
 
-rep("    int64_t ntiles;\n};\n\n// natural log", "    int64_t ntiles;\n    unsigned long long* dbg;\n};\n\n// natural log")
+rep("    int64_t ntiles;\n};\n\n// log(x / p)", "    int64_t ntiles;\n    unsigned long long* dbg;\n};\n\n// log(x / p)")
 macro = '''#define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t1_; asm volatile("s_memtime %0\\n\\ts_waitcnt lgkmcnt(0)" : "=s"(t1_) :: "memory"); __builtin_amdgcn_sched_barrier(0); ph[i] += t1_ - t0_; t0_ = t1_; } while (0)
 '''
 rep("template <int KS, int KTM, int KR, bool DO_G, bool DO_U, bool DO_STATS>\n__global__", macro + "template <int KS, int KTM, int KR, bool DO_G, bool DO_U, bool DO_STATS>\n__global__")
@@ -18,9 +18,9 @@ rep("    d2 hpre[HV];\n    double x[VT][4];\n\n    auto load_tile",
     "    unsigned long long ph[8] = {0,0,0,0,0,0,0,0}; unsigned long long t0_;\n    d2 hpre[HV];\n    double x[VT][4];\n\n    auto load_tile")
 rep("        const int64_t n0 = tile * 16;\n        // ---- stage the H tile", "        const int64_t n0 = tile * 16;\n        STAMP(7);\n        // ---- stage the H tile")
 rep("        // G-phase A operands (H^T): issue the LDS reads now", "        STAMP(0);\n        // G-phase A operands (H^T): issue the LDS reads now")
-rep("        if (DO_U) {\n            // ---- transpose R through LDS", "        STAMP(1);\n        if (DO_U) {\n            // ---- transpose R through LDS")
-rep("        __builtin_amdgcn_wave_barrier();\n\n        // prefetch the next tile", "        __builtin_amdgcn_wave_barrier();\n        STAMP(2);\n\n        // prefetch the next tile")
-rep("        if (DO_U) {\n            // ---- U = R . W^T", "        STAMP(3);\n        if (DO_U) {\n            // ---- U = R . W^T")
+rep("        // prefetch the next tile: X and the staging registers are free from here on", "        STAMP(1);\n        // prefetch the next tile: X and the staging registers are free from here on")
+rep("        if (DO_U) {\n            // ---- transpose R through LDS", "        STAMP(3);\n        if (DO_U) {\n            // ---- transpose R through LDS")
+rep("        if (DO_U) {\n            // ---- U = R . W^T", "        STAMP(2);\n        if (DO_U) {\n            // ---- U = R . W^T")
 rep("            // ---- H update (_utils_klnmf.py:343-361), rows n = q+4r", "            STAMP(4);\n            // ---- H update (_utils_klnmf.py:343-361), rows n = q+4r")
 rep("    };\n\n    if (tile < p.ntiles) load_tile(tile);", "        STAMP(5);\n    };\n\n    if (tile < p.ntiles) load_tile(tile);\n    asm volatile(\"s_memtime %0\\n\\ts_waitcnt lgkmcnt(0)\" : \"=s\"(t0_) :: \"memory\");")
 rep("    // ---- workgroup reductions, fixed order (deterministic)", "    if (p.dbg && lane == 0) { for (int i = 0; i < 8; ++i) p.dbg[((int64_t)blockIdx.x * WAVES + wave) * 8 + i] = ph[i]; }\n    // ---- workgroup reductions, fixed order (deterministic)")
