@@ -86,7 +86,7 @@ class KLNMF(StandardNMF):
     def _check_weights(self, weights: np.ndarray, name: str = "weights") -> None:
         type_checker(name, weights, np.ndarray)
         shape_checker(name, weights, (self.adata.n_obs,))
-        if np.any(weights < 0):
+        if not np.all(weights >= 0):  # also rejects NaN, as the reference's `all(weights >= 0)` does
             raise ValueError("Only non-negative KL-divergence and sparsity penalty weights are allowed.")
 
     def _setup_fitting_parameters(self, fitting_kwargs: dict[str, Any] | None = None) -> None:
