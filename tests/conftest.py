@@ -14,6 +14,13 @@ REF_FIX = os.path.join(GOLDEN, "ref_fixtures")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no libsalnmf.so (it is git-ignored): cross-compile it once (no GPU needed)
+    from salamander_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH) and os.path.exists("/opt/rocm/bin/hipcc"):
+        import __graft_entry__
+
+        __graft_entry__.build()
 
 
 def pytest_collection_modifyitems(config, items):
