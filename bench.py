@@ -125,6 +125,7 @@ def main():
         elapsed = float(t.item())
     objective = engine.objective()
     fwd_ms = engine.profile_objective(10)
+    wh_ms = engine.profile_reconstruct(10)
 
     if rank == 0:
         flops_step = 6.0 * V * K * n_local  # algorithmic flops of one launch of the fused kernel
@@ -173,6 +174,8 @@ def main():
                 "event_total_ms_per_step": total_ms / args.steps,
                 "forward_objective_kernel_ms": fwd_ms,
                 "forward_WH_frac": 2.0 * V * K * n_local / (fwd_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                "WH_only_kernel_ms": wh_ms,
+                "WH_only_frac": 2.0 * V * K * n_local / (wh_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -126,6 +126,8 @@ int salnmf_profile_kl_steps(salnmf_engine* e, int n_steps, int n_given, int samp
                             double* total_ms, double* fused_avg_ms, double* tail_avg_ms);
 /* Same for the forward (W@H) + objective kernel: average duration over n_calls. */
 int salnmf_profile_objective(salnmf_engine* e, int n_calls, double* avg_ms);
+/* Same for the forward kernel alone (H @ W written to a scratch buffer, no objective terms). */
+int salnmf_profile_reconstruct(salnmf_engine* e, int n_calls, double* avg_ms);
 
 #ifdef __cplusplus
 }

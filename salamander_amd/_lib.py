@@ -52,6 +52,7 @@ SIGNATURES = {
     "salnmf_sync": (c_int, [_P]),
     "salnmf_profile_kl_steps": (c_int, [_P, c_int, c_int, c_int, _D, _D, _D]),
     "salnmf_profile_objective": (c_int, [_P, c_int, _D]),
+    "salnmf_profile_reconstruct": (c_int, [_P, c_int, _D]),
 }
 
 _lib = None

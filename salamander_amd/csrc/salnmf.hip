@@ -664,27 +664,39 @@ int salnmf_profile_kl_steps(salnmf_engine* e, int n_steps, int n_given, int samp
     return 0;
 }
 
-int salnmf_profile_objective(salnmf_engine* e, int n_calls, double* avg_ms) {
+// average duration of the forward kernel: mode 0 = W@H + objective terms, mode 2 = W@H alone (written
+// to a scratch reconstruction buffer)
+static int profile_forward(salnmf_engine* e, int mode, int n_calls, double* avg_ms) {
     if (!e) return fail("null engine");
     if (n_calls < 1 || n_calls > 100000) return fail("n_calls out of range");
     HIPCK(hipSetDevice(e->device));
     CK(ensure_events(e, (size_t)2 * n_calls));
     FwdParams p;
     fwd_params(e, p);
-    for (int i = 0; i < n_calls; ++i) {
-        HIPCK(hipEventRecord(e->events[2 * (size_t)i], e->stream));
-        CK(launch_forward<0>(e, p));
-        HIPCK(hipEventRecord(e->events[2 * (size_t)i + 1], e->stream));
+    double* recon = nullptr;
+    if (mode == 2) {
+        HIPCK(hipMalloc(&recon, (size_t)e->Np * VMAX * sizeof(double)));
+        p.out = recon;
     }
-    HIPCK(hipStreamSynchronize(e->stream));
+    int rc = 0;
+    for (int i = 0; i < n_calls && !rc; ++i) {
+        if (hipEventRecord(e->events[2 * (size_t)i], e->stream) != hipSuccess) rc = fail("hipEventRecord failed");
+        if (!rc) rc = (mode == 2) ? launch_forward<2>(e, p) : launch_forward<0>(e, p);
+        if (!rc && hipEventRecord(e->events[2 * (size_t)i + 1], e->stream) != hipSuccess) rc = fail("hipEventRecord failed");
+    }
+    if (hipStreamSynchronize(e->stream) != hipSuccess && !rc) rc = fail("hipStreamSynchronize failed");
     double s = 0;
-    for (int i = 0; i < n_calls; ++i) {
+    for (int i = 0; i < n_calls && !rc; ++i) {
         float a = 0;
-        HIPCK(hipEventElapsedTime(&a, e->events[2 * (size_t)i], e->events[2 * (size_t)i + 1]));
+        if (hipEventElapsedTime(&a, e->events[2 * (size_t)i], e->events[2 * (size_t)i + 1]) != hipSuccess) rc = fail("hipEventElapsedTime failed");
         s += a;
     }
-    if (avg_ms) *avg_ms = s / n_calls;
-    return 0;
+    if (recon) (void)hipFree(recon);
+    if (!rc && avg_ms) *avg_ms = s / n_calls;
+    return rc;
 }
+
+int salnmf_profile_objective(salnmf_engine* e, int n_calls, double* avg_ms) { return profile_forward(e, 0, n_calls, avg_ms); }
+int salnmf_profile_reconstruct(salnmf_engine* e, int n_calls, double* avg_ms) { return profile_forward(e, 2, n_calls, avg_ms); }
 
 }  // extern "C"

@@ -167,3 +167,9 @@ class Engine:
         a = c_double()
         _lib.check(self._lib.salnmf_profile_objective(self._h, int(n_calls), ctypes.byref(a)))
         return a.value
+
+    def profile_reconstruct(self, n_calls: int) -> float:
+        """Average duration (ms) of the forward kernel alone (H @ W into a scratch buffer)."""
+        a = c_double()
+        _lib.check(self._lib.salnmf_profile_reconstruct(self._h, int(n_calls), ctypes.byref(a)))
+        return a.value
