@@ -176,6 +176,36 @@ def test_shapes_one_and_five_steps(V, N, K):
         e.close()
 
 
+@pytest.mark.parametrize("K", list(range(1, 65)))
+def test_every_signature_count(K):
+    """Every K in 1..64 (each (KS, KTM, KR) kernel geometry, incl. all remainder-column variants):
+    joint step with weights / l-half / given signatures, update_W, objective, MvNMF step."""
+    V, N = 96, 203 + K  # ragged last tile
+    X, W0, H0 = orc.synthetic_problem(V, N, K, seed=K)
+    rng = np.random.default_rng(K)
+    wkl, wlh = rng.uniform(0.5, 2, N), rng.uniform(0, 3, N)
+    ng = K // 3
+    e = Engine(N, V, K)
+    e.upload_X(X), e.upload_W(W0), e.upload_H(H0)
+    e.set_weights(wkl, wlh)
+    W, H = W0.T, H0.T
+    for _ in range(2):
+        W, H = orc.update_WH(X.T, W, H, wkl, wlh, ng)
+    e.kl_step(2, ng)
+    assert rel_l2(e.download_W(), W.T) < TOL and rel_l2(e.download_H(), H.T) < TOL
+    assert np.isclose(e.objective(), orc.klnmf_objective(X.T, W, H, wkl, wlh), rtol=1e-12)
+    e.update_W(ng, _lib.CLIP_NON_GIVEN)
+    assert rel_l2(e.download_W(), orc.update_W(X.T, W, H, wkl, ng).T) < TOL
+    # MvNMF step from the same state (unweighted)
+    e.set_weights(None, None)
+    e.upload_W(W.T.copy()), e.upload_H(H.T.copy())
+    Wm, Hm, g = orc.mvnmf_step(X.T, W, H, 1.0, 1.0, 1.0, ng)
+    gg = e.mv_step(1, ng, 1.0, 1.0, 1.0)
+    assert gg == g
+    assert rel_l2(e.download_W(), Wm.T) < 1e-7 and rel_l2(e.download_H(), Hm.T) < 1e-7
+    e.close()
+
+
 def test_unnormalised_inputs_and_function_level_semantics():
     """Function-level calls take any non-negative W, H (not only normalised ones)."""
     rng = np.random.default_rng(3)
