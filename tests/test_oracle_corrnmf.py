@@ -1,0 +1,102 @@
+"""Pins ``oracle/corrnmf_oracle.py`` against the reference's own CorrNMF fixtures.
+
+The data files under ``tests/golden/ref_fixtures/corrnmf`` are the reference's
+``tests/test_data/models/corrnmf/*`` (inputs and expected outputs of
+``tests/test_corrnmf.py:98-175``); the checks mirror that test module.
+"""
+
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from oracle import corrnmf_oracle as co
+from oracle import klnmf_oracle as ko
+
+FIX = os.path.join(os.path.dirname(__file__), "golden", "ref_fixtures", "corrnmf")
+
+
+def load_case(k):
+    sfx = f"nsigs{k}_dim{k}.npy"
+    g = lambda name: np.load(os.path.join(FIX, f"{name}_{sfx}"))  # noqa: E731
+    X = pd.read_csv(os.path.join(FIX, "counts.csv"), index_col=0).T.to_numpy(dtype=np.float64)
+    return {
+        "X": X,  # (N, V)
+        "W": g("signatures_mat_init").T.copy(),  # (K, V)
+        "beta": g("signature_scalings_init"),
+        "alpha": g("sample_scalings_init"),
+        "L": g("signature_embeddings_init").T.copy(),  # (K, dim)
+        "U": g("sample_embeddings_init").T.copy(),  # (N, dim)
+        "variance": float(g("variance_init")),
+        "aux": g("aux"),
+        "objective": float(g("objective_init")),
+        "W_updated": g("signatures_mat_updated").T,
+        "beta_updated": g("signature_scalings_updated"),
+        "alpha_updated": g("sample_scalings_updated"),
+        "L_updated": g("signature_embeddings_updated").T,
+        "U_updated": g("sample_embeddings_updated").T,
+        "variance_updated": float(g("variance_updated")),
+    }
+
+
+@pytest.fixture(params=[1, 2])
+def case(request):
+    return load_case(request.param)
+
+
+def exposures(c):
+    return co.compute_exposures(c["beta"], c["alpha"], c["L"], c["U"])
+
+
+def test_objective(case):
+    got = co.elbo_corrnmf(case["X"], case["W"], exposures(case), case["L"], case["U"], case["variance"])
+    assert np.allclose(got, case["objective"])
+
+
+def test_aux_fixture_is_consistent(case):
+    # the stored aux was produced from the initial state: compute_aux must reproduce it
+    got = co.compute_aux(case["X"], case["W"], exposures(case))
+    assert np.allclose(got, case["aux"])
+
+
+def test_update_signatures(case):
+    H = exposures(case)
+    got = ko.update_W(case["X"].T, case["W"].T, H.T).T
+    assert np.allclose(got, case["W_updated"])
+
+
+def test_update_signature_scalings(case):
+    got = co.update_signature_scalings(case["aux"], case["alpha"], case["L"], case["U"])
+    assert np.allclose(got, case["beta_updated"])
+
+
+def test_update_sample_scalings(case):
+    got = co.update_sample_scalings(case["X"], case["beta"], case["L"], case["U"])
+    assert np.allclose(got, case["alpha_updated"])
+
+
+def test_update_signature_embeddings(case):
+    got = co.update_signature_embeddings(case["aux"], case["L"], case["U"], case["beta"], case["alpha"], case["variance"])
+    assert np.allclose(got, case["L_updated"])
+
+
+def test_update_sample_embeddings(case):
+    got = co.update_sample_embeddings(case["aux"], case["L"], case["U"], case["beta"], case["alpha"], case["variance"])
+    assert np.allclose(got, case["U_updated"])
+
+
+def test_update_variance(case):
+    assert np.allclose(co.update_variance(case["L"], case["U"]), case["variance_updated"])
+
+
+def test_full_step_runs_and_improves_elbo(case):
+    c = case
+    H0 = exposures(c)
+    before = co.elbo_corrnmf(c["X"], c["W"], H0, c["L"], c["U"], c["variance"])
+    W, beta, alpha, L, U, var, _ = co.corrnmf_det_step(c["X"], c["W"], c["beta"], c["alpha"], c["L"], c["U"], c["variance"])
+    for _ in range(5):
+        W, beta, alpha, L, U, var, _ = co.corrnmf_det_step(c["X"], W, beta, alpha, L, U, var)
+    H = co.compute_exposures(beta, alpha, L, U)
+    after = co.elbo_corrnmf(c["X"], W, H, L, U, var)
+    assert np.isfinite(after) and after > before
