@@ -100,6 +100,40 @@ int salnmf_mv_update_W(salnmf_engine* e, int n_given, double lam, double delta,
 /* kl_divergence_penalized, mvnmf.py:27-34. */
 int salnmf_mv_objective(salnmf_engine* e, double lam, double delta, double* out);
 
+/* ---- Correlated NMF, dense pieces.  The exposure matrix is not a free
+ * parameter but exp(signature scaling + sample scaling + <signature embedding, sample
+ * embedding>) (src/salamander/models/corrnmf.py:66-77).  The engine keeps the scalings and
+ * embeddings next to X / W / H; H holds the exposures.  The per-embedding Newton-CG solves
+ * (_utils_corrnmf.py:354-410, SciPy) are NOT part of this library: the host layer runs them
+ * between salnmf_corr_compute_aux and salnmf_corr_update_signatures, as CorrNMFDet does
+ * (corrnmf_det.py:157-169). */
+#define SALNMF_CORR_SIGNATURE_SCALINGS 0   /* [n_signatures]                       */
+#define SALNMF_CORR_SAMPLE_SCALINGS 1      /* [n_samples]                          */
+#define SALNMF_CORR_SIGNATURE_EMBEDDINGS 2 /* [n_signatures][dim_embeddings]       */
+#define SALNMF_CORR_SAMPLE_EMBEDDINGS 3    /* [n_samples][dim_embeddings]          */
+#define SALNMF_CORR_AUX 4                  /* [n_samples][n_signatures] = aux.T    */
+/* Allocate the CorrNMF state for embeddings of dimension dim_embeddings (1..64); all zero. */
+int salnmf_corr_configure(salnmf_engine* e, int dim_embeddings);
+int salnmf_corr_upload(salnmf_engine* e, int which, const double* src);
+int salnmf_corr_download(salnmf_engine* e, int which, double* dst);
+/* update_sample_scalings, _utils_corrnmf.py:141-179 (CorrNMFDet.update_sample_scalings,
+ * corrnmf_det.py:32-44). */
+int salnmf_corr_update_sample_scalings(salnmf_engine* e);
+/* compute_exposures, _utils_corrnmf.py:11-25: overwrites H. */
+int salnmf_corr_compute_exposures(salnmf_engine* e);
+/* compute_aux, _utils_corrnmf.py:28-52: aux[n][k] = H[n][k] * sum_v W[k][v] X[n][v] / (HW)[n][v]
+ * from the current X, W, H.  The same pass leaves the reduced numerator of update_W in
+ * SALNMF_BUF_G for salnmf_corr_update_signatures. */
+int salnmf_corr_compute_aux(salnmf_engine* e);
+/* update_signature_scalings, _utils_corrnmf.py:103-138, from the aux buffer. */
+int salnmf_corr_update_signature_scalings(salnmf_engine* e);
+/* CorrNMFDet.update_signatures (corrnmf_det.py:71-86) = update_W, _utils_klnmf.py:164-217, with
+ * the numerator of the last salnmf_corr_compute_aux (W and the exposures are unchanged in
+ * between in CorrNMFDet._update_parameters). */
+int salnmf_corr_update_signatures(salnmf_engine* e, int n_given);
+/* poisson_llh, _utils_klnmf.py:98-160 (the data term of elbo_corrnmf, _utils_corrnmf.py:92). */
+int salnmf_corr_poisson_llh(salnmf_engine* e, double* out);
+
 /* Multi-GPU: one engine per process/GPU, sample axis sharded; the only exchange is an
  * RCCL all-reduce of the (K x V) numerator per W update (+ scalars for objectives).
  * Rank 0 obtains an id, the host layer broadcasts it, every rank calls comm_init. */

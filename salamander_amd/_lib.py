@@ -18,6 +18,7 @@ UNIQUE_ID_BYTES = 128
 CLIP_ALL = 0
 CLIP_NON_GIVEN = 1
 BUF_G, BUF_W, BUF_H, BUF_X, BUF_OBJ, BUF_RED = range(6)
+CORR_SIGNATURE_SCALINGS, CORR_SAMPLE_SCALINGS, CORR_SIGNATURE_EMBEDDINGS, CORR_SAMPLE_EMBEDDINGS, CORR_AUX = range(5)
 
 # every symbol include/salnmf.h declares: name -> (restype, argtypes)
 _P = c_void_p
@@ -43,6 +44,15 @@ SIGNATURES = {
     "salnmf_mv_step": (c_int, [_P, c_int, c_int, c_double, c_double, _D]),
     "salnmf_mv_update_W": (c_int, [_P, c_int, c_double, c_double, _D]),
     "salnmf_mv_objective": (c_int, [_P, c_double, c_double, _D]),
+    "salnmf_corr_configure": (c_int, [_P, c_int]),
+    "salnmf_corr_upload": (c_int, [_P, c_int, _D]),
+    "salnmf_corr_download": (c_int, [_P, c_int, _D]),
+    "salnmf_corr_update_sample_scalings": (c_int, [_P]),
+    "salnmf_corr_compute_exposures": (c_int, [_P]),
+    "salnmf_corr_compute_aux": (c_int, [_P]),
+    "salnmf_corr_update_signature_scalings": (c_int, [_P]),
+    "salnmf_corr_update_signatures": (c_int, [_P, c_int]),
+    "salnmf_corr_poisson_llh": (c_int, [_P, _D]),
     "salnmf_comm_unique_id": (c_int, [ctypes.c_char_p]),
     "salnmf_comm_init": (c_int, [_P, ctypes.c_char_p, c_int, c_int]),
     "salnmf_kl_step_partial": (c_int, [_P]),

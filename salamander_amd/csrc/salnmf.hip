@@ -4,6 +4,7 @@
 #include "../../include/salnmf.h"
 #include "salnmf_kernels.h"
 #include "salnmf_mv_kernels.h"
+#include "salnmf_corr_kernels.h"
 
 #include <rccl/rccl.h>
 
@@ -68,6 +69,18 @@ struct salnmf_engine {
     double* Wtrial = nullptr;    // [K][V]
     double* cs = nullptr;        // [KP], filler 1
     double* hpin = nullptr;      // pinned host scalars
+    // correlated NMF (row f1): scalings, embeddings, aux; allocated by salnmf_corr_configure
+    int dim = 0;                 // dim_embeddings, 0 = not configured
+    double* alpha = nullptr;     // [Np] sample scalings
+    double* beta = nullptr;      // [K]  signature scalings
+    double* Lemb = nullptr;      // [K][dim]
+    double* Uemb = nullptr;      // [N][dim]
+    double* aux = nullptr;       // [Np][KP], padded like H
+    double* xrowsum = nullptr;   // [Np]
+    double* corrpart = nullptr;  // [cgrid][64] partial sums
+    int cgrid = 0;
+    bool xrowsum_valid = false, lgam_valid = false;
+    double lgam_sum = 0.0;       // sum gammaln(1 + X) over the local shard
     ncclComm_t comm = nullptr;
     int n_ranks = 1, rank = 0;
     std::vector<hipEvent_t> events;
@@ -134,6 +147,8 @@ static FusedParams fused_params(salnmf_engine* e) {
     FusedParams p;
     p.X = e->X;
     p.H = e->H;
+    p.Hout = e->H;
+    p.hfloor = kEps;
     p.W = e->W;
     p.wkl = e->wkl;
     p.wlh = e->wlh;
@@ -212,7 +227,8 @@ void salnmf_destroy(salnmf_engine* e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->comm) ncclCommDestroy(e->comm);
     double* bufs[] = {e->X, e->H, e->W, e->wkl, e->wlh, e->Gpart, e->Hsumpart, e->KLpart, e->red,
-                      e->objpart, e->scal, e->Wunc, e->Wtrial, e->cs, e->scratch};
+                      e->objpart, e->scal, e->Wunc, e->Wtrial, e->cs, e->scratch,
+                      e->alpha, e->beta, e->Lemb, e->Uemb, e->aux, e->xrowsum, e->corrpart};
     for (double* b : bufs)
         if (b) (void)hipFree(b);
     if (e->hpin) (void)hipHostFree(e->hpin);
@@ -331,6 +347,7 @@ static int download_padded(salnmf_engine* e, double* dst, const double* src, int
 }
 
 int salnmf_upload_X(salnmf_engine* e, const double* X, int clip) {
+    if (e) e->xrowsum_valid = e->lgam_valid = false;
     // pad rows / columns are exactly 0 (never clipped): they must contribute X/P = 0
     return upload_padded(e, e ? e->X : nullptr, X, e ? e->V : 0, VMAX, 0.0, 0.0, clip ? kEps : 0.0);
 }
@@ -571,6 +588,183 @@ int salnmf_mv_step(salnmf_engine* e, int n_steps, int n_given, double lam, doubl
         CK((launch_fused<false, true, true>(e, p)));  // update_H + row sums of the new H
         CK(mv_update_W_impl(e, n_given, lam, delta, gamma_inout, true));
     }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ CorrNMF (row f1)
+
+int salnmf_corr_configure(salnmf_engine* e, int dim_embeddings) {
+    if (!e) return fail("null engine");
+    if (dim_embeddings < 1 || dim_embeddings > CORR_DMAX) return fail("dim_embeddings must be in [1, %d], got %d", CORR_DMAX, dim_embeddings);
+    HIPCK(hipSetDevice(e->device));
+    HIPCK(hipStreamSynchronize(e->stream));
+    double** bufs[] = {&e->alpha, &e->beta, &e->Lemb, &e->Uemb, &e->aux, &e->xrowsum, &e->corrpart};
+    for (double** b : bufs) {
+        if (*b) HIPCK(hipFree(*b));
+        *b = nullptr;
+    }
+    e->dim = 0;
+    const size_t Np = e->Np, K = e->K, d = dim_embeddings;
+    e->cgrid = (int)std::min<int64_t>(1024, (e->Np + CORR_TILE - 1) / CORR_TILE);
+    HIPCK(hipMalloc(&e->alpha, Np * sizeof(double)));
+    HIPCK(hipMalloc(&e->beta, K * sizeof(double)));
+    HIPCK(hipMalloc(&e->Lemb, K * d * sizeof(double)));
+    HIPCK(hipMalloc(&e->Uemb, (size_t)e->N * d * sizeof(double)));
+    HIPCK(hipMalloc(&e->aux, Np * e->KP * sizeof(double)));
+    HIPCK(hipMalloc(&e->xrowsum, Np * sizeof(double)));
+    HIPCK(hipMalloc(&e->corrpart, (size_t)e->cgrid * 64 * sizeof(double)));
+    HIPCK(hipMemsetAsync(e->alpha, 0, Np * sizeof(double), e->stream));
+    HIPCK(hipMemsetAsync(e->beta, 0, K * sizeof(double), e->stream));
+    HIPCK(hipMemsetAsync(e->Lemb, 0, K * d * sizeof(double), e->stream));
+    HIPCK(hipMemsetAsync(e->Uemb, 0, (size_t)e->N * d * sizeof(double), e->stream));
+    HIPCK(hipMemsetAsync(e->aux, 0, Np * e->KP * sizeof(double), e->stream));
+    e->dim = dim_embeddings;
+    e->xrowsum_valid = false;
+    return 0;
+}
+
+static int corr_ready(salnmf_engine* e) {
+    if (!e) return fail("null engine");
+    if (e->dim == 0) return fail("salnmf_corr_configure has not been called on this engine");
+    HIPCK(hipSetDevice(e->device));
+    return 0;
+}
+
+int salnmf_corr_upload(salnmf_engine* e, int which, const double* src) {
+    CK(corr_ready(e));
+    if (!src) return fail("null argument");
+    switch (which) {
+        case SALNMF_CORR_SIGNATURE_SCALINGS: return upload(e, e->beta, src, (size_t)e->K);
+        case SALNMF_CORR_SAMPLE_SCALINGS: return upload_padded(e, e->alpha, src, 1, 1, 0.0, 0.0, 0.0);
+        case SALNMF_CORR_SIGNATURE_EMBEDDINGS: return upload(e, e->Lemb, src, (size_t)e->K * e->dim);
+        case SALNMF_CORR_SAMPLE_EMBEDDINGS: return upload(e, e->Uemb, src, (size_t)e->N * e->dim);
+        case SALNMF_CORR_AUX: return upload_padded(e, e->aux, src, e->K, e->KP, 0.0, 0.0, 0.0);
+        default: return fail("unknown CorrNMF buffer %d", which);
+    }
+}
+
+int salnmf_corr_download(salnmf_engine* e, int which, double* dst) {
+    CK(corr_ready(e));
+    if (!dst) return fail("null argument");
+    switch (which) {
+        case SALNMF_CORR_SIGNATURE_SCALINGS: return download(e, dst, e->beta, (size_t)e->K);
+        case SALNMF_CORR_SAMPLE_SCALINGS: return download(e, dst, e->alpha, (size_t)e->N);
+        case SALNMF_CORR_SIGNATURE_EMBEDDINGS: return download(e, dst, e->Lemb, (size_t)e->K * e->dim);
+        case SALNMF_CORR_SAMPLE_EMBEDDINGS: return download(e, dst, e->Uemb, (size_t)e->N * e->dim);
+        case SALNMF_CORR_AUX: return download_padded(e, dst, e->aux, e->K, e->KP);
+        default: return fail("unknown CorrNMF buffer %d", which);
+    }
+}
+
+static CorrParams corr_params(salnmf_engine* e) {
+    CorrParams p;
+    p.alpha = e->alpha;
+    p.beta = e->beta;
+    p.L = e->Lemb;
+    p.U = e->Uemb;
+    p.xrowsum = e->xrowsum;
+    p.out = nullptr;
+    p.N = e->N;
+    p.Np = e->Np;
+    p.K = e->K;
+    p.KP = e->KP;
+    p.dim = e->dim;
+    return p;
+}
+
+int salnmf_corr_update_sample_scalings(salnmf_engine* e) {
+    CK(corr_ready(e));
+    if (!e->xrowsum_valid) {
+        hipLaunchKernelGGL(rowsum_X_kernel, dim3(1024), dim3(256), 0, e->stream, e->X, e->Np, VMAX, e->xrowsum);
+        HIPCK(hipGetLastError());
+        e->xrowsum_valid = true;
+    }
+    CorrParams p = corr_params(e);
+    p.out = e->alpha;
+    p.alpha = nullptr;
+    hipLaunchKernelGGL(corr_logit_kernel<0>, dim3(e->cgrid), dim3(CORR_BLOCK), 0, e->stream, p);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+int salnmf_corr_compute_exposures(salnmf_engine* e) {
+    CK(corr_ready(e));
+    CorrParams p = corr_params(e);
+    p.out = e->H;
+    hipLaunchKernelGGL(corr_logit_kernel<1>, dim3(e->cgrid), dim3(CORR_BLOCK), 0, e->stream, p);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+int salnmf_corr_compute_aux(salnmf_engine* e) {
+    CK(corr_ready(e));
+    FusedParams p = fused_params(e);
+    p.wkl = nullptr;  // CorrNMF is unweighted (corrnmf_det.py:80-85)
+    p.wlh = nullptr;
+    p.Hout = e->aux;
+    p.hfloor = 0.0;
+    CK((launch_fused<true, true, false>(e, p)));
+    // the same pass produced G = (X/(HW))^T H for update_signatures: reduce it now (all ranks), apply later
+    CK(launch_tail(e, e->grid, e->red, 0, 0, 0));
+    return allreduce(e, e->red, (size_t)e->K * e->V);
+}
+
+int salnmf_corr_update_signatures(salnmf_engine* e, int n_given) {
+    CK(corr_ready(e));
+    if (n_given < 0 || n_given > e->K) return fail("n_given out of range");
+    if (n_given >= e->K) return 0;  // _utils_klnmf.py:204-205
+    return launch_tail(e, 0, e->red, n_given, SALNMF_CLIP_NON_GIVEN, 1);
+}
+
+int salnmf_corr_update_signature_scalings(salnmf_engine* e) {
+    CK(corr_ready(e));
+    const int K = e->K;
+    // first_k = sum_n aux[n][k]
+    const int pgrid = (int)std::min<int64_t>(512, (e->N + 255) / 256);
+    CK(ensure_scratch(e, (size_t)512 * 64 + 2 * 64));
+    double* part = e->scratch;
+    double* first = e->scratch + (size_t)512 * 64;
+    double* second = first + 64;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(pgrid), dim3(256), 0, e->stream, e->aux, e->N, e->KP, part);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(K), dim3(256), 0, e->stream, part, pgrid, e->KP, K, first);
+    // second_k = sum_n exp(alpha_n + <L_k, U_n>)
+    CorrParams p = corr_params(e);
+    p.out = e->corrpart;
+    hipLaunchKernelGGL(corr_logit_kernel<2>, dim3(e->cgrid), dim3(CORR_BLOCK), 0, e->stream, p);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(K), dim3(256), 0, e->stream, e->corrpart, e->cgrid, K, K, second);
+    HIPCK(hipGetLastError());
+    CK(allreduce(e, first, 128));  // first and second are adjacent
+    hipLaunchKernelGGL(corr_log_ratio_kernel, dim3(1), dim3(64), 0, e->stream, first, second, K, e->beta);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+int salnmf_corr_poisson_llh(salnmf_engine* e, double* out) {
+    if (!e || !out) return fail("null argument");
+    HIPCK(hipSetDevice(e->device));
+    if (!e->lgam_valid) {
+        const int g = 1024;
+        CK(ensure_scratch(e, (size_t)g + 1));
+        hipLaunchKernelGGL(lgamma_partial_kernel, dim3(g), dim3(256), 0, e->stream, e->X, e->N, e->V, VMAX, e->scratch);
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, e->scratch, g, 1, 1, e->scal + 5);
+        HIPCK(hipGetLastError());
+        CK(allreduce(e, e->scal + 5, 1));
+        double v;
+        CK(read_scalars(e, 5, 1, &v));
+        e->lgam_sum = v;
+        e->lgam_valid = true;
+    }
+    FwdParams p;
+    fwd_params(e, p);
+    p.wkl = nullptr;
+    p.wlh = nullptr;
+    CK(launch_forward<3>(e, p));
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, e->objpart, e->fgrid, 1, 1, e->scal + 6);
+    HIPCK(hipGetLastError());
+    CK(allreduce(e, e->scal + 6, 1));
+    double v;
+    CK(read_scalars(e, 6, 1, &v));
+    *out = v - e->lgam_sum;
     return 0;
 }
 

@@ -1,0 +1,170 @@
+// Dense pieces of correlated NMF on the padded device layout of the KL-NMF
+// engine: exposures H = exp(beta_k + alpha_n + <L_k, U_n>), both scaling updates, column sums
+// of aux, and the constant sum gammaln(1 + X) of the Poisson log-likelihood.
+// Reference arithmetic: src/salamander/models/_utils_corrnmf.py:11-25 (compute_exposures),
+// :103-138 (update_signature_scalings), :141-179 (update_sample_scalings);
+// _utils_klnmf.py:98-160 (poisson_llh).  aux itself (:28-52) is the U phase of fused_kernel
+// with an H-multiply epilogue, see salnmf_corr_compute_aux in salnmf.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace salnmf {
+
+constexpr int CORR_DMAX = 64;   // dim_embeddings <= n_signatures <= 64
+constexpr int CORR_LD = 65;     // odd LDS stride: rows of L / of the logit tile fall into different banks
+constexpr int CORR_TILE = 64;   // samples per workgroup pass (one per lane)
+constexpr int CORR_BLOCK = 256; // 4 waves: wave g handles signatures k = g, g+4, ...
+constexpr int CORR_SLOTS = 16;  // ceil(64 / 4) signatures per thread
+
+struct CorrParams {
+    const double* __restrict__ alpha;    // [Np] sample scalings             (modes 1, 2)
+    const double* __restrict__ beta;     // [K]  signature scalings          (modes 0, 1)
+    const double* __restrict__ L;        // [K][dim] signature embeddings
+    const double* __restrict__ U;        // [N][dim] sample embeddings (compact)
+    const double* __restrict__ xrowsum;  // [Np] sum_v X[n][v]               (mode 0)
+    double* __restrict__ out;            // mode 0: alpha [Np]; mode 1: H [Np][KP]; mode 2: partial [gridDim.x][K]
+    int64_t N, Np;
+    int K, KP, dim;
+};
+
+// One pass over the logits  S[n][k] = <L_k, U_n>  (a thin N x K x dim contraction on the VALU:
+// lane = sample, the signature operand is an LDS broadcast), followed by
+//   MODE 0: alpha_n = log(sum_v X[n][v]) - log(sum_k exp(beta_k + S[n][k]))        (:170-179)
+//   MODE 1: H[n][k] = exp((beta_k + alpha_n) + S[n][k]), pad rows 1, pad columns 0   (:21-25)
+//   MODE 2: partial_k = sum over this workgroup's samples of exp(alpha_n + S[n][k])  (:134-136)
+template <int MODE>
+__global__ void __launch_bounds__(CORR_BLOCK) corr_logit_kernel(CorrParams p) {
+    __shared__ double Ll[CORR_DMAX * CORR_LD];   // L[k][m], zero filled
+    __shared__ double T[CORR_TILE * CORR_LD];    // logit tile [sample][k]
+    __shared__ double bl[CORR_DMAX];
+    const int tid = threadIdx.x;
+    const int s = tid & 63, kg = tid >> 6;
+    const int K = p.K, dim = p.dim;
+    for (int i = tid; i < CORR_DMAX * CORR_LD; i += CORR_BLOCK) {
+        const int k = i / CORR_LD, m = i - k * CORR_LD;
+        Ll[i] = (k < K && m < dim) ? p.L[k * dim + m] : 0.0;
+    }
+    if (tid < CORR_DMAX) bl[tid] = (MODE != 2 && tid < K) ? p.beta[tid] : 0.0;
+    __syncthreads();
+
+    double colacc = 0.0;  // MODE 2: thread k accumulates its signature's sum over the tiles of this workgroup
+    for (int64_t t0 = (int64_t)blockIdx.x * CORR_TILE; t0 < p.Np; t0 += (int64_t)gridDim.x * CORR_TILE) {
+        const int64_t n = t0 + s;
+        const bool live = n < p.N;
+        double acc[CORR_SLOTS];
+#pragma unroll
+        for (int j = 0; j < CORR_SLOTS; ++j) acc[j] = 0.0;
+        for (int m0 = 0; m0 < dim; m0 += 4) {
+            double u[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) u[i] = (live && m0 + i < dim) ? p.U[n * dim + m0 + i] : 0.0;
+#pragma unroll
+            for (int j = 0; j < CORR_SLOTS; ++j) {
+                if (4 * j >= K) break;  // uniform over the workgroup
+                const double* lk = Ll + (kg + 4 * j) * CORR_LD + m0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[j] = __builtin_fma(u[i], lk[i], acc[j]);
+            }
+        }
+        if (MODE == 0) {
+            double part = 0.0;
+#pragma unroll
+            for (int j = 0; j < CORR_SLOTS; ++j) {
+                const int k = kg + 4 * j;
+                if (k < K) part += exp(bl[k] + acc[j]);
+            }
+            T[s * CORR_LD + kg] = part;
+            __syncthreads();
+            if (kg == 0 && n < p.Np) {
+                const double tot = ((T[s * CORR_LD] + T[s * CORR_LD + 1]) + T[s * CORR_LD + 2]) + T[s * CORR_LD + 3];
+                p.out[n] = live ? log(p.xrowsum[n]) - log(tot) : 0.0;
+            }
+            __syncthreads();
+        } else {
+            const double a = live ? p.alpha[n] : 0.0;
+#pragma unroll
+            for (int j = 0; j < CORR_SLOTS; ++j) {
+                const int k = kg + 4 * j;
+                if (k < K) T[s * CORR_LD + k] = (MODE == 1) ? exp((bl[k] + a) + acc[j]) : (live ? exp(a + acc[j]) : 0.0);
+            }
+            __syncthreads();
+            if (MODE == 1) {
+                const int KP = p.KP;
+                for (int i = tid; i < CORR_TILE * KP; i += CORR_BLOCK) {
+                    const int r = i / KP, c = i - r * KP;
+                    const int64_t nn = t0 + r;
+                    if (nn < p.Np) p.out[nn * KP + c] = (nn >= p.N) ? 1.0 : (c < K ? T[r * CORR_LD + c] : 0.0);
+                }
+            } else if (tid < K) {
+                double t = 0.0;
+                for (int r = 0; r < CORR_TILE; ++r) t += T[r * CORR_LD + tid];  // fixed order
+                colacc += t;
+            }
+            __syncthreads();
+        }
+    }
+    if (MODE == 2 && tid < K) p.out[(int64_t)blockIdx.x * K + tid] = colacc;
+}
+
+// out[n] = sum_v X[n][v] on the padded layout [Np][96] (pads are 0): 16 lanes per row, 6 features each
+__global__ void __launch_bounds__(256) rowsum_X_kernel(const double* __restrict__ X, int64_t Np, int ldx, double* __restrict__ out) {
+    const int c16 = threadIdx.x & 15;
+    int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int64_t stride = (int64_t)gridDim.x * 16;
+    for (; row < Np; row += stride) {  // Np is a multiple of 16: all 16-lane groups of a wave stay in step
+        double s = 0.0;
+        for (int v = c16; v < ldx; v += 16) s += X[row * ldx + v];
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) s += __shfl_xor(s, m, 64);
+        if (c16 == 0) out[row] = s;
+    }
+}
+
+// partial[b][c] = sum over the rows n < N of workgroup b's contiguous chunk of A[n][c]  (A is [.][ld], ld <= 64)
+__global__ void __launch_bounds__(256) colsum_partial_kernel(const double* __restrict__ A, int64_t N, int ld,
+                                                             double* __restrict__ partial) {
+    __shared__ double red[256];
+    const int groups = 256 / ld;  // row groups per pass
+    const int c = threadIdx.x % ld, g = threadIdx.x / ld;
+    const int64_t chunk = (N + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = (int64_t)blockIdx.x * chunk, hi = (lo + chunk < N) ? lo + chunk : N;
+    double s = 0.0;
+    if (g < groups)
+        for (int64_t n = lo + g; n < hi; n += groups) s += A[n * ld + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (g == 0) {
+        double t = 0.0;
+        for (int i = 0; i < groups; ++i) t += red[i * ld + c];
+        partial[(int64_t)blockIdx.x * ld + c] = t;
+    }
+}
+
+// partial[b] = sum over workgroup b's grid-stride slice of gammaln(1 + X[n][v]), n < N, v < V
+__global__ void __launch_bounds__(256) lgamma_partial_kernel(const double* __restrict__ X, int64_t N, int V, int ldx,
+                                                             double* __restrict__ partial) {
+    __shared__ double red[256];
+    double s = 0.0;
+    const int64_t total = N * ldx;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int v = (int)(i % ldx);
+        if (v < V) s += lgamma(1.0 + X[i]);
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+// beta_k = log(first_k) - log(second_k)   (_utils_corrnmf.py:137)
+__global__ void corr_log_ratio_kernel(const double* __restrict__ first, const double* __restrict__ second, int K,
+                                      double* __restrict__ beta) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < K) beta[k] = log(first[k]) - log(second[k]);
+}
+
+}  // namespace salnmf

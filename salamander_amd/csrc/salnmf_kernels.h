@@ -103,7 +103,9 @@ struct Geo {
 
 struct FusedParams {
     const double* __restrict__ X;    // [Np][VMAX]
-    double* __restrict__ H;          // [Np][KP]  updated in place when DO_U
+    double* __restrict__ H;          // [Np][KP]  read; DO_U writes the update to Hout (normally == H)
+    double* Hout;                    // [Np][KP]  destination of the H update (CorrNMF aux: a separate buffer)
+    double hfloor;                   // lower clip of the update: EPSILON, or 0 for aux = H * (R W^T) unclipped
     const double* __restrict__ W;    // [K][V]
     const double* __restrict__ wkl;  // [Np] or null
     const double* __restrict__ wlh;  // [Np] or null
@@ -491,13 +493,13 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
             // Unmasked: pad rows / columns just receive finite filler.  Non-temporal stores: 51 MB of H
             // per launch would otherwise sit dirty in L2 and be flushed at the kernel boundary
             // (-1.5 % on the fused + tail pair, tools/ab_bench.hip).
-            double* hdst = p.H + (n0 + q) * KP + c16;
+            double* hdst = p.Hout + (n0 + q) * KP + c16;
             if (p.wlh == nullptr) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int kt = 0; kt < KT; ++kt) {
-                        const double hn = fmax(hcur[r][kt] * u[kt][r], kEps);
+                        const double hn = fmax(hcur[r][kt] * u[kt][r], p.hfloor);
                         __builtin_nontemporal_store(hn, &hdst[4 * r * KP + 16 * kt]);
                         if (DO_STATS) hsum[kt] += (n0 + q + 4 * r < N) ? hn : 0.0;
                     }
@@ -543,8 +545,8 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
                         hn = 0.25 * (t * t);
                         if (p.wkl) hn /= wk2;
                     }
-                    hn = fmax(hn, kEps);
-                    p.H[n * KP + KB + j] = hn;
+                    hn = fmax(hn, p.hfloor);
+                    p.Hout[n * KP + KB + j] = hn;
                     if (DO_STATS) hsum_rem += (n < N) ? hn : 0.0;
                 }
             }
@@ -643,6 +645,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
 //   mode 0: weighted KL partial per workgroup (+ l-half penalty)        klnmf.py:64-80
 //   mode 1: per-sample KL, zeros replaced by EPS in X and WH            _utils_klnmf.py:58-97
 //   mode 2: the reconstruction H @ W                                    signature_nmf.py:221-224
+//   mode 3: Poisson log-likelihood partial (CorrNMF ELBO), no factorial _utils_klnmf.py:98-133
 struct FwdParams {
     const double* __restrict__ X;       // [Np][VMAX]
     const double* __restrict__ H;       // [Np][KP]
@@ -761,6 +764,19 @@ __global__ void __launch_bounds__(BLOCK, (fwd_lds_doubles<KS>() * 8 <= 80 * 1024
                 for (int m = 1; m < 16; m <<= 1) acc += __shfl_xor(acc, m, 64);
                 if (c16 == 0) p.out[n] = acc;
             }
+        } else if (MODE == 3) {
+            // Poisson log-likelihood without the factorial term (_utils_klnmf.py:98-133):
+            // sum over the valid entries of (P != 0 ? X log P : 0) - P
+#pragma unroll
+            for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n0 + q + 4 * r < N && 16 * vt + c16 < V) {
+                        const double xv = x[vt][r], pv = pr[vt][r];
+                        double t = 0.0;
+                        if (pv != 0.0) t = xv * (log_operand_ok(pv) ? log_ratio(pv, 1.0) : log(pv));
+                        total += t - pv;
+                    }
         } else {
             double* dst = p.out + (n0 + q) * VMAX + c16;
 #pragma unroll
@@ -771,7 +787,7 @@ __global__ void __launch_bounds__(BLOCK, (fwd_lds_doubles<KS>() * 8 <= 80 * 1024
         __builtin_amdgcn_wave_barrier();
     }
 
-    if (MODE == 0) {
+    if (MODE == 0 || MODE == 3) {
         red[tid] = total;
         __syncthreads();
         if (tid == 0) {

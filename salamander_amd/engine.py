@@ -126,6 +126,49 @@ class Engine:
         _lib.check(self._lib.salnmf_mv_objective(self._h, float(lam), float(delta), ctypes.byref(out)))
         return out.value
 
+    # -- CorrNMF dense pieces (the embedding solves stay with the host layer)
+    def corr_configure(self, dim_embeddings: int):
+        _lib.check(self._lib.salnmf_corr_configure(self._h, int(dim_embeddings)))
+        self.dim = int(dim_embeddings)
+
+    def _corr_shape(self, which: int):
+        return {
+            _lib.CORR_SIGNATURE_SCALINGS: (self.K,),
+            _lib.CORR_SAMPLE_SCALINGS: (self.N,),
+            _lib.CORR_SIGNATURE_EMBEDDINGS: (self.K, self.dim),
+            _lib.CORR_SAMPLE_EMBEDDINGS: (self.N, self.dim),
+            _lib.CORR_AUX: (self.N, self.K),
+        }[which]
+
+    def corr_upload(self, which: int, values):
+        a = _as_c(values, self._corr_shape(which), "values")
+        _lib.check(self._lib.salnmf_corr_upload(self._h, int(which), _ptr(a)))
+
+    def corr_download(self, which: int) -> np.ndarray:
+        out = np.empty(self._corr_shape(which), dtype=np.float64)
+        _lib.check(self._lib.salnmf_corr_download(self._h, int(which), _ptr(out)))
+        return out
+
+    def corr_update_sample_scalings(self):
+        _lib.check(self._lib.salnmf_corr_update_sample_scalings(self._h))
+
+    def corr_compute_exposures(self):
+        _lib.check(self._lib.salnmf_corr_compute_exposures(self._h))
+
+    def corr_compute_aux(self):
+        _lib.check(self._lib.salnmf_corr_compute_aux(self._h))
+
+    def corr_update_signature_scalings(self):
+        _lib.check(self._lib.salnmf_corr_update_signature_scalings(self._h))
+
+    def corr_update_signatures(self, n_given: int = 0):
+        _lib.check(self._lib.salnmf_corr_update_signatures(self._h, int(n_given)))
+
+    def corr_poisson_llh(self) -> float:
+        out = c_double()
+        _lib.check(self._lib.salnmf_corr_poisson_llh(self._h, ctypes.byref(out)))
+        return out.value
+
     # -- multi-GPU
     @staticmethod
     def comm_unique_id() -> bytes:

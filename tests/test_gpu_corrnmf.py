@@ -1,0 +1,152 @@
+"""GPU parity of the CorrNMF dense pieces through the C ABI.
+
+Checked against (i) the reference's own fixtures (``tests/test_corrnmf.py:98-175`` data) and
+(ii) the pinned NumPy oracle on larger seeded problems, incl. ragged sizes and every kernel
+geometry class.  fp64 throughout; tolerances are relative 1e-12 unless stated.
+"""
+
+import numpy as np
+import pytest
+
+from oracle import corrnmf_oracle as co
+from oracle import klnmf_oracle as ko
+from salamander_amd import _lib
+from salamander_amd.engine import Engine
+from test_oracle_corrnmf import load_case
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-12
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def engine_from(X, W, beta, alpha, L, U):
+    N, V = X.shape
+    K, dim = L.shape
+    e = Engine(N, V, K)
+    e.upload_X(X)
+    e.upload_W(W)
+    e.corr_configure(dim)
+    e.corr_upload(_lib.CORR_SIGNATURE_SCALINGS, beta)
+    e.corr_upload(_lib.CORR_SAMPLE_SCALINGS, alpha)
+    e.corr_upload(_lib.CORR_SIGNATURE_EMBEDDINGS, L)
+    e.corr_upload(_lib.CORR_SAMPLE_EMBEDDINGS, U)
+    return e
+
+
+def synthetic(N, K, dim, V=96, seed=0):
+    rng = np.random.default_rng(seed)
+    X, W0, _ = ko.synthetic_problem(V, N, K, seed=seed)  # X (N, V), W0 (K, V)
+    beta = rng.normal(0.0, 0.3, size=K)
+    alpha = np.log(X.sum(axis=1) / K) + rng.normal(0.0, 0.1, size=N)
+    L = rng.normal(0.0, 0.5, size=(K, dim))
+    U = rng.normal(0.0, 0.5, size=(N, dim))
+    return X, W0, beta, alpha, L, U
+
+
+# ------------------------------------------------------------------ the reference's fixtures
+
+
+@pytest.fixture(params=[1, 2])
+def case(request):
+    return load_case(request.param)
+
+
+def test_fixture_objective(case):
+    c = case
+    e = engine_from(c["X"], c["W"], c["beta"], c["alpha"], c["L"], c["U"])
+    e.corr_compute_exposures()
+    llh = e.corr_poisson_llh()
+    K, dim = c["L"].shape
+    var = c["variance"]
+    elbo = llh - 0.5 * dim * K * np.log(2 * np.pi * var) - np.sum(c["L"] ** 2) / (2 * var)
+    elbo += -0.5 * dim * c["U"].shape[0] * np.log(2 * np.pi * var) - np.sum(c["U"] ** 2) / (2 * var)
+    assert np.allclose(elbo, c["objective"])
+    assert abs(elbo - c["objective"]) <= 1e-12 * abs(c["objective"])
+    e.close()
+
+
+def test_fixture_aux_and_signatures(case):
+    c = case
+    e = engine_from(c["X"], c["W"], c["beta"], c["alpha"], c["L"], c["U"])
+    e.corr_compute_exposures()
+    assert rel(e.download_H(), co.compute_exposures(c["beta"], c["alpha"], c["L"], c["U"])) < RTOL
+    e.corr_compute_aux()
+    aux = e.corr_download(_lib.CORR_AUX).T
+    assert np.allclose(aux, c["aux"])  # the stored nsigs2 fixture is 1.4e-9 away from its own inputs' aux
+    assert rel(aux, co.compute_aux(c["X"], c["W"], co.compute_exposures(c["beta"], c["alpha"], c["L"], c["U"]))) < RTOL
+    e.corr_update_signatures(0)
+    assert np.allclose(e.download_W(), c["W_updated"])
+    e.close()
+
+
+def test_fixture_scalings(case):
+    c = case
+    e = engine_from(c["X"], c["W"], c["beta"], c["alpha"], c["L"], c["U"])
+    e.corr_upload(_lib.CORR_AUX, c["aux"].T)
+    e.corr_update_signature_scalings()
+    assert np.allclose(e.corr_download(_lib.CORR_SIGNATURE_SCALINGS), c["beta_updated"])
+    e.close()
+    e = engine_from(c["X"], c["W"], c["beta"], c["alpha"], c["L"], c["U"])
+    e.corr_update_sample_scalings()
+    assert np.allclose(e.corr_download(_lib.CORR_SAMPLE_SCALINGS), c["alpha_updated"])
+    e.close()
+
+
+# ------------------------------------------------------------------ oracle, larger shapes
+
+
+@pytest.mark.parametrize(
+    "N,K,dim",
+    [(203, 1, 1), (1000, 7, 3), (4099, 16, 16), (2500, 18, 5), (3001, 30, 30), (5000, 50, 50), (777, 50, 2), (1234, 64, 64)],
+)
+def test_dense_pieces_match_oracle(N, K, dim):
+    X, W, beta, alpha, L, U = synthetic(N, K, dim, seed=N + K)
+    e = engine_from(X, W, beta, alpha, L, U)
+    # the order of CorrNMFDet._update_parameters (corrnmf_det.py:157-169), embeddings held fixed
+    e.corr_update_sample_scalings()
+    alpha1 = co.update_sample_scalings(X, beta, L, U)
+    assert np.max(np.abs(e.corr_download(_lib.CORR_SAMPLE_SCALINGS) - alpha1)) < 1e-12
+    e.corr_compute_exposures()
+    H = co.compute_exposures(beta, alpha1, L, U)
+    assert rel(e.download_H(), H) < RTOL
+    e.corr_compute_aux()
+    aux = co.compute_aux(X, W, H)
+    assert rel(e.corr_download(_lib.CORR_AUX).T, aux) < RTOL
+    e.corr_update_signature_scalings()
+    beta1 = co.update_signature_scalings(aux, alpha1, L, U)
+    assert np.max(np.abs(e.corr_download(_lib.CORR_SIGNATURE_SCALINGS) - beta1)) < 1e-12
+    llh = e.corr_poisson_llh()
+    want = co.poisson_llh(X.T, W.T, H.T)
+    assert abs(llh - want) <= 1e-12 * abs(want)
+    n_given = K // 3
+    e.corr_update_signatures(n_given)
+    assert rel(e.download_W(), ko.update_W(X.T, W.T, H.T, n_given_signatures=n_given).T) < RTOL
+    # H must be untouched by the aux pass
+    assert rel(e.download_H(), H) < RTOL
+    e.close()
+
+
+def test_aux_pass_leaves_klnmf_path_intact():
+    # the aux variant shares fused_kernel with the KL-NMF step: a KL step on the same engine afterwards
+    X, W, beta, alpha, L, U = synthetic(1500, 50, 4, seed=9)
+    e = engine_from(X, W, beta, alpha, L, U)
+    e.corr_compute_exposures()
+    H = e.download_H()
+    e.corr_compute_aux()
+    e.kl_step(1)
+    Wn, Hn = ko.update_WH(X.T, W.T, H.T)
+    assert rel(e.download_W(), Wn.T) < RTOL and rel(e.download_H(), Hn.T) < RTOL
+    e.close()
+
+
+def test_corr_calls_need_configure():
+    e = Engine(64, 96, 3)
+    with pytest.raises(RuntimeError, match="corr_configure"):
+        e._lib.salnmf_corr_compute_exposures  # symbol exists
+        _lib.check(e._lib.salnmf_corr_compute_exposures(e._h))
+    e.close()
