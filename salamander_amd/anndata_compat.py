@@ -4,7 +4,7 @@ The reference stores everything in ``anndata.AnnData`` (``signature_nmf.py:269-2
 ``initialize.py:206-216``).  ``anndata`` is an optional dependency here: when it is
 importable the real class is used; otherwise :class:`MiniAnnData` supplies exactly the
 attribute surface the fit path touches: ``X`` get/set, ``obs``,
-``obsm``, ``obs_names``, ``var_names``, ``n_obs``, ``n_vars``, ``to_df()``, ``copy()``
+``obsm``, ``obsp``, ``obs_names``, ``var_names``, ``n_obs``, ``n_vars``, ``to_df()``, ``copy()``
 and row slicing ``adata[:n, :]``.
 """
 
@@ -40,6 +40,7 @@ class MiniAnnData:
         self.obs = pd.DataFrame(index=self._names(obs_names, n_obs))
         self._var_names = self._names(var_names, n_vars)
         self.obsm: dict = {}
+        self.obsp: dict = {}
 
     @staticmethod
     def _names(names, n):

@@ -115,25 +115,98 @@ def check_given_asignatures(given_asignatures, adata, n_signatures) -> None:
         raise ValueError("The number of given signatures exceeds the number of signatures to initialize.")
 
 
-def initialize_standard_nmf(adata, n_signatures, method="nndsvd", given_parameters: dict[str, Any] | None = None, **kwargs):
-    """Builds ``asignatures`` and writes ``adata.obsm['exposures']`` (initialize.py:158-255)."""
-    given_parameters = {} if given_parameters is None else given_parameters.copy()
-    dict_checker("given_parameters", given_parameters, GIVEN_PARAMETERS_STANDARD_NMF)
-    given = given_parameters.get("asignatures")
+def initialize_base(adata, n_signatures, method="nndsvd", given_asignatures=None, **kwargs):
+    """``(asignatures, exposures_mat)`` without touching ``adata`` (initialize.py:158-218)."""
     given_mat = None
-    if given is not None:
-        check_given_asignatures(given, adata, n_signatures)
-        given_mat = np.asarray(given.X)
+    if given_asignatures is not None:
+        check_given_asignatures(given_asignatures, adata, n_signatures)
+        given_mat = np.asarray(given_asignatures.X)
 
     S, E = initialize_mat(np.asarray(adata.X), n_signatures, method, given_mat, **kwargs)
     asignatures = AnnData(S)
     asignatures.var_names = adata.var_names
     names = [f"Sig{k + 1}" for k in range(n_signatures)]
     asignatures.obs_names = names
-    if given is not None:
+    if given_asignatures is not None:
         # given signatures keep their own annotations; the rest are Sig1..Sig(K-g) (initialize.py:211-216)
-        g = given.n_obs
+        g = given_asignatures.n_obs
         asignatures.obs_names = list(np.roll(names, g))
-        asignatures = concat_rows(given, asignatures[g:, :])
+        asignatures = concat_rows(given_asignatures, asignatures[g:, :])
+    return asignatures, E
+
+
+def initialize_standard_nmf(adata, n_signatures, method="nndsvd", given_parameters: dict[str, Any] | None = None, **kwargs):
+    """Builds ``asignatures`` and writes ``adata.obsm['exposures']`` (initialize.py:221-255)."""
+    given_parameters = {} if given_parameters is None else given_parameters.copy()
+    dict_checker("given_parameters", given_parameters, GIVEN_PARAMETERS_STANDARD_NMF)
+    asignatures, E = initialize_base(adata, n_signatures, method, given_parameters.get("asignatures"), **kwargs)
     adata.obsm["exposures"] = E
     return asignatures
+
+
+# ----------------------------------------------------------------------------- correlated NMF
+
+GIVEN_PARAMETERS_CORRNMF = [
+    "asignatures",
+    "signature_scalings",
+    "sample_scalings",
+    "signature_embeddings",
+    "sample_embeddings",
+    "variance",
+]
+
+
+def check_given_parameters_corrnmf(adata, n_signatures, dim_embeddings, given_parameters) -> None:
+    """Keys, types and shapes of a priori known CorrNMF parameters (initialize.py:258-316)."""
+    dict_checker("given_parameters", given_parameters, GIVEN_PARAMETERS_CORRNMF)
+    if "asignatures" in given_parameters:
+        check_given_asignatures(given_parameters["asignatures"], adata, n_signatures)
+    expected = {
+        "signature_scalings": (n_signatures,),
+        "sample_scalings": (adata.n_obs,),
+        "signature_embeddings": (n_signatures, dim_embeddings),
+        "sample_embeddings": (adata.n_obs, dim_embeddings),
+    }
+    for key, shape in expected.items():
+        if key in given_parameters:
+            type_checker(f"given_{key}", given_parameters[key], np.ndarray)
+            shape_checker(f"given_{key}", given_parameters[key], shape)
+    if "variance" in given_parameters:
+        type_checker("given_variance", given_parameters["variance"], [float, int])
+        if given_parameters["variance"] <= 0.0:
+            raise ValueError("The variance has to be a positive real number.")
+
+
+def initialize_corrnmf(
+    adata,
+    n_signatures,
+    dim_embeddings,
+    method="nndsvd",
+    given_parameters: dict[str, Any] | None = None,
+    initialize_sample_embeddings: bool = True,
+    **kwargs,
+):
+    """Signatures as for standard NMF; scalings zero; embeddings standard normal from the global RNG;
+    variance 1 -- each unless given (initialize.py:319-384).  Returns ``(asignatures, variance)``."""
+    if method == "custom":
+        raise ValueError("Custom parameter initializations are currently not supported for (multimodal) correlated NMF.")
+    given_parameters = {} if given_parameters is None else given_parameters.copy()
+    check_given_parameters_corrnmf(adata, n_signatures, dim_embeddings, given_parameters)
+    asignatures, _ = initialize_base(adata, n_signatures, method, given_parameters.get("asignatures"), **kwargs)
+
+    def standard_normal(n):
+        return np.random.multivariate_normal(np.zeros(dim_embeddings), np.identity(dim_embeddings), size=n)
+
+    asignatures.obs["scalings"] = given_parameters.get("signature_scalings", np.zeros(n_signatures))
+    adata.obs["scalings"] = given_parameters.get("sample_scalings", np.zeros(adata.n_obs))
+    if "signature_embeddings" in given_parameters:
+        asignatures.obsm["embeddings"] = given_parameters["signature_embeddings"]
+    else:
+        asignatures.obsm["embeddings"] = standard_normal(n_signatures)
+    if initialize_sample_embeddings:
+        if "sample_embeddings" in given_parameters:
+            adata.obsm["embeddings"] = given_parameters["sample_embeddings"]
+        else:
+            adata.obsm["embeddings"] = standard_normal(adata.n_obs)
+    variance = float(given_parameters.get("variance", 1.0))
+    return asignatures, variance

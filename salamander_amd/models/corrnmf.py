@@ -1,0 +1,109 @@
+"""``CorrNMF``: the shared shell of the correlated-NMF models.
+
+Drop-in for ``src/salamander/models/corrnmf.py``: the exposures are not free parameters but
+``exp(signature scaling + sample scaling + <signature embedding, sample embedding>)``
+(``:66-77``); the objective is the ELBO (``:86-98``, maximised); initialisation per
+``initialize_corrnmf`` (``:104-136``).  The dense pieces run on the device; see
+``corrnmf_det.py`` for the update step.
+"""
+
+from __future__ import annotations
+
+from typing import Any, Literal
+
+import numpy as np
+
+from .. import _lib
+from ..initialization import initialize_corrnmf
+from ..utils import value_checker
+from . import _utils_corrnmf
+from .signature_nmf import SignatureNMF
+
+
+class CorrNMF(SignatureNMF):
+    def __init__(
+        self,
+        n_signatures: int = 1,
+        init_method: str = "nndsvd",
+        dim_embeddings: int | None = None,
+        min_iterations: int = 500,
+        max_iterations: int = 10000,
+        conv_test_freq: int = 10,
+        tol: float = 1e-7,
+        **engine_kwargs,
+    ):
+        super().__init__(n_signatures, init_method, min_iterations, max_iterations, conv_test_freq, tol, **engine_kwargs)
+        # embedding dimension = number of signatures covers independent signatures (corrnmf.py:60-61)
+        self.dim_embeddings = n_signatures if dim_embeddings is None else dim_embeddings
+        self.variance = 1.0
+
+    @property
+    def objective(self) -> Literal["minimize", "maximize"]:
+        return "maximize"
+
+    # ------------------------------------------------------------------ host state -> device
+    def _sync_to_device(self) -> None:
+        """X, signatures and (if present) exposures as for the KL models, plus scalings and embeddings."""
+        if "exposures" not in self.adata.obsm:
+            self.adata.obsm["exposures"] = np.ones((self.adata.n_obs, self.n_signatures))
+        super()._sync_to_device()
+        e = self._engine
+        if getattr(e, "dim", None) != self.dim_embeddings:
+            e.corr_configure(self.dim_embeddings)
+        e.corr_upload(_lib.CORR_SIGNATURE_SCALINGS, np.asarray(self.asignatures.obs["scalings"].values, dtype=np.float64))
+        e.corr_upload(_lib.CORR_SAMPLE_SCALINGS, np.asarray(self.adata.obs["scalings"].values, dtype=np.float64))
+        e.corr_upload(_lib.CORR_SIGNATURE_EMBEDDINGS, self.asignatures.obsm["embeddings"])
+        e.corr_upload(_lib.CORR_SAMPLE_EMBEDDINGS, self.adata.obsm["embeddings"])
+
+    # ------------------------------------------------------------------ reference hooks
+    def compute_exposures(self) -> None:
+        """``adata.obsm['exposures']`` from the scalings and embeddings (corrnmf.py:66-77)."""
+        self.adata.obsm["exposures"] = _utils_corrnmf.compute_exposures(
+            self.asignatures.obs["scalings"].values,
+            self.adata.obs["scalings"].values,
+            self.asignatures.obsm["embeddings"],
+            self.adata.obsm["embeddings"],
+        )
+
+    def compute_reconstruction_errors(self) -> None:
+        """Samplewise KL divergences of the recomputed exposures (corrnmf.py:79-84)."""
+        self.compute_exposures()
+        self._sync_to_device()
+        self.adata.obs["reconstruction_error"] = self._engine.samplewise_kl()
+
+    def objective_function(self, penalize_sample_embeddings: bool = True) -> float:
+        """The evidence lower bound, with the exposures as currently stored (corrnmf.py:86-98)."""
+        return _utils_corrnmf.elbo_corrnmf(
+            self.adata.X,
+            self.asignatures.X,
+            self.adata.obsm["exposures"],
+            self.asignatures.obsm["embeddings"],
+            self.adata.obsm["embeddings"],
+            self.variance,
+            penalize_sample_embeddings=penalize_sample_embeddings,
+        )
+
+    def _initialize(self, given_parameters: dict[str, Any] | None = None, init_kwargs: dict[str, Any] | None = None) -> None:
+        """Signatures, scalings, embeddings and variance; then the exposures (corrnmf.py:104-136)."""
+        init_kwargs = {} if init_kwargs is None else init_kwargs.copy()
+        self.asignatures, self.variance = initialize_corrnmf(
+            self.adata, self.n_signatures, self.dim_embeddings, self.init_method, given_parameters, **init_kwargs
+        )
+        self.compute_exposures()
+
+    def _setup_fitting_parameters(self, fitting_kwargs: dict[str, Any] | None = None) -> None:
+        """No fitting parameters (corrnmf.py:138-144)."""
+        return
+
+    def compute_correlation_scaled(self, data: Literal["samples", "signatures"] = "signatures") -> None:
+        """Cosine similarities of the embeddings -> ``obsp`` (corrnmf.py:146-178)."""
+        value_checker("data", data, ["samples", "signatures"])
+        assert "embeddings" in self.adata.obsm, "Computing the sample or signature correlation requires fitting the CorrNMF model."
+        vectors = np.asarray(self.adata.obsm["embeddings"] if data == "samples" else self.asignatures.obsm["embeddings"])
+        unit = vectors / np.sqrt(np.sum(vectors**2, axis=1))[:, None]
+        correlation = unit @ unit.T
+        np.fill_diagonal(correlation, 1.0)
+        if data == "samples":
+            self.adata.obsp["X_correlation"] = correlation
+        else:
+            self.asignatures.obsp["correlation"] = correlation

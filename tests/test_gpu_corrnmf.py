@@ -150,3 +150,156 @@ def test_corr_calls_need_configure():
         e._lib.salnmf_corr_compute_exposures  # symbol exists
         _lib.check(e._lib.salnmf_corr_compute_exposures(e._h))
     e.close()
+
+
+# ------------------------------------------------------------------ model level: the reference's tests/test_corrnmf.py
+
+
+def model_from(case):
+    import pandas as pd
+
+    import salamander_amd as sal
+    from salamander_amd.models import corrnmf_det
+    from test_oracle_corrnmf import FIX
+    import os
+
+    counts = pd.read_csv(os.path.join(FIX, "counts.csv"), index_col=0).T
+    adata = sal.AnnData(counts)
+    adata.obs["scalings"] = case["alpha"]
+    adata.obsm["embeddings"] = case["U"].copy()
+    asignatures = sal.AnnData(case["W"].copy())
+    asignatures.var_names = adata.var_names
+    asignatures.obs["scalings"] = case["beta"]
+    asignatures.obsm["embeddings"] = case["L"].copy()
+    K, dim = case["L"].shape
+    model = corrnmf_det.CorrNMFDet(n_signatures=K, dim_embeddings=dim)
+    model.adata = adata
+    model.asignatures = asignatures
+    model.compute_exposures()
+    model.variance = case["variance"]
+    return model
+
+
+def test_model_objective_function(case):
+    assert np.allclose(model_from(case).objective_function(), case["objective"])
+
+
+class TestUpdatesCorrNMFDet:
+    def test_update_signatures(self, case):
+        m = model_from(case)
+        m.update_signatures()
+        assert np.allclose(m.asignatures.X, case["W_updated"])
+
+    def test_update_signature_scalings(self, case):
+        m = model_from(case)
+        m.update_signature_scalings(case["aux"])
+        assert np.allclose(m.asignatures.obs["scalings"].values, case["beta_updated"])
+
+    def test_update_sample_scalings(self, case):
+        m = model_from(case)
+        m.update_sample_scalings()
+        assert np.allclose(m.adata.obs["scalings"].values, case["alpha_updated"])
+
+    def test_update_signature_embeddings(self, case):
+        m = model_from(case)
+        m.update_signature_embeddings(case["aux"])
+        assert np.allclose(m.asignatures.obsm["embeddings"], case["L_updated"])
+
+    def test_update_sample_embeddings(self, case):
+        m = model_from(case)
+        m.update_sample_embeddings(case["aux"])
+        assert np.allclose(m.adata.obsm["embeddings"], case["U_updated"])
+
+    def test_update_variance(self, case):
+        m = model_from(case)
+        m.update_variance()
+        assert np.allclose(m.variance, case["variance_updated"])
+
+
+def test_model_update_parameters_matches_oracle_steps(case):
+    c = case
+    m = model_from(c)
+    W, beta, alpha, L, U, var = c["W"], c["beta"], c["alpha"], c["L"], c["U"], c["variance"]
+    for _ in range(3):
+        m._update_parameters()
+        W, beta, alpha, L, U, var, H = co.corrnmf_det_step(c["X"], W, beta, alpha, L, U, var)
+        # the dense pieces agree to rounding; the embeddings to the solver's tolerance
+        assert np.allclose(m.asignatures.X, W, rtol=1e-6, atol=1e-12)
+        assert np.allclose(m.adata.obsm["exposures"], H, rtol=1e-6)
+        assert np.allclose(m.asignatures.obs["scalings"].values, beta, rtol=1e-6, atol=1e-9)
+        assert np.allclose(m.adata.obs["scalings"].values, alpha, rtol=1e-6, atol=1e-9)
+        assert np.allclose(m.asignatures.obsm["embeddings"], L, rtol=1e-5, atol=1e-7)
+        assert np.allclose(m.adata.obsm["embeddings"], U, rtol=1e-5, atol=1e-7)
+        assert np.allclose(m.variance, var, rtol=1e-6)
+
+
+@pytest.mark.parametrize("n_signatures,dim_embeddings", [(1, 1), (2, 1), (2, 2)])
+class TestGivenParametersCorrNMFDet:
+    """tests/test_corrnmf.py:178-245: every given parameter survives a (3-iteration) fit unchanged."""
+
+    @pytest.fixture
+    def model(self, n_signatures, dim_embeddings):
+        from salamander_amd.models import corrnmf_det
+
+        return corrnmf_det.CorrNMFDet(n_signatures=n_signatures, dim_embeddings=dim_embeddings, min_iterations=3, max_iterations=3)
+
+    @pytest.fixture
+    def adata(self):
+        import os
+
+        import pandas as pd
+
+        import salamander_amd as sal
+        from test_oracle_corrnmf import FIX
+
+        return sal.AnnData(pd.read_csv(os.path.join(FIX, "counts.csv"), index_col=0).T)
+
+    def test_given_signatures(self, model, adata):
+        for n_given in range(1, model.n_signatures + 1):
+            given = adata[:n_given, :].copy()
+            given.X = given.X / np.sum(given.X, axis=1, keepdims=True)
+            model.fit(adata, given_parameters={"asignatures": given})
+            assert np.allclose(given.X, model.asignatures.X[:n_given, :])
+
+    def test_given_signature_scalings(self, model, adata):
+        given = np.random.uniform(size=model.n_signatures)
+        model.fit(adata, given_parameters={"signature_scalings": given})
+        assert np.allclose(given, model.asignatures.obs["scalings"].values)
+
+    def test_given_sample_scalings(self, model, adata):
+        given = np.random.uniform(size=adata.n_obs)
+        model.fit(adata, given_parameters={"sample_scalings": given})
+        assert np.allclose(given, model.adata.obs["scalings"].values)
+
+    def test_given_signature_embeddings(self, model, adata):
+        given = np.random.uniform(size=(model.n_signatures, model.dim_embeddings))
+        model.fit(adata, given_parameters={"signature_embeddings": given})
+        assert np.allclose(given, model.asignatures.obsm["embeddings"])
+
+    def test_given_sample_embeddings(self, model, adata):
+        given = np.random.uniform(size=(adata.n_obs, model.dim_embeddings))
+        model.fit(adata, given_parameters={"sample_embeddings": given})
+        assert np.allclose(given, model.adata.obsm["embeddings"])
+
+    def test_given_variance(self, model, adata):
+        model.fit(adata, given_parameters={"variance": 3})
+        assert np.allclose(3, model.variance)
+
+
+def test_fit_history_is_the_elbo_of_the_resident_state():
+    """fit() for 20 iterations on a mid-size problem: the recorded ELBO equals the oracle's on the final state."""
+    import salamander_amd as sal
+    from salamander_amd.models import CorrNMFDet
+
+    rng = np.random.default_rng(5)
+    X, _, _ = ko.synthetic_problem(96, 300, 4, seed=5)
+    adata = sal.AnnData(X)
+    np.random.seed(3)
+    model = CorrNMFDet(n_signatures=4, dim_embeddings=2, init_method="random", min_iterations=20, max_iterations=20)
+    model.fit(adata, init_kwargs={"seed": 3})
+    assert len(model.history["objective_function"]) == 2
+    assert model.history["objective_function"][1] > model.history["objective_function"][0]
+    want = co.elbo_corrnmf(
+        adata.X, model.asignatures.X, adata.obsm["exposures"], model.asignatures.obsm["embeddings"], adata.obsm["embeddings"], model.variance
+    )
+    assert abs(model.history["objective_function"][-1] - want) <= 1e-10 * abs(want)
