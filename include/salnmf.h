@@ -103,9 +103,10 @@ int salnmf_mv_objective(salnmf_engine* e, double lam, double delta, double* out)
 /* ---- Correlated NMF, dense pieces.  The exposure matrix is not a free
  * parameter but exp(signature scaling + sample scaling + <signature embedding, sample
  * embedding>) (src/salamander/models/corrnmf.py:66-77).  The engine keeps the scalings and
- * embeddings next to X / W / H; H holds the exposures.  The per-embedding Newton-CG solves
- * (_utils_corrnmf.py:354-410, SciPy) are NOT part of this library: the host layer runs them
- * between salnmf_corr_compute_aux and salnmf_corr_update_signatures, as CorrNMFDet does
+ * embeddings next to X / W / H; H holds the exposures.  The n_samples sample-embedding solves run
+ * on the device (salnmf_corr_update_sample_embeddings); the n_signatures signature-embedding
+ * solves (each a sum over all samples) are still run by the host layer with SciPy between
+ * salnmf_corr_compute_aux and salnmf_corr_update_signatures, as CorrNMFDet does
  * (corrnmf_det.py:157-169). */
 #define SALNMF_CORR_SIGNATURE_SCALINGS 0   /* [n_signatures]                       */
 #define SALNMF_CORR_SAMPLE_SCALINGS 1      /* [n_samples]                          */
@@ -131,6 +132,16 @@ int salnmf_corr_update_signature_scalings(salnmf_engine* e);
  * the numerator of the last salnmf_corr_compute_aux (W and the exposures are unchanged in
  * between in CorrNMFDet._update_parameters). */
 int salnmf_corr_update_signatures(salnmf_engine* e, int n_given);
+/* CorrNMFDet.update_sample_embeddings (corrnmf_det.py:115-141): one Newton-CG solve per sample
+ * (update_embedding, _utils_corrnmf.py:354-410, objective :182-239, gradient :242-293, Hessian
+ * :296-351) from the current sample embeddings, using the aux buffer, both scalings and the
+ * signature embeddings on the device.  maxiter <= 0 selects SciPy's default (200 * dim);
+ * CorrNMFDet passes 3.  status_out (n_samples ints, or NULL) receives per solve 0 = converged,
+ * 1 = iteration limit, 2 = line search failed, 3 = CG failed (SciPy's warnflag values).
+ * The arithmetic restates SciPy's `_minimize_newtoncg` + `_line_search_wolfe12`
+ * (salamander_amd/csrc/salnmf_newtoncg.h). */
+int salnmf_corr_update_sample_embeddings(salnmf_engine* e, double variance, int maxiter,
+                                         int* status_out);
 /* poisson_llh, _utils_klnmf.py:98-160 (the data term of elbo_corrnmf, _utils_corrnmf.py:92). */
 int salnmf_corr_poisson_llh(salnmf_engine* e, double* out);
 

@@ -739,6 +739,40 @@ int salnmf_corr_update_signature_scalings(salnmf_engine* e) {
     return 0;
 }
 
+int salnmf_corr_update_sample_embeddings(salnmf_engine* e, double variance, int maxiter, int* status_out) {
+    CK(corr_ready(e));
+    if (!(variance > 0.0)) return fail("variance must be positive");
+    SampleEmbeddingParams p;
+    p.aux = e->aux;
+    p.alpha = e->alpha;
+    p.beta = e->beta;
+    p.L = e->Lemb;
+    p.U = e->Uemb;
+    p.status = nullptr;
+    p.variance = variance;
+    p.N = e->N;
+    p.K = e->K;
+    p.KP = e->KP;
+    p.dim = e->dim;
+    p.maxiter = maxiter > 0 ? maxiter : 200 * e->dim;  // scipy's default: 200 * len(x0)
+    int* dstatus = nullptr;
+    if (status_out) {
+        HIPCK(hipMalloc(&dstatus, (size_t)e->N * sizeof(int)));
+        p.status = dstatus;
+    }
+    const int grid = (int)std::min<int64_t>((e->N + 3) / 4, 8192);
+    hipLaunchKernelGGL(corr_sample_embeddings_kernel, dim3(grid), dim3(CORR_BLOCK), 0, e->stream, p);
+    int rc = 0;
+    if (hipGetLastError() != hipSuccess) rc = fail("corr_sample_embeddings_kernel launch failed");
+    if (!rc && status_out) {
+        if (hipMemcpyAsync(status_out, dstatus, (size_t)e->N * sizeof(int), hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
+            hipStreamSynchronize(e->stream) != hipSuccess)
+            rc = fail("status download failed");
+    }
+    if (dstatus) (void)hipFree(dstatus);
+    return rc;
+}
+
 int salnmf_corr_poisson_llh(salnmf_engine* e, double* out) {
     if (!e || !out) return fail("null argument");
     HIPCK(hipSetDevice(e->device));

@@ -9,6 +9,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "salnmf_kernels.h"
+#include "salnmf_newtoncg.h"
+
 namespace salnmf {
 
 constexpr int CORR_DMAX = 64;   // dim_embeddings <= n_signatures <= 64
@@ -165,6 +168,122 @@ __global__ void corr_log_ratio_kernel(const double* __restrict__ first, const do
                                       double* __restrict__ beta) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < K) beta[k] = log(first[k]) - log(second[k]);
+}
+
+// ----------------------------------------------------------------------------------------------
+// Sample embeddings (CorrNMFDet.update_sample_embeddings, corrnmf_det.py:115-141): one strictly
+// convex problem per sample n over u in R^dim,
+//   minimise  -[ sum_k aux[k][n] <L_k, u> - sum_k exp(alpha_n + beta_k + <L_k, u>) - |u|^2 / (2 var) ]
+// (_utils_corrnmf.py:182-239; gradient :242-293, Hessian :296-351), solved by the Newton-CG of
+// salnmf_newtoncg.h with maxiter = 3 (corrnmf_det.py:140) from the current embedding; finally
+// entries within EPSILON of zero are pushed to +-EPSILON (_utils_corrnmf.py:408-409).
+// One wavefront per sample: lane k <-> signature term k, lane m <-> embedding component m.
+struct SampleEmbeddingEval {
+    const double* O;   // LDS [K][CORR_LD]: the signature embeddings
+    const double* so;  // LDS [K]: signature scalings
+    double* vbuf;      // LDS, wave private [64]: a vector to broadcast
+    double* wbuf;      // LDS, wave private [64]: per-term weights
+    double c;          // this sample's scaling
+    double a;          // lane k: aux[k][n]
+    double sg;         // lane m: sum_k aux[k][n] L[k][m]
+    double variance;
+    double hw;         // lane k: exp(c + so_k + <L_k, x>) at the point the Hessian is fixed
+    int K, dim, lane;
+
+    // lane k: <L_k, y>
+    __device__ __forceinline__ double products(double y) {
+        vbuf[lane] = y;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        double s = 0.0;
+        if (lane < K) {
+            const double* row = O + lane * CORR_LD;
+            for (int m = 0; m < dim; ++m) s = __builtin_fma(row[m], vbuf[m], s);
+        }
+        __builtin_amdgcn_wave_barrier();
+        return s;
+    }
+    // lane m: sum_k w_k L[k][m]
+    __device__ __forceinline__ double combine(double w) {
+        wbuf[lane] = w;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        double r = 0.0;
+        if (lane < dim)
+            for (int k = 0; k < K; ++k) r = __builtin_fma(wbuf[k], O[k * CORR_LD + lane], r);
+        __builtin_amdgcn_wave_barrier();
+        return r;
+    }
+    __device__ __forceinline__ double rate(double s) const { return lane < K ? exp((c + so[lane]) + s) : 0.0; }
+
+    __device__ inline double fun(double y) {
+        const double s = products(y);
+        double v = ncg::wave_sum(lane < K ? s * a : 0.0);
+        v -= ncg::wave_sum(rate(s));
+        v -= ncg::wave_sum(y * y) / (2 * variance);
+        return -v;
+    }
+    __device__ inline double grad(double y) {
+        const double s = products(y);
+        double g = -combine(rate(s));
+        g += sg;
+        g -= y / variance;
+        return lane < dim ? -g : 0.0;
+    }
+    __device__ inline void prepare_hess(double x) { hw = rate(products(x)); }
+    __device__ inline double hessp(double p) {
+        const double t = products(p);
+        const double r = combine(hw * t);
+        return lane < dim ? r + p / variance : 0.0;
+    }
+};
+
+struct SampleEmbeddingParams {
+    const double* __restrict__ aux;    // [Np][KP]
+    const double* __restrict__ alpha;  // [Np]
+    const double* __restrict__ beta;   // [K]
+    const double* __restrict__ L;      // [K][dim]
+    double* __restrict__ U;            // [N][dim]  in / out
+    int* __restrict__ status;          // [N] or null: ncg::Status of every solve
+    double variance;
+    int64_t N;
+    int K, KP, dim, maxiter;
+};
+
+__global__ void __launch_bounds__(CORR_BLOCK) corr_sample_embeddings_kernel(SampleEmbeddingParams p) {
+    __shared__ double Ll[CORR_DMAX * CORR_LD];
+    __shared__ double bl[CORR_DMAX];
+    __shared__ double vb[4][64], wb[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = p.K, dim = p.dim;
+    for (int i = tid; i < CORR_DMAX * CORR_LD; i += CORR_BLOCK) {
+        const int k = i / CORR_LD, m = i - k * CORR_LD;
+        Ll[i] = (k < K && m < dim) ? p.L[k * dim + m] : 0.0;
+    }
+    if (tid < CORR_DMAX) bl[tid] = tid < K ? p.beta[tid] : 0.0;
+    __syncthreads();
+    // from here on the waves run independently (no workgroup barrier below)
+    for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < p.N; n += (int64_t)gridDim.x * 4) {
+        SampleEmbeddingEval ev;
+        ev.O = Ll;
+        ev.so = bl;
+        ev.vbuf = vb[wave];
+        ev.wbuf = wb[wave];
+        ev.c = p.alpha[n];
+        ev.a = lane < K ? p.aux[n * p.KP + lane] : 0.0;
+        ev.variance = p.variance;
+        ev.hw = 0.0;
+        ev.K = K;
+        ev.dim = dim;
+        ev.lane = lane;
+        ev.sg = ev.combine(ev.a);
+        double x = lane < dim ? p.U[n * dim + lane] : 0.0;
+        const int st = ncg::minimize(ev, x, dim, p.maxiter);
+        if (x > 0.0 && x < kEps) x = kEps;
+        if (x < 0.0 && x > -kEps) x = -kEps;
+        if (lane < dim) p.U[n * dim + lane] = x;
+        if (p.status && lane == 0) p.status[n] = st;
+    }
 }
 
 }  // namespace salnmf

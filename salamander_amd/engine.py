@@ -164,6 +164,13 @@ class Engine:
     def corr_update_signatures(self, n_given: int = 0):
         _lib.check(self._lib.salnmf_corr_update_signatures(self._h, int(n_given)))
 
+    def corr_update_sample_embeddings(self, variance: float, maxiter: int = 3, return_status: bool = False):
+        """One Newton-CG solve per sample on the device; optionally the per-sample SciPy-style status codes."""
+        status = np.empty(self.N, dtype=np.int32) if return_status else None
+        ptr = status.ctypes.data_as(POINTER(ctypes.c_int)) if return_status else None
+        _lib.check(self._lib.salnmf_corr_update_sample_embeddings(self._h, float(variance), int(maxiter), ptr))
+        return status
+
     def corr_poisson_llh(self) -> float:
         out = c_double()
         _lib.check(self._lib.salnmf_corr_poisson_llh(self._h, ctypes.byref(out)))

@@ -7,11 +7,12 @@ the ELBO) run on the device through the C ABI (``salnmf_corr_*``); each call upl
 arguments to a fresh engine and downloads the result, the resident loop lives in
 ``CorrNMFDet.fit``.
 
-``update_embedding`` is the one exception: the reference optimises every embedding with
-``scipy.optimize.minimize(method="Newton-CG")`` (``_utils_corrnmf.py:400-407``), i.e. the
-arithmetic of that step *is* SciPy's.  It stays a SciPy call on the host here as well -- it is not
-one of the dense pieces of SURVEY.md section 8 row f1 and has no device kernel; the callbacks
-SciPy evaluates are a few vector operations of length ``n_signatures`` (or ``n_samples``).
+The reference optimises every embedding with ``scipy.optimize.minimize(method="Newton-CG")``
+(``_utils_corrnmf.py:400-407``), i.e. the arithmetic of that step *is* SciPy's.  The
+``n_samples`` sample-embedding solves run on the device (``update_sample_embeddings``: one
+wavefront per sample, a restatement of SciPy's Newton-CG and line searches,
+``csrc/salnmf_newtoncg.h``).  ``update_embedding`` -- a single solve through SciPy on the host,
+exactly the reference's call -- remains for the ``n_signatures`` signature embeddings.
 """
 
 from __future__ import annotations
@@ -128,7 +129,26 @@ def update_sample_scalings(data_mat, signature_scalings, signature_embeddings, s
         e.close()
 
 
-# ----------------------------------------------------------------------------- embeddings: SciPy on the host
+# ----------------------------------------------------------------------------- embeddings
+
+
+def update_sample_embeddings(
+    aux, signature_embeddings, sample_embeddings, signature_scalings, sample_scalings, variance, maxiter: int = 3
+) -> np.ndarray:
+    """All sample embeddings, one device Newton-CG solve each (``corrnmf_det.py:115-141``); ``aux (K, N)``."""
+    aux = _f64(aux)
+    e = _corr_engine(aux.shape[1], 1, signature_embeddings, sample_embeddings)
+    try:
+        e.corr_upload(_lib.CORR_SIGNATURE_SCALINGS, _f64(signature_scalings))
+        e.corr_upload(_lib.CORR_SAMPLE_SCALINGS, _f64(sample_scalings))
+        e.corr_upload(_lib.CORR_AUX, _f64(aux.T))
+        e.corr_update_sample_embeddings(variance, maxiter)
+        return e.corr_download(_lib.CORR_SAMPLE_EMBEDDINGS)
+    finally:
+        e.close()
+
+
+# -- a single embedding through SciPy on the host (the signature embeddings)
 
 
 def objective_function_embedding(embedding, embeddings_other, scaling, scalings_other, variance, aux_vector) -> float:

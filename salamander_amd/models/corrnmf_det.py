@@ -4,11 +4,11 @@ Drop-in for ``src/salamander/models/corrnmf_det.py``.  One update (``_update_par
 ``:157-169``) is, in this order: sample scalings, exposures, aux, signature scalings, signature
 embeddings, sample embeddings, variance, signatures.  Everything that is a pass over the
 ``n_samples x n_features`` / ``n_samples x n_signatures`` data -- both scalings, the exposures, aux,
-the signature update and the Poisson term of the ELBO -- runs on the device and stays resident there
-during ``fit``.  The embedding updates are the reference's SciPy Newton-CG solves
-(``_utils_corrnmf.update_embedding``) on the host: their arithmetic is SciPy's, they are not among
-the dense pieces of row f1, and per update only ``aux`` and the scalings travel to the host and the
-new embeddings back.
+the signature update and the Poisson term of the ELBO -- and the ``n_samples`` sample-embedding solves (Newton-CG, one
+wavefront per sample) run on the device and stay resident there during ``fit``.  The
+``n_signatures`` signature-embedding solves are the reference's SciPy Newton-CG calls
+(``_utils_corrnmf.update_embedding``) on the host: per update ``aux``, the scalings and the sample
+embeddings travel to the host and the new signature embeddings back.
 
 The public per-parameter methods (``update_sample_scalings`` ... ``update_signatures``) act on the
 AnnData state one call at a time, as the reference's tests drive them (``tests/test_corrnmf.py:128-175``).
@@ -81,13 +81,8 @@ class CorrNMFDet(CorrNMF):
 
     @staticmethod
     def _solve_sample_embeddings(aux, L, U, signature_scalings, sample_scalings, variance) -> np.ndarray:
-        L = np.asarray(L, dtype=np.float64)
-        U = np.array(U, dtype=np.float64)
-        for d in range(U.shape[0]):
-            U[d] = _utils_corrnmf.update_embedding(
-                U[d], L, sample_scalings[d], signature_scalings, variance, aux[:, d], options={"maxiter": 3}
-            )
-        return U
+        """``maxiter=3`` Newton-CG per sample (corrnmf_det.py:130-141), batched on the device."""
+        return _utils_corrnmf.update_sample_embeddings(aux, L, U, signature_scalings, sample_scalings, variance, maxiter=3)
 
     def update_signature_embeddings(self, aux: np.ndarray) -> None:
         self.asignatures.obsm["embeddings"] = self._solve_signature_embeddings(
@@ -145,15 +140,16 @@ class CorrNMFDet(CorrNMF):
             solve_L = "signature_embeddings" not in given
             solve_U = "sample_embeddings" not in given
             if solve_L or solve_U:
-                aux = e.corr_download(_lib.CORR_AUX).T
-                beta = e.corr_download(_lib.CORR_SIGNATURE_SCALINGS)
-                alpha = e.corr_download(_lib.CORR_SAMPLE_SCALINGS)
                 if solve_L:
+                    aux = e.corr_download(_lib.CORR_AUX).T
+                    beta = e.corr_download(_lib.CORR_SIGNATURE_SCALINGS)
+                    alpha = e.corr_download(_lib.CORR_SAMPLE_SCALINGS)
                     self._L = self._solve_signature_embeddings(aux, self._L, self._U, beta, alpha, self.variance)
                     e.corr_upload(_lib.CORR_SIGNATURE_EMBEDDINGS, self._L)
                 if solve_U:
-                    self._U = self._solve_sample_embeddings(aux, self._L, self._U, beta, alpha, self.variance)
-                    e.corr_upload(_lib.CORR_SAMPLE_EMBEDDINGS, self._U)
+                    # resident: aux, both scalings, the new signature embeddings and U are all on the device
+                    e.corr_update_sample_embeddings(self.variance, 3)
+                    self._U = e.corr_download(_lib.CORR_SAMPLE_EMBEDDINGS)
             if "variance" not in given:
                 self.variance = self._variance_of(self._L, self._U)
             e.corr_update_signatures(self._n_given(given))

@@ -303,3 +303,76 @@ def test_fit_history_is_the_elbo_of_the_resident_state():
         adata.X, model.asignatures.X, adata.obsm["exposures"], model.asignatures.obsm["embeddings"], adata.obsm["embeddings"], model.variance
     )
     assert abs(model.history["objective_function"][-1] - want) <= 1e-10 * abs(want)
+
+
+# ------------------------------------------------------------------ device Newton-CG vs SciPy
+
+
+def embedding_problem(N, K, dim, seed):
+    rng = np.random.default_rng(seed)
+    X, W, _ = ko.synthetic_problem(96, N, K, seed=seed)
+    beta = rng.normal(0, 0.3, K)
+    L = rng.normal(0, 0.7, (K, dim))
+    U = rng.normal(0, 0.7, (N, dim))
+    alpha = co.update_sample_scalings(X, beta, L, U)
+    aux = co.compute_aux(X, W, co.compute_exposures(beta, alpha, L, U))
+    return X, W, beta, alpha, L, U, aux
+
+
+@pytest.mark.parametrize(
+    "N,K,dim,maxiter",
+    [(300, 1, 1, 3), (300, 2, 2, 3), (300, 7, 3, 3), (200, 30, 30, 3), (200, 50, 8, 3), (120, 64, 64, 3), (200, 7, 3, 0), (100, 30, 30, 0)],
+)
+def test_sample_embedding_solves_match_scipy(N, K, dim, maxiter):
+    """One device Newton-CG solve per sample against scipy.optimize.minimize(method='Newton-CG') on the
+    same problems (the reference's call, ``_utils_corrnmf.py:400-407``), incl. SciPy's status codes.
+
+    The iterates agree to rounding (median error ~1e-15); a rounding-level difference can flip a
+    termination test and then shows up at the solver's own tolerance, hence the two-level check."""
+    from scipy import optimize
+
+    X, W, beta, alpha, L, U, aux = embedding_problem(N, K, dim, seed=N + K + dim)
+    var = 0.8
+    e = engine_from(X, W, beta, alpha, L, U)
+    e.corr_upload(_lib.CORR_AUX, np.ascontiguousarray(aux.T))
+    status = e.corr_update_sample_embeddings(var, maxiter, return_status=True)
+    got = e.corr_download(_lib.CORR_SAMPLE_EMBEDDINGS)
+    e.close()
+    want = np.empty_like(U)
+    want_status = np.empty(N, dtype=int)
+    opts = {"maxiter": maxiter} if maxiter > 0 else {}
+    for n in range(N):
+        sg = (aux[:, n, None] * L).sum(axis=0)
+        res = optimize.minimize(
+            fun=lambda x: co.embedding_objective(x, L, alpha[n], beta, var, aux[:, n]),
+            x0=U[n].copy(),
+            method="Newton-CG",
+            jac=lambda x: co.embedding_gradient(x, L, alpha[n], beta, var, sg),
+            hess=lambda x: co.embedding_hessian(x, L, alpha[n], beta, var),
+            options=opts,
+        )
+        want[n], want_status[n] = res.x, res.status
+    scale = np.maximum(np.abs(want).max(axis=1), 1e-3)
+    err = np.abs(got - want).max(axis=1) / scale
+    if maxiter > 0:  # the reference's setting: the three iterates agree to rounding
+        assert np.median(err) < 1e-12
+        assert (err < 1e-8).mean() >= 0.9
+    # runs to convergence accumulate rounding differences over many CG solves and stop within xtol of the optimum
+    assert err.max() < (2e-4 if maxiter > 0 else 10 * dim * 1e-5)  # SciPy's own stopping tolerance is dim * 1e-5
+    # at full convergence the last line search works at rounding level: success vs 'precision loss' may differ
+    assert (status == want_status).mean() >= (0.97 if maxiter > 0 else 0.8)
+
+
+def test_sample_embeddings_tiny_entries_are_pushed_away_from_zero():
+    # an embedding whose optimum is ~0 in one coordinate: the EPSILON rule of _utils_corrnmf.py:408-409
+    X, W, beta, alpha, L, U, aux = embedding_problem(64, 3, 2, seed=1)
+    L[:, 1] = 0.0  # the objective does not depend on coordinate 1 except through the prior -> optimum 0
+    U[:, 1] = 1e-9
+    e = engine_from(X, W, beta, alpha, L, U)
+    e.corr_upload(_lib.CORR_AUX, np.ascontiguousarray(aux.T))
+    e.corr_update_sample_embeddings(1.0, 3)
+    got = e.corr_download(_lib.CORR_SAMPLE_EMBEDDINGS)
+    e.close()
+    want = co.update_sample_embeddings(aux, L, U, beta, alpha, 1.0)  # SciPy, maxiter=3
+    assert np.all((np.abs(got[:, 1]) >= co.EPSILON) | (got[:, 1] == 0.0))
+    assert np.allclose(got, want, rtol=1e-6, atol=1e-12)
