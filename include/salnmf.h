@@ -103,11 +103,12 @@ int salnmf_mv_objective(salnmf_engine* e, double lam, double delta, double* out)
 /* ---- Correlated NMF, dense pieces.  The exposure matrix is not a free
  * parameter but exp(signature scaling + sample scaling + <signature embedding, sample
  * embedding>) (src/salamander/models/corrnmf.py:66-77).  The engine keeps the scalings and
- * embeddings next to X / W / H; H holds the exposures.  The n_samples sample-embedding solves run
- * on the device (salnmf_corr_update_sample_embeddings); the n_signatures signature-embedding
- * solves (each a sum over all samples) are still run by the host layer with SciPy between
- * salnmf_corr_compute_aux and salnmf_corr_update_signatures, as CorrNMFDet does
- * (corrnmf_det.py:157-169). */
+ * embeddings next to X / W / H; H holds the exposures.  Both families of embedding solves
+ * (scipy.optimize.minimize(method="Newton-CG") in the reference, _utils_corrnmf.py:354-410) run on
+ * the device: salnmf_corr_update_signature_embeddings and salnmf_corr_update_sample_embeddings.
+ * One CorrNMFDet._update_parameters (corrnmf_det.py:157-169) is the sequence
+ *   update_sample_scalings, compute_exposures, compute_aux, update_signature_scalings,
+ *   update_signature_embeddings, update_sample_embeddings, [variance: host scalar], update_signatures. */
 #define SALNMF_CORR_SIGNATURE_SCALINGS 0   /* [n_signatures]                       */
 #define SALNMF_CORR_SAMPLE_SCALINGS 1      /* [n_samples]                          */
 #define SALNMF_CORR_SIGNATURE_EMBEDDINGS 2 /* [n_signatures][dim_embeddings]       */
@@ -142,6 +143,16 @@ int salnmf_corr_update_signatures(salnmf_engine* e, int n_given);
  * (salamander_amd/csrc/salnmf_newtoncg.h). */
 int salnmf_corr_update_sample_embeddings(salnmf_engine* e, double variance, int maxiter,
                                          int* status_out);
+/* CorrNMFDet.update_signature_embeddings (corrnmf_det.py:88-113): one Newton-CG solve per signature
+ * (same objective with the roles of signatures and samples exchanged; every evaluation is a pass
+ * over all samples, one workgroup per signature).  maxiter <= 0 selects SciPy's default, which is
+ * what the reference uses here; status_out has n_signatures ints or is NULL. */
+int salnmf_corr_update_signature_embeddings(salnmf_engine* e, double variance, int maxiter,
+                                            int* status_out);
+/* out2[0] = sum of squares of the signature embeddings, out2[1] = of the sample embeddings: what
+ * update_variance (corrnmf_det.py:60-69) and the prior terms of elbo_corrnmf
+ * (_utils_corrnmf.py:93-98) need from the device-resident embeddings. */
+int salnmf_corr_embedding_sumsq(salnmf_engine* e, double* out2);
 /* poisson_llh, _utils_klnmf.py:98-160 (the data term of elbo_corrnmf, _utils_corrnmf.py:92). */
 int salnmf_corr_poisson_llh(salnmf_engine* e, double* out);
 

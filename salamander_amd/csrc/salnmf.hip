@@ -78,6 +78,7 @@ struct salnmf_engine {
     double* aux = nullptr;       // [Np][KP], padded like H
     double* xrowsum = nullptr;   // [Np]
     double* corrpart = nullptr;  // [cgrid][64] partial sums
+    double* hwbuf = nullptr;     // [K][Np] Hessian weights of the signature-embedding solves (lazily allocated)
     int cgrid = 0;
     bool xrowsum_valid = false, lgam_valid = false;
     double lgam_sum = 0.0;       // sum gammaln(1 + X) over the local shard
@@ -228,7 +229,7 @@ void salnmf_destroy(salnmf_engine* e) {
     if (e->comm) ncclCommDestroy(e->comm);
     double* bufs[] = {e->X, e->H, e->W, e->wkl, e->wlh, e->Gpart, e->Hsumpart, e->KLpart, e->red,
                       e->objpart, e->scal, e->Wunc, e->Wtrial, e->cs, e->scratch,
-                      e->alpha, e->beta, e->Lemb, e->Uemb, e->aux, e->xrowsum, e->corrpart};
+                      e->alpha, e->beta, e->Lemb, e->Uemb, e->aux, e->xrowsum, e->corrpart, e->hwbuf};
     for (double* b : bufs)
         if (b) (void)hipFree(b);
     if (e->hpin) (void)hipHostFree(e->hpin);
@@ -598,7 +599,7 @@ int salnmf_corr_configure(salnmf_engine* e, int dim_embeddings) {
     if (dim_embeddings < 1 || dim_embeddings > CORR_DMAX) return fail("dim_embeddings must be in [1, %d], got %d", CORR_DMAX, dim_embeddings);
     HIPCK(hipSetDevice(e->device));
     HIPCK(hipStreamSynchronize(e->stream));
-    double** bufs[] = {&e->alpha, &e->beta, &e->Lemb, &e->Uemb, &e->aux, &e->xrowsum, &e->corrpart};
+    double** bufs[] = {&e->alpha, &e->beta, &e->Lemb, &e->Uemb, &e->aux, &e->xrowsum, &e->corrpart, &e->hwbuf};
     for (double** b : bufs) {
         if (*b) HIPCK(hipFree(*b));
         *b = nullptr;
@@ -771,6 +772,56 @@ int salnmf_corr_update_sample_embeddings(salnmf_engine* e, double variance, int 
     }
     if (dstatus) (void)hipFree(dstatus);
     return rc;
+}
+
+int salnmf_corr_update_signature_embeddings(salnmf_engine* e, double variance, int maxiter, int* status_out) {
+    CK(corr_ready(e));
+    if (!(variance > 0.0)) return fail("variance must be positive");
+    if (e->n_ranks > 1) return fail("signature-embedding solves need all samples on one engine (sample-sharded engines are not supported)");
+    if (!e->hwbuf) HIPCK(hipMalloc(&e->hwbuf, (size_t)e->K * e->Np * sizeof(double)));
+    SignatureEmbeddingParams p;
+    p.aux = e->aux;
+    p.alpha = e->alpha;
+    p.beta = e->beta;
+    p.U = e->Uemb;
+    p.L = e->Lemb;
+    p.hw = e->hwbuf;
+    p.status = nullptr;
+    p.variance = variance;
+    p.N = e->N;
+    p.Np = e->Np;
+    p.K = e->K;
+    p.KP = e->KP;
+    p.dim = e->dim;
+    p.maxiter = maxiter > 0 ? maxiter : 200 * e->dim;
+    int* dstatus = nullptr;
+    if (status_out) {
+        HIPCK(hipMalloc(&dstatus, (size_t)e->K * sizeof(int)));
+        p.status = dstatus;
+    }
+    hipLaunchKernelGGL(corr_signature_embeddings_kernel, dim3(e->K), dim3(SIGT), 0, e->stream, p);
+    int rc = 0;
+    if (hipGetLastError() != hipSuccess) rc = fail("corr_signature_embeddings_kernel launch failed");
+    if (!rc && status_out) {
+        if (hipMemcpyAsync(status_out, dstatus, (size_t)e->K * sizeof(int), hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
+            hipStreamSynchronize(e->stream) != hipSuccess)
+            rc = fail("status download failed");
+    }
+    if (dstatus) (void)hipFree(dstatus);
+    return rc;
+}
+
+int salnmf_corr_embedding_sumsq(salnmf_engine* e, double* out2) {
+    CK(corr_ready(e));
+    if (!out2) return fail("null argument");
+    const int g = 256;
+    CK(ensure_scratch(e, (size_t)2 * g));
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(g), dim3(256), 0, e->stream, e->Lemb, (int64_t)e->K * e->dim, e->scratch);
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(g), dim3(256), 0, e->stream, e->Uemb, e->N * (int64_t)e->dim, e->scratch + g);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, e->scratch, g, 1, 1, e->scal + 5);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, e->scratch + g, g, 1, 1, e->scal + 6);
+    HIPCK(hipGetLastError());
+    return read_scalars(e, 5, 2, out2);
 }
 
 int salnmf_corr_poisson_llh(salnmf_engine* e, double* out) {

@@ -163,6 +163,21 @@ __global__ void __launch_bounds__(256) lgamma_partial_kernel(const double* __res
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
+// partial[b] = sum over workgroup b's grid-stride slice of a[i]^2 (fixed order; the variance update and the
+// Gaussian prior terms of the ELBO, corrnmf_det.py:65-69 / _utils_corrnmf.py:93-98)
+__global__ void __launch_bounds__(256) sumsq_partial_kernel(const double* __restrict__ a, int64_t n, double* __restrict__ partial) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s = __builtin_fma(a[i], a[i], s);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
 // beta_k = log(first_k) - log(second_k)   (_utils_corrnmf.py:137)
 __global__ void corr_log_ratio_kernel(const double* __restrict__ first, const double* __restrict__ second, int K,
                                       double* __restrict__ beta) {
@@ -236,6 +251,7 @@ struct SampleEmbeddingEval {
         const double r = combine(hw * t);
         return lane < dim ? r + p / variance : 0.0;
     }
+    __device__ inline bool exhausted() const { return false; }  // every loop of the solve is bounded and cheap here
 };
 
 struct SampleEmbeddingParams {
@@ -284,6 +300,180 @@ __global__ void __launch_bounds__(CORR_BLOCK) corr_sample_embeddings_kernel(Samp
         if (lane < dim) p.U[n * dim + lane] = x;
         if (p.status && lane == 0) p.status[n] = st;
     }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Signature embeddings (CorrNMFDet.update_signature_embeddings, corrnmf_det.py:88-113): one problem
+// per signature k over l in R^dim whose terms run over ALL samples,
+//   minimise  -[ sum_n aux[k][n] <U_n, l> - sum_n exp(beta_k + alpha_n + <U_n, l>) - |l|^2 / (2 var) ]
+// One WORKGROUP per signature.  Every wave runs the Newton-CG control flow of salnmf_newtoncg.h
+// redundantly on bit-identical scalars (vectors are replicated per wave, lane m = component m); an
+// evaluation is a cooperative pass over the samples in tiles of SIGT rows staged in LDS:
+//   phase A  thread j: s_j = <U_j, y>, weight_j (exp / aux / Hessian weight)
+//   phase B  wave w, lane m: sum over the tile's samples j = w, w + 4, ... of weight_j U[j][m]
+// followed by fixed-order cross-wave sums, so that all waves see the same bits.
+constexpr int SIGT = 256;       // samples per tile = threads per workgroup
+constexpr int SIG_BUDGET = 60000;  // evaluation passes per solve; SciPy's own limits are far above any real solve
+
+struct SignatureEmbeddingParams {
+    const double* __restrict__ aux;    // [Np][KP]
+    const double* __restrict__ alpha;  // [Np]
+    const double* __restrict__ beta;   // [K]
+    const double* __restrict__ U;      // [N][dim]
+    double* __restrict__ L;            // [K][dim]  in / out
+    double* __restrict__ hw;           // [K][Np] scratch: Hessian weights of signature k
+    int* __restrict__ status;          // [K] or null
+    double variance;
+    int64_t N, Np;
+    int K, KP, dim, maxiter;
+};
+
+struct SignatureEmbeddingEval {
+    const SignatureEmbeddingParams* p;
+    double* Ut;     // LDS [SIGT][CORR_LD]
+    double* wt;     // LDS [SIGT]
+    double* ybuf;   // LDS [64]
+    double* red;    // LDS [4][64]
+    double* sred;   // LDS [SIGT]
+    double c;       // beta_k
+    double sg;      // lane m: sum_n aux[k][n] U[n][m]
+    double variance;
+    double* hw;     // this signature's row of the scratch
+    int k, dim, tid, lane, wave, budget;
+
+    __device__ inline void broadcast(double y) {
+        __syncthreads();  // previous readers of ybuf are done
+        if (wave == 0) ybuf[lane] = y;
+        __syncthreads();
+    }
+    // stage rows [t0, t0 + SIGT) of U into LDS (coalesced), zero beyond N
+    __device__ inline void stage(int64_t t0) {
+        const int64_t base = t0 * dim, end = p->N * dim;
+        for (int i = tid; i < SIGT * dim; i += SIGT) {
+            const int j = i / dim, m = i - j * dim;
+            Ut[j * CORR_LD + m] = (base + i < end) ? p->U[base + i] : 0.0;
+        }
+        __syncthreads();
+    }
+    __device__ inline double row_dot(int j) const {
+        double s = 0.0;
+        const double* row = Ut + j * CORR_LD;
+        for (int m = 0; m < dim; ++m) s = __builtin_fma(row[m], ybuf[m], s);
+        return s;
+    }
+    // lane m of every wave: sum over all samples of weight_n * U[n][m]; MODE selects the weight
+    //   0: aux[k][n]                      (summand_grad)
+    //   1: exp((c + alpha_n) + <U_n, y>)  (gradient)
+    //   2: hw_n * <U_n, y>                (Hessian-vector product)
+    template <int MODE>
+    __device__ inline double weighted_sum(double y) {
+        --budget;
+        if (MODE != 0) broadcast(y);
+        double r = 0.0;
+        for (int64_t t0 = 0; t0 < p->N; t0 += SIGT) {
+            stage(t0);
+            const int64_t n = t0 + tid;
+            double w = 0.0;
+            if (n < p->N) {
+                if (MODE == 0) w = p->aux[n * p->KP + k];
+                else if (MODE == 1) w = exp((c + p->alpha[n]) + row_dot(tid));
+                else w = hw[n] * row_dot(tid);
+            }
+            wt[tid] = w;
+            __syncthreads();
+            if (lane < dim) {
+#pragma unroll 4
+                for (int j = wave; j < SIGT; j += 4) r = __builtin_fma(wt[j], Ut[j * CORR_LD + lane], r);
+            }
+            __syncthreads();
+        }
+        red[wave * 64 + lane] = r;
+        __syncthreads();
+        const double tot = ((red[lane] + red[64 + lane]) + red[128 + lane]) + red[192 + lane];
+        __syncthreads();
+        return lane < dim ? tot : 0.0;
+    }
+    // deterministic workgroup sum of one value per thread; every thread returns the same bits
+    __device__ inline double block_sum(double v) {
+        sred[tid] = v;
+        __syncthreads();
+        for (int h = SIGT / 2; h > 0; h >>= 1) {
+            if (tid < h) sred[tid] += sred[tid + h];
+            __syncthreads();
+        }
+        const double t = sred[0];
+        __syncthreads();
+        return t;
+    }
+    __device__ inline double fun(double y) {
+        --budget;
+        broadcast(y);
+        double lin = 0.0, ex = 0.0;
+        for (int64_t t0 = 0; t0 < p->N; t0 += SIGT) {
+            stage(t0);
+            const int64_t n = t0 + tid;
+            if (n < p->N) {
+                const double s = row_dot(tid);
+                lin = __builtin_fma(s, p->aux[n * p->KP + k], lin);
+                ex += exp((c + p->alpha[n]) + s);
+            }
+            __syncthreads();
+        }
+        double v = block_sum(lin);
+        v -= block_sum(ex);
+        v -= ncg::wave_sum(y * y) / (2 * variance);
+        return -v;
+    }
+    __device__ inline double grad(double y) {
+        double g = -weighted_sum<1>(y);
+        g += sg;
+        g -= y / variance;
+        return lane < dim ? -g : 0.0;
+    }
+    __device__ inline void prepare_hess(double x) {
+        --budget;
+        broadcast(x);
+        for (int64_t t0 = 0; t0 < p->N; t0 += SIGT) {
+            stage(t0);
+            const int64_t n = t0 + tid;
+            if (n < p->N) hw[n] = exp((c + p->alpha[n]) + row_dot(tid));
+            __syncthreads();
+        }
+    }
+    __device__ inline double hessp(double v) {
+        const double r = weighted_sum<2>(v);
+        return lane < dim ? r + v / variance : 0.0;
+    }
+    __device__ inline bool exhausted() const { return budget <= 0; }
+};
+
+__global__ void __launch_bounds__(SIGT) corr_signature_embeddings_kernel(SignatureEmbeddingParams p) {
+    __shared__ double Ut[SIGT * CORR_LD];
+    __shared__ double wt[SIGT], sred[SIGT], ybuf[64], red[4 * 64];
+    SignatureEmbeddingEval ev;
+    ev.p = &p;
+    ev.Ut = Ut;
+    ev.wt = wt;
+    ev.ybuf = ybuf;
+    ev.red = red;
+    ev.sred = sred;
+    ev.k = blockIdx.x;
+    ev.c = p.beta[ev.k];
+    ev.variance = p.variance;
+    ev.hw = p.hw + (int64_t)ev.k * p.Np;
+    ev.dim = p.dim;
+    ev.tid = threadIdx.x;
+    ev.lane = threadIdx.x & 63;
+    ev.wave = threadIdx.x >> 6;
+    ev.budget = SIG_BUDGET;
+    ev.sg = 0.0;
+    ev.sg = ev.weighted_sum<0>(0.0);
+    double x = ev.lane < p.dim ? p.L[ev.k * p.dim + ev.lane] : 0.0;
+    const int st = ncg::minimize(ev, x, p.dim, p.maxiter);
+    if (x > 0.0 && x < kEps) x = kEps;
+    if (x < 0.0 && x > -kEps) x = -kEps;
+    if (ev.wave == 0 && ev.lane < p.dim) p.L[ev.k * p.dim + ev.lane] = x;
+    if (p.status && threadIdx.x == 0) p.status[ev.k] = st;
 }
 
 }  // namespace salnmf

@@ -22,6 +22,8 @@
 //   double grad(double y)         per-lane component of the gradient at y
 //   void   prepare_hess(double x) fix the Hessian at x
 //   double hessp(double p)        per-lane component of (Hessian at the fixed point) . p
+//   bool   exhausted()            true once an evaluation budget is spent (a guard against runaway solves;
+//                                 uniform over the wave); the solve then stops with status MAXITER
 #pragma once
 #include <hip/hip_runtime.h>
 #include <float.h>
@@ -305,7 +307,7 @@ __device__ inline int minimize(E& ev, double& x, int dim, int maxiter, int* n_it
     bool have_old_old = false;
     int status = OK;
     while (update_l1norm > xtol) {
-        if (k >= maxiter) { status = MAXITER; break; }
+        if (k >= maxiter || ev.exhausted()) { status = MAXITER; break; }
         // search direction: CG on  H p = -g  from p = 0, stopped by the forcing term or by curvature
         const double gfk = ev.grad(xk);
         const double b = -gfk;
@@ -318,7 +320,7 @@ __device__ inline int minimize(E& ev, double& x, int dim, int maxiter, int* n_it
         ev.prepare_hess(xk);
         bool cg_done = false;
         for (int k2 = 0; k2 < cg_maxiter; ++k2) {
-            if (l1norm(ri) <= termcond) { cg_done = true; break; }
+            if (l1norm(ri) <= termcond || ev.exhausted()) { cg_done = true; break; }
             const double Ap = ev.hessp(psupi);
             const double curv = dot(psupi, Ap);
             if (0 <= curv && curv <= 3 * float64eps) { cg_done = true; break; }

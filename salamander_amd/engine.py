@@ -171,6 +171,19 @@ class Engine:
         _lib.check(self._lib.salnmf_corr_update_sample_embeddings(self._h, float(variance), int(maxiter), ptr))
         return status
 
+    def corr_update_signature_embeddings(self, variance: float, maxiter: int = 0, return_status: bool = False):
+        """One Newton-CG solve per signature on the device (SciPy's default iteration limit when maxiter <= 0)."""
+        status = np.empty(self.K, dtype=np.int32) if return_status else None
+        ptr = status.ctypes.data_as(POINTER(ctypes.c_int)) if return_status else None
+        _lib.check(self._lib.salnmf_corr_update_signature_embeddings(self._h, float(variance), int(maxiter), ptr))
+        return status
+
+    def corr_embedding_sumsq(self):
+        """(sum of squares of the signature embeddings, of the sample embeddings) of the resident state."""
+        out = (c_double * 2)()
+        _lib.check(self._lib.salnmf_corr_embedding_sumsq(self._h, out))
+        return out[0], out[1]
+
     def corr_poisson_llh(self) -> float:
         out = c_double()
         _lib.check(self._lib.salnmf_corr_poisson_llh(self._h, ctypes.byref(out)))

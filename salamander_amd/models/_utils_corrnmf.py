@@ -8,11 +8,12 @@ arguments to a fresh engine and downloads the result, the resident loop lives in
 ``CorrNMFDet.fit``.
 
 The reference optimises every embedding with ``scipy.optimize.minimize(method="Newton-CG")``
-(``_utils_corrnmf.py:400-407``), i.e. the arithmetic of that step *is* SciPy's.  The
-``n_samples`` sample-embedding solves run on the device (``update_sample_embeddings``: one
-wavefront per sample, a restatement of SciPy's Newton-CG and line searches,
-``csrc/salnmf_newtoncg.h``).  ``update_embedding`` -- a single solve through SciPy on the host,
-exactly the reference's call -- remains for the ``n_signatures`` signature embeddings.
+(``_utils_corrnmf.py:400-407``), i.e. the arithmetic of that step *is* SciPy's.  Here the solves run
+on the device as well (``csrc/salnmf_newtoncg.h`` restates SciPy's truncated Newton iteration and
+its two line searches): ``update_sample_embeddings`` -- one wavefront per sample -- and
+``update_signature_embeddings`` -- one workgroup per signature, every evaluation a pass over all
+samples.  ``update_embedding`` solves a single embedding through the same kernels.  SciPy is not
+imported anywhere in this package.
 """
 
 from __future__ import annotations
@@ -129,68 +130,69 @@ def update_sample_scalings(data_mat, signature_scalings, signature_embeddings, s
         e.close()
 
 
-# ----------------------------------------------------------------------------- embeddings
+# ----------------------------------------------------------------------------- embeddings (device Newton-CG)
 
 
-def update_sample_embeddings(
-    aux, signature_embeddings, sample_embeddings, signature_scalings, sample_scalings, variance, maxiter: int = 3
-) -> np.ndarray:
-    """All sample embeddings, one device Newton-CG solve each (``corrnmf_det.py:115-141``); ``aux (K, N)``."""
+def _embedding_engine(aux, signature_embeddings, sample_embeddings, signature_scalings, sample_scalings) -> Engine:
     aux = _f64(aux)
     e = _corr_engine(aux.shape[1], 1, signature_embeddings, sample_embeddings)
     try:
         e.corr_upload(_lib.CORR_SIGNATURE_SCALINGS, _f64(signature_scalings))
         e.corr_upload(_lib.CORR_SAMPLE_SCALINGS, _f64(sample_scalings))
         e.corr_upload(_lib.CORR_AUX, _f64(aux.T))
+    except Exception:
+        e.close()
+        raise
+    return e
+
+
+def update_sample_embeddings(
+    aux, signature_embeddings, sample_embeddings, signature_scalings, sample_scalings, variance, maxiter: int = 3
+) -> np.ndarray:
+    """All sample embeddings, one Newton-CG solve each with ``maxiter=3`` (``corrnmf_det.py:115-141``); ``aux (K, N)``."""
+    e = _embedding_engine(aux, signature_embeddings, sample_embeddings, signature_scalings, sample_scalings)
+    try:
         e.corr_update_sample_embeddings(variance, maxiter)
         return e.corr_download(_lib.CORR_SAMPLE_EMBEDDINGS)
     finally:
         e.close()
 
 
-# -- a single embedding through SciPy on the host (the signature embeddings)
-
-
-def objective_function_embedding(embedding, embeddings_other, scaling, scalings_other, variance, aux_vector) -> float:
-    """Negative surrogate objective of one embedding (:182-239)."""
-    products = embeddings_other @ embedding
-    value = float(products @ np.asarray(aux_vector))
-    value -= float(np.exp(scaling + scalings_other + products).sum())
-    value -= float(embedding @ embedding) / (2 * variance)
-    return -value
-
-
-def gradient_embedding(embedding, embeddings_other, scaling, scalings_other, variance, summand_grad) -> np.ndarray:
-    """Its negative gradient (:242-293)."""
-    rates = np.exp(scaling + scalings_other + embeddings_other @ embedding)
-    return rates @ embeddings_other - summand_grad + embedding / variance
-
-
-def hessian_embedding(embedding, embeddings_other, scaling, scalings_other, variance, outer_prods_embeddings_other=None):
-    """Its negative Hessian (:296-351); the optional precomputed outer products are not needed."""
-    rates = np.exp(scaling + scalings_other + embeddings_other @ embedding)
-    return (embeddings_other.T * rates) @ embeddings_other + np.identity(len(embedding)) / variance
+def update_signature_embeddings(
+    aux, signature_embeddings, sample_embeddings, signature_scalings, sample_scalings, variance, maxiter: int = 0
+) -> np.ndarray:
+    """All signature embeddings, one Newton-CG solve each, SciPy's default iteration limit (``corrnmf_det.py:88-113``)."""
+    e = _embedding_engine(aux, signature_embeddings, sample_embeddings, signature_scalings, sample_scalings)
+    try:
+        e.corr_update_signature_embeddings(variance, maxiter)
+        return e.corr_download(_lib.CORR_SIGNATURE_EMBEDDINGS)
+    finally:
+        e.close()
 
 
 def update_embedding(
     embedding_init, embeddings_other, scaling, scalings_other, variance, aux_vec, outer_prods_embeddings_other=None, **kwargs
 ) -> np.ndarray:
-    """One embedding by SciPy's Newton-CG, entries within EPSILON of zero pushed to +-EPSILON (:354-410)."""
-    from scipy import optimize
+    """Optimise one signature or sample embedding (:354-410).
 
-    others = np.asarray(embeddings_other, dtype=np.float64)
-    aux_vec = np.asarray(aux_vec, dtype=np.float64)
-    summand_grad = aux_vec @ others
-    result = optimize.minimize(
-        fun=objective_function_embedding,
-        x0=np.array(embedding_init, dtype=np.float64),
-        args=(others, scaling, scalings_other, variance, aux_vec),
-        method="Newton-CG",
-        jac=lambda x, *a: gradient_embedding(x, others, scaling, scalings_other, variance, summand_grad),
-        hess=lambda x, *a: hessian_embedding(x, others, scaling, scalings_other, variance),
-        **kwargs,
-    )
-    embedding = result.x
-    embedding[(embedding > 0) & (embedding < EPSILON)] = EPSILON
-    embedding[(embedding < 0) & (embedding > -EPSILON)] = -EPSILON
-    return embedding
+    ``embeddings_other (n_other, dim)``, ``scalings_other (n_other,)``, ``aux_vec (n_other,)``; the only
+    keyword the reference passes on is ``options={"maxiter": 3}`` for sample embeddings.  ``scaling`` may be
+    an array over the other embeddings (multimodal use, :208-210): it is folded into ``scalings_other``.
+    """
+    options = dict(kwargs.pop("options", None) or {})
+    maxiter = int(options.pop("maxiter", 0) or 0)
+    if kwargs or options:
+        raise TypeError(f"unsupported Newton-CG arguments: {sorted(kwargs) + sorted(options)}")
+    x0 = _f64(np.atleast_1d(embedding_init))[None, :]
+    others = _f64(embeddings_other)
+    aux_vec = _f64(np.atleast_1d(aux_vec))
+    scalings_other = _f64(np.atleast_1d(scalings_other))
+    if np.ndim(scaling) > 0:  # exp(scaling_i + scalings_other_i + ...): only the sum matters
+        scalings_other = scalings_other + _f64(scaling)
+        scaling = 0.0
+    one = np.array([float(scaling)])
+    if others.shape[0] <= 64:
+        # few terms: the "sample" layout -- the embedding is a sample, the others are the signatures
+        return update_sample_embeddings(aux_vec[:, None], others, x0, scalings_other, one, variance, maxiter)[0]
+    # many terms: the "signature" layout -- the embedding is the one signature, the others are the samples
+    return update_signature_embeddings(aux_vec[None, :], x0, others, one, scalings_other, variance, maxiter)[0]

@@ -4,11 +4,10 @@ Drop-in for ``src/salamander/models/corrnmf_det.py``.  One update (``_update_par
 ``:157-169``) is, in this order: sample scalings, exposures, aux, signature scalings, signature
 embeddings, sample embeddings, variance, signatures.  Everything that is a pass over the
 ``n_samples x n_features`` / ``n_samples x n_signatures`` data -- both scalings, the exposures, aux,
-the signature update and the Poisson term of the ELBO -- and the ``n_samples`` sample-embedding solves (Newton-CG, one
-wavefront per sample) run on the device and stay resident there during ``fit``.  The
-``n_signatures`` signature-embedding solves are the reference's SciPy Newton-CG calls
-(``_utils_corrnmf.update_embedding``) on the host: per update ``aux``, the scalings and the sample
-embeddings travel to the host and the new signature embeddings back.
+the signature update and the Poisson term of the ELBO -- and both families of embedding solves (Newton-CG: one workgroup per
+signature, one wavefront per sample; ``csrc/salnmf_newtoncg.h``) run on the device, and the whole state
+stays resident there during ``fit``: per update only the two sums of squares behind the variance come
+back to the host.
 
 The public per-parameter methods (``update_sample_scalings`` ... ``update_signatures``) act on the
 AnnData state one call at a time, as the reference's tests drive them (``tests/test_corrnmf.py:128-175``).
@@ -70,22 +69,9 @@ class CorrNMFDet(CorrNMF):
         )
         self.asignatures.X = W.T
 
-    # -- embeddings: one SciPy Newton-CG solve per row, on the host (corrnmf_det.py:88-141)
-    @staticmethod
-    def _solve_signature_embeddings(aux, L, U, signature_scalings, sample_scalings, variance) -> np.ndarray:
-        L = np.array(L, dtype=np.float64)
-        U = np.asarray(U, dtype=np.float64)
-        for k in range(L.shape[0]):
-            L[k] = _utils_corrnmf.update_embedding(L[k], U, signature_scalings[k], sample_scalings, variance, aux[k])
-        return L
-
-    @staticmethod
-    def _solve_sample_embeddings(aux, L, U, signature_scalings, sample_scalings, variance) -> np.ndarray:
-        """``maxiter=3`` Newton-CG per sample (corrnmf_det.py:130-141), batched on the device."""
-        return _utils_corrnmf.update_sample_embeddings(aux, L, U, signature_scalings, sample_scalings, variance, maxiter=3)
-
+    # -- embeddings: one Newton-CG solve per row, batched on the device (corrnmf_det.py:88-141)
     def update_signature_embeddings(self, aux: np.ndarray) -> None:
-        self.asignatures.obsm["embeddings"] = self._solve_signature_embeddings(
+        self.asignatures.obsm["embeddings"] = _utils_corrnmf.update_signature_embeddings(
             np.asarray(aux),
             self.asignatures.obsm["embeddings"],
             self.adata.obsm["embeddings"],
@@ -95,13 +81,14 @@ class CorrNMFDet(CorrNMF):
         )
 
     def update_sample_embeddings(self, aux: np.ndarray) -> None:
-        self.adata.obsm["embeddings"] = self._solve_sample_embeddings(
+        self.adata.obsm["embeddings"] = _utils_corrnmf.update_sample_embeddings(
             np.asarray(aux),
             self.asignatures.obsm["embeddings"],
             self.adata.obsm["embeddings"],
             np.asarray(self.asignatures.obs["scalings"].values),
             np.asarray(self.adata.obs["scalings"].values),
             self.variance,
+            maxiter=3,
         )
 
     def update_embeddings(self, aux: np.ndarray, given_parameters: dict[str, Any] | None = None) -> None:
@@ -120,12 +107,15 @@ class CorrNMFDet(CorrNMF):
     # ------------------------------------------------------------------ device-resident loop used by fit()
     def _sync_to_device(self) -> None:
         if self.distributed:
-            # a signature embedding depends on all samples: its solve would need a host-side exchange per callback
+            # a signature embedding depends on all samples: every evaluation of its solve would need an exchange
             raise NotImplementedError("CorrNMFDet does not support sample-sharded (distributed=True) fitting.")
         super()._sync_to_device()
-        # host copies of what the SciPy solves read and write between device passes
-        self._L = np.array(self.asignatures.obsm["embeddings"], dtype=np.float64)
-        self._U = np.array(self.adata.obsm["embeddings"], dtype=np.float64)
+
+    def _resident_variance(self) -> float:
+        """update_variance on the resident embeddings (corrnmf_det.py:65-69)."""
+        ss_sig, ss_samples = self._engine.corr_embedding_sumsq()
+        count = (self.n_signatures + self.adata.n_obs) * self.dim_embeddings
+        return float(np.clip((ss_sig + ss_samples) / count, EPSILON, None))
 
     def _device_steps(self, n_steps: int, given_parameters) -> None:
         given = _given(given_parameters)
@@ -137,31 +127,28 @@ class CorrNMFDet(CorrNMF):
             e.corr_compute_aux()
             if "signature_scalings" not in given:
                 e.corr_update_signature_scalings()
-            solve_L = "signature_embeddings" not in given
-            solve_U = "sample_embeddings" not in given
-            if solve_L or solve_U:
-                if solve_L:
-                    aux = e.corr_download(_lib.CORR_AUX).T
-                    beta = e.corr_download(_lib.CORR_SIGNATURE_SCALINGS)
-                    alpha = e.corr_download(_lib.CORR_SAMPLE_SCALINGS)
-                    self._L = self._solve_signature_embeddings(aux, self._L, self._U, beta, alpha, self.variance)
-                    e.corr_upload(_lib.CORR_SIGNATURE_EMBEDDINGS, self._L)
-                if solve_U:
-                    # resident: aux, both scalings, the new signature embeddings and U are all on the device
-                    e.corr_update_sample_embeddings(self.variance, 3)
-                    self._U = e.corr_download(_lib.CORR_SAMPLE_EMBEDDINGS)
+            if "signature_embeddings" not in given:
+                e.corr_update_signature_embeddings(self.variance, 0)
+            if "sample_embeddings" not in given:
+                e.corr_update_sample_embeddings(self.variance, 3)
             if "variance" not in given:
-                self.variance = self._variance_of(self._L, self._U)
+                self.variance = self._resident_variance()
             e.corr_update_signatures(self._n_given(given))
 
     def _device_objective(self) -> float:
         """ELBO of the resident state; the exposures are those of the last update, as in the reference's loop."""
-        return self._engine.corr_poisson_llh() + _utils_corrnmf.embedding_priors(self._L, self._U, self.variance)
+        ss_sig, ss_samples = self._engine.corr_embedding_sumsq()
+        dim, var = self.dim_embeddings, self.variance
+        log_norm = np.log(2 * np.pi * var)
+        value = self._engine.corr_poisson_llh()
+        value -= 0.5 * dim * self.n_signatures * log_norm + ss_sig / (2 * var)
+        value -= 0.5 * dim * self.adata.n_obs * log_norm + ss_samples / (2 * var)
+        return float(value)
 
     def _sync_from_device(self) -> None:
         super()._sync_from_device()
         e = self._engine
         self.asignatures.obs["scalings"] = e.corr_download(_lib.CORR_SIGNATURE_SCALINGS)
         self.adata.obs["scalings"] = e.corr_download(_lib.CORR_SAMPLE_SCALINGS)
-        self.asignatures.obsm["embeddings"] = self._L
-        self.adata.obsm["embeddings"] = self._U
+        self.asignatures.obsm["embeddings"] = e.corr_download(_lib.CORR_SIGNATURE_EMBEDDINGS)
+        self.adata.obsm["embeddings"] = e.corr_download(_lib.CORR_SAMPLE_EMBEDDINGS)

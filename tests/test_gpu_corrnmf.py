@@ -376,3 +376,71 @@ def test_sample_embeddings_tiny_entries_are_pushed_away_from_zero():
     want = co.update_sample_embeddings(aux, L, U, beta, alpha, 1.0)  # SciPy, maxiter=3
     assert np.all((np.abs(got[:, 1]) >= co.EPSILON) | (got[:, 1] == 0.0))
     assert np.allclose(got, want, rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize("N,K,dim", [(10, 1, 1), (10, 2, 2), (300, 3, 2), (1000, 7, 3), (2000, 30, 30), (3000, 50, 8), (1500, 64, 64)])
+def test_signature_embedding_solves_match_scipy(N, K, dim):
+    """One workgroup per signature, every evaluation a pass over all samples; SciPy's default iteration
+    limit as in the reference (corrnmf_det.py:103-113).  Run to convergence, so compared at the solver's
+    tolerance; in practice the iterates coincide to ~1e-14."""
+    X, W, beta, alpha, L, U, aux = embedding_problem(N, K, dim, seed=N + K + dim)
+    beta = co.update_signature_scalings(aux, alpha, L, U)
+    var = 0.8
+    e = engine_from(X, W, beta, alpha, L, U)
+    e.corr_upload(_lib.CORR_AUX, np.ascontiguousarray(aux.T))
+    status = e.corr_update_signature_embeddings(var, 0, return_status=True)
+    got = e.corr_download(_lib.CORR_SIGNATURE_EMBEDDINGS)
+    # the sample side is untouched
+    assert np.array_equal(e.corr_download(_lib.CORR_SAMPLE_EMBEDDINGS), U)
+    e.close()
+    want = co.update_signature_embeddings(aux, L, U, beta, alpha, var)
+    scale = np.maximum(np.abs(want).max(axis=1), 1e-3)
+    err = np.abs(got - want).max(axis=1) / scale
+    assert err.max() < 10 * dim * 1e-5
+    assert np.median(err) < 1e-6
+    assert np.all((status == 0) | (status == 2))  # converged, or stopped at rounding level in the last line search
+
+
+def test_update_embedding_single_problem_both_layouts():
+    """_utils_corrnmf.update_embedding: few terms -> wavefront kernel, many terms -> workgroup kernel."""
+    from salamander_amd.models import _utils_corrnmf as uc
+
+    rng = np.random.default_rng(4)
+    for n_other, dim, kwargs in [(5, 2, {"options": {"maxiter": 3}}), (40, 6, {}), (500, 3, {})]:
+        others = rng.normal(0, 0.6, (n_other, dim))
+        scalings_other = rng.normal(0, 0.3, n_other)
+        aux_vec = rng.gamma(2.0, 3.0, n_other)
+        x0 = rng.normal(0, 0.5, dim)
+        got = uc.update_embedding(x0, others, 0.3, scalings_other, 0.9, aux_vec, None, **kwargs)
+        want = co.update_embedding(x0, others, 0.3, scalings_other, 0.9, aux_vec, **kwargs)
+        assert np.allclose(got, want, rtol=1e-6, atol=1e-9)
+    with pytest.raises(TypeError):
+        uc.update_embedding(x0, others, 0.3, scalings_other, 0.9, aux_vec, None, tol=1e-3)
+
+
+def test_resident_fit_equals_per_parameter_updates():
+    """fit() (everything resident) against the same updates driven one public method at a time."""
+    import salamander_amd as sal
+    from salamander_amd.models import CorrNMFDet
+
+    X, _, _ = ko.synthetic_problem(96, 257, 5, seed=11)
+    np.random.seed(2)
+    a = CorrNMFDet(n_signatures=5, dim_embeddings=3, init_method="random", min_iterations=4, max_iterations=4)
+    a.fit(sal.AnnData(X.copy()), init_kwargs={"seed": 2})
+    np.random.seed(2)
+    b = CorrNMFDet(n_signatures=5, dim_embeddings=3, init_method="random")
+    b._setup_adata(sal.AnnData(X.copy()))
+    b._initialize(None, {"seed": 2})
+    for _ in range(4):
+        b.update_sample_scalings()
+        b.compute_exposures()
+        aux = b._compute_aux()
+        b.update_signature_scalings(aux)
+        b.update_embeddings(aux)
+        b.update_variance()
+        b.update_signatures()
+    assert np.allclose(a.asignatures.X, b.asignatures.X, rtol=1e-9, atol=1e-14)
+    assert np.allclose(a.asignatures.obsm["embeddings"], b.asignatures.obsm["embeddings"], rtol=1e-8, atol=1e-12)
+    assert np.allclose(a.adata.obsm["embeddings"], b.adata.obsm["embeddings"], rtol=1e-8, atol=1e-12)
+    assert np.allclose(a.adata.obs["scalings"].values, b.adata.obs["scalings"].values, rtol=1e-9, atol=1e-12)
+    assert np.allclose(a.variance, b.variance, rtol=1e-10)
