@@ -346,12 +346,25 @@ struct SignatureEmbeddingEval {
         if (wave == 0) ybuf[lane] = y;
         __syncthreads();
     }
-    // stage rows [t0, t0 + SIGT) of U into LDS (coalesced), zero beyond N
+    // stage rows [t0, t0 + SIGT) of U into LDS (coalesced), zero beyond N; loads issued in batches of 8
     __device__ inline void stage(int64_t t0) {
         const int64_t base = t0 * dim, end = p->N * dim;
-        for (int i = tid; i < SIGT * dim; i += SIGT) {
-            const int j = i / dim, m = i - j * dim;
-            Ut[j * CORR_LD + m] = (base + i < end) ? p->U[base + i] : 0.0;
+        const int total = SIGT * dim;
+        for (int i0 = tid; i0 < total; i0 += 8 * SIGT) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * SIGT;
+                v[u] = (i < total && base + i < end) ? p->U[base + i] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * SIGT;
+                if (i < total) {
+                    const int j = i / dim, m = i - j * dim;
+                    Ut[j * CORR_LD + m] = v[u];
+                }
+            }
         }
         __syncthreads();
     }
