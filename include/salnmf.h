@@ -143,6 +143,13 @@ int salnmf_corr_update_signatures(salnmf_engine* e, int n_given);
  * (salamander_amd/csrc/salnmf_newtoncg.h). */
 int salnmf_corr_update_sample_embeddings(salnmf_engine* e, double variance, int maxiter,
                                          int* status_out);
+/* MultimodalCorrNMF.update_sample_embeddings (mmcorrnmf.py:398-428): the sample embeddings are
+ * shared by the modalities, so one solve per sample sees the signatures (embeddings, scalings, aux)
+ * of all of them and that modality's sample scaling per term.  engines[i] is modality i (1..4
+ * engines on one device with equal n_samples and dim_embeddings, at most 128 signatures in total);
+ * the result is written to every engine's sample embeddings. */
+int salnmf_corr_update_sample_embeddings_multi(salnmf_engine* const* engines, int n_engines,
+                                               double variance, int maxiter, int* status_out);
 /* CorrNMFDet.update_signature_embeddings (corrnmf_det.py:88-113): one Newton-CG solve per signature
  * (same objective with the roles of signatures and samples exchanged; every evaluation is a pass
  * over all samples, one workgroup per signature).  maxiter <= 0 selects SciPy's default, which is

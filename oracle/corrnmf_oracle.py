@@ -176,3 +176,54 @@ def corrnmf_det_step(X, W, beta, alpha, L, U, variance, n_given=0):
     variance = update_variance(L_new, U_new)
     W_new = kl.update_W(X.T, W.T, H.T, n_given_signatures=n_given).T
     return W_new, beta, alpha, L_new, U_new, variance, H
+
+
+# --------------------------------------------------------------------------- multimodal CorrNMF (mmcorrnmf.py)
+# Per modality: data X_m (N, V_m), signatures W_m (K_m, V_m), scalings beta_m (K_m,), alpha_m (N,),
+# signature embeddings L_m (K_m, dim).  Shared: sample embeddings U (N, dim) and the variance.
+# Pinned by the reference's fixtures tests/test_data/models/multimodal_corrnmf/* (tests/test_oracle_corrnmf.py).
+
+
+def mm_elbo(Xs, Ws, Hs, Ls, U, variance) -> float:
+    """``MultimodalCorrNMF.objective_function`` (``mmcorrnmf.py:168-194``)."""
+    U = np.asarray(U, dtype=np.float64)
+    value = sum(elbo_corrnmf(X, W, H, L, U, variance, penalize_sample_embeddings=False) for X, W, H, L in zip(Xs, Ws, Hs, Ls))
+    value -= 0.5 * U.shape[1] * U.shape[0] * np.log(2 * np.pi * variance)
+    value -= np.sum(U**2) / (2 * variance)
+    return float(value)
+
+
+def mm_update_sample_embeddings(auxs, Ls, U, betas, alphas, variance) -> np.ndarray:
+    """Joint solve per sample over the concatenated signatures of all modalities (``mmcorrnmf.py:398-428``).
+
+    The per-term "scaling" is the sample's scaling in the term's modality (``:412-418``)."""
+    L_all = np.concatenate([np.asarray(L, dtype=np.float64) for L in Ls])
+    beta_all = np.concatenate([np.asarray(b, dtype=np.float64) for b in betas])
+    aux_all = np.concatenate([np.asarray(a, dtype=np.float64) for a in auxs])
+    U = np.array(U, dtype=np.float64)
+    for n in range(U.shape[0]):
+        scalings = np.concatenate([np.repeat(alpha[n], len(b)) for alpha, b in zip(alphas, betas)])
+        U[n] = update_embedding(U[n], L_all, scalings, beta_all, variance, aux_all[:, n], options={"maxiter": 3})
+    return U
+
+
+def mm_update_variance(Ls, U) -> float:
+    """``mmcorrnmf.py:305-317``."""
+    both = np.concatenate([np.concatenate([np.asarray(L) for L in Ls]), np.asarray(U)])
+    return float(np.clip(np.mean(both**2), EPSILON, None))
+
+
+def mm_step(Xs, Ws, betas, alphas, Ls, U, variance, n_given=None):
+    """One ``MultimodalCorrNMF._update_parameters`` (``mmcorrnmf.py:443-453``) on plain arrays."""
+    from . import klnmf_oracle as kl
+
+    n_given = [0] * len(Xs) if n_given is None else n_given
+    alphas = [update_sample_scalings(X, b, L, U) for X, b, L in zip(Xs, betas, Ls)]
+    Hs = [compute_exposures(b, a, L, U) for b, a, L in zip(betas, alphas, Ls)]
+    auxs = [compute_aux(X, W, H) for X, W, H in zip(Xs, Ws, Hs)]
+    betas = [update_signature_scalings(aux, a, L, U) for aux, a, L in zip(auxs, alphas, Ls)]
+    Ls_new = [update_signature_embeddings(aux, L, U, b, a, variance) for aux, L, b, a in zip(auxs, Ls, betas, alphas)]
+    U_new = mm_update_sample_embeddings(auxs, Ls_new, U, betas, alphas, variance)
+    variance = mm_update_variance(Ls_new, U_new)
+    Ws_new = [kl.update_W(X.T, W.T, H.T, n_given_signatures=g).T for X, W, H, g in zip(Xs, Ws, Hs, n_given)]
+    return Ws_new, betas, alphas, Ls_new, U_new, variance, Hs

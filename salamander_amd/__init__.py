@@ -8,8 +8,8 @@ extension or a gfx950 device is missing -- there is no CPU fallback.
 
 from . import models
 from ._lib import EngineUnavailable
-from .anndata_compat import AnnData
+from .anndata_compat import AnnData, MuData
 from .engine import Engine
 
 __version__ = "0.1.0"
-__all__ = ["models", "Engine", "AnnData", "EngineUnavailable"]
+__all__ = ["models", "Engine", "AnnData", "MuData", "EngineUnavailable"]

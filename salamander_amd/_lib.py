@@ -53,6 +53,7 @@ SIGNATURES = {
     "salnmf_corr_update_signature_scalings": (c_int, [_P]),
     "salnmf_corr_update_signatures": (c_int, [_P, c_int]),
     "salnmf_corr_update_sample_embeddings": (c_int, [_P, c_double, c_int, POINTER(c_int)]),
+    "salnmf_corr_update_sample_embeddings_multi": (c_int, [POINTER(_P), c_int, c_double, c_int, POINTER(c_int)]),
     "salnmf_corr_update_signature_embeddings": (c_int, [_P, c_double, c_int, POINTER(c_int)]),
     "salnmf_corr_embedding_sumsq": (c_int, [_P, _D]),
     "salnmf_corr_poisson_llh": (c_int, [_P, _D]),

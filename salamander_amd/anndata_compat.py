@@ -113,9 +113,53 @@ class MiniAnnData:
         return f"MiniAnnData object with n_obs x n_vars = {self.n_obs} x {self.n_vars}"
 
 
+class MiniMuData:
+    """Minimal multimodal container: named modalities over the same samples + shared ``obsm``.
+
+    The attribute surface ``MultimodalCorrNMF`` touches (``mmcorrnmf.py:61-64,200-215,490``):
+    ``mod`` (dict name -> AnnData), ``mdata[name]``, ``obsm``, ``obs_names``, ``n_obs``, ``n_mod``, ``update()``.
+    """
+
+    def __init__(self, mods: dict):
+        self.mod = dict(mods)
+        self.obsm: dict = {}
+
+    def __getitem__(self, name):
+        return self.mod[name]
+
+    @property
+    def n_mod(self) -> int:
+        return len(self.mod)
+
+    @property
+    def obs_names(self):
+        first = next(iter(self.mod.values()), None)
+        return pd.Index([]) if first is None else first.obs_names
+
+    @property
+    def n_obs(self) -> int:
+        return len(self.obs_names)
+
+    def update(self) -> None:
+        """The real MuData refreshes its global annotations here; nothing is cached in this container."""
+
+    def __repr__(self):
+        return f"MiniMuData object with n_obs = {self.n_obs} and modalities {list(self.mod)}"
+
+
+try:  # pragma: no cover - depends on the environment
+    import mudata as _md
+
+    _REAL_MU = _md.MuData
+except Exception:
+    _md = None
+    _REAL_MU = None
+
 # The class new containers are built with, and the classes accepted as input.
 AnnData = _REAL if _REAL is not None else MiniAnnData
 ANNDATA_TYPES = [c for c in (_REAL, MiniAnnData) if c is not None]
+MuData = _REAL_MU if _REAL_MU is not None else MiniMuData
+MUDATA_TYPES = [c for c in (_REAL_MU, MiniMuData) if c is not None]
 
 
 def concat_rows(first, second):

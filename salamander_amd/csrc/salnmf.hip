@@ -740,38 +740,70 @@ int salnmf_corr_update_signature_scalings(salnmf_engine* e) {
     return 0;
 }
 
-int salnmf_corr_update_sample_embeddings(salnmf_engine* e, double variance, int maxiter, int* status_out) {
-    CK(corr_ready(e));
+static int sample_embeddings_impl(salnmf_engine* const* engines, int n_engines, double variance, int maxiter, int* status_out) {
+    if (!engines || n_engines < 1 || n_engines > CORR_MODS) return fail("between 1 and %d engines expected", CORR_MODS);
+    salnmf_engine* e0 = engines[0];
+    CK(corr_ready(e0));
     if (!(variance > 0.0)) return fail("variance must be positive");
     SampleEmbeddingParams p;
-    p.aux = e->aux;
-    p.alpha = e->alpha;
-    p.beta = e->beta;
-    p.L = e->Lemb;
-    p.U = e->Uemb;
+    int terms = 0;
+    for (int i = 0; i < CORR_MODS; ++i) {
+        salnmf_engine* e = engines[i < n_engines ? i : 0];
+        if (i < n_engines) {
+            if (!e || e->dim == 0) return fail("engine %d is not configured for CorrNMF", i);
+            if (e->device != e0->device || e->N != e0->N || e->dim != e0->dim)
+                return fail("engine %d differs from engine 0 in device, n_samples or dim_embeddings", i);
+            terms += e->K;
+        }
+        p.aux[i] = e->aux;
+        p.alpha[i] = e->alpha;
+        p.beta[i] = e->beta;
+        p.L[i] = e->Lemb;
+        p.K[i] = i < n_engines ? e->K : 0;
+        p.KP[i] = e->KP;
+    }
+    if (terms > CORR_TERMS) return fail("at most %d signatures over all modalities, got %d", CORR_TERMS, terms);
+    p.n_mod = n_engines;
+    p.U = e0->Uemb;
     p.status = nullptr;
     p.variance = variance;
-    p.N = e->N;
-    p.K = e->K;
-    p.KP = e->KP;
-    p.dim = e->dim;
-    p.maxiter = maxiter > 0 ? maxiter : 200 * e->dim;  // scipy's default: 200 * len(x0)
+    p.N = e0->N;
+    p.dim = e0->dim;
+    p.maxiter = maxiter > 0 ? maxiter : 200 * e0->dim;  // scipy's default: 200 * len(x0)
+    // the modalities' engines have their own streams: everything they queued must be complete first
+    for (int i = 1; i < n_engines; ++i) HIPCK(hipStreamSynchronize(engines[i]->stream));
     int* dstatus = nullptr;
     if (status_out) {
-        HIPCK(hipMalloc(&dstatus, (size_t)e->N * sizeof(int)));
+        HIPCK(hipMalloc(&dstatus, (size_t)e0->N * sizeof(int)));
         p.status = dstatus;
     }
-    const int grid = (int)std::min<int64_t>((e->N + 3) / 4, 8192);
-    hipLaunchKernelGGL(corr_sample_embeddings_kernel, dim3(grid), dim3(CORR_BLOCK), 0, e->stream, p);
+    const int grid = (int)std::min<int64_t>((e0->N + 3) / 4, 8192);
+    if (terms <= 64)
+        hipLaunchKernelGGL(corr_sample_embeddings_kernel<1>, dim3(grid), dim3(CORR_BLOCK), 0, e0->stream, p);
+    else
+        hipLaunchKernelGGL(corr_sample_embeddings_kernel<2>, dim3(grid), dim3(CORR_BLOCK), 0, e0->stream, p);
     int rc = 0;
     if (hipGetLastError() != hipSuccess) rc = fail("corr_sample_embeddings_kernel launch failed");
-    if (!rc && status_out) {
-        if (hipMemcpyAsync(status_out, dstatus, (size_t)e->N * sizeof(int), hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
-            hipStreamSynchronize(e->stream) != hipSuccess)
+    // the sample embeddings are shared: every modality's engine gets the result
+    for (int i = 1; i < n_engines && !rc; ++i)
+        if (hipMemcpyAsync(engines[i]->Uemb, e0->Uemb, (size_t)e0->N * e0->dim * sizeof(double), hipMemcpyDeviceToDevice, e0->stream) != hipSuccess)
+            rc = fail("copy of the shared sample embeddings failed");
+    if (!rc && (status_out || n_engines > 1)) {
+        if (status_out && hipMemcpyAsync(status_out, dstatus, (size_t)e0->N * sizeof(int), hipMemcpyDeviceToHost, e0->stream) != hipSuccess)
             rc = fail("status download failed");
+        if (!rc && hipStreamSynchronize(e0->stream) != hipSuccess) rc = fail("hipStreamSynchronize failed");
     }
     if (dstatus) (void)hipFree(dstatus);
     return rc;
+}
+
+int salnmf_corr_update_sample_embeddings(salnmf_engine* e, double variance, int maxiter, int* status_out) {
+    return sample_embeddings_impl(&e, 1, variance, maxiter, status_out);
+}
+
+int salnmf_corr_update_sample_embeddings_multi(salnmf_engine* const* engines, int n_engines, double variance, int maxiter,
+                                               int* status_out) {
+    return sample_embeddings_impl(engines, n_engines, variance, maxiter, status_out);
 }
 
 int salnmf_corr_update_signature_embeddings(salnmf_engine* e, double variance, int maxiter, int* status_out) {

@@ -186,112 +186,162 @@ __global__ void corr_log_ratio_kernel(const double* __restrict__ first, const do
 }
 
 // ----------------------------------------------------------------------------------------------
-// Sample embeddings (CorrNMFDet.update_sample_embeddings, corrnmf_det.py:115-141): one strictly
-// convex problem per sample n over u in R^dim,
-//   minimise  -[ sum_k aux[k][n] <L_k, u> - sum_k exp(alpha_n + beta_k + <L_k, u>) - |u|^2 / (2 var) ]
+// Sample embeddings (CorrNMFDet.update_sample_embeddings, corrnmf_det.py:115-141;
+// MultimodalCorrNMF.update_sample_embeddings, mmcorrnmf.py:398-428): one strictly convex problem per
+// sample n over u in R^dim whose terms are the signatures of all modalities,
+//   minimise  -[ sum_i aux_i[n] <L_i, u> - sum_i exp(alpha_{mod(i)}[n] + beta_i + <L_i, u>) - |u|^2 / (2 var) ]
 // (_utils_corrnmf.py:182-239; gradient :242-293, Hessian :296-351), solved by the Newton-CG of
-// salnmf_newtoncg.h with maxiter = 3 (corrnmf_det.py:140) from the current embedding; finally
-// entries within EPSILON of zero are pushed to +-EPSILON (_utils_corrnmf.py:408-409).
-// One wavefront per sample: lane k <-> signature term k, lane m <-> embedding component m.
-struct SampleEmbeddingEval {
-    const double* O;   // LDS [K][CORR_LD]: the signature embeddings
-    const double* so;  // LDS [K]: signature scalings
-    double* vbuf;      // LDS, wave private [64]: a vector to broadcast
-    double* wbuf;      // LDS, wave private [64]: per-term weights
-    double c;          // this sample's scaling
-    double a;          // lane k: aux[k][n]
-    double sg;         // lane m: sum_k aux[k][n] L[k][m]
-    double variance;
-    double hw;         // lane k: exp(c + so_k + <L_k, x>) at the point the Hessian is fixed
-    int K, dim, lane;
+// salnmf_newtoncg.h with maxiter = 3 (corrnmf_det.py:140, mmcorrnmf.py:427) from the current
+// embedding; finally entries within EPSILON of zero are pushed to +-EPSILON (_utils_corrnmf.py:408-409).
+// One wavefront per sample: lane m <-> embedding component m, lane l <-> terms l (and l + 64 when
+// the modalities have more than 64 signatures in total, TPL = 2).
+constexpr int CORR_MODS = 4;     // modalities per joint solve
+constexpr int CORR_TERMS = 128;  // signatures of all modalities together
 
-    // lane k: <L_k, y>
-    __device__ __forceinline__ double products(double y) {
+template <int TPL>
+struct SampleEmbeddingEval {
+    const double* O;   // LDS [terms][CORR_LD]: the signature embeddings of all modalities
+    const double* so;  // LDS [terms]: signature scalings
+    double* vbuf;      // LDS, wave private [64]: a vector to broadcast
+    double* wbuf;      // LDS, wave private [64 * TPL]: per-term weights
+    double c[TPL];     // sample scaling of the modality of this lane's term(s)
+    double a[TPL];     // aux of this lane's term(s) for this sample
+    double hw[TPL];    // exp(c + so + <L_i, x>) at the point the Hessian is fixed
+    double sg;         // lane m: sum_i aux_i L[i][m]
+    double variance;
+    int T, dim, lane;  // T = number of terms
+
+    // <L_i, y> for this lane's term(s)
+    __device__ __forceinline__ void products(double y, double (&s)[TPL]) {
         vbuf[lane] = y;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        double s = 0.0;
-        if (lane < K) {
-            const double* row = O + lane * CORR_LD;
-            for (int m = 0; m < dim; ++m) s = __builtin_fma(row[m], vbuf[m], s);
+#pragma unroll
+        for (int t = 0; t < TPL; ++t) {
+            const int i = lane + 64 * t;
+            double acc = 0.0;
+            if (i < T) {
+                const double* row = O + i * CORR_LD;
+                for (int m = 0; m < dim; ++m) acc = __builtin_fma(row[m], vbuf[m], acc);
+            }
+            s[t] = acc;
         }
         __builtin_amdgcn_wave_barrier();
-        return s;
     }
-    // lane m: sum_k w_k L[k][m]
-    __device__ __forceinline__ double combine(double w) {
-        wbuf[lane] = w;
+    // lane m: sum_i w_i L[i][m]
+    __device__ __forceinline__ double combine(const double (&w)[TPL]) {
+#pragma unroll
+        for (int t = 0; t < TPL; ++t) wbuf[lane + 64 * t] = w[t];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         double r = 0.0;
         if (lane < dim)
-            for (int k = 0; k < K; ++k) r = __builtin_fma(wbuf[k], O[k * CORR_LD + lane], r);
+            for (int i = 0; i < T; ++i) r = __builtin_fma(wbuf[i], O[i * CORR_LD + lane], r);
         __builtin_amdgcn_wave_barrier();
         return r;
     }
-    __device__ __forceinline__ double rate(double s) const { return lane < K ? exp((c + so[lane]) + s) : 0.0; }
-
+    __device__ __forceinline__ double rate(int t, double s) const {
+        const int i = lane + 64 * t;
+        return i < T ? exp((c[t] + so[i]) + s) : 0.0;
+    }
     __device__ inline double fun(double y) {
-        const double s = products(y);
-        double v = ncg::wave_sum(lane < K ? s * a : 0.0);
-        v -= ncg::wave_sum(rate(s));
+        double s[TPL];
+        products(y, s);
+        double lin = 0.0, ex = 0.0;
+#pragma unroll
+        for (int t = 0; t < TPL; ++t) {
+            lin += (lane + 64 * t < T) ? s[t] * a[t] : 0.0;
+            ex += rate(t, s[t]);
+        }
+        double v = ncg::wave_sum(lin);
+        v -= ncg::wave_sum(ex);
         v -= ncg::wave_sum(y * y) / (2 * variance);
         return -v;
     }
     __device__ inline double grad(double y) {
-        const double s = products(y);
-        double g = -combine(rate(s));
+        double s[TPL], w[TPL];
+        products(y, s);
+#pragma unroll
+        for (int t = 0; t < TPL; ++t) w[t] = rate(t, s[t]);
+        double g = -combine(w);
         g += sg;
         g -= y / variance;
         return lane < dim ? -g : 0.0;
     }
-    __device__ inline void prepare_hess(double x) { hw = rate(products(x)); }
+    __device__ inline void prepare_hess(double x) {
+        double s[TPL];
+        products(x, s);
+#pragma unroll
+        for (int t = 0; t < TPL; ++t) hw[t] = rate(t, s[t]);
+    }
     __device__ inline double hessp(double p) {
-        const double t = products(p);
-        const double r = combine(hw * t);
+        double s[TPL], w[TPL];
+        products(p, s);
+#pragma unroll
+        for (int t = 0; t < TPL; ++t) w[t] = hw[t] * s[t];
+        const double r = combine(w);
         return lane < dim ? r + p / variance : 0.0;
     }
     __device__ inline bool exhausted() const { return false; }  // every loop of the solve is bounded and cheap here
 };
 
 struct SampleEmbeddingParams {
-    const double* __restrict__ aux;    // [Np][KP]
-    const double* __restrict__ alpha;  // [Np]
-    const double* __restrict__ beta;   // [K]
-    const double* __restrict__ L;      // [K][dim]
-    double* __restrict__ U;            // [N][dim]  in / out
-    int* __restrict__ status;          // [N] or null: ncg::Status of every solve
+    const double* aux[CORR_MODS];    // [Np][KP_mod]
+    const double* alpha[CORR_MODS];  // [Np]
+    const double* beta[CORR_MODS];   // [K_mod]
+    const double* L[CORR_MODS];      // [K_mod][dim]
+    int K[CORR_MODS], KP[CORR_MODS];
+    int n_mod;
+    double* U;                       // [N][dim]  in / out (shared by the modalities)
+    int* status;                     // [N] or null: ncg::Status of every solve
     double variance;
     int64_t N;
-    int K, KP, dim, maxiter;
+    int dim, maxiter;
 };
 
+template <int TPL>
 __global__ void __launch_bounds__(CORR_BLOCK) corr_sample_embeddings_kernel(SampleEmbeddingParams p) {
-    __shared__ double Ll[CORR_DMAX * CORR_LD];
-    __shared__ double bl[CORR_DMAX];
-    __shared__ double vb[4][64], wb[4][64];
+    __shared__ double Ll[64 * TPL * CORR_LD];
+    __shared__ double bl[64 * TPL];
+    __shared__ int tmod[64 * TPL], tk[64 * TPL];  // term -> (modality, signature)
+    __shared__ double vb[4][64], wb[4][64 * TPL];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int K = p.K, dim = p.dim;
-    for (int i = tid; i < CORR_DMAX * CORR_LD; i += CORR_BLOCK) {
-        const int k = i / CORR_LD, m = i - k * CORR_LD;
-        Ll[i] = (k < K && m < dim) ? p.L[k * dim + m] : 0.0;
+    const int dim = p.dim;
+    int T = 0;
+    for (int mo = 0; mo < p.n_mod; ++mo) T += p.K[mo];
+    for (int i = tid; i < 64 * TPL; i += CORR_BLOCK) {
+        int mo = 0, k = i;
+        while (mo < p.n_mod && k >= p.K[mo]) { k -= p.K[mo]; ++mo; }
+        tmod[i] = mo < p.n_mod ? mo : 0;
+        tk[i] = mo < p.n_mod ? k : 0;
+        bl[i] = mo < p.n_mod ? p.beta[mo][k] : 0.0;
     }
-    if (tid < CORR_DMAX) bl[tid] = tid < K ? p.beta[tid] : 0.0;
+    __syncthreads();
+    for (int i = tid; i < 64 * TPL * CORR_LD; i += CORR_BLOCK) {
+        const int t = i / CORR_LD, m = i - t * CORR_LD;
+        Ll[i] = (t < T && m < dim) ? p.L[tmod[t]][tk[t] * dim + m] : 0.0;
+    }
     __syncthreads();
     // from here on the waves run independently (no workgroup barrier below)
     for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < p.N; n += (int64_t)gridDim.x * 4) {
-        SampleEmbeddingEval ev;
+        SampleEmbeddingEval<TPL> ev;
         ev.O = Ll;
         ev.so = bl;
         ev.vbuf = vb[wave];
         ev.wbuf = wb[wave];
-        ev.c = p.alpha[n];
-        ev.a = lane < K ? p.aux[n * p.KP + lane] : 0.0;
         ev.variance = p.variance;
-        ev.hw = 0.0;
-        ev.K = K;
+        ev.T = T;
         ev.dim = dim;
         ev.lane = lane;
+#pragma unroll
+        for (int t = 0; t < TPL; ++t) {
+            const int i = lane + 64 * t;
+            const bool live = i < T;
+            const int mo = tmod[i];
+            ev.c[t] = live ? p.alpha[mo][n] : 0.0;
+            ev.a[t] = live ? p.aux[mo][n * p.KP[mo] + tk[i]] : 0.0;
+            ev.hw[t] = 0.0;
+        }
         ev.sg = ev.combine(ev.a);
         double x = lane < dim ? p.U[n * dim + lane] : 0.0;
         const int st = ncg::minimize(ev, x, dim, p.maxiter);

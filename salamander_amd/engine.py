@@ -171,6 +171,16 @@ class Engine:
         _lib.check(self._lib.salnmf_corr_update_sample_embeddings(self._h, float(variance), int(maxiter), ptr))
         return status
 
+    @staticmethod
+    def corr_update_sample_embeddings_multi(engines, variance: float, maxiter: int = 3, return_status: bool = False):
+        """Joint solve of the sample embeddings shared by several modalities (one engine each)."""
+        engines = list(engines)
+        handles = (ctypes.c_void_p * len(engines))(*[e._h for e in engines])
+        status = np.empty(engines[0].N, dtype=np.int32) if return_status else None
+        ptr = status.ctypes.data_as(POINTER(ctypes.c_int)) if return_status else None
+        _lib.check(engines[0]._lib.salnmf_corr_update_sample_embeddings_multi(handles, len(engines), float(variance), int(maxiter), ptr))
+        return status
+
     def corr_update_signature_embeddings(self, variance: float, maxiter: int = 0, return_status: bool = False):
         """One Newton-CG solve per signature on the device (SciPy's default iteration limit when maxiter <= 0)."""
         status = np.empty(self.K, dtype=np.int32) if return_status else None

@@ -210,3 +210,46 @@ def initialize_corrnmf(
             adata.obsm["embeddings"] = standard_normal(adata.n_obs)
     variance = float(given_parameters.get("variance", 1.0))
     return asignatures, variance
+
+
+def check_given_parameters_mmcorrnmf(mdata, ns_signatures, dim_embeddings, given_parameters) -> None:
+    """Per-modality dictionaries plus the shared 'sample_embeddings' / 'variance' (initialize.py:387-416)."""
+    dict_checker("given_parameters", given_parameters, list(mdata.mod.keys()) + ["sample_embeddings", "variance"])
+    for (mod_name, adata), n_signatures in zip(mdata.mod.items(), ns_signatures):
+        given_mod = given_parameters.get(mod_name, {})
+        check_given_parameters_corrnmf(adata, n_signatures, dim_embeddings, given_mod)
+        if "sample_embeddings" in given_mod:
+            raise KeyError(
+                "The sample embeddings are shared across modalities in multimodal correlated NMF. "
+                "They cannot be provided as given parameters on the modality level."
+            )
+        if "variance" in given_mod:
+            raise KeyError(
+                "The variance parameters of multimodal correlated NMF is shared across modalies. "
+                "It cannot be provided as a given parameter on the modality level."
+            )
+
+
+def initialize_mmcorrnmf(mdata, ns_signatures, dim_embeddings, method="nndsvd", given_parameters: dict[str, Any] | None = None, **kwargs):
+    """One ``initialize_corrnmf`` per modality (without sample embeddings), new signature names prefixed with the
+    modality, shared sample embeddings and variance (initialize.py:419-470).  Returns ``(asignatures dict, variance)``."""
+    given_parameters = {} if given_parameters is None else given_parameters.copy()
+    check_given_parameters_mmcorrnmf(mdata, ns_signatures, dim_embeddings, given_parameters)
+    asignatures = {}
+    for (mod_name, adata), n_signatures in zip(mdata.mod.items(), ns_signatures):
+        given_mod = given_parameters.get(mod_name, {})
+        asigs, _ = initialize_corrnmf(
+            adata, n_signatures, dim_embeddings, method, given_mod, initialize_sample_embeddings=False, **kwargs
+        )
+        n_given = given_mod["asignatures"].n_obs if "asignatures" in given_mod else 0
+        names = list(asigs.obs_names)
+        asigs.obs_names = names[:n_given] + [f"{mod_name} {name}" for name in names[n_given:]]
+        asignatures[mod_name] = asigs
+    if "sample_embeddings" in given_parameters:
+        mdata.obsm["embeddings"] = given_parameters["sample_embeddings"]
+    else:
+        mdata.obsm["embeddings"] = np.random.multivariate_normal(
+            np.zeros(dim_embeddings), np.identity(dim_embeddings), size=mdata.n_obs
+        )
+    variance = float(given_parameters.get("variance", 1.0))
+    return asignatures, variance

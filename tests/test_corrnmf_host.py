@@ -107,3 +107,67 @@ def test_correlation_of_embeddings(adata):
     assert m.adata.obsp["X_correlation"].shape == (12, 12)
     with pytest.raises(ValueError):
         m.compute_correlation_scaled("features")
+
+
+# ------------------------------------------------------------------ multimodal initialisation (initialize.py:387-470)
+
+from salamander_amd.initialization import initialize_mmcorrnmf  # noqa: E402
+
+
+@pytest.fixture
+def mdata():
+    rng = np.random.default_rng(1)
+    names = [f"s{i}" for i in range(9)]
+    a = sal.AnnData(rng.poisson(20.0, size=(9, 96)).astype(float), obs_names=names)
+    b = sal.AnnData(rng.poisson(15.0, size=(9, 83)).astype(float), obs_names=names)
+    return sal.MuData({"sbs": a, "indel": b})
+
+
+def test_initialize_mmcorrnmf_defaults(mdata):
+    np.random.seed(0)
+    asigs, variance = initialize_mmcorrnmf(mdata, [2, 3], 2, "flat")
+    assert list(asigs) == ["sbs", "indel"]
+    assert asigs["sbs"].X.shape == (2, 96) and asigs["indel"].X.shape == (3, 83)
+    assert list(asigs["indel"].obs_names) == ["indel Sig1", "indel Sig2", "indel Sig3"]
+    assert mdata.obsm["embeddings"].shape == (9, 2) and variance == 1.0
+    for name in ("sbs", "indel"):
+        assert "embeddings" not in mdata[name].obsm  # sample embeddings are shared, not per modality
+        assert np.array_equal(mdata[name].obs["scalings"].values, np.zeros(9))
+        assert asigs[name].obsm["embeddings"].shape[1] == 2
+
+
+def test_initialize_mmcorrnmf_given(mdata):
+    U = np.ones((9, 2))
+    given_sig = sal.AnnData(np.full((1, 96), 1 / 96), obs_names=["SBS1"], var_names=mdata["sbs"].var_names)
+    asigs, variance = initialize_mmcorrnmf(
+        mdata, [2, 2], 2, "flat", {"sbs": {"asignatures": given_sig, "signature_scalings": np.array([1.0, 2.0])}, "sample_embeddings": U, "variance": 2}
+    )
+    assert list(asigs["sbs"].obs_names) == ["SBS1", "sbs Sig1"]
+    assert np.array_equal(asigs["sbs"].obs["scalings"].values, [1.0, 2.0])
+    assert mdata.obsm["embeddings"] is U and variance == 2.0
+
+
+@pytest.mark.parametrize(
+    "given,exc",
+    [({"rna": {}}, ValueError), ({"sbs": {"sample_embeddings": np.zeros((9, 2))}}, KeyError), ({"indel": {"variance": 1.0}}, KeyError),
+     ({"sbs": {"signature_scalings": np.zeros(5)}}, ValueError)],
+)
+def test_initialize_mmcorrnmf_rejects(mdata, given, exc):
+    with pytest.raises(exc):
+        initialize_mmcorrnmf(mdata, [2, 2], 2, "flat", given)
+
+
+def test_multimodal_model_setup_checks(mdata):
+    from salamander_amd.models import MultimodalCorrNMF
+
+    m = MultimodalCorrNMF(ns_signatures=[2, 3])
+    assert m.dim_embeddings == 3 and m.mod_names == ["mod1", "mod2"] and m.objective == "maximize"
+    with pytest.raises(TypeError):
+        m._setup_mdata({"sbs": None})
+    with pytest.raises(ValueError, match="modalities"):
+        MultimodalCorrNMF(ns_signatures=[2])._setup_mdata(mdata)
+    bad = sal.MuData({"a": mdata["sbs"], "b": sal.AnnData(np.ones((9, 4)))})
+    with pytest.raises(ValueError, match="sample names"):
+        m._setup_mdata(bad)
+    m._setup_mdata(mdata)
+    assert m.mod_names == ["sbs", "indel"] and m.sample_names == [f"s{i}" for i in range(9)]

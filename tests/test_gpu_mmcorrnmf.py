@@ -1,0 +1,231 @@
+"""GPU tests of ``MultimodalCorrNMF`` (SURVEY.md 8f row f1, config c5's model): the reference's
+``tests/test_mmcorrnmf.py`` re-run against the device implementation, plus oracle comparisons."""
+
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+import salamander_amd as sal
+from oracle import corrnmf_oracle as co
+from oracle import klnmf_oracle as ko
+from salamander_amd import _lib
+from salamander_amd.engine import Engine
+from salamander_amd.models.mmcorrnmf import MultimodalCorrNMF
+from test_oracle_corrnmf import MMFIX, load_mm_case
+
+pytestmark = pytest.mark.gpu
+
+NS_SIGNATURES = [2, 3]
+DIM_EMBEDDINGS = 2
+
+
+def make_mdata(c=None):
+    adatas = {}
+    for m in range(2):
+        counts = pd.read_csv(os.path.join(MMFIX, f"model{m}_counts.csv"), index_col=0).T
+        adatas[f"mod{m}"] = sal.AnnData(counts)
+    mdata = sal.MuData(adatas)
+    if c is not None:
+        mdata.obsm["embeddings"] = c["U"].copy()
+        for m in range(2):
+            mdata[f"mod{m}"].obs["scalings"] = c["alphas"][m]
+    return mdata
+
+
+@pytest.fixture
+def case():
+    return load_mm_case()
+
+
+@pytest.fixture
+def model_init(case):
+    c = case
+    mdata = make_mdata(c)
+    asignatures = {}
+    for m in range(2):
+        asigs = sal.AnnData(c["Ws"][m].copy())
+        asigs.var_names = mdata[f"mod{m}"].var_names
+        asigs.obs["scalings"] = c["betas"][m]
+        asigs.obsm["embeddings"] = c["Ls"][m].copy()
+        asignatures[f"mod{m}"] = asigs
+    model = MultimodalCorrNMF(ns_signatures=NS_SIGNATURES, dim_embeddings=DIM_EMBEDDINGS)
+    model.mdata = mdata
+    model.asignatures = asignatures
+    model.compute_exposures()
+    model.variance = c["variance"]
+    return model
+
+
+def auxs_of(c):
+    return {f"mod{m}": c["auxs"][m] for m in range(2)}
+
+
+def test_init_signature_names(model_init):
+    given = {}
+    for name, adata in model_init.mdata.mod.items():
+        asigs = sal.AnnData(np.zeros((1, adata.n_vars)))
+        asigs.obs_names = ["A"]
+        asigs.var_names = adata.var_names
+        given[name] = {"asignatures": asigs}
+    model_init._initialize(given)
+    for name, asigs in model_init.asignatures.items():
+        for k, sig_name in enumerate(asigs.obs_names):
+            assert sig_name == ("A" if k == 0 else f"{name} Sig{k}")
+
+
+def test_objective_function(model_init, case):
+    assert np.allclose(model_init.objective_function(), case["objective"])
+
+
+class TestUpdatesMultimodalCorrNMF:
+    def test_update_signatures(self, model_init, case):
+        model_init.update_signatures()
+        for m, (name, sigs) in enumerate(model_init.asignatures.items()):
+            assert np.allclose(sigs.X, case["W_updated"][m])
+
+    def test_update_sample_scalings(self, model_init, case):
+        model_init.update_sample_scalings()
+        for m, (name, adata) in enumerate(model_init.mdata.mod.items()):
+            assert np.allclose(adata.obs["scalings"], case["alpha_updated"][m])
+
+    def test_update_signature_scalings(self, model_init, case):
+        model_init.update_signature_scalings(auxs_of(case))
+        for m, (name, sigs) in enumerate(model_init.asignatures.items()):
+            assert np.allclose(sigs.obs["scalings"], case["beta_updated"][m])
+
+    def test_compute_aux(self, model_init, case):
+        for m, (name, aux) in enumerate(model_init._compute_auxs().items()):
+            assert np.allclose(aux, case["auxs"][m])
+
+    def test_update_signature_embeddings(self, model_init, case):
+        model_init.update_signature_embeddings(auxs_of(case))
+        for m, (name, asigs) in enumerate(model_init.asignatures.items()):
+            assert np.allclose(asigs.obsm["embeddings"], case["L_updated"][m])
+
+    def test_update_sample_embeddings(self, model_init, case):
+        model_init.update_sample_embeddings(auxs_of(case))
+        assert np.allclose(model_init.mdata.obsm["embeddings"], case["U_updated"])
+
+    def test_update_variance(self, model_init, case):
+        model_init.update_variance()
+        assert np.allclose(model_init.variance, case["variance_updated"])
+
+
+def test_update_parameters_matches_oracle_steps(model_init, case):
+    c = case
+    Ws, betas, alphas, Ls, U, var = c["Ws"], c["betas"], c["alphas"], c["Ls"], c["U"], c["variance"]
+    for _ in range(3):
+        model_init._update_parameters()
+        Ws, betas, alphas, Ls, U, var, Hs = co.mm_step(c["Xs"], Ws, betas, alphas, Ls, U, var)
+        for m, name in enumerate(model_init.mod_names):
+            assert np.allclose(model_init.asignatures[name].X, Ws[m], rtol=1e-6, atol=1e-12)
+            assert np.allclose(model_init.mdata[name].obsm["exposures"], Hs[m], rtol=1e-6)
+            assert np.allclose(model_init.asignatures[name].obs["scalings"].values, betas[m], rtol=1e-6, atol=1e-9)
+            assert np.allclose(model_init.mdata[name].obs["scalings"].values, alphas[m], rtol=1e-6, atol=1e-9)
+            assert np.allclose(model_init.asignatures[name].obsm["embeddings"], Ls[m], rtol=1e-5, atol=1e-7)
+        assert np.allclose(model_init.mdata.obsm["embeddings"], U, rtol=1e-5, atol=1e-7)
+        assert np.allclose(model_init.variance, var, rtol=1e-6)
+
+
+@pytest.mark.parametrize("ns_signatures,dim_embeddings", [([1, 2], 1), ([2, 2], 1), ([2, 2], 2)])
+class TestGivenParametersMultimodalCorrNMF:
+    @pytest.fixture()
+    def model(self, ns_signatures, dim_embeddings):
+        return MultimodalCorrNMF(ns_signatures=ns_signatures, dim_embeddings=dim_embeddings, max_iterations=3)
+
+    @pytest.fixture()
+    def mdata(self):
+        return make_mdata()
+
+    def test_given_asignatures(self, model, mdata):
+        mod0, mod1 = mdata.mod.keys()
+        n_sigs0 = model.ns_signatures[0]
+        for n_given in range(1, n_sigs0 + 1):
+            given0 = mdata.mod[mod0][:n_given, :].copy()
+            given0.X = given0.X.astype(float)
+            given0.X = given0.X / np.sum(given0.X, axis=1, keepdims=True)
+            given_parameters = {mod0: {"asignatures": given0}}
+            model.fit(mdata, given_parameters=given_parameters)
+            assert np.allclose(given0.X, model.asignatures[mod0].X[:n_given, :])
+            assert not np.allclose(given0.X, model.asignatures[mod1].X[:n_given, :])
+            if n_given < n_sigs0:
+                other = model.asignatures[mod0].X[n_given:, :].copy()
+                model._update_parameters(given_parameters)
+                assert not np.allclose(other, model.asignatures[mod0].X[n_given:, :])
+
+    def test_given_signature_scalings(self, model, mdata):
+        mod0, mod1 = mdata.mod.keys()
+        n_sigs0 = model.ns_signatures[0]
+        given = np.random.uniform(size=n_sigs0)
+        model.fit(mdata, given_parameters={mod0: {"signature_scalings": given}})
+        assert np.allclose(given, model.asignatures[mod0].obs["scalings"])
+        assert not np.allclose(given, model.asignatures[mod1].obs["scalings"][:n_sigs0])
+
+    def test_given_signature_embeddings(self, model, mdata):
+        mod0, mod1 = mdata.mod.keys()
+        n_sigs0 = model.ns_signatures[0]
+        given = np.random.uniform(size=(n_sigs0, model.dim_embeddings))
+        model.fit(mdata, given_parameters={mod0: {"signature_embeddings": given}})
+        assert np.allclose(given, model.asignatures[mod0].obsm["embeddings"])
+        assert not np.allclose(given, model.asignatures[mod1].obsm["embeddings"][:n_sigs0, :])
+
+    def test_given_sample_scalings(self, model, mdata):
+        mod0, mod1 = mdata.mod.keys()
+        given = np.random.uniform(size=mdata.n_obs)
+        model.fit(mdata, given_parameters={mod0: {"sample_scalings": given}})
+        assert np.allclose(given, model.mdata.mod[mod0].obs["scalings"])
+        assert not np.allclose(given, model.mdata.mod[mod1].obs["scalings"])
+
+    def test_given_sample_embeddings(self, model, mdata):
+        given = np.random.uniform(size=(mdata.n_obs, model.dim_embeddings))
+        model.fit(mdata, given_parameters={"sample_embeddings": given})
+        assert np.allclose(given, model.mdata.obsm["embeddings"])
+
+    def test_given_variance(self, model, mdata):
+        model.fit(mdata, given_parameters={"variance": 3.0})
+        assert np.allclose(3.0, model.variance)
+
+
+@pytest.mark.parametrize("Ks,dim,N", [([7, 5], 3, 300), ([40, 40], 8, 200), ([64, 64], 16, 64), ([3, 4, 5], 2, 150)])
+def test_joint_sample_embedding_solve_matches_scipy(Ks, dim, N):
+    """salnmf_corr_update_sample_embeddings_multi on 2-3 modalities incl. more than 64 signatures in total
+    (two terms per lane) against the oracle's SciPy solves."""
+    rng = np.random.default_rng(sum(Ks) + dim)
+    U = rng.normal(0, 0.6, (N, dim))
+    Xs, Ws, betas, alphas, Ls, auxs, engines = [], [], [], [], [], [], []
+    for m, K in enumerate(Ks):
+        X, W, _ = ko.synthetic_problem(96, N, K, seed=10 + m)
+        beta, L = rng.normal(0, 0.3, K), rng.normal(0, 0.6, (K, dim))
+        alpha = co.update_sample_scalings(X, beta, L, U)
+        aux = co.compute_aux(X, W, co.compute_exposures(beta, alpha, L, U))
+        e = Engine(N, 96, K)
+        e.corr_configure(dim)
+        e.corr_upload(_lib.CORR_SIGNATURE_SCALINGS, beta)
+        e.corr_upload(_lib.CORR_SAMPLE_SCALINGS, alpha)
+        e.corr_upload(_lib.CORR_SIGNATURE_EMBEDDINGS, L)
+        e.corr_upload(_lib.CORR_SAMPLE_EMBEDDINGS, U)
+        e.corr_upload(_lib.CORR_AUX, np.ascontiguousarray(aux.T))
+        engines.append(e)
+        betas.append(beta); alphas.append(alpha); Ls.append(L); auxs.append(aux)
+    status = Engine.corr_update_sample_embeddings_multi(engines, 0.9, 3, return_status=True)
+    got = [e.corr_download(_lib.CORR_SAMPLE_EMBEDDINGS) for e in engines]
+    for e in engines:
+        e.close()
+    for g in got[1:]:
+        assert np.array_equal(g, got[0])  # every modality's engine holds the shared result
+    want = co.mm_update_sample_embeddings(auxs, Ls, U, betas, alphas, 0.9)
+    err = np.abs(got[0] - want).max(axis=1) / np.maximum(np.abs(want).max(axis=1), 1e-3)
+    assert np.median(err) < 1e-12 and err.max() < 2e-4
+    assert set(np.unique(status)) <= {0, 1, 2}
+
+
+def test_multi_solve_rejects_mismatched_engines():
+    a, b = Engine(32, 96, 3), Engine(48, 96, 3)
+    a.corr_configure(2)
+    b.corr_configure(2)
+    with pytest.raises(RuntimeError, match="differs"):
+        Engine.corr_update_sample_embeddings_multi([a, b], 1.0, 3)
+    a.close()
+    b.close()

@@ -100,3 +100,85 @@ def test_full_step_runs_and_improves_elbo(case):
     H = co.compute_exposures(beta, alpha, L, U)
     after = co.elbo_corrnmf(c["X"], W, H, L, U, var)
     assert np.isfinite(after) and after > before
+
+
+# ------------------------------------------------------------------ multimodal (tests/test_mmcorrnmf.py:16-255 data)
+
+MMFIX = os.path.join(os.path.dirname(__file__), "golden", "ref_fixtures", "multimodal_corrnmf")
+
+
+def load_mm_case():
+    g = lambda name: np.load(os.path.join(MMFIX, name + ".npy"))  # noqa: E731
+    c = {"Xs": [], "Ws": [], "betas": [], "alphas": [], "Ls": [], "auxs": [], "W_updated": [], "beta_updated": [], "alpha_updated": [], "L_updated": []}
+    for m in range(2):
+        counts = pd.read_csv(os.path.join(MMFIX, f"model{m}_counts.csv"), index_col=0)  # (V, N)
+        X = counts.T.to_numpy(dtype=np.float64)
+        c["Xs"].append(X)
+        c["Ws"].append(g(f"model{m}_signatures_mat_init").T.copy())
+        c["betas"].append(g(f"model{m}_signature_scalings_init"))
+        c["alphas"].append(g(f"model{m}_sample_scalings_init"))
+        c["Ls"].append(g(f"model{m}_signature_embeddings_init").T.copy())
+        # aux_kd = sum_v x_vd p_vkd with the stored p (tests/test_mmcorrnmf.py:101-106)
+        c["auxs"].append(np.einsum("vd,vkd->kd", counts.to_numpy(dtype=np.float64), g(f"model{m}_p")))
+        c["W_updated"].append(g(f"model{m}_signatures_mat_updated").T)
+        c["beta_updated"].append(g(f"model{m}_signature_scalings_updated"))
+        c["alpha_updated"].append(g(f"model{m}_sample_scalings_updated"))
+        c["L_updated"].append(g(f"model{m}_signature_embeddings_updated").T)
+    c["U"] = g("sample_embeddings_init").T.copy()
+    c["U_updated"] = g("sample_embeddings_updated").T
+    c["variance"] = float(g("variance_init"))
+    c["variance_updated"] = float(g("variance_updated"))
+    c["objective"] = float(g("objective_init"))
+    return c
+
+
+@pytest.fixture
+def mm():
+    return load_mm_case()
+
+
+def mm_exposures(c):
+    return [co.compute_exposures(b, a, L, c["U"]) for b, a, L in zip(c["betas"], c["alphas"], c["Ls"])]
+
+
+def test_mm_objective(mm):
+    assert np.allclose(co.mm_elbo(mm["Xs"], mm["Ws"], mm_exposures(mm), mm["Ls"], mm["U"], mm["variance"]), mm["objective"])
+
+
+def test_mm_aux(mm):
+    for X, W, H, aux in zip(mm["Xs"], mm["Ws"], mm_exposures(mm), mm["auxs"]):
+        assert np.allclose(co.compute_aux(X, W, H), aux)
+
+
+def test_mm_signatures_and_scalings(mm):
+    Hs = mm_exposures(mm)
+    for m in range(2):
+        assert np.allclose(ko.update_W(mm["Xs"][m].T, mm["Ws"][m].T, Hs[m].T).T, mm["W_updated"][m])
+        assert np.allclose(co.update_sample_scalings(mm["Xs"][m], mm["betas"][m], mm["Ls"][m], mm["U"]), mm["alpha_updated"][m])
+        got = co.update_signature_scalings(mm["auxs"][m], mm["alphas"][m], mm["Ls"][m], mm["U"])
+        assert np.allclose(got, mm["beta_updated"][m])
+
+
+def test_mm_signature_embeddings(mm):
+    for m in range(2):
+        got = co.update_signature_embeddings(mm["auxs"][m], mm["Ls"][m], mm["U"], mm["betas"][m], mm["alphas"][m], mm["variance"])
+        assert np.allclose(got, mm["L_updated"][m])
+
+
+def test_mm_sample_embeddings(mm):
+    got = co.mm_update_sample_embeddings(mm["auxs"], mm["Ls"], mm["U"], mm["betas"], mm["alphas"], mm["variance"])
+    assert np.allclose(got, mm["U_updated"])
+
+
+def test_mm_variance(mm):
+    assert np.allclose(co.mm_update_variance(mm["Ls"], mm["U"]), mm["variance_updated"])
+
+
+def test_mm_step_improves_elbo(mm):
+    c = mm
+    before = co.mm_elbo(c["Xs"], c["Ws"], mm_exposures(c), c["Ls"], c["U"], c["variance"])
+    Ws, betas, alphas, Ls, U, var = c["Ws"], c["betas"], c["alphas"], c["Ls"], c["U"], c["variance"]
+    for _ in range(5):
+        Ws, betas, alphas, Ls, U, var, Hs = co.mm_step(c["Xs"], Ws, betas, alphas, Ls, U, var)
+    Hs = [co.compute_exposures(b, a, L, U) for b, a, L in zip(betas, alphas, Ls)]
+    assert co.mm_elbo(c["Xs"], Ws, Hs, Ls, U, var) > before
