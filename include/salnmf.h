@@ -176,6 +176,8 @@ int salnmf_comm_init(salnmf_engine* e, const char* id, int n_ranks, int rank);
  *   finish : W tail from SALNMF_BUF_G (after the caller's all-reduce) */
 int salnmf_kl_step_partial(salnmf_engine* e);
 int salnmf_kl_step_finish(salnmf_engine* e, int n_given, int clip_mode);
+/* Device address of one of the engine's buffers (SALNMF_BUF_*).  Query it when needed instead of caching it:
+ * an MvNMF step exchanges the W buffer with its trial buffer rather than copying. */
 void* salnmf_device_ptr(salnmf_engine* e, int which);
 void* salnmf_stream(salnmf_engine* e);
 int salnmf_sync(salnmf_engine* e);

@@ -58,6 +58,9 @@ struct salnmf_engine {
     int grid = 0;   // workgroups of the fused kernel (one per CU)
     int fgrid = 0;  // workgroups of the forward kernels (two per CU)
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;  // MvNMF: the small W-only kernels run here, beside the passes over the samples
+    hipEvent_t evW = nullptr, evPrepW = nullptr, evTrial = nullptr, evLogdet = nullptr;
+    int mv_grid = 0, mv_fgrid = 0;  // grids that leave one CU free for stream2
     double *X = nullptr, *H = nullptr, *W = nullptr, *wkl = nullptr, *wlh = nullptr;
     double* Gpart = nullptr;     // [grid][K][V]
     double* Hsumpart = nullptr;  // [grid][K]
@@ -67,6 +70,8 @@ struct salnmf_engine {
     double* scal = nullptr;      // device scalars: [0]=objective, [1]=f0, [2]=f1, [3]=logdet0, [4]=logdet1
     double* Wunc = nullptr;      // MvNMF scratch [K][V]
     double* Wtrial = nullptr;    // [K][V]
+    double* mvA = nullptr;       // [K][V]  W @ Y_minus
+    double* mvB = nullptr;       // [K][V]  W @ |Y|
     double* cs = nullptr;        // [KP], filler 1
     double* hpin = nullptr;      // pinned host scalars
     // correlated NMF (row f1): scalings, embeddings, aux; allocated by salnmf_corr_configure
@@ -81,6 +86,7 @@ struct salnmf_engine {
     double* hwbuf = nullptr;     // [K][Np] Hessian weights of the signature-embedding solves (lazily allocated)
     int cgrid = 0;
     bool xrowsum_valid = false, lgam_valid = false;
+    bool h_pending = false;      // H is to be read as clip(H * cs): the rescale of an accepted MvNMF trial, applied by the next reader
     double lgam_sum = 0.0;       // sum gammaln(1 + X) over the local shard
     ncclComm_t comm = nullptr;
     int n_ranks = 1, rank = 0;
@@ -106,8 +112,8 @@ static int pick_ks(int K) {
     X(13, 3, 1) X(13, 3, 2) X(13, 3, 3) X(13, 3, 4)
 
 template <bool DO_G, bool DO_U, bool DO_STATS>
-static int launch_fused(salnmf_engine* e, const FusedParams& p) {
-    dim3 g(e->grid), b(BLOCK);
+static int launch_fused(salnmf_engine* e, const FusedParams& p, int grid = 0) {
+    dim3 g(grid > 0 ? grid : e->grid), b(BLOCK);
     bool done = false;
 #define SALNMF_CASE(ks, ktm, kr)                                                                           \
     if (!done && e->KS == ks && e->KTM == ktm && e->KR == kr) {                                            \
@@ -122,8 +128,8 @@ static int launch_fused(salnmf_engine* e, const FusedParams& p) {
 }
 
 template <int MODE>
-static int launch_forward(salnmf_engine* e, const FwdParams& p) {
-    dim3 g(e->fgrid), b(BLOCK);
+static int launch_forward(salnmf_engine* e, const FwdParams& p, int grid = 0) {
+    dim3 g(grid > 0 ? grid : e->fgrid), b(BLOCK);
 #define SALNMF_CASE(ks)                                                        \
     case ks:                                                                   \
         hipLaunchKernelGGL((forward_kernel<ks, MODE>), g, b, 0, e->stream, p); \
@@ -153,7 +159,7 @@ static FusedParams fused_params(salnmf_engine* e) {
     p.W = e->W;
     p.wkl = e->wkl;
     p.wlh = e->wlh;
-    p.hscale = nullptr;
+    p.hscale = e->h_pending ? e->cs : nullptr;
     p.Gpart = e->Gpart;
     p.Hsumpart = e->Hsumpart;
     p.KLpart = e->KLpart;
@@ -164,7 +170,7 @@ static FusedParams fused_params(salnmf_engine* e) {
     return p;
 }
 
-static int launch_tail(salnmf_engine* e, int nslabs, double* G, int n_given, int clip_mode, int do_tail) {
+static int launch_tail(salnmf_engine* e, int nslabs, double* G, int n_given, int clip_mode, int do_tail, bool with_stats = false) {
     TailParams t;
     t.Gpart = e->Gpart;
     t.G = G;
@@ -175,6 +181,11 @@ static int launch_tail(salnmf_engine* e, int nslabs, double* G, int n_given, int
     t.n_given = n_given;
     t.clip_mode = clip_mode;
     t.do_tail = do_tail;
+    t.hsum_part = with_stats ? e->Hsumpart : nullptr;
+    t.hsum_out = e->red + (size_t)e->K * e->V;
+    t.kl_part = with_stats ? e->KLpart : nullptr;
+    t.kl_out = e->red + (size_t)e->K * e->V + e->K;
+    t.nparts = nslabs;
     hipLaunchKernelGGL(tail_kernel, dim3(e->K), dim3(TAIL_BLOCK), 0, e->stream, t);
     HIPCK(hipGetLastError());
     return 0;
@@ -183,6 +194,15 @@ static int launch_tail(salnmf_engine* e, int nslabs, double* G, int n_given, int
 static int allreduce(salnmf_engine* e, double* buf, size_t count) {
     if (!e->comm) return 0;
     NCCLCK(ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, e->comm, e->stream));
+    return 0;
+}
+
+// materialise a pending rescale of H (needed only by readers that cannot apply it on the fly)
+static int flush_H_scale(salnmf_engine* e) {
+    if (!e->h_pending) return 0;
+    hipLaunchKernelGGL(scale_H_kernel, dim3(2048), dim3(256), 0, e->stream, e->H, e->cs, (int64_t)e->Np * e->KP, e->KP);
+    HIPCK(hipGetLastError());
+    e->h_pending = false;
     return 0;
 }
 
@@ -195,6 +215,7 @@ static int kl_step_once(salnmf_engine* e, int n_given, hipEvent_t* ev) {
         CK((launch_fused<false, true, false>(e, p)));
     else
         CK((launch_fused<true, true, false>(e, p)));
+    e->h_pending = false;  // the pass wrote H in full
     if (ev) HIPCK(hipEventRecord(ev[1], e->stream));
     if (!all_given) {
         if (e->comm) {
@@ -228,12 +249,18 @@ void salnmf_destroy(salnmf_engine* e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->comm) ncclCommDestroy(e->comm);
     double* bufs[] = {e->X, e->H, e->W, e->wkl, e->wlh, e->Gpart, e->Hsumpart, e->KLpart, e->red,
-                      e->objpart, e->scal, e->Wunc, e->Wtrial, e->cs, e->scratch,
+                      e->objpart, e->scal, e->Wunc, e->Wtrial, e->mvA, e->mvB, e->cs, e->scratch,
                       e->alpha, e->beta, e->Lemb, e->Uemb, e->aux, e->xrowsum, e->corrpart, e->hwbuf};
     for (double* b : bufs)
         if (b) (void)hipFree(b);
     if (e->hpin) (void)hipHostFree(e->hpin);
     for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : {e->evW, e->evPrepW, e->evTrial, e->evLogdet})
+        if (ev) (void)hipEventDestroy(ev);
+    if (e->stream2) {
+        (void)hipStreamSynchronize(e->stream2);
+        (void)hipStreamDestroy(e->stream2);
+    }
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -272,6 +299,13 @@ int salnmf_create(int device, int n_features, int64_t n_samples, int n_signature
     int64_t wg_needed = (e->ntiles + WAVES - 1) / WAVES;
     e->grid = (int)std::min<int64_t>(prop.multiProcessorCount, wg_needed);
     e->fgrid = (int)std::min<int64_t>(2 * prop.multiProcessorCount, wg_needed);
+    // MvNMF overlaps single-workgroup kernels on a second stream with the passes over the samples.  Workgroups are
+    // dealt round-robin to the 8 XCDs and a one-workgroup kernel lands on the first XCD, whichever kernel is
+    // dispatched first: leaving one CU per XCD free (3 % of the pass) guarantees it a place
+    const int cus = prop.multiProcessorCount;
+    const int spare = (cus % 8 == 0 && cus >= 64) ? 8 : 1;
+    e->mv_grid = (e->grid >= cus && e->grid > spare) ? e->grid - spare : e->grid;
+    e->mv_fgrid = (e->fgrid >= 2 * cus && e->fgrid > 2 * spare) ? e->fgrid - 2 * spare : e->fgrid;
     const size_t K = e->K, V = e->V, Np = e->Np, KP = e->KP;
     auto cleanup = [&](int rc) {
         salnmf_destroy(e);
@@ -280,6 +314,9 @@ int salnmf_create(int device, int n_features, int64_t n_samples, int n_signature
 #define ALLOC(ptr, n)                                                      \
     if (hipMalloc(&(ptr), (n) * sizeof(double)) != hipSuccess) return cleanup(fail("hipMalloc of %zu doubles failed", (size_t)(n)));
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return cleanup(fail("stream create failed"));
+    if (hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess) return cleanup(fail("stream create failed"));
+    for (hipEvent_t* ev : {&e->evW, &e->evPrepW, &e->evTrial, &e->evLogdet})
+        if (hipEventCreateWithFlags(ev, hipEventDisableTiming) != hipSuccess) return cleanup(fail("event create failed"));
     ALLOC(e->X, Np * VMAX);
     ALLOC(e->H, Np * KP);
     ALLOC(e->W, K * V);
@@ -291,6 +328,8 @@ int salnmf_create(int device, int n_features, int64_t n_samples, int n_signature
     ALLOC(e->scal, 8);
     ALLOC(e->Wunc, K * V);
     ALLOC(e->Wtrial, K * V);
+    ALLOC(e->mvA, K * V);
+    ALLOC(e->mvB, K * V);
     ALLOC(e->cs, KP);
 #undef ALLOC
     {
@@ -354,6 +393,7 @@ int salnmf_upload_X(salnmf_engine* e, const double* X, int clip) {
 }
 int salnmf_upload_W(salnmf_engine* e, const double* W) { return upload(e, e ? e->W : nullptr, W, (size_t)e->K * e->V); }
 int salnmf_upload_H(salnmf_engine* e, const double* H) {
+    if (e) e->h_pending = false;
     // pad columns 0, pad rows 1: finite, and positive in the rows so that P > 0 there
     return upload_padded(e, e ? e->H : nullptr, H, e ? e->K : 0, e ? e->KP : 0, 0.0, 1.0, 0.0);
 }
@@ -384,7 +424,12 @@ static int download(salnmf_engine* e, double* dst, const double* src, size_t n) 
     return 0;
 }
 int salnmf_download_W(salnmf_engine* e, double* W) { return download(e, W, e ? e->W : nullptr, (size_t)e->K * e->V); }
-int salnmf_download_H(salnmf_engine* e, double* H) { return download_padded(e, H, e ? e->H : nullptr, e ? e->K : 0, e ? e->KP : 0); }
+int salnmf_download_H(salnmf_engine* e, double* H) {
+    if (!e) return fail("null engine");
+    HIPCK(hipSetDevice(e->device));
+    CK(flush_H_scale(e));
+    return download_padded(e, H, e->H, e->K, e->KP);
+}
 
 int salnmf_kl_step(salnmf_engine* e, int n_steps, int n_given) {
     if (!e) return fail("null engine");
@@ -398,7 +443,9 @@ int salnmf_update_H(salnmf_engine* e) {
     if (!e) return fail("null engine");
     HIPCK(hipSetDevice(e->device));
     FusedParams p = fused_params(e);
-    return launch_fused<false, true, false>(e, p);
+    CK((launch_fused<false, true, false>(e, p)));
+    e->h_pending = false;
+    return 0;
 }
 
 int salnmf_kl_step_partial(salnmf_engine* e) {
@@ -406,6 +453,7 @@ int salnmf_kl_step_partial(salnmf_engine* e) {
     HIPCK(hipSetDevice(e->device));
     FusedParams p = fused_params(e);
     CK((launch_fused<true, true, false>(e, p)));
+    e->h_pending = false;
     return launch_tail(e, e->grid, e->red, 0, 0, 0);
 }
 
@@ -436,7 +484,7 @@ static int fwd_params(salnmf_engine* e, FwdParams& p) {
     p.W = e->W;
     p.wkl = e->wkl;
     p.wlh = e->wlh;
-    p.hscale = nullptr;
+    p.hscale = e->h_pending ? e->cs : nullptr;
     p.out = e->objpart;
     p.N = e->N;
     p.V = e->V;
@@ -446,17 +494,18 @@ static int fwd_params(salnmf_engine* e, FwdParams& p) {
 }
 
 // objective of (W, H[, hscale]) -> device scalar e->scal[slot] (all-reduced), no host sync
-static int objective_to_slot(salnmf_engine* e, const double* W, const double* hscale, bool weighted, int slot) {
+static int objective_to_slot(salnmf_engine* e, const double* W, const double* hscale, bool weighted, int slot, int grid = 0) {
     FwdParams p;
     fwd_params(e, p);
     p.W = W;
-    p.hscale = hscale;
+    if (hscale) p.hscale = hscale;  // else: the pending rescale, if any
     if (!weighted) {
         p.wkl = nullptr;
         p.wlh = nullptr;
     }
-    CK(launch_forward<0>(e, p));
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, e->objpart, e->fgrid, 1, 1, e->scal + slot);
+    const int fgrid = grid > 0 ? grid : e->fgrid;
+    CK(launch_forward<0>(e, p, fgrid));
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, e->objpart, fgrid, 1, 1, e->scal + slot);
     HIPCK(hipGetLastError());
     return allreduce(e, e->scal + slot, 1);
 }
@@ -522,38 +571,60 @@ int salnmf_mv_objective(salnmf_engine* e, double lam, double delta, double* out)
     return 0;
 }
 
-// MvNMF._update_W (mvnmf.py:190-195) on the current (W, H)
-static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double delta, double* gamma, bool have_hsum) {
+// MvNMF._update_W (mvnmf.py:190-195) on the current (W, H).
+// Two streams: everything that depends on W alone -- Gram matrix, Cholesky, inverse, A = W Y_minus, B = W |Y|,
+// log det, and later the log det of a trial W -- is single-workgroup latency-bound work and runs on stream2
+// while the passes over the samples (which leave one CU free, mv_grid / mv_fgrid) run on the main stream.
+//   w_ready: the caller recorded evW on the main stream after the last write of W and already started
+//            mv_prepare_W on stream2 (mv_step does, so that it also overlaps the update_H pass)
+static int mv_start_prepare_W(salnmf_engine* e, double delta, bool record_w_event) {
+    if (record_w_event) HIPCK(hipEventRecord(e->evW, e->stream));  // else: recorded when W was last written
+    HIPCK(hipStreamWaitEvent(e->stream2, e->evW, 0));
+    hipLaunchKernelGGL(mv_prepare_W_kernel, dim3(1), dim3(MV_BLOCK), 0, e->stream2, e->W, e->K, e->V, delta, e->mvA, e->mvB, e->scal + 3);
+    HIPCK(hipGetLastError());
+    HIPCK(hipEventRecord(e->evPrepW, e->stream2));
+    return 0;
+}
+
+static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double delta, double* gamma, bool have_hsum, bool w_ready) {
     if (n_given >= e->K) return 0;
     const int K = e->K, V = e->V;
+    CK(flush_H_scale(e));  // a stand-alone call after an earlier step; inside mv_step the update_H pass consumed it
+    if (!w_ready) CK(mv_start_prepare_W(e, delta, true));
     // pass over the shard: G = (X/(WH)) @ H.T partials and the KL partial; the rowsums_H partials
     // come from the preceding update_H pass (have_hsum) or, for a stand-alone _update_W, from a
     // column-sum kernel over the current H
     FusedParams p = fused_params(e);
     p.wkl = nullptr;  // the MvNMF path is unweighted (mvnmf.py:56)
     p.wlh = nullptr;
-    CK((launch_fused<true, false, true>(e, p)));
-    CK(launch_tail(e, e->grid, e->red, 0, 0, 0));
-    if (have_hsum) {
-        hipLaunchKernelGGL(sum_partials_kernel, dim3(K), dim3(256), 0, e->stream, e->Hsumpart, e->grid, K, K, e->red + K * V);
-    } else {
+    CK((launch_fused<true, false, true>(e, p, e->mv_grid)));
+    // one launch reduces the G slabs, the row sums of H (from the update_H pass) and the KL partials
+    CK(launch_tail(e, e->mv_grid, e->red, 0, 0, 0, true));
+    if (!have_hsum) {  // stand-alone _update_W: the row sums come from a column-sum kernel over the current H instead
         hipLaunchKernelGGL(colsum_kernel, dim3(K), dim3(256), 0, e->stream, e->H, e->N, e->KP, e->red + K * V);
+        HIPCK(hipGetLastError());
     }
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, e->KLpart, e->grid, 1, 1, e->red + K * V + K);
-    HIPCK(hipGetLastError());
     CK(allreduce(e, e->red, (size_t)K * V + K + 1));
-    // W_unconstrained and log det(W^T W + delta I); f0 = KL + lam * logdet -> scal[1]
-    hipLaunchKernelGGL(mv_prepare_kernel, dim3(1), dim3(MV_BLOCK), 0, e->stream, e->W, e->red, e->red + K * V,
-                       e->red + K * V + K, K, V, n_given, lam, delta, e->Wunc, e->scal + 1);
+    // W_unconstrained from A, B (stream2) and the reduced sums; f0 = KL + lam * logdet(W) -> scal[1]
+    HIPCK(hipStreamWaitEvent(e->stream, e->evPrepW, 0));
+    hipLaunchKernelGGL(mv_prepare_final_kernel, dim3((K * V + 255) / 256), dim3(256), 0, e->stream, e->W, e->mvA, e->mvB, e->red,
+                       e->red + K * V, e->red + K * V + K, e->scal + 3, K, V, n_given, lam, e->Wunc, e->scal + 1);
     HIPCK(hipGetLastError());
     double g = *gamma;
     bool blend = false;
     for (;;) {
-        // trial W: normalise + clip, column sums for H, its logdet -> scal[4]
-        hipLaunchKernelGGL(mv_trial_kernel, dim3(1), dim3(MV_BLOCK), 0, e->stream, e->W, e->Wunc, blend ? g : 1.0,
-                           blend ? 1 : 0, K, V, delta, e->Wtrial, e->cs, e->scal + 4);
+        // trial W: normalise + clip and the column sums for H on the main stream; its logdet -> scal[4] on stream2,
+        // beside the forward pass that evaluates KL(W_trial, clip(H * colsum))
+        hipLaunchKernelGGL(mv_trial_light_kernel, dim3(1), dim3(MV_BLOCK), 0, e->stream, e->W, e->Wunc, blend ? g : 1.0,
+                           blend ? 1 : 0, K, V, e->Wtrial, e->cs);
         HIPCK(hipGetLastError());
-        CK(objective_to_slot(e, e->Wtrial, e->cs, false, 2));
+        HIPCK(hipEventRecord(e->evTrial, e->stream));
+        HIPCK(hipStreamWaitEvent(e->stream2, e->evTrial, 0));
+        hipLaunchKernelGGL(mv_logdet_kernel, dim3(1), dim3(MV_BLOCK), 0, e->stream2, e->Wtrial, K, V, delta, e->scal + 4);
+        HIPCK(hipGetLastError());
+        HIPCK(hipEventRecord(e->evLogdet, e->stream2));
+        CK(objective_to_slot(e, e->Wtrial, e->cs, false, 2, e->mv_fgrid));
+        HIPCK(hipStreamWaitEvent(e->stream, e->evLogdet, 0));
         double v[5];
         CK(read_scalars(e, 0, 5, v));
         const double f0 = v[1], f1 = v[2] + lam * v[4];
@@ -565,17 +636,18 @@ static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double de
         break;
     }
     *gamma = std::min(1.0, 1.2 * g);  // mvnmf.py:91
-    // accept: W <- W_trial, H <- clip(H * colsum)
-    HIPCK(hipMemcpyAsync(e->W, e->Wtrial, (size_t)K * V * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
-    hipLaunchKernelGGL(scale_H_kernel, dim3(2048), dim3(256), 0, e->stream, e->H, e->cs, (int64_t)e->Np * e->KP, e->KP);
-    HIPCK(hipGetLastError());
+    // accept: W <- W_trial, H <- clip(H * colsum).  The rescale of H is not a pass of its own: every reader of H
+    // applies clip(H * cs) on the fly until the next update_H pass writes H in full (flush_H_scale otherwise)
+    std::swap(e->W, e->Wtrial);  // no copy: the trial buffer becomes W
+    HIPCK(hipEventRecord(e->evW, e->stream));  // W is final for the next step's W-only kernels
+    e->h_pending = true;
     return 0;
 }
 
 int salnmf_mv_update_W(salnmf_engine* e, int n_given, double lam, double delta, double* gamma_inout) {
     if (!e || !gamma_inout) return fail("null argument");
     HIPCK(hipSetDevice(e->device));
-    return mv_update_W_impl(e, n_given, lam, delta, gamma_inout, false);
+    return mv_update_W_impl(e, n_given, lam, delta, gamma_inout, false, false);
 }
 
 int salnmf_mv_step(salnmf_engine* e, int n_steps, int n_given, double lam, double delta, double* gamma_inout) {
@@ -586,8 +658,13 @@ int salnmf_mv_step(salnmf_engine* e, int n_steps, int n_given, double lam, doubl
         FusedParams p = fused_params(e);
         p.wkl = nullptr;  // MvNMF._update_H passes no weights (mvnmf.py:162-165)
         p.wlh = nullptr;
-        CK((launch_fused<false, true, true>(e, p)));  // update_H + row sums of the new H
-        CK(mv_update_W_impl(e, n_given, lam, delta, gamma_inout, true));
+        const bool update_W = n_given < e->K;
+        if (update_W && i == 0) HIPCK(hipEventRecord(e->evW, e->stream));  // later steps: recorded by the accept
+        CK((launch_fused<false, true, true>(e, p, e->mv_grid)));      // update_H + row sums of the new H
+        e->h_pending = false;
+        // W-only algebra on stream2, beside both passes; queued after the pass so that the host does not delay it
+        if (update_W) CK(mv_start_prepare_W(e, delta, false));
+        CK(mv_update_W_impl(e, n_given, lam, delta, gamma_inout, true, true));
     }
     return 0;
 }
@@ -692,6 +769,7 @@ int salnmf_corr_compute_exposures(salnmf_engine* e) {
     CK(corr_ready(e));
     CorrParams p = corr_params(e);
     p.out = e->H;
+    e->h_pending = false;  // H is overwritten in full
     hipLaunchKernelGGL(corr_logit_kernel<1>, dim3(e->cgrid), dim3(CORR_BLOCK), 0, e->stream, p);
     HIPCK(hipGetLastError());
     return 0;
@@ -914,7 +992,9 @@ void* salnmf_device_ptr(salnmf_engine* e, int which) {
     switch (which) {
         case SALNMF_BUF_G: return e->red;
         case SALNMF_BUF_W: return e->W;
-        case SALNMF_BUF_H: return e->H;
+        case SALNMF_BUF_H:
+            if (hipSetDevice(e->device) != hipSuccess || flush_H_scale(e)) return nullptr;
+            return e->H;
         case SALNMF_BUF_X: return e->X;
         case SALNMF_BUF_OBJ: return e->scal;
         case SALNMF_BUF_RED: return e->red;

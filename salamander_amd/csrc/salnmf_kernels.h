@@ -248,7 +248,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
     constexpr int KB = 16 * KTM;                                   // first remainder column
     constexpr int NVP = KR == 0 ? 0 : (KR == 1 ? 4 : (KR == 2 ? 8 : 16));  // 4*KR values, padded to a power of two
     static_assert(KR >= 0 && KR <= 4 && KB + KR <= KP, "remainder columns must fit the padded layout");
-    __shared__ __attribute__((aligned(16))) double lds[G_::LDS_DOUBLES];
+    __shared__ __attribute__((aligned(16))) double lds[G_::LDS_DOUBLES + KP];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -262,6 +262,8 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
     double* Hl = lds + G_::WROWS * WS + wave * (G_::HL + G_::RL);
     double* Rl = Hl + G_::HL;
 
+    double* hsl = lds + G_::LDS_DOUBLES;  // [KP] copy of hscale
+    if (p.hscale && tid < KP) hsl[tid] = p.hscale[tid];
     stage_W<G_::WROWS>(Wl, p.W, K, V, tid);
     __syncthreads();
 
@@ -313,18 +315,21 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         for (int vt = 0; vt < VT; ++vt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) x[vt][r] = xsrc[4 * r * VMAX + 16 * vt];
-        if (p.hscale) {  // MvNMF line-search trial: H is read as clip(H * colsum(W_trial))
-#pragma unroll
-            for (int j = 0; j < HV; ++j) {
-                hpre[j][0] = fmax(hpre[j][0] * p.hscale[hcol[j]], kEps);
-                hpre[j][1] = fmax(hpre[j][1] * p.hscale[hcol[j] + 1], kEps);
-            }
-        }
     };
 
     auto process_tile = [&](int64_t tile) __attribute__((always_inline)) {
         const int64_t n0 = tile * 16;
         // ---- stage the H tile (wave private; LDS ops of one wave are executed in order)
+        if (p.hscale) {
+            // MvNMF: H is read as clip(H * colsum(W_trial)) (a line-search trial, or the rescale of an accepted
+            // one that no pass has materialised yet).  Applied here, where the prefetched tile is consumed
+            // anyway, from the LDS copy of the scale
+#pragma unroll
+            for (int j = 0; j < HV; ++j) {
+                hpre[j][0] = fmax(hpre[j][0] * hsl[hcol[j]], kEps);
+                hpre[j][1] = fmax(hpre[j][1] * hsl[hcol[j] + 1], kEps);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < HV; ++j) {
             *reinterpret_cast<d2*>(Hl + hrow[j] * LS + hcol[j]) = hpre[j];
@@ -812,6 +817,13 @@ struct TailParams {
     int n_given;
     int clip_mode;
     int do_tail;
+    // optional (MvNMF): the same launch also reduces the per-workgroup row sums of H and KL partials, in the
+    // summation order of sum_partials_kernel
+    const double* __restrict__ hsum_part;  // [nparts][K] or null
+    double* __restrict__ hsum_out;         // [K]
+    const double* __restrict__ kl_part;    // [nparts] or null
+    double* __restrict__ kl_out;           // [1]
+    int nparts;
 };
 
 constexpr int TAIL_PARTS = 8;
@@ -825,6 +837,24 @@ __global__ void __launch_bounds__(TAIL_BLOCK) tail_kernel(TailParams p) {
     const int v = threadIdx.x % VMAX;
     const int part = threadIdx.x / VMAX;
     const int V = p.V, K = p.K;
+    if (p.hsum_part) {  // uniform over the grid
+        __shared__ double hred[256];
+        for (int which = 0; which < ((k == 0 && p.kl_part) ? 2 : 1); ++which) {
+            const double* part = which == 0 ? p.hsum_part + k : p.kl_part;
+            const int stride = which == 0 ? K : 1;
+            double s = 0.0;
+            if (threadIdx.x < 256)
+                for (int i = threadIdx.x; i < p.nparts; i += 256) s += part[(int64_t)i * stride];
+            if (threadIdx.x < 256) hred[threadIdx.x] = s;
+            __syncthreads();
+            for (int h = 128; h > 0; h >>= 1) {
+                if ((int)threadIdx.x < h) hred[threadIdx.x] += hred[threadIdx.x + h];
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) (which == 0 ? p.hsum_out[k] : p.kl_out[0]) = hred[0];
+            __syncthreads();
+        }
+    }
     if (p.nslabs > 0) {
         // 16 independent loads in flight per round; the sum order is fixed (slab index ascending)
         double s = 0.0;
