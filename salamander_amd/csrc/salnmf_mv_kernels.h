@@ -114,121 +114,7 @@ __global__ void __launch_bounds__(MV_BLOCK) mv_logdet_kernel(const double* __res
     if (threadIdx.x == 0) *out = ld;
 }
 
-// W_unconstrained (mvnmf.py:37-66) from the reduced G = (X/(WH)) @ H.T, rowsums of H, and W;
-// also f0 = KL + lam * log det(W W^T + delta I) (mvnmf.py:79).
-__global__ void __launch_bounds__(MV_BLOCK)
-    mv_prepare_kernel(const double* __restrict__ W, const double* __restrict__ G, const double* __restrict__ hsum,
-                      const double* __restrict__ kl, int K, int V, int n_given, double lam, double delta,
-                      double* __restrict__ Wunc, double* __restrict__ f0_out) {
-    __shared__ double Wl[MV_KMAX * MV_WS];
-    __shared__ double S[MV_KMAX * MV_LD];   // Gram -> Cholesky factor L -> Y = S^-1
-    __shared__ double Li[MV_KMAX * MV_LD];  // L^-1
-    mv_load_W(W, Wl, K, V);
-    mv_gram(Wl, S, K, V, delta);
-    double ld = mv_cholesky_logdet(S, K);
-    if (threadIdx.x == 0) *f0_out = *kl + lam * ld;
-
-    // L^-1 by forward substitution, one column per thread
-    for (int c = threadIdx.x; c < K; c += MV_BLOCK) {
-        for (int i = 0; i < c; ++i) Li[i * MV_LD + c] = 0.0;
-        Li[c * MV_LD + c] = 1.0 / S[c * MV_LD + c];
-        for (int i = c + 1; i < K; ++i) {
-            const double s = mv_dot(S + i * MV_LD + c, 1, Li + c * MV_LD + c, MV_LD, i - c);
-            Li[i * MV_LD + c] = -s / S[i * MV_LD + i];
-        }
-    }
-    __syncthreads();
-    // Y = L^-T L^-1 (overwrites S)
-    for (int idx = threadIdx.x; idx < K * K; idx += MV_BLOCK) {
-        int a = idx / K, b = idx - a * K;
-        int m0 = a > b ? a : b;
-        const double s = mv_dot(Li + m0 * MV_LD + a, MV_LD, Li + m0 * MV_LD + b, MV_LD, K - m0);
-        S[a * MV_LD + b] = s;
-    }
-    __syncthreads();
-    // per entry (k, v): A = (W @ Y_minus)[v,k], B = (W @ |Y|)[v,k]; closed-form root
-    for (int idx = threadIdx.x; idx < K * V; idx += MV_BLOCK) {
-        int k = idx / V, v = idx - k * V;
-        double A = 0.0, B = 0.0;
-        int m = 0;
-        for (; m + 8 <= K; m += 8) {  // batches of 8 independent LDS reads per operand
-            double y[8], wv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                y[u] = S[(m + u) * MV_LD + k];
-                wv[u] = Wl[(m + u) * MV_WS + v];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                A += wv[u] * fmax(0.0, -y[u]);
-                B += wv[u] * fabs(y[u]);
-            }
-        }
-        for (; m < K; ++m) {
-            const double y = S[m * MV_LD + k], wv = Wl[m * MV_WS + v];
-            A += wv * fmax(0.0, -y);
-            B += wv * fabs(y);
-        }
-        double w = Wl[k * MV_WS + v];
-        double b = hsum[k] - 4.0 * lam * A;
-        double root = sqrt(b * b + 8.0 * lam * B * G[idx]);
-        double wu = w * (root - b) / (4.0 * lam * B);
-        Wunc[idx] = (k < n_given) ? w : fmax(wu, 1.1920928955078125e-07);
-    }
-}
-
-// One line-search trial (mvnmf.py:80-81, 85-88): Wt = blend ? (1-g) W + g Wunc : Wunc;
-// cs = row sums; Wtrial = clip(Wt / cs); logdet of the trial.  H's counterpart
-// clip(H * cs) is applied on the fly by the forward pass (hscale) and on acceptance.
-__global__ void __launch_bounds__(MV_BLOCK)
-    mv_trial_kernel(const double* __restrict__ W, const double* __restrict__ Wunc, double gamma, int blend, int K, int V,
-                    double delta, double* __restrict__ Wtrial, double* __restrict__ cs, double* __restrict__ logdet_out) {
-    __shared__ double Wl[MV_KMAX * MV_WS];
-    __shared__ double S[MV_KMAX * MV_LD];
-    __shared__ double rs[MV_KMAX];
-    {
-        constexpr int PT = (MV_KMAX * MV_VMAX + MV_BLOCK - 1) / MV_BLOCK;
-        double a[PT], b[PT];
-        const int total = K * V;
-#pragma unroll
-        for (int j = 0; j < PT; ++j) {
-            int idx = threadIdx.x + MV_BLOCK * j;
-            a[j] = idx < total ? Wunc[idx] : 0.0;
-            b[j] = (blend && idx < total) ? W[idx] : 0.0;
-        }
-#pragma unroll
-        for (int j = 0; j < PT; ++j) {
-            int idx = threadIdx.x + MV_BLOCK * j;
-            if (idx < total) {
-                int k = idx / V, v = idx - k * V;
-                double wt = a[j];
-                if (blend) wt = (1 - gamma) * b[j] + gamma * wt;
-                Wl[k * MV_WS + v] = wt;
-            }
-        }
-    }
-    __syncthreads();
-    for (int k = threadIdx.x; k < K; k += MV_BLOCK) {
-        double s = 0.0;
-#pragma unroll 8
-        for (int v = 0; v < V; ++v) s += Wl[k * MV_WS + v];
-        rs[k] = s;
-        cs[k] = s;
-    }
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < K * V; idx += MV_BLOCK) {
-        int k = idx / V, v = idx - k * V;
-        double w = fmax(Wl[k * MV_WS + v] / rs[k], 1.1920928955078125e-07);
-        Wl[k * MV_WS + v] = w;
-        Wtrial[idx] = w;
-    }
-    __syncthreads();
-    mv_gram(Wl, S, K, V, delta);
-    double ld = mv_cholesky_logdet(S, K);
-    if (threadIdx.x == 0) *logdet_out = ld;
-}
-
-// ---- the same work split so that everything that depends on W alone can run on a second stream while the
+// ---- MvNMF W step, split so that everything that depends on W alone can run on a second stream while the
 // passes over the samples run (salnmf.hip: mv_update_W_impl)
 
 // W-only half of update_W_unconstrained: A = W @ Y_minus, B = W @ |Y| with Y = (W W^T + delta I)^-1
