@@ -85,7 +85,7 @@ def main():
     import torch
 
     import salamander_amd as sal
-    from oracle import klnmf_oracle as orc  # synthetic inputs + the cpu_baseline leg only
+    from salamander_amd.synthetic import synthetic_problem
 
     dist = None
     if world > 1:
@@ -96,7 +96,7 @@ def main():
 
     n_local = args.samples_per_gpu
     # every rank's shard comes from its own seed; W0 is rank 0's (broadcast below)
-    X, W0, H0 = orc.synthetic_problem(V, n_local, K, seed=rank)
+    X, W0, H0 = synthetic_problem(V, n_local, K, seed=rank)
     engine = sal.Engine(n_local, V, K, device=local_rank)
     if world > 1:
         from salamander_amd.distributed import attach_communicator, broadcast_from_rank0

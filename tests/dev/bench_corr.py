@@ -6,7 +6,7 @@ Each piece is timed as wall clock over a batch of asynchronous launches + one sy
 """
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import klnmf_oracle as orc
 from salamander_amd import Engine, _lib
 
@@ -85,5 +85,5 @@ for N, dim in [(50000, 40), (200000, 40)]:
                     "host_dense_s": t_dense, "host_signature_solves_s_extrapolated": t_sig_cpu, "host_sample_solves_s_extrapolated": t_smp_cpu,
                     "host_sample": f"{ks} of {K} signature solves, {ns} of {N} sample solves, SciPy Newton-CG via the oracle"})
     e.close()
-os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
-json.dump(results, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "corrnmf_step.json"), "w"), indent=1)
+os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "gpurun_out"), exist_ok=True)
+json.dump(results, open(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "gpurun_out", "corrnmf_step.json"), "w"), indent=1)

@@ -1,7 +1,7 @@
 """Development aid: device signature-embedding Newton-CG solves vs scipy (via the oracle)."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import corrnmf_oracle as co, klnmf_oracle as ko
 from salamander_amd import Engine, _lib
 

@@ -1,7 +1,7 @@
 """Ad-hoc GPU check of the engine against the oracle (development aid, not a test)."""
 import sys, time
 import numpy as np
-sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))))
 from oracle import klnmf_oracle as orc
 from salamander_amd.engine import Engine
 

@@ -1,9 +1,9 @@
 """Wall-clock to fixed KL: the target is the KL the CPU path (NumPy oracle)
 reaches after 500 joint steps from the shared init on config c2; the GPU time is the wall-clock of
 KLNMF.fit (device-resident loop, objective every 10 steps) until its objective is <= that target.
-Prints one JSON object.  Run on the GPU box: python tools/time_to_kl.py [n_samples] [cpu_steps]"""
+Prints one JSON object.  Run on the GPU box: python tests/dev/time_to_kl.py [n_samples] [cpu_steps]"""
 import json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import salamander_amd as sal
 from oracle import klnmf_oracle as orc

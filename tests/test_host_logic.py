@@ -274,3 +274,13 @@ def test_mvnmf_gamma_persists_and_resets(fake_engine, counts, golden):
 def test_out_of_scope_helpers_say_so():
     with pytest.raises(NotImplementedError):
         sal.models.KLNMF().plot_signatures()
+
+
+def test_package_synthetic_generator_equals_the_oracles():
+    """bench.py and tools draw inputs from salamander_amd.synthetic; tests from the oracle: same data for a seed."""
+    from oracle import klnmf_oracle as orc
+    from salamander_amd.synthetic import synthetic_problem
+
+    for V, N, K, seed in [(96, 257, 7, 3), (83, 100, 50, 0)]:
+        for a, b in zip(synthetic_problem(V, N, K, seed=seed), orc.synthetic_problem(V, N, K, seed=seed)):
+            assert np.array_equal(a, b)

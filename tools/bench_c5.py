@@ -10,7 +10,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import salamander_amd as sal
-from oracle import klnmf_oracle as orc
+from salamander_amd import synthetic as orc
 from salamander_amd.models import MultimodalCorrNMF
 
 out = []

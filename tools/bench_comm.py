@@ -3,7 +3,7 @@ import os, sys, time
 import numpy as np
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch.distributed as dist
-from oracle import klnmf_oracle as orc
+from salamander_amd import synthetic as orc
 from salamander_amd import Engine
 from salamander_amd.distributed import attach_communicator
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29544")

@@ -2,7 +2,7 @@
 import sys, time
 import numpy as np
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
-from oracle import klnmf_oracle as orc
+from salamander_amd import synthetic as orc
 from salamander_amd import Engine
 V, N, K = 96, 100000, 30
 X, W0, H0 = orc.synthetic_problem(V, N, K, seed=2)

@@ -2,7 +2,7 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from oracle import klnmf_oracle as orc
+from salamander_amd import synthetic as orc
 from salamander_amd import Engine
 V, K = 96, 50
 for N in (100000, 125000, 250000, 1000000):

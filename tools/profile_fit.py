@@ -3,7 +3,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import salamander_amd as sal
-from oracle import klnmf_oracle as orc
+from salamander_amd import synthetic as orc
 V, N, K = 96, 100000, 50
 X, W0, H0 = orc.synthetic_problem(V, N, K, seed=0)
 def t(label, f):
