@@ -53,3 +53,27 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(base, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"
+
+
+def test_oracle_is_used_only_where_allowed():
+    """Outside tests/: only bench.py's cpu_baseline leg and __graft_entry__.smoke() may import the oracle."""
+    import ast
+
+    tools = os.path.join(ROOT, "tools")
+    for f in os.listdir(tools):
+        if f.endswith(".py"):
+            src = open(os.path.join(tools, f)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"tools/{f} imports the oracle"
+    for name, allowed in (("bench.py", {"cpu_baseline"}), ("__graft_entry__.py", {"smoke"})):
+        tree = ast.parse(open(os.path.join(ROOT, name)).read())
+        for node in ast.walk(tree):
+            if isinstance(node, ast.FunctionDef):
+                for sub in ast.walk(node):
+                    if isinstance(sub, (ast.Import, ast.ImportFrom)):
+                        mods = [a.name for a in sub.names] if isinstance(sub, ast.Import) else [sub.module or ""]
+                        if any(m.split(".")[0] == "oracle" for m in mods):
+                            assert node.name in allowed, f"{name}:{node.name} imports the oracle"
+        for node in tree.body:  # no module-level import of the oracle
+            if isinstance(node, (ast.Import, ast.ImportFrom)):
+                mods = [a.name for a in node.names] if isinstance(node, ast.Import) else [node.module or ""]
+                assert not any(m.split(".")[0] == "oracle" for m in mods), f"{name} imports the oracle at module level"
