@@ -83,7 +83,6 @@ struct salnmf_engine {
     double* aux = nullptr;       // [Np][KP], padded like H
     double* xrowsum = nullptr;   // [Np]
     double* corrpart = nullptr;  // [cgrid][64] partial sums
-    double* hwbuf = nullptr;     // [K][Np] Hessian weights of the signature-embedding solves (lazily allocated)
     int cgrid = 0;
     bool xrowsum_valid = false, lgam_valid = false;
     bool h_pending = false;      // H is to be read as clip(H * cs): the rescale of an accepted MvNMF trial, applied by the next reader
@@ -250,7 +249,7 @@ void salnmf_destroy(salnmf_engine* e) {
     if (e->comm) ncclCommDestroy(e->comm);
     double* bufs[] = {e->X, e->H, e->W, e->wkl, e->wlh, e->Gpart, e->Hsumpart, e->KLpart, e->red,
                       e->objpart, e->scal, e->Wunc, e->Wtrial, e->mvA, e->mvB, e->cs, e->scratch,
-                      e->alpha, e->beta, e->Lemb, e->Uemb, e->aux, e->xrowsum, e->corrpart, e->hwbuf};
+                      e->alpha, e->beta, e->Lemb, e->Uemb, e->aux, e->xrowsum, e->corrpart};
     for (double* b : bufs)
         if (b) (void)hipFree(b);
     if (e->hpin) (void)hipHostFree(e->hpin);
@@ -676,7 +675,7 @@ int salnmf_corr_configure(salnmf_engine* e, int dim_embeddings) {
     if (dim_embeddings < 1 || dim_embeddings > CORR_DMAX) return fail("dim_embeddings must be in [1, %d], got %d", CORR_DMAX, dim_embeddings);
     HIPCK(hipSetDevice(e->device));
     HIPCK(hipStreamSynchronize(e->stream));
-    double** bufs[] = {&e->alpha, &e->beta, &e->Lemb, &e->Uemb, &e->aux, &e->xrowsum, &e->corrpart, &e->hwbuf};
+    double** bufs[] = {&e->alpha, &e->beta, &e->Lemb, &e->Uemb, &e->aux, &e->xrowsum, &e->corrpart};
     for (double** b : bufs) {
         if (*b) HIPCK(hipFree(*b));
         *b = nullptr;
@@ -888,14 +887,12 @@ int salnmf_corr_update_signature_embeddings(salnmf_engine* e, double variance, i
     CK(corr_ready(e));
     if (!(variance > 0.0)) return fail("variance must be positive");
     if (e->n_ranks > 1) return fail("signature-embedding solves need all samples on one engine (sample-sharded engines are not supported)");
-    if (!e->hwbuf) HIPCK(hipMalloc(&e->hwbuf, (size_t)e->K * e->Np * sizeof(double)));
     SignatureEmbeddingParams p;
     p.aux = e->aux;
     p.alpha = e->alpha;
     p.beta = e->beta;
     p.U = e->Uemb;
     p.L = e->Lemb;
-    p.hw = e->hwbuf;
     p.status = nullptr;
     p.variance = variance;
     p.N = e->N;

@@ -268,6 +268,25 @@ struct SampleEmbeddingEval {
         g -= y / variance;
         return lane < dim ? -g : 0.0;
     }
+    __device__ inline void fun_grad(double y, double& f, double& g) {
+        double s[TPL], w[TPL];
+        products(y, s);
+        double lin = 0.0, ex = 0.0;
+#pragma unroll
+        for (int t = 0; t < TPL; ++t) {
+            w[t] = rate(t, s[t]);
+            lin += (lane + 64 * t < T) ? s[t] * a[t] : 0.0;
+            ex += w[t];
+        }
+        double v = ncg::wave_sum(lin);
+        v -= ncg::wave_sum(ex);
+        v -= ncg::wave_sum(y * y) / (2 * variance);
+        f = -v;
+        double gg = -combine(w);
+        gg += sg;
+        gg -= y / variance;
+        g = lane < dim ? -gg : 0.0;
+    }
     __device__ inline void prepare_hess(double x) {
         double s[TPL];
         products(x, s);
@@ -359,9 +378,12 @@ __global__ void __launch_bounds__(CORR_BLOCK) corr_sample_embeddings_kernel(Samp
 // One WORKGROUP per signature.  Every wave runs the Newton-CG control flow of salnmf_newtoncg.h
 // redundantly on bit-identical scalars (vectors are replicated per wave, lane m = component m); an
 // evaluation is a cooperative pass over the samples in tiles of SIGT rows staged in LDS:
-//   phase A  thread j: s_j = <U_j, y>, weight_j (exp / aux / Hessian weight)
+//   phase A  thread j: s_j = <U_j, y>, weight_j (exp / aux)
 //   phase B  wave w, lane m: sum over the tile's samples j = w, w + 4, ... of weight_j U[j][m]
-// followed by fixed-order cross-wave sums, so that all waves see the same bits.
+// followed by fixed-order cross-wave sums, so that all waves see the same bits.  The Hessian
+// sum_n w_n U_n U_n^T + I / var is formed densely ONCE per Newton iteration (as SciPy does with hess=) on the
+// fp64 MFMA units -- per tile a (dim x 256) . (256 x dim) product -- and kept in LDS, so that the
+// conjugate-gradient iterations need no pass over the samples at all.
 constexpr int SIGT = 256;       // samples per tile = threads per workgroup
 constexpr int SIG_BUDGET = 60000;  // evaluation passes per solve; SciPy's own limits are far above any real solve
 
@@ -371,7 +393,6 @@ struct SignatureEmbeddingParams {
     const double* __restrict__ beta;   // [K]
     const double* __restrict__ U;      // [N][dim]
     double* __restrict__ L;            // [K][dim]  in / out
-    double* __restrict__ hw;           // [K][Np] scratch: Hessian weights of signature k
     int* __restrict__ status;          // [K] or null
     double variance;
     int64_t N, Np;
@@ -388,7 +409,6 @@ struct SignatureEmbeddingEval {
     double c;       // beta_k
     double sg;      // lane m: sum_n aux[k][n] U[n][m]
     double variance;
-    double* hw;     // this signature's row of the scratch
     int k, dim, tid, lane, wave, budget;
 
     __device__ inline void broadcast(double y) {
@@ -416,6 +436,12 @@ struct SignatureEmbeddingEval {
                 }
             }
         }
+        // the MFMA tiles of the Hessian read component columns up to the next multiple of 16: keep them zero
+        const int dpad = 16 * ((dim + 15) / 16) - dim;
+        for (int i = tid; i < SIGT * dpad; i += SIGT) {
+            const int j = i / dpad, m = dim + (i - j * dpad);
+            Ut[j * CORR_LD + m] = 0.0;
+        }
         __syncthreads();
     }
     __device__ inline double row_dot(int j) const {
@@ -427,7 +453,6 @@ struct SignatureEmbeddingEval {
     // lane m of every wave: sum over all samples of weight_n * U[n][m]; MODE selects the weight
     //   0: aux[k][n]                      (summand_grad)
     //   1: exp((c + alpha_n) + <U_n, y>)  (gradient)
-    //   2: hw_n * <U_n, y>                (Hessian-vector product)
     template <int MODE>
     __device__ inline double weighted_sum(double y) {
         --budget;
@@ -439,8 +464,7 @@ struct SignatureEmbeddingEval {
             double w = 0.0;
             if (n < p->N) {
                 if (MODE == 0) w = p->aux[n * p->KP + k];
-                else if (MODE == 1) w = exp((c + p->alpha[n]) + row_dot(tid));
-                else w = hw[n] * row_dot(tid);
+                else w = exp((c + p->alpha[n]) + row_dot(tid));
             }
             wt[tid] = w;
             __syncthreads();
@@ -493,18 +517,104 @@ struct SignatureEmbeddingEval {
         g -= y / variance;
         return lane < dim ? -g : 0.0;
     }
-    __device__ inline void prepare_hess(double x) {
+    // objective and gradient in ONE pass over the samples (a line-search evaluation needs both)
+    __device__ inline void fun_grad(double y, double& f, double& g) {
         --budget;
-        broadcast(x);
+        broadcast(y);
+        double lin = 0.0, ex = 0.0, r = 0.0;
         for (int64_t t0 = 0; t0 < p->N; t0 += SIGT) {
             stage(t0);
             const int64_t n = t0 + tid;
-            if (n < p->N) hw[n] = exp((c + p->alpha[n]) + row_dot(tid));
+            double w = 0.0;
+            if (n < p->N) {
+                const double s = row_dot(tid);
+                lin = __builtin_fma(s, p->aux[n * p->KP + k], lin);
+                w = exp((c + p->alpha[n]) + s);
+                ex += w;
+            }
+            wt[tid] = w;
+            __syncthreads();
+            if (lane < dim) {
+#pragma unroll 4
+                for (int j = wave; j < SIGT; j += 4) r = __builtin_fma(wt[j], Ut[j * CORR_LD + lane], r);
+            }
             __syncthreads();
         }
+        red[wave * 64 + lane] = r;
+        __syncthreads();
+        const double tot = ((red[lane] + red[64 + lane]) + red[128 + lane]) + red[192 + lane];
+        __syncthreads();
+        double v = block_sum(lin);
+        v -= block_sum(ex);
+        v -= ncg::wave_sum(y * y) / (2 * variance);
+        f = -v;
+        double gg = -(lane < dim ? tot : 0.0);
+        gg += sg;
+        gg -= y / variance;
+        g = lane < dim ? -gg : 0.0;
     }
+    // Dense Hessian at x into LDS: Al[m][j] = sum_n w_n U[n][m] U[n][j], w_n = exp((c + alpha_n) + <U_n, x>).
+    // Per tile every wave multiplies its 64 staged samples on the MFMA units: A operand U^T (component x sample),
+    // B operand diag(w) U (sample x component) -- the same LDS elements, the B side scaled by the weight.
+    __device__ inline void prepare_hess(double x) {
+        --budget;
+        broadcast(x);
+        const int DT = (dim + 15) / 16;
+        const int c16 = lane & 15, q = lane >> 4;
+        d4 acc[10];  // upper-triangular 16 x 16 tiles (mt <= nt), DT <= 4
+#pragma unroll
+        for (int i = 0; i < 10; ++i) acc[i] = (d4){0, 0, 0, 0};
+        for (int64_t t0 = 0; t0 < p->N; t0 += SIGT) {
+            stage(t0);
+            const int64_t n = t0 + tid;
+            wt[tid] = (n < p->N) ? exp((c + p->alpha[n]) + row_dot(tid)) : 0.0;
+            __syncthreads();
+            const double* base = Ut + (64 * wave + q) * CORR_LD + c16;
+            for (int sgrp = 0; sgrp < 16; ++sgrp) {  // 4 samples per MFMA step
+                const double wv = wt[64 * wave + 4 * sgrp + q];
+                double a[4], b[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    a[t] = t < DT ? base[4 * sgrp * CORR_LD + 16 * t] : 0.0;
+                    b[t] = wv * a[t];
+                }
+                int idx = 0;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = mt; nt < 4; ++nt, ++idx)
+                        if (nt < DT) acc[idx] = mfma(a[mt], b[nt], acc[idx]);  // uniform over the workgroup
+            }
+            __syncthreads();
+        }
+        // cross-wave sum in fixed order; the tile buffer is free now: wave w's copy at Ut + w * 64 * CORR_LD
+        double* mine = Ut + wave * 64 * CORR_LD;
+        int idx = 0;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = mt; nt < 4; ++nt, ++idx)
+                if (nt < DT) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * mt + q + 4 * r, col = 16 * nt + c16;
+                        mine[row * CORR_LD + col] = acc[idx][r];
+                        if (mt != nt) mine[col * CORR_LD + row] = acc[idx][r];  // lower triangle = mirror
+                    }
+                }
+        __syncthreads();
+        for (int i = tid; i < 64 * CORR_LD; i += SIGT)
+            Ut[i] = ((Ut[i] + Ut[64 * CORR_LD + i]) + Ut[2 * 64 * CORR_LD + i]) + Ut[3 * 64 * CORR_LD + i];
+        __syncthreads();
+    }
+    // (Hessian at the fixed point) . v from the LDS copy: no pass over the samples
     __device__ inline double hessp(double v) {
-        const double r = weighted_sum<2>(v);
+        broadcast(v);
+        double r = 0.0;
+        if (lane < dim) {
+            const double* row = Ut + lane * CORR_LD;
+            for (int j = 0; j < dim; ++j) r = __builtin_fma(row[j], ybuf[j], r);
+        }
         return lane < dim ? r + v / variance : 0.0;
     }
     __device__ inline bool exhausted() const { return budget <= 0; }
@@ -523,7 +633,6 @@ __global__ void __launch_bounds__(SIGT) corr_signature_embeddings_kernel(Signatu
     ev.k = blockIdx.x;
     ev.c = p.beta[ev.k];
     ev.variance = p.variance;
-    ev.hw = p.hw + (int64_t)ev.k * p.Np;
     ev.dim = p.dim;
     ev.tid = threadIdx.x;
     ev.lane = threadIdx.x & 63;

@@ -20,6 +20,7 @@
 // The evaluator E supplies the problem:
 //   double fun(double y)          objective at the point y (per-lane component) -> uniform scalar
 //   double grad(double y)         per-lane component of the gradient at y
+//   void   fun_grad(double y, double& f, double& g)   both at once (one pass over the problem's terms)
 //   void   prepare_hess(double x) fix the Hessian at x
 //   double hessp(double p)        per-lane component of (Hessian at the fixed point) . p
 //   bool   exhausted()            true once an evaluation budget is spent (a guard against runaway solves;
@@ -38,6 +39,10 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 __device__ __forceinline__ double dot(double a, double b) { return wave_sum(a * b); }
+// x + t * p with the product rounded first (no fused multiply-add): the trial points of a line search and the
+// accepted iterate must be the same bits, as they are in NumPy, so that a gradient evaluated by the line search
+// can be reused for the next Newton iteration (SciPy's ScalarFunction memoises exactly this evaluation)
+__device__ __forceinline__ double point(double x, double t, double p) { return __dadd_rn(x, __dmul_rn(t, p)); }
 __device__ __forceinline__ double l1norm(double a) { return wave_sum(fabs(a)); }
 
 enum Status { OK = 0, MAXITER = 1, LINESEARCH_FAILED = 2, CG_FAILED = 3 };
@@ -134,7 +139,7 @@ __device__ inline void dcstep(StepState& s, double fp, double dp, double stpmin,
 // phi(alpha) = f(xk + alpha pk).  Returns true and the accepted step / values on convergence.
 template <class E>
 __device__ inline bool search_wolfe1(E& ev, double xk, double pk, double phi0, bool have_old, double old_phi0, double derphi0,
-                                     double& stp_out, double& phi_out) {
+                                     double& stp_out, double& phi_out, double& grad_out) {
     constexpr double ftol = 1e-4, gtol = 0.9, xtol = 1e-14, stpmin = 1e-8, stpmax = 50.0;
     constexpr double p5 = 0.5, p66 = 0.66, xtrapl = 1.1, xtrapu = 4.0;
     double alpha1 = 1.0;
@@ -156,8 +161,9 @@ __device__ inline bool search_wolfe1(E& ev, double xk, double pk, double phi0, b
     // the START call consumed iteration 0 of the reference's loop; each later one evaluates then iterates
     for (int it = 1; it < 100; ++it) {
         if (!isfinite(stp)) return false;
-        const double f = ev.fun(xk + stp * pk);
-        const double g = dot(ev.grad(xk + stp * pk), pk);
+        double f, gvec;
+        ev.fun_grad(point(xk, stp, pk), f, gvec);
+        const double g = dot(gvec, pk);
         const double ftest = finit + stp * gtest;
         if (stage == 1 && f <= ftest && g >= 0) stage = 2;
         // tests in the reference's order: a later one overrides an earlier one
@@ -167,7 +173,7 @@ __device__ inline bool search_wolfe1(E& ev, double xk, double pk, double phi0, b
         if (stp == stpmax && f <= ftest && g <= gtest) task = 1;
         if (stp == stpmin && (f > ftest || g >= gtest)) task = 1;
         if (f <= ftest && fabs(g) <= gtol * -ginit) task = 2;
-        if (task == 2) { stp_out = stp; phi_out = f; return true; }
+        if (task == 2) { stp_out = stp; phi_out = f; grad_out = gvec; return true; }
         if (task == 1) return false;
         s.stp = stp;
         if (stage == 1 && f <= s.fx && f > ftest) {
@@ -228,7 +234,7 @@ __device__ inline bool quadmin(double a, double fa, double fpa, double b, double
 
 template <class E>
 __device__ inline bool zoom(E& ev, double xk, double pk, double a_lo, double a_hi, double phi_lo, double phi_hi, double derphi_lo,
-                            double phi0, double derphi0, double& a_star, double& val_star) {
+                            double phi0, double derphi0, double& a_star, double& val_star, double& grad_out) {
     constexpr double c1 = 1e-4, c2 = 0.9, delta1 = 0.2, delta2 = 0.1;
     double phi_rec = phi0, a_rec = 0.0;
     for (int i = 0; i <= 10; ++i) {
@@ -246,13 +252,14 @@ __device__ inline bool zoom(E& ev, double xk, double pk, double a_lo, double a_h
             have = quadmin(a_lo, phi_lo, derphi_lo, a_hi, phi_hi, a_j);
             if (!have || a_j > b - qchk || a_j < a + qchk) a_j = a_lo + 0.5 * dalpha;
         }
-        const double phi_aj = ev.fun(xk + a_j * pk);
+        const double phi_aj = ev.fun(point(xk, a_j, pk));
         if (phi_aj > phi0 + c1 * a_j * derphi0 || phi_aj >= phi_lo) {
             phi_rec = phi_hi; a_rec = a_hi;
             a_hi = a_j; phi_hi = phi_aj;
         } else {
-            const double derphi_aj = dot(ev.grad(xk + a_j * pk), pk);
-            if (fabs(derphi_aj) <= -c2 * derphi0) { a_star = a_j; val_star = phi_aj; return true; }
+            const double gvec = ev.grad(point(xk, a_j, pk));
+            const double derphi_aj = dot(gvec, pk);
+            if (fabs(derphi_aj) <= -c2 * derphi0) { a_star = a_j; val_star = phi_aj; grad_out = gvec; return true; }
             if (derphi_aj * (a_hi - a_lo) >= 0) {
                 phi_rec = phi_hi; a_rec = a_hi;
                 a_hi = a_lo; phi_hi = phi_lo;
@@ -268,29 +275,32 @@ __device__ inline bool zoom(E& ev, double xk, double pk, double a_lo, double a_h
 // ---- bracketing search (Nocedal & Wright alg. 3.5) used when the More-Thuente search gives up
 template <class E>
 __device__ inline bool search_wolfe2(E& ev, double xk, double pk, double phi0, bool have_old, double old_phi0, double derphi0,
-                                     double& stp_out, double& phi_out) {
+                                     double& stp_out, double& phi_out, double& grad_out, bool& have_grad) {
     constexpr double c1 = 1e-4, c2 = 0.9;
     double alpha0 = 0.0, alpha1 = 1.0;
     if (have_old && derphi0 != 0.0) alpha1 = fmin(1.0, 1.01 * 2 * (phi0 - old_phi0) / derphi0);
     if (alpha1 < 0) alpha1 = 1.0;
-    double phi_a1 = ev.fun(xk + alpha1 * pk), phi_a0 = phi0, derphi_a0 = derphi0;
+    double phi_a1 = ev.fun(point(xk, alpha1, pk)), phi_a0 = phi0, derphi_a0 = derphi0;
+    have_grad = true;
     for (int i = 0; i < 10; ++i) {
         if (alpha1 == 0.0) return false;  // rounding errors prevent progress
         if (phi_a1 > phi0 + c1 * alpha1 * derphi0 || (phi_a1 >= phi_a0 && i > 0))
-            return zoom(ev, xk, pk, alpha0, alpha1, phi_a0, phi_a1, derphi_a0, phi0, derphi0, stp_out, phi_out);
-        const double derphi_a1 = dot(ev.grad(xk + alpha1 * pk), pk);
-        if (fabs(derphi_a1) <= -c2 * derphi0) { stp_out = alpha1; phi_out = phi_a1; return true; }
+            return zoom(ev, xk, pk, alpha0, alpha1, phi_a0, phi_a1, derphi_a0, phi0, derphi0, stp_out, phi_out, grad_out);
+        const double gvec = ev.grad(point(xk, alpha1, pk));
+        const double derphi_a1 = dot(gvec, pk);
+        if (fabs(derphi_a1) <= -c2 * derphi0) { stp_out = alpha1; phi_out = phi_a1; grad_out = gvec; return true; }
         if (derphi_a1 >= 0)
-            return zoom(ev, xk, pk, alpha1, alpha0, phi_a1, phi_a0, derphi_a1, phi0, derphi0, stp_out, phi_out);
+            return zoom(ev, xk, pk, alpha1, alpha0, phi_a1, phi_a0, derphi_a1, phi0, derphi0, stp_out, phi_out, grad_out);
         alpha0 = alpha1;
         alpha1 = 2 * alpha1;
         phi_a0 = phi_a1;
-        phi_a1 = ev.fun(xk + alpha1 * pk);
+        phi_a1 = ev.fun(point(xk, alpha1, pk));
         derphi_a0 = derphi_a1;
     }
-    // budget exhausted: the reference accepts the last trial step (with a warning)
+    // budget exhausted: the reference accepts the last trial step (with a warning); no gradient at that point yet
     stp_out = alpha1;
     phi_out = phi_a1;
+    have_grad = false;
     return true;
 }
 
@@ -306,10 +316,12 @@ __device__ inline int minimize(E& ev, double& x, int dim, int maxiter, int* n_it
     double old_fval = ev.fun(xk), old_old_fval = 0.0;
     bool have_old_old = false;
     int status = OK;
+    double g_next = 0.0;  // gradient at xk when the line search already evaluated it there
+    bool have_g_next = false;
     while (update_l1norm > xtol) {
         if (k >= maxiter || ev.exhausted()) { status = MAXITER; break; }
         // search direction: CG on  H p = -g  from p = 0, stopped by the forcing term or by curvature
-        const double gfk = ev.grad(xk);
+        const double gfk = have_g_next ? g_next : ev.grad(xk);
         const double b = -gfk;
         const double maggrad = l1norm(b);
         const double eta = fmin(0.5, sqrt(maggrad));
@@ -342,14 +354,15 @@ __device__ inline int minimize(E& ev, double& x, int dim, int maxiter, int* n_it
         const double pk = xsupi;
         const double derphi0 = dot(gfk, pk);
         double alphak = 0.0, new_fval = 0.0;
-        bool ok = search_wolfe1(ev, xk, pk, old_fval, have_old_old, old_old_fval, derphi0, alphak, new_fval);
-        if (!ok) ok = search_wolfe2(ev, xk, pk, old_fval, have_old_old, old_old_fval, derphi0, alphak, new_fval);
+        have_g_next = true;
+        bool ok = search_wolfe1(ev, xk, pk, old_fval, have_old_old, old_old_fval, derphi0, alphak, new_fval, g_next);
+        if (!ok) ok = search_wolfe2(ev, xk, pk, old_fval, have_old_old, old_old_fval, derphi0, alphak, new_fval, g_next, have_g_next);
         if (!ok) { status = LINESEARCH_FAILED; break; }
         old_old_fval = old_fval;
         have_old_old = true;
         old_fval = new_fval;
-        const double update = alphak * pk;
-        xk += update;
+        const double update = __dmul_rn(alphak, pk);
+        xk = __dadd_rn(xk, update);  // the same bits as the accepted trial point of the line search
         ++k;
         update_l1norm = l1norm(update);
     }
