@@ -401,7 +401,8 @@ struct SignatureEmbeddingParams {
 
 struct SignatureEmbeddingEval {
     const SignatureEmbeddingParams* p;
-    double* Ut;     // LDS [SIGT][CORR_LD]
+    double* Ut;     // LDS [SIGT][ldu]: the staged tile of U; after a Hessian pass also 4 staging copies [64][CORR_LD]
+    double* Al;     // LDS [64][CORR_LD]: the dense Hessian sum (a region of its own when spec, else the start of Ut)
     double* wt;     // LDS [SIGT]
     double* ybuf;   // LDS [64]
     double* red;    // LDS [4][64]
@@ -409,7 +410,10 @@ struct SignatureEmbeddingEval {
     double c;       // beta_k
     double sg;      // lane m: sum_n aux[k][n] U[n][m]
     double variance;
-    int k, dim, tid, lane, wave, budget;
+    double hpt;     // lane m: component of the point the Hessian in Al belongs to
+    bool hvalid;    // Al holds the Hessian at hpt
+    bool spec;      // Al does not alias the tile buffer: every objective+gradient pass also forms the Hessian
+    int k, dim, ldu, DT, tid, lane, wave, budget;
 
     __device__ inline void broadcast(double y) {
         __syncthreads();  // previous readers of ybuf are done
@@ -432,48 +436,34 @@ struct SignatureEmbeddingEval {
                 const int i = i0 + u * SIGT;
                 if (i < total) {
                     const int j = i / dim, m = i - j * dim;
-                    Ut[j * CORR_LD + m] = v[u];
+                    Ut[j * ldu + m] = v[u];
                 }
             }
         }
         // the MFMA tiles of the Hessian read component columns up to the next multiple of 16: keep them zero
-        const int dpad = 16 * ((dim + 15) / 16) - dim;
+        const int dpad = 16 * DT - dim;
         for (int i = tid; i < SIGT * dpad; i += SIGT) {
             const int j = i / dpad, m = dim + (i - j * dpad);
-            Ut[j * CORR_LD + m] = 0.0;
+            Ut[j * ldu + m] = 0.0;
         }
         __syncthreads();
     }
     __device__ inline double row_dot(int j) const {
         double s = 0.0;
-        const double* row = Ut + j * CORR_LD;
+        const double* row = Ut + j * ldu;
         for (int m = 0; m < dim; ++m) s = __builtin_fma(row[m], ybuf[m], s);
         return s;
     }
-    // lane m of every wave: sum over all samples of weight_n * U[n][m]; MODE selects the weight
-    //   0: aux[k][n]                      (summand_grad)
-    //   1: exp((c + alpha_n) + <U_n, y>)  (gradient)
-    template <int MODE>
-    __device__ inline double weighted_sum(double y) {
-        --budget;
-        if (MODE != 0) broadcast(y);
-        double r = 0.0;
-        for (int64_t t0 = 0; t0 < p->N; t0 += SIGT) {
-            stage(t0);
-            const int64_t n = t0 + tid;
-            double w = 0.0;
-            if (n < p->N) {
-                if (MODE == 0) w = p->aux[n * p->KP + k];
-                else w = exp((c + p->alpha[n]) + row_dot(tid));
-            }
-            wt[tid] = w;
-            __syncthreads();
-            if (lane < dim) {
+    // lane m of every wave: the tile's contribution  sum_j wt[j] * U[j][m]  of this wave's samples j = wave, wave + 4, ...
+    __device__ inline double tile_weighted(double r) const {
+        if (lane < dim) {
 #pragma unroll 4
-                for (int j = wave; j < SIGT; j += 4) r = __builtin_fma(wt[j], Ut[j * CORR_LD + lane], r);
-            }
-            __syncthreads();
+            for (int j = wave; j < SIGT; j += 4) r = __builtin_fma(wt[j], Ut[j * ldu + lane], r);
         }
+        return r;
+    }
+    // fixed-order sum of one per-lane value over the 4 waves; every wave returns the same bits
+    __device__ inline double cross_wave(double r) {
         red[wave * 64 + lane] = r;
         __syncthreads();
         const double tot = ((red[lane] + red[64 + lane]) + red[128 + lane]) + red[192 + lane];
@@ -491,6 +481,75 @@ struct SignatureEmbeddingEval {
         const double t = sred[0];
         __syncthreads();
         return t;
+    }
+    // ---- dense Hessian  sum_n w_n U[n][m] U[n][j]  on the fp64 MFMA units, accumulated over the tiles of a pass.
+    // Every wave multiplies its 64 staged samples: A operand U^T (component x sample), B operand diag(w) U
+    // (sample x component) -- the same LDS elements, the B side scaled by the weight in wt.
+    __device__ inline void hess_tile(d4 (&acc)[10]) const {
+        const int c16 = lane & 15, q = lane >> 4;
+        const double* base = Ut + (64 * wave + q) * ldu + c16;
+        for (int sgrp = 0; sgrp < 16; ++sgrp) {  // 4 samples per MFMA step
+            const double wv = wt[64 * wave + 4 * sgrp + q];
+            double a[4], b[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                a[t] = t < DT ? base[4 * sgrp * ldu + 16 * t] : 0.0;
+                b[t] = wv * a[t];
+            }
+            int idx = 0;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = mt; nt < 4; ++nt, ++idx)
+                    if (nt < DT) acc[idx] = mfma(a[mt], b[nt], acc[idx]);  // uniform over the workgroup
+        }
+    }
+    // after the last tile: cross-wave sum in fixed order into Al; the tile buffer is free and serves as staging
+    __device__ inline void hess_finish(const d4 (&acc)[10], double at) {
+        const int c16 = lane & 15, q = lane >> 4;
+        double* mine = Ut + wave * (16 * DT) * CORR_LD;
+        int idx = 0;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = mt; nt < 4; ++nt, ++idx)
+                if (nt < DT) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * mt + q + 4 * r, col = 16 * nt + c16;
+                        mine[row * CORR_LD + col] = acc[idx][r];
+                        if (mt != nt) mine[col * CORR_LD + row] = acc[idx][r];  // lower triangle = mirror
+                    }
+                }
+        __syncthreads();
+        const int n = 16 * DT * CORR_LD;
+        for (int i = tid; i < n; i += SIGT) {
+            const double t = ((Ut[i] + Ut[n + i]) + Ut[2 * n + i]) + Ut[3 * n + i];
+            Al[i] = t;  // Al == Ut when not spec: element i is read and written by this thread only
+        }
+        __syncthreads();
+        hpt = at;
+        hvalid = spec;  // an aliased Al does not survive the next pass
+    }
+
+    // lane m of every wave: sum over all samples of weight_n * U[n][m];  MODE 0: weight aux[k][n] (summand_grad),
+    // MODE 1: weight exp((c + alpha_n) + <U_n, y>) (gradient)
+    template <int MODE>
+    __device__ inline double weighted_sum(double y) {
+        --budget;
+        if (MODE != 0) broadcast(y);
+        double r = 0.0;
+        for (int64_t t0 = 0; t0 < p->N; t0 += SIGT) {
+            stage(t0);
+            const int64_t n = t0 + tid;
+            double w = 0.0;
+            if (n < p->N) w = (MODE == 0) ? p->aux[n * p->KP + k] : exp((c + p->alpha[n]) + row_dot(tid));
+            wt[tid] = w;
+            __syncthreads();
+            r = tile_weighted(r);
+            __syncthreads();
+        }
+        return cross_wave(r);
     }
     __device__ inline double fun(double y) {
         --budget;
@@ -517,11 +576,17 @@ struct SignatureEmbeddingEval {
         g -= y / variance;
         return lane < dim ? -g : 0.0;
     }
-    // objective and gradient in ONE pass over the samples (a line-search evaluation needs both)
+    // Objective and gradient in ONE pass over the samples (a line-search evaluation needs both).  The weights of
+    // the gradient are those of the Hessian at the same point, and the first trial point of a line search is
+    // usually accepted: when Al has a region of its own, the pass also forms the Hessian there, and the
+    // prepare_hess of the next Newton iteration finds it ready.
     __device__ inline void fun_grad(double y, double& f, double& g) {
         --budget;
         broadcast(y);
         double lin = 0.0, ex = 0.0, r = 0.0;
+        d4 acc[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) acc[i] = (d4){0, 0, 0, 0};
         for (int64_t t0 = 0; t0 < p->N; t0 += SIGT) {
             stage(t0);
             const int64_t n = t0 + tid;
@@ -534,34 +599,27 @@ struct SignatureEmbeddingEval {
             }
             wt[tid] = w;
             __syncthreads();
-            if (lane < dim) {
-#pragma unroll 4
-                for (int j = wave; j < SIGT; j += 4) r = __builtin_fma(wt[j], Ut[j * CORR_LD + lane], r);
-            }
+            r = tile_weighted(r);
+            if (spec) hess_tile(acc);
             __syncthreads();
         }
-        red[wave * 64 + lane] = r;
-        __syncthreads();
-        const double tot = ((red[lane] + red[64 + lane]) + red[128 + lane]) + red[192 + lane];
-        __syncthreads();
+        const double tot = cross_wave(r);
         double v = block_sum(lin);
         v -= block_sum(ex);
         v -= ncg::wave_sum(y * y) / (2 * variance);
         f = -v;
-        double gg = -(lane < dim ? tot : 0.0);
+        double gg = -tot;
         gg += sg;
         gg -= y / variance;
         g = lane < dim ? -gg : 0.0;
+        if (spec) hess_finish(acc, y);
     }
-    // Dense Hessian at x into LDS: Al[m][j] = sum_n w_n U[n][m] U[n][j], w_n = exp((c + alpha_n) + <U_n, x>).
-    // Per tile every wave multiplies its 64 staged samples on the MFMA units: A operand U^T (component x sample),
-    // B operand diag(w) U (sample x component) -- the same LDS elements, the B side scaled by the weight.
+    // Dense Hessian at x into Al, unless the last objective+gradient pass already left it there
     __device__ inline void prepare_hess(double x) {
+        if (hvalid && __all(x == hpt || lane >= dim)) return;
         --budget;
         broadcast(x);
-        const int DT = (dim + 15) / 16;
-        const int c16 = lane & 15, q = lane >> 4;
-        d4 acc[10];  // upper-triangular 16 x 16 tiles (mt <= nt), DT <= 4
+        d4 acc[10];
 #pragma unroll
         for (int i = 0; i < 10; ++i) acc[i] = (d4){0, 0, 0, 0};
         for (int64_t t0 = 0; t0 < p->N; t0 += SIGT) {
@@ -569,50 +627,17 @@ struct SignatureEmbeddingEval {
             const int64_t n = t0 + tid;
             wt[tid] = (n < p->N) ? exp((c + p->alpha[n]) + row_dot(tid)) : 0.0;
             __syncthreads();
-            const double* base = Ut + (64 * wave + q) * CORR_LD + c16;
-            for (int sgrp = 0; sgrp < 16; ++sgrp) {  // 4 samples per MFMA step
-                const double wv = wt[64 * wave + 4 * sgrp + q];
-                double a[4], b[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    a[t] = t < DT ? base[4 * sgrp * CORR_LD + 16 * t] : 0.0;
-                    b[t] = wv * a[t];
-                }
-                int idx = 0;
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                    for (int nt = mt; nt < 4; ++nt, ++idx)
-                        if (nt < DT) acc[idx] = mfma(a[mt], b[nt], acc[idx]);  // uniform over the workgroup
-            }
+            hess_tile(acc);
             __syncthreads();
         }
-        // cross-wave sum in fixed order; the tile buffer is free now: wave w's copy at Ut + w * 64 * CORR_LD
-        double* mine = Ut + wave * 64 * CORR_LD;
-        int idx = 0;
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int nt = mt; nt < 4; ++nt, ++idx)
-                if (nt < DT) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = 16 * mt + q + 4 * r, col = 16 * nt + c16;
-                        mine[row * CORR_LD + col] = acc[idx][r];
-                        if (mt != nt) mine[col * CORR_LD + row] = acc[idx][r];  // lower triangle = mirror
-                    }
-                }
-        __syncthreads();
-        for (int i = tid; i < 64 * CORR_LD; i += SIGT)
-            Ut[i] = ((Ut[i] + Ut[64 * CORR_LD + i]) + Ut[2 * 64 * CORR_LD + i]) + Ut[3 * 64 * CORR_LD + i];
-        __syncthreads();
+        hess_finish(acc, x);
     }
     // (Hessian at the fixed point) . v from the LDS copy: no pass over the samples
     __device__ inline double hessp(double v) {
         broadcast(v);
         double r = 0.0;
         if (lane < dim) {
-            const double* row = Ut + lane * CORR_LD;
+            const double* row = Al + lane * CORR_LD;
             for (int j = 0; j < dim; ++j) r = __builtin_fma(row[j], ybuf[j], r);
         }
         return lane < dim ? r + v / variance : 0.0;
@@ -620,12 +645,22 @@ struct SignatureEmbeddingEval {
     __device__ inline bool exhausted() const { return budget <= 0; }
 };
 
+// LDS pool: the tile [SIGT][16 DT + 1] followed (DT <= 3) by a Hessian region [64][CORR_LD] of its own; with
+// DT = 4 the tile alone fills the pool and the Hessian aliases it (no speculation)
+constexpr int SIG_POOL = SIGT * 49 + 64 * CORR_LD;
+static_assert(SIG_POOL >= SIGT * CORR_LD, "the widest tile must fit the pool");
+
 __global__ void __launch_bounds__(SIGT) corr_signature_embeddings_kernel(SignatureEmbeddingParams p) {
-    __shared__ double Ut[SIGT * CORR_LD];
+    __shared__ double pool[SIG_POOL];
     __shared__ double wt[SIGT], sred[SIGT], ybuf[64], red[4 * 64];
     SignatureEmbeddingEval ev;
     ev.p = &p;
-    ev.Ut = Ut;
+    ev.dim = p.dim;
+    ev.DT = (p.dim + 15) / 16;
+    ev.ldu = 16 * ev.DT + 1;
+    ev.spec = ev.DT <= 3;
+    ev.Ut = pool;
+    ev.Al = ev.spec ? pool + SIGT * 49 : pool;
     ev.wt = wt;
     ev.ybuf = ybuf;
     ev.red = red;
@@ -633,11 +668,12 @@ __global__ void __launch_bounds__(SIGT) corr_signature_embeddings_kernel(Signatu
     ev.k = blockIdx.x;
     ev.c = p.beta[ev.k];
     ev.variance = p.variance;
-    ev.dim = p.dim;
     ev.tid = threadIdx.x;
     ev.lane = threadIdx.x & 63;
     ev.wave = threadIdx.x >> 6;
     ev.budget = SIG_BUDGET;
+    ev.hpt = 0.0;
+    ev.hvalid = false;
     ev.sg = 0.0;
     ev.sg = ev.weighted_sum<0>(0.0);
     double x = ev.lane < p.dim ? p.L[ev.k * p.dim + ev.lane] : 0.0;

@@ -313,11 +313,12 @@ __device__ inline int minimize(E& ev, double& x, int dim, int maxiter, int* n_it
     double update_l1norm = DBL_MAX;
     double xk = x;
     int k = 0;
-    double old_fval = ev.fun(xk), old_old_fval = 0.0;
+    double old_fval, old_old_fval = 0.0;
     bool have_old_old = false;
     int status = OK;
-    double g_next = 0.0;  // gradient at xk when the line search already evaluated it there
-    bool have_g_next = false;
+    double g_next;  // gradient at xk when an evaluation at that very point already produced it
+    bool have_g_next = true;
+    ev.fun_grad(xk, old_fval, g_next);
     while (update_l1norm > xtol) {
         if (k >= maxiter || ev.exhausted()) { status = MAXITER; break; }
         // search direction: CG on  H p = -g  from p = 0, stopped by the forcing term or by curvature
