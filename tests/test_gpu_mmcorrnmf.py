@@ -229,3 +229,51 @@ def test_multi_solve_rejects_mismatched_engines():
         Engine.corr_update_sample_embeddings_multi([a, b], 1.0, 3)
     a.close()
     b.close()
+
+
+def test_c5_like_scale_subset_matches_scipy():
+    """Config c5's shape at a tenth of its samples -- (96 + 83) x 20 000, 40 signatures per modality, dim 40,
+    80 terms per sample solve (two per lane) -- checked on a random subset against SciPy."""
+    rng = np.random.default_rng(5)
+    N, Ks, Vs, dim, var = 20000, [40, 40], [96, 83], 40, 0.7
+    U = rng.normal(0, 0.3, (N, dim))
+    betas, alphas, Ls, auxs, engines = [], [], [], [], []
+    for m, (K, V) in enumerate(zip(Ks, Vs)):
+        X, W, _ = ko.synthetic_problem(V, N, K, seed=20 + m)
+        beta, L = rng.normal(0, 0.3, K), rng.normal(0, 0.3, (K, dim))
+        e = Engine(N, V, K)
+        e.upload_X(X)
+        e.upload_W(W)
+        e.corr_configure(dim)
+        e.corr_upload(_lib.CORR_SIGNATURE_SCALINGS, beta)
+        e.corr_upload(_lib.CORR_SIGNATURE_EMBEDDINGS, L)
+        e.corr_upload(_lib.CORR_SAMPLE_EMBEDDINGS, U)
+        e.corr_update_sample_scalings()
+        e.corr_compute_exposures()
+        e.corr_compute_aux()
+        e.corr_update_signature_scalings()
+        engines.append(e)
+        betas.append(e.corr_download(_lib.CORR_SIGNATURE_SCALINGS))
+        alphas.append(e.corr_download(_lib.CORR_SAMPLE_SCALINGS))
+        auxs.append(e.corr_download(_lib.CORR_AUX).T.copy())
+        Ls.append(L)
+    # signature embeddings of modality 0: two of the 40 solves against SciPy
+    engines[0].corr_update_signature_embeddings(var, 0)
+    L0 = engines[0].corr_download(_lib.CORR_SIGNATURE_EMBEDDINGS)
+    for k in (3, 27):
+        want = co.update_embedding(Ls[0][k], U, betas[0][k], alphas[0], var, auxs[0][k])
+        assert np.allclose(L0[k], want, rtol=1e-5, atol=1e-8)
+    # joint sample solve over both modalities (with modality 0's new signature embeddings), 120 samples against SciPy
+    Ls[0] = L0
+    Engine.corr_update_sample_embeddings_multi(engines, var, 3)
+    got = engines[1].corr_download(_lib.CORR_SAMPLE_EMBEDDINGS)
+    L_all, beta_all, aux_all = np.concatenate(Ls), np.concatenate(betas), np.concatenate(auxs)
+    idx = rng.choice(N, size=120, replace=False)
+    worst = 0.0
+    for n in idx:
+        scalings = np.concatenate([np.repeat(alphas[m][n], Ks[m]) for m in range(2)])
+        want = co.update_embedding(U[n], L_all, scalings, beta_all, var, aux_all[:, n], options={"maxiter": 3})
+        worst = max(worst, np.abs(got[n] - want).max() / max(np.abs(want).max(), 1e-3))
+    assert worst < 2e-4
+    for e in engines:
+        e.close()
