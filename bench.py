@@ -14,8 +14,9 @@ on c2.  Inputs are resident in HBM before the timed region.
 
 Rank 0 prints ONE JSON line.  ``roofline`` prices the dominant kernel (the fused update
 pass) on algorithmic flops 6*V*K*N against the fp64 MFMA peak; its duration is measured
-with HIP events on the engine's stream around the launches of every 8th step inside the
-timed region (an event record costs a few microseconds of stream time).
+with HIP events on the engine's stream around the launches of every 25th step inside the
+timed region (an event record costs a few microseconds of stream time, so denser sampling would
+slow the very loop it measures).
 ``cpu_baseline`` times the NumPy oracle (the restated reference arithmetic) on this box's
 host cores, rank 0, N = 1 only.
 """
@@ -116,7 +117,7 @@ def main():
     engine.kl_step(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    total_ms, fused_ms, tail_ms = engine.profile_kl_steps(args.steps, 0, 8)  # HIP events on every 8th step; syncs the stream
+    total_ms, fused_ms, tail_ms = engine.profile_kl_steps(args.steps, 0, 25)  # HIP events on every 25th step; syncs the stream
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
