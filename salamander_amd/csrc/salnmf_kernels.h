@@ -669,7 +669,7 @@ struct FwdParams {
 // are not software-pipelined here, so the second wave hides the first one's memory latency.
 // Only the 4*KS rows of W that the contraction touches are staged, which keeps LDS <= 80 KB.
 template <int KS>
-constexpr int fwd_lds_doubles() { return 4 * KS * WS + WAVES * Geo<KS>::HL + BLOCK; }
+constexpr int fwd_lds_doubles() { return 4 * KS * WS + WAVES * Geo<KS>::HL + BLOCK + Geo<KS>::KP; }
 
 template <int KS, int MODE>
 __global__ void __launch_bounds__(BLOCK, (fwd_lds_doubles<KS>() * 8 <= 80 * 1024 ? 2 : 1)) forward_kernel(FwdParams p) {
@@ -689,6 +689,8 @@ __global__ void __launch_bounds__(BLOCK, (fwd_lds_doubles<KS>() * 8 <= 80 * 1024
     double* Wl = lds;
     double* Hl = lds + FROWS * WS + wave * G_::HL;
     double* red = lds + FROWS * WS + WAVES * G_::HL;
+    double* hsl = red + BLOCK;  // [KP] copy of hscale
+    if (p.hscale && tid < KP) hsl[tid] = p.hscale[tid];
 
     stage_W<FROWS>(Wl, p.W, K, V, tid);
     __syncthreads();
@@ -722,8 +724,8 @@ __global__ void __launch_bounds__(BLOCK, (fwd_lds_doubles<KS>() * 8 <= 80 * 1024
 #pragma unroll
         for (int j = 0; j < HV; ++j) {
             if (p.hscale) {
-                hv[j][0] = fmax(hv[j][0] * p.hscale[hcol[j]], kEps);
-                hv[j][1] = fmax(hv[j][1] * p.hscale[hcol[j] + 1], kEps);
+                hv[j][0] = fmax(hv[j][0] * hsl[hcol[j]], kEps);
+                hv[j][1] = fmax(hv[j][1] * hsl[hcol[j] + 1], kEps);
             }
             if (MODE == 0 && p.wlh) {  // l-half penalty, klnmf.py:75-79
                 int64_t n = n0 + hrow[j];
