@@ -2,10 +2,12 @@
 
 TEST INFRASTRUCTURE ONLY -- see ``oracle/__init__.py``.  Never on the product path.
 
-Parity status: **pinned** for everything below by the reference's own fixtures
-``tests/test_data/models/corrnmf/*.npy`` (committed as data under
-``tests/golden/ref_fixtures/corrnmf/``; checked in ``tests/test_oracle_corrnmf.py``):
-objective (ELBO), aux, both scalings, both embedding updates, variance, signatures.
+Parity status: **pinned** for everything below (``tests/test_oracle_corrnmf.py``) by
+(i) the reference's own fixtures ``tests/test_data/models/{corrnmf,multimodal_corrnmf}/*`` (committed as data
+under ``tests/golden/ref_fixtures/``): objective (ELBO), aux, both scalings, both embedding updates, variance,
+signatures; and (ii) vectors produced by executing the reference's ``_utils_corrnmf`` functions in the build
+container on larger problems (``tests/golden/make_golden.py --corr`` -> ``tests/golden/corr_synth.npz``:
+K = 7 and 12, every function and a three-update CorrNMFDet trajectory).
 The embedding update delegates to ``scipy.optimize.minimize(method="Newton-CG")`` exactly
 as the reference does (``_utils_corrnmf.py:400-407``); SciPy is a third-party dependency of
 the reference (pinned 1.13.1 in its ``poetry.lock``, 1.15.3 installed here), so beyond the

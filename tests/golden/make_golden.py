@@ -17,6 +17,9 @@ Outputs (all float64):
   kl_synth.npz      synthetic 96x256, K=50: update_WH trajectories, weights, l-half, given
   kl_pcawg.npz      data/pcawg_breast_sbs.csv (96x192), K=5 trajectory  (config c1)
   mv_synth.npz      MvNMF steps incl. a case whose line search backtracks (gamma < 1)
+  corr_synth.npz    correlated NMF (row f1): every function of _utils_corrnmf and a 3-update CorrNMFDet
+                    trajectory on synthetic counts, K in {7, 12} -- run with ``--corr`` (only this file is
+                    regenerated; the embedding solves go through the installed SciPy, as in the reference)
 """
 
 from __future__ import annotations
@@ -113,11 +116,82 @@ def synthetic(V, N, K, seed, mean_mutations=2000.0):
     return X.T.copy(), W0.T.copy(), H0.T.copy()  # reference shapes (V,N), (V,K), (K,N)
 
 
+def load_reference_corrnmf():
+    """The reference's _utils_corrnmf module (after load_reference()), executed as NumPy + SciPy."""
+    src = os.path.join(REF, "src", "salamander", "models", "_utils_corrnmf.py")
+    spec = importlib.util.spec_from_file_location("salamander.models._utils_corrnmf", src)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["salamander.models._utils_corrnmf"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def corr_golden(uk, uc):
+    """corr_synth.npz: the reference's CorrNMF functions beyond its own fixtures (K <= 2, N = 10)."""
+    out = {}
+    for tag, (N, K, dim, seed) in {"a": (60, 7, 3, 31), "b": (40, 12, 12, 32)}.items():
+        X, W0, _ = synthetic(96, N, K, seed)  # X (V, N), W0 (V, K)
+        X, W = X.T.copy(), W0.T.copy()  # the CorrNMF call sites are sample-major: (N, V), (K, V)
+        rng = np.random.default_rng(seed)
+        beta = rng.normal(0, 0.3, K)
+        alpha = np.log(X.sum(axis=1) / K) + rng.normal(0, 0.1, N)
+        L = rng.normal(0, 0.5, (K, dim))
+        U = rng.normal(0, 0.5, (N, dim))
+        var = 0.8
+        out.update({f"{tag}_X": X, f"{tag}_W": W, f"{tag}_beta": beta, f"{tag}_alpha": alpha, f"{tag}_L": L, f"{tag}_U": U, f"{tag}_var": var})
+        H = uc.compute_exposures(beta, alpha, L, U)
+        aux = uc.compute_aux(X, W, H)
+        out[f"{tag}_H"], out[f"{tag}_aux"] = H, aux
+        out[f"{tag}_elbo"] = uc.elbo_corrnmf(X, W, H, L, U, var)
+        out[f"{tag}_elbo_nopen"] = uc.elbo_corrnmf(X, W, H, L, U, var, penalize_sample_embeddings=False)
+        out[f"{tag}_beta_upd"] = uc.update_signature_scalings(aux, alpha, L, U)
+        out[f"{tag}_alpha_upd"] = uc.update_sample_scalings(X, beta, L, U)
+
+        def solve_L(aux, L, U, beta, alpha, var):
+            outer = np.einsum("Dm,Dn->Dmn", U, U)
+            Ln = L.copy()
+            for k in range(L.shape[0]):
+                Ln[k] = uc.update_embedding(L[k].copy(), U, beta[k], alpha, var, aux[k], outer)
+            return Ln
+
+        def solve_U(aux, L, U, beta, alpha, var):
+            outer = np.einsum("Km,Kn->Kmn", L, L)
+            Un = U.copy()
+            for d in range(U.shape[0]):
+                Un[d] = uc.update_embedding(U[d].copy(), L, alpha[d], beta, var, aux[:, d], outer, options={"maxiter": 3})
+            return Un
+
+        out[f"{tag}_L_upd"] = solve_L(aux, L, U, beta, alpha, var)
+        out[f"{tag}_U_upd"] = solve_U(aux, L, U, beta, alpha, var)
+        # three updates in the order of CorrNMFDet._update_parameters (corrnmf_det.py:157-169)
+        Wt, bt, at, Lt, Ut, vt = W.copy(), beta.copy(), alpha.copy(), L.copy(), U.copy(), var
+        elbos = []
+        for _ in range(3):
+            at = uc.update_sample_scalings(X, bt, Lt, Ut)
+            Ht = uc.compute_exposures(bt, at, Lt, Ut)
+            auxt = uc.compute_aux(X, Wt, Ht)
+            bt = uc.update_signature_scalings(auxt, at, Lt, Ut)
+            Lt = solve_L(auxt, Lt, Ut, bt, at, vt)
+            Ut = solve_U(auxt, Lt, Ut, bt, at, vt)
+            vt = float(np.clip(np.mean(np.concatenate([Lt, Ut]) ** 2), uk.EPSILON, None))
+            Wt = uk.update_W(X.T, Wt.T, Ht.T, n_given_signatures=0).T
+            elbos.append(uc.elbo_corrnmf(X, Wt, Ht, Lt, Ut, vt))
+        out.update({f"{tag}_W3": Wt, f"{tag}_beta3": bt, f"{tag}_alpha3": at, f"{tag}_L3": Lt, f"{tag}_U3": Ut, f"{tag}_var3": vt, f"{tag}_H3": Ht, f"{tag}_elbos": np.array(elbos)})
+    import scipy
+
+    out["scipy_version"] = np.array(scipy.__version__)
+    np.savez_compressed(os.path.join(HERE, "corr_synth.npz"), **out)
+    print("corr_synth.npz written (scipy", scipy.__version__ + ")")
+
+
 def main():
     if not os.path.isdir(REF):
         print("no /root/reference here: nothing to do")
         return
     uk, mv = load_reference()
+    if "--corr" in sys.argv:
+        corr_golden(uk, load_reference_corrnmf())
+        return
     EPS = uk.EPSILON
     copy_ref_fixtures()
 

@@ -444,3 +444,75 @@ def test_resident_fit_equals_per_parameter_updates():
     assert np.allclose(a.adata.obsm["embeddings"], b.adata.obsm["embeddings"], rtol=1e-8, atol=1e-12)
     assert np.allclose(a.adata.obs["scalings"].values, b.adata.obs["scalings"].values, rtol=1e-9, atol=1e-12)
     assert np.allclose(a.variance, b.variance, rtol=1e-10)
+
+
+# ------------------------------------------------------------------ vectors produced by executing the reference (corr_synth.npz)
+
+
+@pytest.fixture(params=["a", "b"])
+def ref(request):
+    from test_oracle_corrnmf import load_corr_synth
+
+    return load_corr_synth(request.param)
+
+
+def test_device_matches_reference_executed_vectors(ref):
+    """Every CorrNMF piece on the device against outputs of the reference's own functions (K = 7 and 12)."""
+    r = ref
+    var = float(r["var"])
+    e = engine_from(r["X"], r["W"], r["beta"], r["alpha"], r["L"], r["U"])
+    e.corr_compute_exposures()
+    assert rel(e.download_H(), r["H"]) < RTOL
+    e.corr_compute_aux()
+    assert rel(e.corr_download(_lib.CORR_AUX).T, r["aux"]) < RTOL
+    K, dim = r["L"].shape
+    prior = -0.5 * dim * K * np.log(2 * np.pi * var) - np.sum(r["L"] ** 2) / (2 * var)
+    llh = e.corr_poisson_llh()
+    assert np.isclose(llh + prior, float(r["elbo_nopen"]), rtol=1e-12)
+    ss_sig, ss_samples = e.corr_embedding_sumsq()
+    assert np.isclose(ss_sig, np.sum(r["L"] ** 2), rtol=1e-13) and np.isclose(ss_samples, np.sum(r["U"] ** 2), rtol=1e-13)
+    e.corr_update_signature_scalings()
+    assert np.max(np.abs(e.corr_download(_lib.CORR_SIGNATURE_SCALINGS) - r["beta_upd"])) < 1e-12
+    e.close()
+    e = engine_from(r["X"], r["W"], r["beta"], r["alpha"], r["L"], r["U"])
+    e.corr_update_sample_scalings()
+    assert np.max(np.abs(e.corr_download(_lib.CORR_SAMPLE_SCALINGS) - r["alpha_upd"])) < 1e-12
+    e.close()
+    # the embedding solves from the stored aux (independent of each other, as in the reference's tests)
+    e = engine_from(r["X"], r["W"], r["beta"], r["alpha"], r["L"], r["U"])
+    e.corr_upload(_lib.CORR_AUX, np.ascontiguousarray(r["aux"].T))
+    e.corr_update_signature_embeddings(var, 0)
+    assert np.allclose(e.corr_download(_lib.CORR_SIGNATURE_EMBEDDINGS), r["L_upd"], rtol=1e-6, atol=1e-9)
+    e.close()
+    e = engine_from(r["X"], r["W"], r["beta"], r["alpha"], r["L"], r["U"])
+    e.corr_upload(_lib.CORR_AUX, np.ascontiguousarray(r["aux"].T))
+    e.corr_update_sample_embeddings(var, 3)
+    assert np.allclose(e.corr_download(_lib.CORR_SAMPLE_EMBEDDINGS), r["U_upd"], rtol=1e-6, atol=1e-9)
+    e.close()
+
+
+def test_model_three_updates_match_reference_executed_trajectory(ref):
+    import salamander_amd as sal
+    from salamander_amd.models import CorrNMFDet
+
+    r = ref
+    K, dim = r["L"].shape
+    adata = sal.AnnData(r["X"].copy())
+    adata.obs["scalings"] = r["alpha"]
+    adata.obsm["embeddings"] = r["U"].copy()
+    asigs = sal.AnnData(r["W"].copy())
+    asigs.obs["scalings"] = r["beta"]
+    asigs.obsm["embeddings"] = r["L"].copy()
+    m = CorrNMFDet(n_signatures=K, dim_embeddings=dim)
+    m.adata, m.asignatures, m.variance = adata, asigs, float(r["var"])
+    m.compute_exposures()
+    for _ in range(3):
+        m._update_parameters()
+    assert np.allclose(m.asignatures.X, r["W3"], rtol=1e-6, atol=1e-12)
+    assert np.allclose(adata.obsm["exposures"], r["H3"], rtol=1e-6)
+    assert np.allclose(asigs.obs["scalings"].values, r["beta3"], rtol=1e-6, atol=1e-9)
+    assert np.allclose(adata.obs["scalings"].values, r["alpha3"], rtol=1e-6, atol=1e-9)
+    assert np.allclose(asigs.obsm["embeddings"], r["L3"], rtol=1e-5, atol=1e-7)
+    assert np.allclose(adata.obsm["embeddings"], r["U3"], rtol=1e-5, atol=1e-7)
+    assert np.isclose(m.variance, float(r["var3"]), rtol=1e-6)
+    assert np.isclose(m.objective_function(), float(r["elbos"][-1]), rtol=1e-9)

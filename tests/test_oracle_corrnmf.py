@@ -182,3 +182,55 @@ def test_mm_step_improves_elbo(mm):
         Ws, betas, alphas, Ls, U, var, Hs = co.mm_step(c["Xs"], Ws, betas, alphas, Ls, U, var)
     Hs = [co.compute_exposures(b, a, L, U) for b, a, L in zip(betas, alphas, Ls)]
     assert co.mm_elbo(c["Xs"], Ws, Hs, Ls, U, var) > before
+
+
+# ------------------------------------------------------------------ vectors produced by executing the reference (corr_synth.npz)
+
+CORR_SYNTH = os.path.join(os.path.dirname(__file__), "golden", "corr_synth.npz")
+
+
+def load_corr_synth(tag):
+    g = np.load(CORR_SYNTH)
+    return {k[len(tag) + 1 :]: g[k] for k in g.files if k.startswith(tag + "_")}
+
+
+@pytest.fixture(params=["a", "b"])
+def ref(request):
+    return load_corr_synth(request.param)
+
+
+def test_reference_executed_dense_pieces(ref):
+    r = ref
+    var = float(r["var"])
+    H = co.compute_exposures(r["beta"], r["alpha"], r["L"], r["U"])
+    assert np.allclose(H, r["H"], rtol=1e-13, atol=0)
+    aux = co.compute_aux(r["X"], r["W"], H)
+    assert np.allclose(aux, r["aux"], rtol=1e-12, atol=0)
+    assert np.isclose(co.elbo_corrnmf(r["X"], r["W"], H, r["L"], r["U"], var), float(r["elbo"]), rtol=1e-13)
+    assert np.isclose(
+        co.elbo_corrnmf(r["X"], r["W"], H, r["L"], r["U"], var, penalize_sample_embeddings=False), float(r["elbo_nopen"]), rtol=1e-13
+    )
+    assert np.allclose(co.update_signature_scalings(aux, r["alpha"], r["L"], r["U"]), r["beta_upd"], rtol=0, atol=1e-13)
+    assert np.allclose(co.update_sample_scalings(r["X"], r["beta"], r["L"], r["U"]), r["alpha_upd"], rtol=0, atol=1e-13)
+
+
+def test_reference_executed_embedding_solves(ref):
+    r = ref
+    var = float(r["var"])
+    L1 = co.update_signature_embeddings(r["aux"], r["L"], r["U"], r["beta"], r["alpha"], var)
+    U1 = co.update_sample_embeddings(r["aux"], r["L"], r["U"], r["beta"], r["alpha"], var)
+    assert np.allclose(L1, r["L_upd"], rtol=1e-6, atol=1e-9)
+    assert np.allclose(U1, r["U_upd"], rtol=1e-6, atol=1e-9)
+
+
+def test_reference_executed_three_updates(ref):
+    r = ref
+    W, beta, alpha, L, U, var = r["W"], r["beta"], r["alpha"], r["L"], r["U"], float(r["var"])
+    for _ in range(3):
+        W, beta, alpha, L, U, var, H = co.corrnmf_det_step(r["X"], W, beta, alpha, L, U, var)
+    assert np.allclose(W, r["W3"], rtol=1e-6, atol=1e-12)
+    assert np.allclose(H, r["H3"], rtol=1e-6)
+    assert np.allclose(beta, r["beta3"], rtol=1e-6, atol=1e-9) and np.allclose(alpha, r["alpha3"], rtol=1e-6, atol=1e-9)
+    assert np.allclose(L, r["L3"], rtol=1e-5, atol=1e-7) and np.allclose(U, r["U3"], rtol=1e-5, atol=1e-7)
+    assert np.isclose(var, float(r["var3"]), rtol=1e-6)
+    assert np.isclose(co.elbo_corrnmf(r["X"], W, H, L, U, var), float(r["elbos"][-1]), rtol=1e-9)
