@@ -177,6 +177,29 @@ def corr_golden(uk, uc):
             Wt = uk.update_W(X.T, Wt.T, Ht.T, n_given_signatures=0).T
             elbos.append(uc.elbo_corrnmf(X, Wt, Ht, Lt, Ut, vt))
         out.update({f"{tag}_W3": Wt, f"{tag}_beta3": bt, f"{tag}_alpha3": at, f"{tag}_L3": Lt, f"{tag}_U3": Ut, f"{tag}_var3": vt, f"{tag}_H3": Ht, f"{tag}_elbos": np.array(elbos)})
+    # the joint sample-embedding solve of MultimodalCorrNMF (mmcorrnmf.py:398-428): concatenated signatures of two
+    # modalities, per-term scaling = that modality's sample scaling
+    rng = np.random.default_rng(40)
+    N, Ks, dim, var = 30, [5, 6], 3, 0.9
+    U = rng.normal(0, 0.5, (N, dim))
+    mods = []
+    for m, K in enumerate(Ks):
+        X, W0, _ = synthetic([96, 83][m], N, K, 41 + m)
+        X, W = X.T.copy(), W0.T.copy()
+        beta, L = rng.normal(0, 0.3, K), rng.normal(0, 0.5, (K, dim))
+        alpha = uc.update_sample_scalings(X, beta, L, U)
+        aux = uc.compute_aux(X, W, uc.compute_exposures(beta, alpha, L, U))
+        mods.append((X, W, beta, alpha, L, aux))
+        out.update({f"mm{m}_X": X, f"mm{m}_W": W, f"mm{m}_beta": beta, f"mm{m}_alpha": alpha, f"mm{m}_L": L, f"mm{m}_aux": aux})
+    L_all = np.concatenate([mo[4] for mo in mods])
+    beta_all = np.concatenate([mo[2] for mo in mods])
+    aux_all = np.concatenate([mo[5] for mo in mods])
+    outer = np.einsum("Km,Kn->Kmn", L_all, L_all)
+    Un = U.copy()
+    for d in range(N):
+        scalings = np.concatenate([np.repeat(mo[3][d], K) for mo, K in zip(mods, Ks)])
+        Un[d] = uc.update_embedding(U[d].copy(), L_all, scalings, beta_all, var, aux_all[:, d], outer, options={"maxiter": 3})
+    out.update(mm_U=U, mm_U_upd=Un, mm_var=var)
     import scipy
 
     out["scipy_version"] = np.array(scipy.__version__)

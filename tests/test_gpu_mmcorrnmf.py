@@ -277,3 +277,25 @@ def test_c5_like_scale_subset_matches_scipy():
     assert worst < 2e-4
     for e in engines:
         e.close()
+
+
+def test_joint_solve_matches_reference_executed_vectors():
+    from test_oracle_corrnmf import load_mm_synth
+
+    mods, U, U_upd, var = load_mm_synth()
+    engines = []
+    for m in mods:
+        N, V = m["X"].shape
+        e = Engine(N, V, len(m["beta"]))
+        e.corr_configure(U.shape[1])
+        e.corr_upload(_lib.CORR_SIGNATURE_SCALINGS, m["beta"])
+        e.corr_upload(_lib.CORR_SAMPLE_SCALINGS, m["alpha"])
+        e.corr_upload(_lib.CORR_SIGNATURE_EMBEDDINGS, m["L"])
+        e.corr_upload(_lib.CORR_SAMPLE_EMBEDDINGS, U)
+        e.corr_upload(_lib.CORR_AUX, np.ascontiguousarray(m["aux"].T))
+        engines.append(e)
+    Engine.corr_update_sample_embeddings_multi(engines, var, 3)
+    got = engines[0].corr_download(_lib.CORR_SAMPLE_EMBEDDINGS)
+    for e in engines:
+        e.close()
+    assert np.allclose(got, U_upd, rtol=1e-6, atol=1e-9)

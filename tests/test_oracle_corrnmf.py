@@ -234,3 +234,15 @@ def test_reference_executed_three_updates(ref):
     assert np.allclose(L, r["L3"], rtol=1e-5, atol=1e-7) and np.allclose(U, r["U3"], rtol=1e-5, atol=1e-7)
     assert np.isclose(var, float(r["var3"]), rtol=1e-6)
     assert np.isclose(co.elbo_corrnmf(r["X"], W, H, L, U, var), float(r["elbos"][-1]), rtol=1e-9)
+
+
+def load_mm_synth():
+    g = np.load(CORR_SYNTH)
+    mods = [{k: g[f"mm{m}_{k}"] for k in ("X", "W", "beta", "alpha", "L", "aux")} for m in range(2)]
+    return mods, g["mm_U"], g["mm_U_upd"], float(g["mm_var"])
+
+
+def test_reference_executed_joint_sample_solve():
+    mods, U, U_upd, var = load_mm_synth()
+    got = co.mm_update_sample_embeddings([m["aux"] for m in mods], [m["L"] for m in mods], U, [m["beta"] for m in mods], [m["alpha"] for m in mods], var)
+    assert np.allclose(got, U_upd, rtol=1e-6, atol=1e-9)
