@@ -59,7 +59,9 @@ struct salnmf_engine {
     int fgrid = 0;  // workgroups of the forward kernels (two per CU)
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // MvNMF: the small W-only kernels run here, beside the passes over the samples
-    hipEvent_t evW = nullptr, evPrepW = nullptr, evTrial = nullptr, evLogdet = nullptr;
+    hipStream_t stream3 = nullptr;  // MvNMF: read-back of the line-search scalars past a speculative pass on the main stream
+    hipEvent_t evW = nullptr, evPrepW = nullptr, evTrial = nullptr, evLogdet = nullptr, evObj = nullptr;
+    double* Halt = nullptr;      // [Np][KP] second H buffer of the speculative update_H pass (lazily allocated)
     int mv_grid = 0, mv_fgrid = 0;  // grids that leave one CU free for stream2
     double *X = nullptr, *H = nullptr, *W = nullptr, *wkl = nullptr, *wlh = nullptr;
     double* Gpart = nullptr;     // [grid][K][V]
@@ -248,18 +250,19 @@ void salnmf_destroy(salnmf_engine* e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->comm) ncclCommDestroy(e->comm);
     double* bufs[] = {e->X, e->H, e->W, e->wkl, e->wlh, e->Gpart, e->Hsumpart, e->KLpart, e->red,
-                      e->objpart, e->scal, e->Wunc, e->Wtrial, e->mvA, e->mvB, e->cs, e->scratch,
+                      e->objpart, e->scal, e->Wunc, e->Wtrial, e->mvA, e->mvB, e->cs, e->scratch, e->Halt,
                       e->alpha, e->beta, e->Lemb, e->Uemb, e->aux, e->xrowsum, e->corrpart};
     for (double* b : bufs)
         if (b) (void)hipFree(b);
     if (e->hpin) (void)hipHostFree(e->hpin);
     for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
-    for (hipEvent_t ev : {e->evW, e->evPrepW, e->evTrial, e->evLogdet})
+    for (hipEvent_t ev : {e->evW, e->evPrepW, e->evTrial, e->evLogdet, e->evObj})
         if (ev) (void)hipEventDestroy(ev);
-    if (e->stream2) {
-        (void)hipStreamSynchronize(e->stream2);
-        (void)hipStreamDestroy(e->stream2);
-    }
+    for (hipStream_t st : {e->stream2, e->stream3})
+        if (st) {
+            (void)hipStreamSynchronize(st);
+            (void)hipStreamDestroy(st);
+        }
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -314,7 +317,8 @@ int salnmf_create(int device, int n_features, int64_t n_samples, int n_signature
     if (hipMalloc(&(ptr), (n) * sizeof(double)) != hipSuccess) return cleanup(fail("hipMalloc of %zu doubles failed", (size_t)(n)));
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return cleanup(fail("stream create failed"));
     if (hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess) return cleanup(fail("stream create failed"));
-    for (hipEvent_t* ev : {&e->evW, &e->evPrepW, &e->evTrial, &e->evLogdet})
+    if (hipStreamCreateWithFlags(&e->stream3, hipStreamNonBlocking) != hipSuccess) return cleanup(fail("stream create failed"));
+    for (hipEvent_t* ev : {&e->evW, &e->evPrepW, &e->evTrial, &e->evLogdet, &e->evObj})
         if (hipEventCreateWithFlags(ev, hipEventDisableTiming) != hipSuccess) return cleanup(fail("event create failed"));
     ALLOC(e->X, Np * VMAX);
     ALLOC(e->H, Np * KP);
@@ -585,7 +589,13 @@ static int mv_start_prepare_W(salnmf_engine* e, double delta, bool record_w_even
     return 0;
 }
 
-static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double delta, double* gamma, bool have_hsum, bool w_ready) {
+//   speculate: the caller will run another step right after this one.  While the host waits for the scalars of the
+//            first trial, the GPU already runs that step's update_H pass with the trial as W into a second H buffer;
+//            if the trial is accepted (the common case) the buffers are swapped and *speculated = true tells the caller
+//            to skip its update_H pass, otherwise the result is dropped.  The scalars come back on a side stream.
+static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double delta, double* gamma, bool have_hsum, bool w_ready,
+                            bool speculate = false, bool* speculated = nullptr) {
+    if (speculated) *speculated = false;
     if (n_given >= e->K) return 0;
     const int K = e->K, V = e->V;
     CK(flush_H_scale(e));  // a stand-alone call after an earlier step; inside mv_step the update_H pass consumed it
@@ -623,14 +633,46 @@ static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double de
         HIPCK(hipGetLastError());
         HIPCK(hipEventRecord(e->evLogdet, e->stream2));
         CK(objective_to_slot(e, e->Wtrial, e->cs, false, 2, e->mv_fgrid));
-        HIPCK(hipStreamWaitEvent(e->stream, e->evLogdet, 0));
         double v[5];
-        CK(read_scalars(e, 0, 5, v));
+        const bool spec = speculate && !blend;
+        if (spec) {
+            HIPCK(hipEventRecord(e->evObj, e->stream));
+            if (!e->Halt) HIPCK(hipMalloc(&e->Halt, (size_t)e->Np * e->KP * sizeof(double)));
+            FusedParams sp = fused_params(e);
+            sp.wkl = nullptr;
+            sp.wlh = nullptr;
+            sp.W = e->Wtrial;
+            sp.hscale = e->cs;
+            sp.Hout = e->Halt;
+            CK((launch_fused<false, true, true>(e, sp, e->mv_grid)));  // the next step's update_H, assuming acceptance
+            // ... and its W-only algebra, behind the trial's log det on stream2 (A, B of this step are consumed already)
+            hipLaunchKernelGGL(mv_prepare_W_kernel, dim3(1), dim3(MV_BLOCK), 0, e->stream2, e->Wtrial, K, V, delta, e->mvA, e->mvB, e->scal + 3);
+            HIPCK(hipGetLastError());
+            HIPCK(hipEventRecord(e->evPrepW, e->stream2));
+            HIPCK(hipStreamWaitEvent(e->stream3, e->evObj, 0));
+            HIPCK(hipStreamWaitEvent(e->stream3, e->evLogdet, 0));
+            HIPCK(hipMemcpyAsync(e->hpin, e->scal, 5 * sizeof(double), hipMemcpyDeviceToHost, e->stream3));
+            HIPCK(hipStreamSynchronize(e->stream3));
+            for (int i = 0; i < 5; ++i) v[i] = e->hpin[i];
+        } else {
+            HIPCK(hipStreamWaitEvent(e->stream, e->evLogdet, 0));
+            CK(read_scalars(e, 0, 5, v));
+        }
         const double f0 = v[1], f1 = v[2] + lam * v[4];
         if (f1 > f0 && g > 1e-16) {  // mvnmf.py:84
             g *= 0.8;
             blend = true;
             continue;
+        }
+        if (spec) {
+            // accepted at the first trial: the speculative pass is the next step's update_H
+            *gamma = std::min(1.0, 1.2 * g);
+            std::swap(e->W, e->Wtrial);
+            std::swap(e->H, e->Halt);  // written in full from clip(H * cs): nothing pending
+            HIPCK(hipEventRecord(e->evW, e->stream));
+            e->h_pending = false;
+            if (speculated) *speculated = true;
+            return 0;
         }
         break;
     }
@@ -653,17 +695,21 @@ int salnmf_mv_step(salnmf_engine* e, int n_steps, int n_given, double lam, doubl
     if (!e || !gamma_inout) return fail("null argument");
     if (n_given < 0 || n_given > e->K) return fail("n_given out of range");
     HIPCK(hipSetDevice(e->device));
+    bool have_H = false;  // this step's update_H pass already ran speculatively during the previous step
     for (int i = 0; i < n_steps; ++i) {
-        FusedParams p = fused_params(e);
-        p.wkl = nullptr;  // MvNMF._update_H passes no weights (mvnmf.py:162-165)
-        p.wlh = nullptr;
         const bool update_W = n_given < e->K;
         if (update_W && i == 0) HIPCK(hipEventRecord(e->evW, e->stream));  // later steps: recorded by the accept
-        CK((launch_fused<false, true, true>(e, p, e->mv_grid)));      // update_H + row sums of the new H
-        e->h_pending = false;
-        // W-only algebra on stream2, beside both passes; queued after the pass so that the host does not delay it
-        if (update_W) CK(mv_start_prepare_W(e, delta, false));
-        CK(mv_update_W_impl(e, n_given, lam, delta, gamma_inout, true, true));
+        if (!have_H) {
+            FusedParams p = fused_params(e);
+            p.wkl = nullptr;  // MvNMF._update_H passes no weights (mvnmf.py:162-165)
+            p.wlh = nullptr;
+            CK((launch_fused<false, true, true>(e, p, e->mv_grid)));  // update_H + row sums of the new H
+            e->h_pending = false;
+        }
+        // W-only algebra on stream2, beside the passes; queued after the pass so that the host does not delay it
+        // (an accepted speculation ran it already, for exactly this W)
+        if (update_W && !have_H) CK(mv_start_prepare_W(e, delta, false));
+        CK(mv_update_W_impl(e, n_given, lam, delta, gamma_inout, true, true, i + 1 < n_steps, &have_H));
     }
     return 0;
 }

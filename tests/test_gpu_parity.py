@@ -145,6 +145,30 @@ def test_golden_mvnmf(golden, tag):
     e.close()
 
 
+@pytest.mark.parametrize("tag", ["a", "g", "bt1", "bt2"])
+def test_golden_mvnmf_all_steps_in_one_call(golden, tag):
+    """The same trajectories with all steps in ONE mv_step call: inside a call the next step's update_H pass and
+    W-only algebra run speculatively while the host waits for the line-search scalars; the backtracking cases
+    (bt1, bt2) make that speculation fail and be dropped.  Then a lazily rescaled H must survive other readers."""
+    g = golden.mv
+    lam, delta, steps, ng = g[f"{tag}_par"]
+    e = make_engine(g[f"{tag}_X"], g[f"{tag}_W0"], g[f"{tag}_H0"])
+    gamma = e.mv_step(int(steps), int(ng), lam, delta, 1.0)
+    assert np.isclose(gamma, g[f"{tag}_gammas"][-1], rtol=1e-12)
+    assert np.isclose(e.mv_objective(lam, delta), g[f"{tag}_obj"], rtol=1e-9)  # reads H through the pending rescale
+    skl = e.samplewise_kl()
+    assert rel_l2(e.download_W(), g[f"{tag}_W"].T) < 1e-7 and rel_l2(e.download_H(), g[f"{tag}_H"].T) < 1e-7
+    assert np.allclose(skl, orc.samplewise_kl_divergence(g[f"{tag}_X"], g[f"{tag}_W"], g[f"{tag}_H"]), rtol=1e-6)
+    # split differently: 3 steps + the rest, with a KL-NMF update_W in between left out -- same result as one call
+    e2 = make_engine(g[f"{tag}_X"], g[f"{tag}_W0"], g[f"{tag}_H0"])
+    k = min(3, int(steps) - 1)
+    gamma2 = e2.mv_step(k, int(ng), lam, delta, 1.0)
+    gamma2 = e2.mv_step(int(steps) - k, int(ng), lam, delta, gamma2)
+    assert gamma2 == gamma and np.array_equal(e2.download_W(), e.download_W()) and np.array_equal(e2.download_H(), e.download_H())
+    e.close()
+    e2.close()
+
+
 # ------------------------------------------------------------------ shapes: ragged N, V < 96, every K bucket
 @pytest.mark.parametrize(
     "V,N,K",
