@@ -76,6 +76,27 @@ class EngineUnavailable(RuntimeError):
     """The HIP extension (or a gfx950 device) is missing.  There is no fallback."""
 
 
+def _share_torch_hip_runtime() -> None:
+    """Make this library share PyTorch-ROCm's bundled HIP / HSA / RCCL runtime when torch is installed.
+
+    The torch wheel ships its own ``libamdhip64.so`` (SONAME ``libamdhip64.so.7``) and asks for it by the
+    unversioned file name; ``libsalnmf.so`` asks for the SONAME.  Whichever is loaded first decides: with
+    torch's copy first both resolve to it; with the system copy first torch later loads a second runtime, and of
+    two HIP runtimes in one process the one that initialises second sees no device.  Importing torch before the
+    first ``dlopen`` of this library is the order that works (opening torch's libraries by hand instead makes the
+    process abort in their destructors at exit).  Without torch the system libraries are used."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        if importlib.util.find_spec("torch") is not None:
+            import torch  # noqa: F401
+    except Exception:  # a broken torch install must not take the engine down with it
+        pass
+
+
 def load():
     """Load ``libsalnmf.so`` and declare every prototype.  Loading needs no GPU."""
     global _lib
@@ -86,6 +107,7 @@ def load():
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  salamander_amd has no CPU fallback."
         )
+    _share_torch_hip_runtime()
     lib = ctypes.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

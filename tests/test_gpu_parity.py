@@ -350,9 +350,16 @@ def test_rccl_communicator_single_rank_path():
             e.upload_X(X), e.upload_W(W0), e.upload_H(H0)
             e.kl_step(5, 2)
             res.append((e.download_W(), e.download_H(), e.objective()))
+            # the MvNMF step through the same communicator: all-reduce of [G | row sums | KL] and of the trial's
+            # KL, next to the two-stream / speculative machinery (identical bits expected at world size 1)
+            gamma = e.mv_step(4, 1, 1.0, 1.0, 1.0)
+            gamma = e.mv_update_W(0, 1.0, 1.0, gamma)
+            res[-1] += (gamma, e.mv_objective(1.0, 1.0), e.download_W(), e.download_H())
             e.close()
         assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
         assert res[0][2] == res[1][2]
+        assert res[0][3] == res[1][3] and res[0][4] == res[1][4]
+        assert np.array_equal(res[0][5], res[1][5]) and np.array_equal(res[0][6], res[1][6])
     finally:
         if created:
             dist.destroy_process_group()
@@ -395,3 +402,26 @@ def _post_init(g):
 
     S0, E0 = initialize_mat(g["X"].T, g["W0"].shape[1], "custom", signatures_mat=g["W0"].T.copy(), exposures_mat=g["H0"].T.copy())
     return S0.T, E0.T
+
+
+def test_engine_and_torch_share_one_hip_runtime_in_either_import_order():
+    """PyTorch-ROCm bundles its own HIP runtime; of two runtimes in one process the second sees no device.
+    ``_lib.load()`` imports torch first so that both use one copy -- in a fresh process, engine first then torch."""
+    import subprocess
+    import sys
+
+    code = (
+        "from salamander_amd import Engine\n"
+        "e = Engine(64, 96, 3)\n"
+        "import torch\n"
+        "assert torch.cuda.is_available()\n"
+        "assert torch.ones(3, device='cuda').sum().item() == 3.0\n"
+        "e.close()\n"
+        "maps = open('/proc/self/maps').read()\n"
+        "assert len({l.split()[-1] for l in maps.splitlines() if 'libamdhip64' in l}) == 1\n"
+        "print('ok')\n"
+    )
+    from conftest import ROOT
+
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.returncode, r.stdout[-500:], r.stderr[-2000:])
