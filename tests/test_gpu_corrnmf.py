@@ -516,3 +516,47 @@ def test_model_three_updates_match_reference_executed_trajectory(ref):
     assert np.allclose(adata.obsm["embeddings"], r["U3"], rtol=1e-5, atol=1e-7)
     assert np.isclose(m.variance, float(r["var3"]), rtol=1e-6)
     assert np.isclose(m.objective_function(), float(r["elbos"][-1]), rtol=1e-9)
+
+
+@pytest.mark.parametrize("N,K,dim,V", [(1, 1, 1, 96), (17, 1, 1, 7), (33, 64, 1, 16), (5, 3, 3, 83), (250, 2, 2, 96)])
+def test_edge_shapes_full_update_matches_oracle(N, K, dim, V):
+    """Degenerate shapes through one full resident update: a single sample, a single signature, V < 96, ragged N."""
+    import salamander_amd as sal
+    from salamander_amd.models import CorrNMFDet
+
+    rng = np.random.default_rng(N + K + dim + V)
+    X, W, _ = ko.synthetic_problem(V, N, K, seed=N + K)
+    adata = sal.AnnData(X.copy())
+    adata.obs["scalings"] = np.log(X.sum(axis=1) / K)
+    adata.obsm["embeddings"] = rng.normal(0, 0.3, (N, dim))
+    sigs = sal.AnnData(W.copy())
+    sigs.obs["scalings"] = rng.normal(0, 0.1, K)
+    sigs.obsm["embeddings"] = rng.normal(0, 0.3, (K, dim))
+    want = co.corrnmf_det_step(X, W, sigs.obs["scalings"].values.copy(), adata.obs["scalings"].values.copy(),
+                               sigs.obsm["embeddings"].copy(), adata.obsm["embeddings"].copy(), 1.0)
+    m = CorrNMFDet(n_signatures=K, dim_embeddings=dim)
+    m.adata, m.asignatures = adata, sigs
+    m.compute_exposures()
+    m._update_parameters()
+    assert np.allclose(m.asignatures.X, want[0], rtol=1e-6, atol=1e-12)
+    assert np.allclose(adata.obsm["exposures"], want[6], rtol=1e-9)
+    assert np.allclose(sigs.obsm["embeddings"], want[3], rtol=1e-4, atol=1e-6)
+    assert np.allclose(adata.obsm["embeddings"], want[4], rtol=1e-4, atol=1e-6)
+    assert np.isclose(m.variance, want[5], rtol=1e-5)
+
+
+def test_embedding_solves_terminate_on_non_finite_input():
+    """NaN / inf in the inputs must not hang a solve: every loop of the Newton-CG is bounded and NaN fails its tests."""
+    X, W, beta, alpha, L, U, aux = embedding_problem(40, 3, 2, seed=3)
+    U[5, 0] = np.nan
+    aux[1, 7] = np.inf
+    e = engine_from(X, W, beta, alpha, L, U)
+    e.corr_upload(_lib.CORR_AUX, np.ascontiguousarray(aux.T))
+    e.corr_update_sample_embeddings(1.0, 3)
+    e.corr_update_signature_embeddings(1.0, 0)
+    e.sync()
+    got = e.corr_download(_lib.CORR_SAMPLE_EMBEDDINGS)
+    e.close()
+    clean = np.ones(40, dtype=bool)
+    clean[[5, 7]] = False
+    assert np.isfinite(got[clean]).all()
