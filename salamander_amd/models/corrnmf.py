@@ -50,20 +50,19 @@ class CorrNMF(SignatureNMF):
         e = self._engine
         if getattr(e, "dim", None) != self.dim_embeddings:
             e.corr_configure(self.dim_embeddings)
-        e.corr_upload(_lib.CORR_SIGNATURE_SCALINGS, np.asarray(self.asignatures.obs["scalings"].values, dtype=np.float64))
-        e.corr_upload(_lib.CORR_SAMPLE_SCALINGS, np.asarray(self.adata.obs["scalings"].values, dtype=np.float64))
-        e.corr_upload(_lib.CORR_SIGNATURE_EMBEDDINGS, self.asignatures.obsm["embeddings"])
-        e.corr_upload(_lib.CORR_SAMPLE_EMBEDDINGS, self.adata.obsm["embeddings"])
+        buffers = (_lib.CORR_SIGNATURE_SCALINGS, _lib.CORR_SAMPLE_SCALINGS, _lib.CORR_SIGNATURE_EMBEDDINGS, _lib.CORR_SAMPLE_EMBEDDINGS)
+        for which, values in zip(buffers, self._factors()):
+            e.corr_upload(which, np.asarray(values, dtype=np.float64))
 
     # ------------------------------------------------------------------ reference hooks
+    def _factors(self):
+        """(signature scalings, sample scalings, signature embeddings, sample embeddings) of the host state."""
+        sig, smp = self.asignatures, self.adata
+        return sig.obs["scalings"].values, smp.obs["scalings"].values, sig.obsm["embeddings"], smp.obsm["embeddings"]
+
     def compute_exposures(self) -> None:
         """``adata.obsm['exposures']`` from the scalings and embeddings (corrnmf.py:66-77)."""
-        self.adata.obsm["exposures"] = _utils_corrnmf.compute_exposures(
-            self.asignatures.obs["scalings"].values,
-            self.adata.obs["scalings"].values,
-            self.asignatures.obsm["embeddings"],
-            self.adata.obsm["embeddings"],
-        )
+        self.adata.obsm["exposures"] = _utils_corrnmf.compute_exposures(*self._factors())
 
     def compute_reconstruction_errors(self) -> None:
         """Samplewise KL divergences of the recomputed exposures (corrnmf.py:79-84)."""
@@ -73,15 +72,9 @@ class CorrNMF(SignatureNMF):
 
     def objective_function(self, penalize_sample_embeddings: bool = True) -> float:
         """The evidence lower bound, with the exposures as currently stored (corrnmf.py:86-98)."""
-        return _utils_corrnmf.elbo_corrnmf(
-            self.adata.X,
-            self.asignatures.X,
-            self.adata.obsm["exposures"],
-            self.asignatures.obsm["embeddings"],
-            self.adata.obsm["embeddings"],
-            self.variance,
-            penalize_sample_embeddings=penalize_sample_embeddings,
-        )
+        _, _, sig_embeddings, sample_embeddings = self._factors()
+        llh = _utils_corrnmf.poisson_llh(self.adata.X, self.asignatures.X, self.adata.obsm["exposures"])
+        return llh + _utils_corrnmf.embedding_priors(sig_embeddings, sample_embeddings, self.variance, penalize_sample_embeddings)
 
     def _initialize(self, given_parameters: dict[str, Any] | None = None, init_kwargs: dict[str, Any] | None = None) -> None:
         """Signatures, scalings, embeddings and variance; then the exposures (corrnmf.py:104-136)."""
@@ -98,8 +91,10 @@ class CorrNMF(SignatureNMF):
     def compute_correlation_scaled(self, data: Literal["samples", "signatures"] = "signatures") -> None:
         """Cosine similarities of the embeddings -> ``obsp`` (corrnmf.py:146-178)."""
         value_checker("data", data, ["samples", "signatures"])
-        assert "embeddings" in self.adata.obsm, "Computing the sample or signature correlation requires fitting the CorrNMF model."
-        vectors = np.asarray(self.adata.obsm["embeddings"] if data == "samples" else self.asignatures.obsm["embeddings"])
+        if "embeddings" not in self.adata.obsm:
+            raise AssertionError("Computing the sample or signature correlation requires fitting the CorrNMF model.")
+        holder = self.adata if data == "samples" else self.asignatures
+        vectors = np.asarray(holder.obsm["embeddings"])
         unit = vectors / np.sqrt(np.sum(vectors**2, axis=1))[:, None]
         correlation = unit @ unit.T
         np.fill_diagonal(correlation, 1.0)
