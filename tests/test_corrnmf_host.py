@@ -171,3 +171,10 @@ def test_multimodal_model_setup_checks(mdata):
         m._setup_mdata(bad)
     m._setup_mdata(mdata)
     assert m.mod_names == ["sbs", "indel"] and m.sample_names == [f"s{i}" for i in range(9)]
+
+
+def test_corrnmf_det_refuses_sample_sharding(adata):
+    m = CorrNMFDet(n_signatures=2, dim_embeddings=2, distributed=True)
+    m.adata = adata
+    with pytest.raises(NotImplementedError, match="sample-sharded"):
+        m._sync_to_device()
