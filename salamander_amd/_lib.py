@@ -77,24 +77,34 @@ class EngineUnavailable(RuntimeError):
 
 
 def _share_torch_hip_runtime() -> None:
-    """Make this library share PyTorch-ROCm's bundled HIP / HSA / RCCL runtime when torch is installed.
+    """Make this library share PyTorch-ROCm's bundled HIP runtime when torch is installed.
 
     The torch wheel ships its own ``libamdhip64.so`` (SONAME ``libamdhip64.so.7``) and asks for it by the
-    unversioned file name; ``libsalnmf.so`` asks for the SONAME.  Whichever is loaded first decides: with
-    torch's copy first both resolve to it; with the system copy first torch later loads a second runtime, and of
-    two HIP runtimes in one process the one that initialises second sees no device.  Importing torch before the
-    first ``dlopen`` of this library is the order that works (opening torch's libraries by hand instead makes the
-    process abort in their destructors at exit).  Without torch the system libraries are used."""
+    unversioned file name; ``libsalnmf.so`` asks for the SONAME.  Whichever is loaded first decides: with torch's
+    copy first both resolve to it; with the system copy first torch later loads a second runtime, and of two HIP
+    runtimes in one process the one that initialises second sees no device.  So torch's ``libamdhip64.so`` is
+    opened first, by path and without importing torch (20 ms instead of seconds); a later ``import torch`` finds
+    it loaded.  Only the HIP runtime is preloaded: opening torch's ``librccl.so`` by hand makes the process abort
+    in its destructors at exit, so without torch imported first this library talks to the system RCCL (with
+    torch imported first, as in ``bench.py`` and every ``torch.distributed`` launch, to torch's).
+    ``SALNMF_SHARE_TORCH_RUNTIME=0`` disables the preload; without torch the system libraries are used."""
     import importlib.util
     import sys
 
-    if "torch" in sys.modules:
+    if "torch" in sys.modules or os.environ.get("SALNMF_SHARE_TORCH_RUNTIME", "1") == "0":
         return
     try:
-        if importlib.util.find_spec("torch") is not None:
-            import torch  # noqa: F401
-    except Exception:  # a broken torch install must not take the engine down with it
-        pass
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass  # an incomplete torch install: fall back to the system runtime
 
 
 def load():

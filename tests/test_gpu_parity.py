@@ -406,7 +406,7 @@ def _post_init(g):
 
 def test_engine_and_torch_share_one_hip_runtime_in_either_import_order():
     """PyTorch-ROCm bundles its own HIP runtime; of two runtimes in one process the second sees no device.
-    ``_lib.load()`` imports torch first so that both use one copy -- in a fresh process, engine first then torch."""
+    ``_lib.load()`` opens torch's HIP runtime first so that both use one copy -- in a fresh process, engine first then torch."""
     import subprocess
     import sys
 
