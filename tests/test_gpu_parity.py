@@ -425,3 +425,54 @@ def test_engine_and_torch_share_one_hip_runtime_in_either_import_order():
 
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+
+
+def test_mvnmf_mixed_call_sequences_match_oracle():
+    """State machine check: MvNMF steps leave H lazily rescaled, W / H buffers swapped and (inside a call) the next
+    update_H pass possibly pre-computed; every other entry point in between must see the same state as the oracle."""
+    V, N, K = 96, 700, 9
+    X, W0, H0 = orc.synthetic_problem(V, N, K, seed=77)
+    lam, delta = 2.0, 0.5
+
+    def mv(W, H, gamma, steps, ng=0):
+        for _ in range(steps):
+            W, H, gamma = orc.mvnmf_step(X.T, W, H, lam, delta, gamma, ng)
+        return W, H, gamma
+
+    e = Engine(N, V, K)
+    e.upload_X(X), e.upload_W(W0), e.upload_H(H0)
+    W, H, g = W0.T, H0.T, 1.0
+    # 1. MvNMF steps, then plain KL steps, then MvNMF again
+    g_dev = e.mv_step(3, 0, lam, delta, 1.0)
+    W, H, g = mv(W, H, g, 3)
+    e.kl_step(2, 1)
+    for _ in range(2):
+        W, H = orc.update_WH(X.T, W, H, None, None, 1)
+    g_dev = e.mv_step(2, 2, lam, delta, g_dev)
+    W, H, g = mv(W, H, g, 2, ng=2)
+    assert np.isclose(g_dev, g, rtol=1e-12)
+    assert rel_l2(e.download_W(), W.T) < 1e-8 and rel_l2(e.download_H(), H.T) < 1e-8
+    # 2. read-only consumers on a pending rescale (no download in between)
+    g_dev = e.mv_step(2, 0, lam, delta, g_dev)
+    W, H, g = mv(W, H, g, 2)
+    assert np.allclose(e.samplewise_kl(), orc.samplewise_kl_divergence(X.T, W, H), rtol=1e-7)
+    assert rel_l2(e.reconstruct(), (W @ H).T) < 1e-8
+    assert np.isclose(e.objective(), orc.kl_divergence(X.T, W, H), rtol=1e-9)
+    # 3. a stand-alone update_H, then a stand-alone MvNMF W update
+    e.update_H()
+    H = orc.update_H(X.T, W, H)
+    g_dev = e.mv_update_W(0, lam, delta, g_dev)
+    Wu = orc.update_W_unconstrained(X.T, W, H, lam, delta, 0)
+    W, H, g = orc.line_search(X.T, W, H, lam, delta, g, Wu)
+    assert np.isclose(g_dev, g, rtol=1e-12)
+    assert rel_l2(e.download_W(), W.T) < 1e-8 and rel_l2(e.download_H(), H.T) < 1e-8
+    # 4. new exposures uploaded over a pending rescale, new signatures too
+    g_dev = e.mv_step(1, 0, lam, delta, g_dev)
+    W, H, g = mv(W, H, g, 1)
+    e.upload_H(H0)
+    e.upload_W(W0)
+    g_dev = e.mv_step(2, 0, lam, delta, g_dev)
+    W, H, g = mv(W0.T, H0.T, g, 2)
+    assert np.isclose(g_dev, g, rtol=1e-12)
+    assert rel_l2(e.download_W(), W.T) < 1e-8 and rel_l2(e.download_H(), H.T) < 1e-8
+    e.close()
