@@ -1,31 +1,41 @@
-"""Headline benchmark: KL-NMF update-steps/sec at 96 x N, k = 50 (BASELINE.json).
+"""Headline benchmark: KL-NMF update-steps/sec (and wall-clock to fixed KL) at 96 x N, k = 50 (BASELINE.json).
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one joint KLNMF update (W and H both updated = one ``update_WH`` call of the
-reference, ``_utils_klnmf.py:281-361``) of the device-resident state.  Per GPU the workload
-is config c2 of BASELINE.json -- synthetic Poisson counts 96 x 100 000, k = 50, fp64; with
-N GPUs the sample axis is sharded (N x 100 000 samples in total, weak scaling) and every
-step contains one RCCL all-reduce of the 50 x 96 numerator.  ``value`` = shard-steps all
-ranks completed per second = N x (global steps / s); at N = 1 that is plain update-steps/s
-on c2.  Inputs are resident in HBM before the timed region.
+A "step" is one joint KLNMF update (W and H both updated = one ``update_WH`` call of the reference,
+``_utils_klnmf.py:281-361``) of the device-resident state.  fp64, synthetic Poisson counts.
 
-Rank 0 prints ONE JSON line.  ``roofline`` prices the dominant kernel (the fused update
-pass) on algorithmic flops 6*V*K*N against the fp64 MFMA peak; its duration is measured
-with HIP events on the engine's stream around the launches of every 25th step inside the
-timed region (an event record costs a few microseconds of stream time, so denser sampling would
-slow the very loop it measures).
-``cpu_baseline`` times the NumPy oracle (the restated reference arithmetic) on this box's
-host cores, rank 0, N = 1 only.
+Workload
+  * ``--gpus 1``: config c2 of BASELINE.json, 96 x 100 000, k = 50 -- the configuration the metric is quoted on.
+  * ``--gpus N`` (N > 1): config c3, 96 x 1 000 000 **in total**, the sample axis split over the ranks with
+    ``distributed.shard_bounds`` (**strong scaling**); every step contains one RCCL all-reduce of the 50 x 96
+    numerator.  ``value`` = global update-steps/s of the whole job (NOT multiplied by N).  Rank 0 also runs the
+    same 10^6-sample problem alone on its GPU and reports that figure (``config.one_gpu_same_problem``) --
+    the number an N-GPU value has to be compared with; c2 at N = 1 is a different (10x smaller) problem.
+    ``--weak`` restores round 1's weak-scaling reading (100 000 samples per GPU, value = N x global steps/s).
+
+Timing: W untimed warm-up steps, then blocks of EXACTLY K steps, each bracketed by barrier +
+stream/torch synchronisation on both sides, maximum over ranks per block.  One block of 20 steps is 1.6 ms,
+too short to carry a number, so the block is repeated until the GPU has been busy for ~2.5 s and the line
+reports the MEDIAN block (``ms_per_step`` = median / K, with min / max / first block beside it).  Events and
+buffers are created by an untimed pass first.  Inputs are resident in HBM before any timed region.
+
+Rank 0 prints ONE JSON line.  ``roofline`` prices the dominant kernel (the fused update pass) on algorithmic
+flops 6*V*K*N_local against the fp64 MFMA peak; its duration is the mean over >= 100 launches sampled with HIP
+events on the engine's stream in a separate, untimed pass.  ``cpu_baseline`` times the NumPy oracle (the
+restated reference arithmetic) on this box's host cores (rank 0, N = 1 only); the same CPU run defines the
+target of ``time_to_kl``.  ``extra`` carries the other single-GPU configurations (c4 MvNMF, default-init fit).
 """
 
 from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
+import statistics
 import sys
 import time
 
@@ -35,46 +45,170 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-V, N_PER_GPU, K = 96, 100000, 50
+V, K = 96, 50
+N_C2 = 100000        # config c2 (1 GPU)
+N_C3 = 1000000       # config c3 (sharded)
+BLOCK_ROWS = 125000  # generation block of the 10^6 problem (seed = block index)
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix peak (spec); 77.8 measured by tools/mfma_f64_probe.hip
 
 
-def cpu_baseline(X, W0, H0, budget_s=15.0):
-    """The oracle's update_WH on the host cores: 3 warm-up steps, then timed steps for ~budget_s."""
+def cpu_baseline(X, W0, H0, max_steps=500, budget_s=150.0):
+    """The oracle's update_WH on the host cores from the shared init: 3 untimed warm-up steps on copies, then up
+    to ``max_steps`` timed steps (stopping early at a multiple of 10 once ``budget_s`` is spent).  Returns the
+    baseline record and (steps, objective after those steps, seconds) for time_to_kl."""
     from oracle import klnmf_oracle as orc
 
-    Xt, W, H = np.asfortranarray(X.T), W0.T.copy(), H0.T.copy()  # the layouts the reference computes on
+    Xt = np.asfortranarray(X.T)  # the layouts the reference computes on
+    W, H = W0.T.copy(), H0.T.copy()
     for _ in range(3):
         W, H = orc.update_WH(Xt, W, H)
+    W, H = W0.T.copy(), H0.T.copy()
     n, t0 = 0, time.perf_counter()
-    while True:
+    while n < max_steps:
         W, H = orc.update_WH(Xt, W, H)
         n += 1
         dt = time.perf_counter() - t0
-        if dt > budget_s or n >= 200:
+        if dt > budget_s and n % 10 == 0:
             break
+    dt = time.perf_counter() - t0
+    target = float(orc.kl_divergence(Xt, W, H))
     try:
         from threadpoolctl import threadpool_info
 
         cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [os.cpu_count() or 1])
     except Exception:
         cores = os.cpu_count() or 1
-    return {
+    rec = {
         "value": n / dt,
         "unit": "update-steps/s",
         "cores": int(cores),
         "kind": "port",
-        "sample": f"{n} timed update_WH steps (after 3 warm-up) of the NumPy oracle on the full 96x{X.shape[0]} k={K} workload, numpy {np.__version__}",
+        "sample": f"{n} timed update_WH steps from the shared init (after 3 warm-up steps) of the NumPy oracle on the full "
+        f"96x{X.shape[0]} k={K} workload, numpy {np.__version__}, {dt:.1f} s",
     }
+    return rec, (n, target, dt)
+
+
+def time_to_kl(sal, X, W0, H0, cpu_steps, target, cpu_seconds, device):
+    """Wall-clock until the device-resident loop (objective every 10 steps, as fit does) is at or below the KL
+    the CPU path reached after ``cpu_steps`` steps from the same init; then the same through KLNMF.fit."""
+    N = X.shape[0]
+    e = sal.Engine(N, V, K, device=device)
+    e.upload_X(X), e.upload_W(W0), e.upload_H(H0)
+    e.objective()
+    e.sync()
+    limit = cpu_steps + 100
+    t0 = time.perf_counter()
+    steps, obj = 0, float("inf")
+    while steps < limit:
+        e.kl_step(10)
+        steps += 10
+        obj = e.objective()
+        if obj <= target * (1 + 1e-12):
+            break
+    loop_s = time.perf_counter() - t0
+    e.close()
+    adata = sal.AnnData(X.copy())
+    model = sal.models.KLNMF(K, "custom", min_iterations=steps, max_iterations=steps, device=device)
+    t0 = time.perf_counter()
+    model.fit(adata, init_kwargs={"signatures_mat": W0.copy(), "exposures_mat": H0.copy()})
+    fit_s = time.perf_counter() - t0
+    return {
+        "target": f"KL the NumPy oracle reaches after {cpu_steps} update_WH steps from the shared init",
+        "cpu_steps": cpu_steps,
+        "target_kl": target,
+        "cpu_seconds": cpu_seconds,
+        "gpu_steps_to_target": steps,
+        "gpu_objective_there": obj,
+        "reached": bool(obj <= target * (1 + 1e-12)),
+        "gpu_loop_seconds": loop_s,
+        "gpu_fit_seconds_end_to_end": fit_s,
+        "fit_objective_last": float(model.history["objective_function"][-1]) if model.history["objective_function"] else None,
+    }
+
+
+def extra_c4(sal, device):
+    """Config c4: MvNMF n_signatures=30 on 96 x 100 000 (lam = delta = 1), device-resident steps."""
+    from salamander_amd.synthetic import synthetic_problem
+
+    Kc = 30
+    X, W0, H0 = synthetic_problem(V, N_C2, Kc, seed=2)
+    e = sal.Engine(N_C2, V, Kc, device=device)
+    e.upload_X(X), e.upload_W(W0), e.upload_H(H0)
+    g = e.mv_step(10, 0, 1.0, 1.0, 1.0)
+    e.sync()
+    blocks = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        g = e.mv_step(50, 0, 1.0, 1.0, g)
+        e.sync()
+        blocks.append((time.perf_counter() - t0) / 50)
+    e.close()
+    t = statistics.median(blocks)
+    flops = 12.0 * V * Kc * N_C2  # SURVEY.md 8d: >= 12 V K N per MvNMF iteration
+    return {
+        "workload": f"c4: MvNMF n_signatures={Kc}, {V}x{N_C2}, lam=delta=1, 5 blocks of 50 device-resident steps (median)",
+        "us_per_step": t * 1e6,
+        "steps_per_s": 1.0 / t,
+        "us_per_step_min": min(blocks) * 1e6,
+        "us_per_step_max": max(blocks) * 1e6,
+        "algorithmic_flops_per_step": flops,
+        "frac_of_fp64_mfma_peak": flops / t / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+        "gamma_after": g,
+    }
+
+
+def extra_default_init_fit(sal, device):
+    """KLNMF(50).fit(adata) with the DEFAULT init_method on c2: seconds of initialisation next to the loop."""
+    from salamander_amd.synthetic import synthetic_problem
+
+    X, _, _ = synthetic_problem(V, N_C2, K, seed=0)
+    adata = sal.AnnData(X.copy())
+    model = sal.models.KLNMF(K, min_iterations=500, max_iterations=500, device=device)
+    t0 = time.perf_counter()
+    model._setup_adata(adata)
+    model._initialize(None, None)
+    init_s = time.perf_counter() - t0
+    adata = sal.AnnData(X.copy())
+    model = sal.models.KLNMF(K, min_iterations=500, max_iterations=500, device=device)
+    t0 = time.perf_counter()
+    model.fit(adata)
+    fit_s = time.perf_counter() - t0
+    return {
+        "workload": f"KLNMF({K}).fit(adata), init_method='{model.init_method}' (the default), {V}x{N_C2}, 500 iterations",
+        "init_seconds": init_s,
+        "fit_seconds_end_to_end": fit_s,
+        "objective_last": float(model.history["objective_function"][-1]),
+    }
+
+
+def problem_rows(start, stop):
+    """Rows [start, stop) of the 10^6-sample problem: 125 000-row blocks, block b drawn with seed b
+    (per-shard seeds, no 8 GB host temporary).  W0 is block 0's."""
+    from salamander_amd.synthetic import synthetic_problem
+
+    Xs, Hs = [], []
+    for b in range(start // BLOCK_ROWS, (stop - 1) // BLOCK_ROWS + 1):
+        Xb, _, Hb = synthetic_problem(V, BLOCK_ROWS, K, seed=b)
+        lo, hi = max(start, b * BLOCK_ROWS) - b * BLOCK_ROWS, min(stop, (b + 1) * BLOCK_ROWS) - b * BLOCK_ROWS
+        Xs.append(Xb[lo:hi])
+        Hs.append(Hb[lo:hi])
+    return np.concatenate(Xs), np.concatenate(Hs)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--samples-per-gpu", type=int, default=N_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle run (and time_to_kl)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra single-GPU configurations")
+    ap.add_argument("--cpu-steps", type=int, default=500, help="CPU oracle steps that define the time-to-KL target")
+    ap.add_argument("--cpu-budget", type=float, default=150.0, help="seconds after which the CPU run stops early")
+    ap.add_argument("--samples-total", type=int, default=0, help="override the total number of samples")
+    ap.add_argument("--weak", action="store_true", help="N > 1: 100 000 samples per GPU instead of 10^6 in total")
+    ap.add_argument("--no-one-gpu-reference", action="store_true", help="N > 1: skip rank 0's run of the whole problem on one GPU")
+    ap.add_argument("--busy-seconds", type=float, default=2.5, help="repeat the K-step block until the GPU was busy this long")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -83,9 +217,10 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
 
-    import torch
+    import torch  # before salamander_amd: the engine must bind torch's HIP runtime and RCCL (salamander_amd/_lib.py)
 
     import salamander_amd as sal
+    from salamander_amd.distributed import shard_bounds
     from salamander_amd.synthetic import synthetic_problem
 
     dist = None
@@ -95,9 +230,22 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    n_local = args.samples_per_gpu
-    # every rank's shard comes from its own seed; W0 is rank 0's (broadcast below)
-    X, W0, H0 = synthetic_problem(V, n_local, K, seed=rank)
+    strong = world > 1 and not args.weak
+    if world == 1:
+        n_total = args.samples_total or N_C2
+        X, W0, H0 = synthetic_problem(V, n_total, K, seed=0)
+        n_local = n_total
+    elif strong:
+        n_total = args.samples_total or N_C3
+        lo, hi = shard_bounds(n_total, world, rank)
+        X, H0 = problem_rows(lo, hi)
+        _, W0, _ = synthetic_problem(V, 16, K, seed=0)  # W0 depends on the seed only (drawn after X: same draws need same N)
+        n_local = hi - lo
+    else:
+        n_local = N_C2
+        n_total = n_local * world
+        X, W0, H0 = synthetic_problem(V, n_local, K, seed=rank)
+
     engine = sal.Engine(n_local, V, K, device=local_rank)
     if world > 1:
         from salamander_amd.distributed import attach_communicator, broadcast_from_rank0
@@ -114,76 +262,157 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    engine.kl_step(args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    total_ms, fused_ms, tail_ms = engine.profile_kl_steps(args.steps, 0, 25)  # HIP events on every 25th step; syncs the stream
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return float(t.item())
+
+    # untimed: warm-up steps, and one profiling pass so that every event / lazily sized buffer exists
+    engine.kl_step(args.warmup)
+    engine.profile_kl_steps(8, 0, 2)
+
+    def timed_block():
+        barrier()
+        t0 = time.perf_counter()
+        engine.kl_step(args.steps)
+        barrier()
+        return max_over_ranks(time.perf_counter() - t0)
+
+    first = timed_block()
+    n_blocks = int(min(1000, max(5, math.ceil(args.busy_seconds / max(first, 1e-6)))))
+    blocks = [timed_block() for _ in range(n_blocks)]
+    median = statistics.median(blocks)
+
+    # untimed: kernel durations from HIP events around every 2nd step of 200 (100 samples each)
+    barrier()
+    _, fused_ms, tail_ms = engine.profile_kl_steps(200, 0, 2)
     objective = engine.objective()
-    fwd_ms = engine.profile_objective(10)
-    wh_ms = engine.profile_reconstruct(10)
+    fwd_ms = engine.profile_objective(20)
+    wh_ms = engine.profile_reconstruct(20)
+    barrier()
+
+    one_gpu = None
+    if strong and not args.no_one_gpu_reference:
+        # the same problem on ONE GPU (rank 0's), the figure the N-GPU value is to be compared with
+        if rank == 0:
+            Xa, Ha = problem_rows(0, n_total)
+            e1 = sal.Engine(n_total, V, K, device=local_rank)
+            e1.upload_X(Xa), e1.upload_W(W0), e1.upload_H(Ha)
+            del Xa, Ha
+            e1.kl_step(5)
+            e1.sync()
+            ts = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                e1.kl_step(args.steps)
+                e1.sync()
+                ts.append((time.perf_counter() - t0) / args.steps)
+            e1.close()
+            t1 = statistics.median(ts)
+            one_gpu = {
+                "n_gpus": 1,
+                "n_samples": n_total,
+                "ms_per_step": t1 * 1e3,
+                "steps_per_s": 1.0 / t1,
+                "speedup_of_this_run": (args.steps / median) * t1,
+                "how": f"rank 0 alone, median of 5 blocks of {args.steps} steps, same 10^6-sample problem",
+            }
+        barrier()
 
     if rank == 0:
         flops_step = 6.0 * V * K * n_local  # algorithmic flops of one launch of the fused kernel
         achieved = flops_step / (fused_ms * 1e-3) / 1e12
-        traffic = None
+        traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("fused_kernel_hbm_bytes_per_launch")
+                rec = json.load(open(pmc))
+                traffic = rec.get("fused_kernel_hbm_bytes_per_launch")
+                traffic_source = (
+                    f"NOT measured in this run: profiles/pmc_summary.json ({rec.get('date', 'round 1')}), rocprofv3 --pmc "
+                    "FETCH_SIZE / WRITE_SIZE passes of this command at c2 (FETCH x2 gfx950 correction applied)"
+                )
             except Exception:
                 traffic = None
+        steps_per_s = args.steps / median
         line = {
-            "metric": "KL-NMF update-steps/sec (96x100000-sample shard per GPU, k=50)",
-            "value": world * args.steps / elapsed,
+            "metric": "KL-NMF update-steps/sec (96xN, k=50)",
+            "value": steps_per_s * (world if (world > 1 and not strong) else 1),
             "unit": "update-steps/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": median / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"c2: KLNMF n_signatures={K} on synthetic Poisson counts {V}x{n_local} per GPU (joint update_WH steps, device resident)",
+                "workload": (
+                    f"c3: KLNMF n_signatures={K} on synthetic Poisson counts {V}x{n_total} in total, sample-sharded over {world} GPUs "
+                    f"({n_local} rows on rank 0), joint update_WH steps, device resident"
+                    if strong
+                    else f"c2: KLNMF n_signatures={K} on synthetic Poisson counts {V}x{n_local} per GPU (joint update_WH steps, device resident)"
+                ),
                 "n_features": V,
                 "n_samples_per_gpu": n_local,
-                "n_samples_total": n_local * world,
+                "n_samples_total": n_total,
                 "n_signatures": K,
                 "parallelism": f"sample-sharded x{world}; one RCCL all-reduce of {K}x{V} f64 per step" if world > 1 else "single GPU",
-                "global_steps_per_s": args.steps / elapsed,
+                "global_steps_per_s": steps_per_s,
                 "objective_after_run": objective,
+                "one_gpu_same_problem": one_gpu,
+            },
+            "timing": {
+                "blocks": n_blocks,
+                "steps_per_block": args.steps,
+                "block_ms_median": median * 1e3,
+                "block_ms_min": min(blocks) * 1e3,
+                "block_ms_max": max(blocks) * 1e3,
+                "first_block_ms": first * 1e3,
+                "ms_per_step_best_block": min(blocks) / args.steps * 1e3,
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": "fused_kernel<13,G,U> (P=H.W, R=X/P, G+=H^T.R, U=R.W^T, H update)",
+                "kernel": "fused_kernel<13,3,2,G,U> (P=H.W, R=X/P, G+=H^T.R, U=R.W^T, H update)",
                 "achieved": achieved,
                 "peak": FP64_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
                 "traffic": traffic,
+                "traffic_source": traffic_source,
                 "algorithmic_flops_per_launch": flops_step,
                 "kernel_avg_ms": fused_ms,
+                "kernel_samples": 100,
                 "tail_avg_ms": tail_ms,
-                "event_total_ms_per_step": total_ms / args.steps,
+                "step_frac_of_peak": flops_step / (median / args.steps) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                 "forward_objective_kernel_ms": fwd_ms,
                 "forward_WH_frac": 2.0 * V * K * n_local / (fwd_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                 "WH_only_kernel_ms": wh_ms,
                 "WH_only_frac": 2.0 * V * K * n_local / (wh_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(X, W0, H0)
+        engine.close()
+        if world == 1:
+            if not args.no_cpu_baseline:
+                rec, (n_cpu, target, cpu_s) = cpu_baseline(X, W0, H0, args.cpu_steps, args.cpu_budget)
+                line["cpu_baseline"] = rec
+                line["time_to_kl"] = time_to_kl(sal, X, W0, H0, n_cpu, target, cpu_s, local_rank)
+            if not args.no_extra:
+                extra = {}
+                for name, fn in (("c4_mvnmf", extra_c4), ("c2_default_init_fit", extra_default_init_fit)):
+                    try:
+                        extra[name] = fn(sal, local_rank)
+                    except Exception as exc:  # an extra must never cost the headline line
+                        extra[name] = {"error": f"{type(exc).__name__}: {exc}"}
+                line["extra"] = extra
         print(json.dumps(line), flush=True)
+    else:
+        engine.close()
 
-    engine.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -116,10 +116,19 @@ template <bool DO_G, bool DO_U, bool DO_STATS>
 static int launch_fused(salnmf_engine* e, const FusedParams& p, int grid = 0) {
     dim3 g(grid > 0 ? grid : e->grid), b(BLOCK);
     bool done = false;
-#define SALNMF_CASE(ks, ktm, kr)                                                                           \
-    if (!done && e->KS == ks && e->KTM == ktm && e->KR == kr) {                                            \
-        hipLaunchKernelGGL((fused_kernel<ks, ktm, kr, DO_G, DO_U, DO_STATS>), g, b, 0, e->stream, p);      \
-        done = true;                                                                                       \
+    // per-sample weights select the WTS instantiation (KLNMF only: the MvNMF / CorrNMF passes, which are the
+    // ones that collect statistics, are unweighted)
+    const bool wts = p.wkl || p.wlh;
+    if (wts && DO_STATS) return fail("internal: weighted pass with statistics is not instantiated");
+#define SALNMF_CASE(ks, ktm, kr)                                                                                   \
+    if (!done && e->KS == ks && e->KTM == ktm && e->KR == kr) {                                                    \
+        if constexpr (!DO_STATS) {                                                                                 \
+            if (wts) hipLaunchKernelGGL((fused_kernel<ks, ktm, kr, DO_G, DO_U, false, true>), g, b, 0, e->stream, p);  \
+            else hipLaunchKernelGGL((fused_kernel<ks, ktm, kr, DO_G, DO_U, false, false>), g, b, 0, e->stream, p);     \
+        } else {                                                                                                   \
+            hipLaunchKernelGGL((fused_kernel<ks, ktm, kr, DO_G, DO_U, DO_STATS, false>), g, b, 0, e->stream, p);   \
+        }                                                                                                          \
+        done = true;                                                                                               \
     }
     SALNMF_GEOMETRIES(SALNMF_CASE)
 #undef SALNMF_CASE
@@ -394,7 +403,10 @@ int salnmf_upload_X(salnmf_engine* e, const double* X, int clip) {
     // pad rows / columns are exactly 0 (never clipped): they must contribute X/P = 0
     return upload_padded(e, e ? e->X : nullptr, X, e ? e->V : 0, VMAX, 0.0, 0.0, clip ? kEps : 0.0);
 }
-int salnmf_upload_W(salnmf_engine* e, const double* W) { return upload(e, e ? e->W : nullptr, W, (size_t)e->K * e->V); }
+int salnmf_upload_W(salnmf_engine* e, const double* W) {
+    if (!e) return fail("null engine");
+    return upload(e, e->W, W, (size_t)e->K * e->V);
+}
 int salnmf_upload_H(salnmf_engine* e, const double* H) {
     if (e) e->h_pending = false;
     // pad columns 0, pad rows 1: finite, and positive in the rows so that P > 0 there
@@ -426,7 +438,10 @@ static int download(salnmf_engine* e, double* dst, const double* src, size_t n) 
     HIPCK(hipStreamSynchronize(e->stream));
     return 0;
 }
-int salnmf_download_W(salnmf_engine* e, double* W) { return download(e, W, e ? e->W : nullptr, (size_t)e->K * e->V); }
+int salnmf_download_W(salnmf_engine* e, double* W) {
+    if (!e) return fail("null engine");
+    return download(e, W, e->W, (size_t)e->K * e->V);
+}
 int salnmf_download_H(salnmf_engine* e, double* H) {
     if (!e) return fail("null engine");
     HIPCK(hipSetDevice(e->device));

@@ -56,6 +56,10 @@ __device__ __forceinline__ void mfma_agpr(d4& c, double a, double b) {
     asm("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
 
+// Lower clip with numpy's semantics (ndarray.clip, _utils_klnmf.py:341,347): a NaN stays a NaN, so that a
+// poisoned fit shows up in the objective instead of being masked (fmax would return the bound).
+__device__ __forceinline__ double clip_lo(double x, double lo) { return x < lo ? lo : x; }
+
 // x / p for the path's operands.  Same FMA sequence as hipcc's IEEE fp64 divide (reciprocal, two
 // Newton steps, residual correction) without its range-scaling / fix-up instructions, which only
 // act on operands outside ~[1e-280, 1e280].  Bit-identical to `x / p` on 16.7 M probes covering
@@ -163,18 +167,27 @@ __device__ __forceinline__ double kl_term_fast(double x, double p) { return __bu
 template <int WROWS>
 __device__ __forceinline__ void stage_W(double* Wl, const double* __restrict__ W, int K, int V, int tid) {
     constexpr int WPT = (WROWS * VMAX + BLOCK - 1) / BLOCK;
+    constexpr int TOTAL = WPT * BLOCK;
     double wreg[WPT];
+    // Every workgroup reads the same 38 KB at the same moment: the 32 workgroups that share an XCD's L2 start
+    // at 32 different offsets so that they do not all queue on the same L2 channel.  Unconditional loads from
+    // clamped addresses (all in flight together), the padding is selected afterwards: per-element branches
+    // would serialise the loads.
+    const int rot = 0;
 #pragma unroll
     for (int j = 0; j < WPT; ++j) {
-        int idx = tid + BLOCK * j;
+        int idx = tid + BLOCK * j + rot;
+        idx = idx >= TOTAL ? idx - TOTAL : idx;
         int k = idx / VMAX, v = idx - k * VMAX;
-        wreg[j] = (k < K) ? ((v < V) ? W[k * V + v] : 1.0) : 0.0;
+        wreg[j] = W[(k < K ? k : K - 1) * V + (v < V ? v : V - 1)];
     }
 #pragma unroll
     for (int j = 0; j < WPT; ++j) {
-        int idx = tid + BLOCK * j;
+        int idx = tid + BLOCK * j + rot;
+        idx = idx >= TOTAL ? idx - TOTAL : idx;
         int k = idx / VMAX, v = idx - k * VMAX;
-        if (k < WROWS) Wl[k * WS + v] = wreg[j];
+        const double w = (k < K) ? ((v < V) ? wreg[j] : 1.0) : 0.0;
+        if (k < WROWS) Wl[k * WS + v] = w;
     }
 }
 
@@ -240,7 +253,11 @@ __device__ __forceinline__ double tile_kl(const double (&x)[VT][4], const d4 (&p
 // Output-side signature columns: KTM full 16-wide tiles go through MFMA; KR (0..4) remainder
 // columns k = 16*KTM + j are done on the VALU instead of spending a whole MFMA tile on them
 // (K = 50: KTM = 3, KR = 2 -- 222 instead of 270 MFMAs per tile).  KR = 0: KTM = ceil(K/16).
-template <int KS, int KTM, int KR, bool DO_G, bool DO_U, bool DO_STATS>
+//
+// WTS: the instantiation that honours p.wkl / p.wlh.  The unweighted one has no conditional loads in
+// the tile loop, so hipcc can count vmcnt exactly: with them it falls back to `s_waitcnt vmcnt(0)` at the
+// loop's back edge, which exposes the latency of the H stores of every tile (~1.1 k cycles per tile).
+template <int KS, int KTM, int KR, bool DO_G, bool DO_U, bool DO_STATS, bool WTS = false>
 __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
     using G_ = Geo<KS>;
     constexpr int KT = KTM;  // MFMA tiles on the output side
@@ -257,6 +274,8 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
     const int q = lane >> 4;
     const int V = p.V, K = p.K;
     const int64_t N = p.N;
+    const double* __restrict__ const wkl = WTS ? p.wkl : nullptr;
+    const double* __restrict__ const wlh = WTS ? p.wlh : nullptr;
 
     double* Wl = lds;
     double* Hl = lds + G_::WROWS * WS + wave * (G_::HL + G_::RL);
@@ -264,8 +283,6 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
 
     double* hsl = lds + G_::LDS_DOUBLES;  // [KP] copy of hscale
     if (p.hscale && tid < KP) hsl[tid] = p.hscale[tid];
-    stage_W<G_::WROWS>(Wl, p.W, K, V, tid);
-    __syncthreads();
 
     d4 g[KT][VT];
     if (DO_G) {
@@ -326,8 +343,8 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
             // anyway, from the LDS copy of the scale
 #pragma unroll
             for (int j = 0; j < HV; ++j) {
-                hpre[j][0] = fmax(hpre[j][0] * hsl[hcol[j]], kEps);
-                hpre[j][1] = fmax(hpre[j][1] * hsl[hcol[j] + 1], kEps);
+                hpre[j][0] = clip_lo(hpre[j][0] * hsl[hcol[j]], kEps);
+                hpre[j][1] = clip_lo(hpre[j][1] * hsl[hcol[j] + 1], kEps);
             }
         }
 #pragma unroll
@@ -393,10 +410,10 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
 
         // ---- G += (w_kl . Ht)^T . R   (A = H[n=4r+q][k=16kt+c16], B = register r of R)
         if (DO_G) {
-            if (p.wkl) {
+            if (wkl) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    double wk = p.wkl[n0 + 4 * r + q];
+                    double wk = wkl[n0 + 4 * r + q];
 #pragma unroll
                     for (int kt = 0; kt < KT; ++kt) ga[r][kt] *= wk;
                 }
@@ -411,11 +428,11 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
                 // remainder rows: G[KB+j][v] += sum over this lane's rows n = q+4r of H[n][KB+j] * R[n][v]
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    double wk = p.wkl ? p.wkl[n0 + 4 * r + q] : 1.0;
+                    double wk = wkl ? wkl[n0 + 4 * r + q] : 1.0;
 #pragma unroll
                     for (int j = 0; j < KR; ++j) {
                         double hv = Hl[(4 * r + q) * LS + KB + j];
-                        if (p.wkl) hv *= wk;
+                        if (wkl) hv *= wk;
 #pragma unroll
                         for (int vt = 0; vt < VT; ++vt) grem[j][vt] = __builtin_fma(hv, pr[vt][r], grem[j][vt]);
                     }
@@ -499,12 +516,12 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
             // per launch would otherwise sit dirty in L2 and be flushed at the kernel boundary
             // (-1.5 % on the fused + tail pair, tools/ab_bench.hip).
             double* hdst = p.Hout + (n0 + q) * KP + c16;
-            if (p.wlh == nullptr) {
+            if (wlh == nullptr) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int kt = 0; kt < KT; ++kt) {
-                        const double hn = fmax(hcur[r][kt] * u[kt][r], p.hfloor);
+                        const double hn = clip_lo(hcur[r][kt] * u[kt][r], p.hfloor);
                         __builtin_nontemporal_store(hn, &hdst[4 * r * KP + 16 * kt]);
                         if (DO_STATS) hsum[kt] += (n0 + q + 4 * r < N) ? hn : 0.0;
                     }
@@ -512,18 +529,18 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int64_t n = n0 + q + 4 * r;
-                    const double wl = p.wlh[n];
+                    const double wl = wlh[n];
                     double wk2 = 1.0;
-                    if (p.wkl) { double w = p.wkl[n]; wk2 = w * w; }
+                    if (wkl) { double w = wkl[n]; wk2 = w * w; }
 #pragma unroll
                     for (int kt = 0; kt < KT; ++kt) {
                         double inter = 4.0 * hcur[r][kt] * u[kt][r];
-                        if (p.wkl) inter *= wk2;
+                        if (wkl) inter *= wk2;
                         double disc = 0.25 * wl * wl + inter;
                         double t = wl / 2 - sqrt(disc);
                         double hn = 0.25 * (t * t);
-                        if (p.wkl) hn /= wk2;
-                        hn = fmax(hn, kEps);
+                        if (wkl) hn /= wk2;
+                        hn = clip_lo(hn, kEps);
                         __builtin_nontemporal_store(hn, &hdst[4 * r * KP + 16 * kt]);
                         if (DO_STATS) hsum[kt] += (n < N) ? hn : 0.0;
                     }
@@ -537,20 +554,20 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
                     const int64_t n = n0 + q + 4 * r;
                     const double h = Hl[(q + 4 * r) * LS + KB + j];
                     double hn;
-                    if (p.wlh == nullptr) {
+                    if (wlh == nullptr) {
                         hn = h * urem[0];
                     } else {
-                        const double wl = p.wlh[n];
+                        const double wl = wlh[n];
                         double wk2 = 1.0;
-                        if (p.wkl) { double w = p.wkl[n]; wk2 = w * w; }
+                        if (wkl) { double w = wkl[n]; wk2 = w * w; }
                         double inter = 4.0 * h * urem[0];
-                        if (p.wkl) inter *= wk2;
+                        if (wkl) inter *= wk2;
                         double disc = 0.25 * wl * wl + inter;
                         double t = wl / 2 - sqrt(disc);
                         hn = 0.25 * (t * t);
-                        if (p.wkl) hn /= wk2;
+                        if (wkl) hn /= wk2;
                     }
-                    hn = fmax(hn, p.hfloor);
+                    hn = clip_lo(hn, p.hfloor);
                     p.Hout[n * KP + KB + j] = hn;
                     if (DO_STATS) hsum_rem += (n < N) ? hn : 0.0;
                 }
@@ -558,6 +575,8 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         }
     };
 
+    stage_W<G_::WROWS>(Wl, p.W, K, V, tid);
+    __syncthreads();
     if (tile < p.ntiles) load_tile(tile);
     for (; tile < p.ntiles; tile += tstride) process_tile(tile);
 
@@ -570,41 +589,80 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
             for (int vt = 0; vt < VT; ++vt) asm volatile("" : "+a"(g[kt][vt]));  // orders the reads below after the drain
-        // Cross-wave sum through LDS (all of it is free now), fixed order (wave 0 + 1 + 2 + 3).
-        // Two rounds of VT/2 feature tiles each, so that every wave has a private slot of
-        // [16*KT][HW] doubles: plain unmasked stores, no read-modify-write chains.
-        constexpr int HT = VT / 2, HW = 16 * HT, SLOT = (16 * KT + (KR > 0 ? 16 : 0)) * HW;
-        static_assert(WAVES * SLOT <= G_::LDS_DOUBLES, "reduction slots must fit in LDS");
+        // Cross-wave sum as a reduce-scatter through LDS (all of it is free now): accumulator tile t = (kt, vt) is
+        // owned by wave t % 4.  Every wave parks the tiles it does not own in the accumulator layout (one
+        // conflict-free ds_write per register, no index arithmetic), ONE barrier, then the owner adds the four
+        // contributions in the fixed order wave 0 + 1 + 2 + 3 and stores its tiles: 128-byte row segments.
+        // ROUNDS = 2 (feature halves) only where the parked tiles do not fit (KT = 4).
+        constexpr int REMD = KR > 0 ? WAVES * KR * VMAX : 0;  // parked remainder rows
+        constexpr int ROUNDS = (3 * KT * VT * 256 + REMD <= G_::LDS_DOUBLES) ? 1 : 2;
+        constexpr int VTR = VT / ROUNDS, NT = KT * VTR;
+        static_assert(3 * NT * 256 + REMD <= G_::LDS_DOUBLES, "parked accumulator tiles must fit in LDS");
+        auto owned = [](int o) constexpr { return o < NT ? (NT - o + 3) / 4 : 0; };   // tiles owned by wave o
+        auto pbase = [&](int o) constexpr { int b = 0; for (int i = 0; i < o; ++i) b += 3 * owned(i); return b; };
+        double* remL = lds + 3 * NT * 256;  // [WAVES][KR][VMAX]
+        const int wv = __builtin_amdgcn_readfirstlane(wave);  // provably uniform: scalar branches below
         double* out = p.Gpart + (int64_t)blockIdx.x * K * V;
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            double* mine = lds + wave * SLOT;
+        for (int half = 0; half < ROUNDS; ++half) {
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-                for (int h = 0; h < HT; ++h)
+                for (int h = 0; h < VTR; ++h) {
+                    const int t = kt * VTR + h, o = t % WAVES, i = t / WAVES;
+                    if (wv != o) {
+                        const int src = wv < o ? wv : wv - 1;
+                        double* dst = lds + ((pbase(o) + src * owned(o) + i) * 4) * 64 + lane;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        mine[(16 * kt + q + 4 * r) * HW + 16 * h + c16] = g[kt][half * HT + h][r];
-            if (KR > 0) {
+                        for (int r = 0; r < 4; ++r) dst[r * 64] = g[kt][half * VTR + h][r];
+                    }
+                }
+            if (KR > 0 && half == 0) {
 #pragma unroll
                 for (int j = 0; j < KR; ++j)
 #pragma unroll
-                    for (int h = 0; h < HT; ++h) {
-                        double t = grem[j][half * HT + h];  // sum the four q groups (lanes l, l^16, l^32, l^48)
+                    for (int vt = 0; vt < VT; ++vt) {
+                        double t = grem[j][vt];  // sum the four q groups (lanes l, l^16, l^32, l^48)
                         t += __shfl_xor(t, 16, 64);
                         t += __shfl_xor(t, 32, 64);
-                        if (q == 0) mine[(KB + j) * HW + 16 * h + c16] = t;
+                        if (q == 0) remL[(wv * KR + j) * VMAX + 16 * vt + c16] = t;
                     }
             }
             __syncthreads();
-            for (int i = tid; i < K * HW; i += BLOCK) {
-                int k = i / HW, vv = i - k * HW;
-                int v = half * HW + vv;
-                double t = ((lds[i] + lds[SLOT + i]) + lds[2 * SLOT + i]) + lds[3 * SLOT + i];
-                if (v < V) out[k * V + v] = t;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int h = 0; h < VTR; ++h) {
+                    const int t = kt * VTR + h, o = t % WAVES, i = t / WAVES;
+                    if (wv == o) {
+                        const int vt = half * VTR + h;
+                        double acc[4];
+#pragma unroll
+                        for (int w = 0; w < WAVES; ++w) {
+                            const int src = w < o ? w : w - 1;
+                            const double* from = lds + ((pbase(o) + src * owned(o) + i) * 4) * 64 + lane;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const double v = (w == o) ? g[kt][vt][r] : from[r * 64];
+                                acc[r] = (w == 0) ? v : acc[r] + v;
+                            }
+                        }
+                        const int v = 16 * vt + c16;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int k = 16 * kt + q + 4 * r;
+                            if (k < K && v < V) out[k * V + v] = acc[r];
+                        }
+                    }
+                }
+            if (KR > 0 && half == 0) {
+                for (int i = tid; i < KR * VMAX; i += BLOCK) {
+                    const int j = i / VMAX, v = i - j * VMAX;
+                    const double t = ((remL[j * VMAX + v] + remL[(KR + j) * VMAX + v]) + remL[(2 * KR + j) * VMAX + v]) + remL[(3 * KR + j) * VMAX + v];
+                    if (v < V) out[(KB + j) * V + v] = t;
+                }
             }
-            __syncthreads();
+            if (half + 1 < ROUNDS) __syncthreads();
         }
     }
     if (DO_STATS && DO_U) {
@@ -724,8 +782,8 @@ __global__ void __launch_bounds__(BLOCK, (fwd_lds_doubles<KS>() * 8 <= 80 * 1024
 #pragma unroll
         for (int j = 0; j < HV; ++j) {
             if (p.hscale) {
-                hv[j][0] = fmax(hv[j][0] * hsl[hcol[j]], kEps);
-                hv[j][1] = fmax(hv[j][1] * hsl[hcol[j] + 1], kEps);
+                hv[j][0] = clip_lo(hv[j][0] * hsl[hcol[j]], kEps);
+                hv[j][1] = clip_lo(hv[j][1] * hsl[hcol[j] + 1], kEps);
             }
             if (MODE == 0 && p.wlh) {  // l-half penalty, klnmf.py:75-79
                 int64_t n = n0 + hrow[j];
@@ -904,9 +962,9 @@ __global__ void __launch_bounds__(TAIL_BLOCK) tail_kernel(TailParams p) {
         double w = wn[v] / rowsum;
         if (k < p.n_given) {
             w = wold;
-            if (p.clip_mode == 0) w = fmax(w, kEps);
+            if (p.clip_mode == 0) w = clip_lo(w, kEps);
         } else {
-            w = fmax(w, kEps);
+            w = clip_lo(w, kEps);
         }
         p.W[k * V + v] = w;
     }
@@ -951,7 +1009,7 @@ __global__ void __launch_bounds__(256) colsum_kernel(const double* __restrict__ 
 __global__ void scale_H_kernel(double* __restrict__ H, const double* __restrict__ scale, int64_t total, int ldh) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < total; i += stride) H[i] = fmax(H[i] * scale[i % ldh], kEps);
+    for (; i < total; i += stride) H[i] = clip_lo(H[i] * scale[i % ldh], kEps);
 }
 
 // compact [rows][cols] -> padded [prows][ld] (clip_lo > 0 clips the copied entries from below)
@@ -967,7 +1025,7 @@ __global__ void pad_kernel(double* __restrict__ dst, const double* __restrict__ 
         else if (c >= cols) v = fill_cols;
         else {
             v = src[r * cols + c];
-            if (clip_lo > 0.0) v = fmax(v, clip_lo);
+            if (clip_lo > 0.0) v = v < clip_lo ? clip_lo : v;
         }
         dst[i] = v;
     }

@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "salnmf_kernels.h"
+
 namespace salnmf {
 
 constexpr int MV_BLOCK = 1024;  // one workgroup, four waves per SIMD: the parallel phases are fp64-issue bound
@@ -184,7 +186,7 @@ __global__ void mv_prepare_final_kernel(const double* __restrict__ W, const doub
     const double b = hsum[k] - 4.0 * lam * A[idx];
     const double root = sqrt(b * b + 8.0 * lam * B[idx] * G[idx]);
     const double wu = w * (root - b) / (4.0 * lam * B[idx]);
-    Wunc[idx] = (k < n_given) ? w : fmax(wu, 1.1920928955078125e-07);
+    Wunc[idx] = (k < n_given) ? w : clip_lo(wu, kEps);
 }
 
 // the part of a line-search trial the forward pass needs (mvnmf.py:80-81, 85-88): blend, row sums, normalise, clip
@@ -223,7 +225,7 @@ __global__ void __launch_bounds__(MV_BLOCK)
     __syncthreads();
     for (int idx = threadIdx.x; idx < K * V; idx += MV_BLOCK) {
         int k = idx / V, v = idx - k * V;
-        Wtrial[idx] = fmax(Wl[k * MV_WS + v] / rs[k], 1.1920928955078125e-07);
+        Wtrial[idx] = clip_lo(Wl[k * MV_WS + v] / rs[k], kEps);
     }
 }
 

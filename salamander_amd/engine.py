@@ -41,13 +41,21 @@ class Engine:
         self.device = int(device)
         handle = ctypes.c_void_p()
         _lib.check(self._lib.salnmf_create(self.device, self.V, self.N, self.K, ctypes.byref(handle)))
-        self._h = handle
+        self._handle = handle
 
     # -- lifetime
+    @property
+    def _h(self):
+        """The C handle; a closed engine raises instead of handing NULL to the library."""
+        h = getattr(self, "_handle", None)
+        if not h:
+            raise RuntimeError("salnmf: this Engine has been closed")
+        return h
+
     def close(self):
-        if getattr(self, "_h", None):
-            self._lib.salnmf_destroy(self._h)
-            self._h = None
+        if getattr(self, "_handle", None):
+            self._lib.salnmf_destroy(self._handle)
+            self._handle = None
 
     def __del__(self):
         try:

@@ -206,8 +206,9 @@ class SignatureNMF(ABC):
                 # printed before the update of that iteration, with the latest known objective
                 print(f"iteration: {n_iteration + 1}; objective: {of_values[-1]:.2f}")
             stop = (n_iteration // freq + 1) * freq
-            if self.max_iterations > n_iteration:
-                stop = min(stop, self.max_iterations)
+            # the reference tests `n_iteration >= max_iterations` after every single update: the cap is the next
+            # iteration at the latest (max_iterations <= 0 still runs exactly one update)
+            stop = min(stop, max(self.max_iterations, n_iteration + 1))
             if verbose:
                 next_print = ((n_iteration + 1) // verbosity_freq + 1) * verbosity_freq
                 stop = min(stop, next_print - 1)

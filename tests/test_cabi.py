@@ -45,6 +45,36 @@ def test_no_compute_without_device():
         Engine(16, 96, 2)
 
 
+def test_closed_engine_raises_instead_of_passing_null():
+    """Every method of a closed Engine raises (the C ABI also rejects NULL handles, see the GPU suite)."""
+    from salamander_amd import Engine
+
+    e = Engine.__new__(Engine)
+    e._lib, e._handle, e.N, e.V, e.K = _lib.load(), None, 16, 96, 2
+    import numpy as np
+
+    for call in (lambda: e.upload_W(np.ones((2, 96))), lambda: e.download_W(), lambda: e.kl_step(1), lambda: e.sync()):
+        with pytest.raises(RuntimeError, match="closed"):
+            call()
+    e.close()  # idempotent
+
+
+def test_null_handle_is_an_error_code_not_a_crash():
+    lib = _lib.load()
+    import ctypes
+
+    buf = (ctypes.c_double * 4)()
+    for fn, args in (
+        (lib.salnmf_upload_W, (None, buf)),
+        (lib.salnmf_download_W, (None, buf)),
+        (lib.salnmf_upload_X, (None, buf, 0)),
+        (lib.salnmf_kl_step, (None, 1, 0)),
+        (lib.salnmf_sync, (None,)),
+    ):
+        assert fn(*args) != 0
+        assert _lib.last_error()
+
+
 def test_product_never_imports_oracle():
     """The oracle is test infrastructure: nothing under salamander_amd/ may reference it."""
     pkg = os.path.join(ROOT, "salamander_amd")

@@ -205,15 +205,23 @@ def test_fit_clips_callers_adata_and_writes_results(fake_engine, counts):
 
 @pytest.mark.parametrize(
     "min_it,max_it,freq,expect_chunks",
-    [(30, 30, 10, [10, 10, 10]), (25, 25, 10, [10, 10, 5]), (3, 3, 10, [3]), (12, 12, 5, [5, 5, 2])],
+    [
+        (30, 30, 10, [10, 10, 10]),
+        (25, 25, 10, [10, 10, 5]),
+        (3, 3, 10, [3]),
+        (12, 12, 5, [5, 5, 2]),
+        # the reference tests `n_iteration >= max_iterations` after the first update: a cap <= 0 still runs one
+        (0, 0, 10, [1]),
+        (0, -5, 10, [1]),
+    ],
 )
 def test_fit_loop_chunks_and_history_cadence(fake_engine, counts, min_it, max_it, freq, expect_chunks):
     adata = make_adata(counts)
     m = sal.models.KLNMF(2, "flat", min_iterations=min_it, max_iterations=max_it, conv_test_freq=freq)
     m.fit(adata)
     assert m._engine.steps_log == expect_chunks
-    assert m.n_iterations_ == max_it
-    assert len(m.history["objective_function"]) == max_it // freq
+    assert m.n_iterations_ == max(max_it, 1)
+    assert len(m.history["objective_function"]) == max(max_it, 1) // freq
 
 
 def test_fit_equals_oracle_fit_including_convergence_stop(fake_engine, counts):
