@@ -71,8 +71,16 @@ int salnmf_download_W(salnmf_engine* e, double* W);
 int salnmf_download_H(salnmf_engine* e, double* H);
 
 /* n_steps joint KLNMF updates, device resident: update_WH, _utils_klnmf.py:281-361.
- * The first n_given rows of W are never changed. */
+ * The first n_given rows of W are never changed.
+ * Opt-in (salnmf_set_persistent / SALNMF_PERSISTENT=1): with n_steps >= 2, no per-sample weights and no communicator
+ * attached, the steps run in ONE persistent launch (workgroups stay resident; the W tail and its hand-offs happen
+ * inside the kernel) -- same bits as step-by-step launches, measured 10 % slower on MI355X, hence off
+ * by default.  A wait inside that kernel that gives up (another process holding CUs) is reported by the next
+ * synchronising call as an error; the resident state is then invalid. */
 int salnmf_kl_step(salnmf_engine* e, int n_steps, int n_given);
+/* Switch the persistent multi-step launch of salnmf_kl_step on (1) or off (0, the default; the environment
+ * variable SALNMF_PERSISTENT=1 changes the default).  Measurement aid. */
+int salnmf_set_persistent(salnmf_engine* e, int on);
 /* update_H with the current W: _utils_klnmf.py:220-278. */
 int salnmf_update_H(salnmf_engine* e);
 /* update_W (clip_mode = SALNMF_CLIP_NON_GIVEN): _utils_klnmf.py:164-217. */

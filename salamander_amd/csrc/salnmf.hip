@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -64,7 +65,7 @@ struct salnmf_engine {
     double* Halt = nullptr;      // [Np][KP] second H buffer of the speculative update_H pass (lazily allocated)
     int mv_grid = 0, mv_fgrid = 0;  // grids that leave one CU free for stream2
     double *X = nullptr, *H = nullptr, *W = nullptr, *wkl = nullptr, *wlh = nullptr;
-    double* Gpart = nullptr;     // [grid][K][V]
+    double* Gpart = nullptr;     // [grid][K][VMAX]
     double* Hsumpart = nullptr;  // [grid][K]
     double* KLpart = nullptr;    // [grid]
     double* red = nullptr;       // [K*V | K | 1 | pad]  G, rowsums_H, KL of the local shard (then all-reduced)
@@ -89,10 +90,15 @@ struct salnmf_engine {
     bool xrowsum_valid = false, lgam_valid = false;
     bool h_pending = false;      // H is to be read as clip(H * cs): the rescale of an accepted MvNMF trial, applied by the next reader
     double lgam_sum = 0.0;       // sum gammaln(1 + X) over the local shard
+    unsigned* psync = nullptr;   // persistent kernel: device sync words (SYNC_WORDS), zeroed before every launch
+    unsigned* pabort = nullptr;  // pinned host word the persistent kernel sets when a wait gives up
+    bool persistent = false;     // multi-step kl_step calls run as one persistent launch (opt-in: SALNMF_PERSISTENT=1)
     ncclComm_t comm = nullptr;
     int n_ranks = 1, rank = 0;
     std::vector<hipEvent_t> events;
 };
+
+static int check_abort(salnmf_engine* e);
 
 static const int kKS[] = {1, 2, 4, 8, 10, 13, 16};
 
@@ -264,6 +270,8 @@ void salnmf_destroy(salnmf_engine* e) {
     for (double* b : bufs)
         if (b) (void)hipFree(b);
     if (e->hpin) (void)hipHostFree(e->hpin);
+    if (e->psync) (void)hipFree(e->psync);
+    if (e->pabort) (void)hipHostFree(e->pabort);
     for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : {e->evW, e->evPrepW, e->evTrial, e->evLogdet, e->evObj})
         if (ev) (void)hipEventDestroy(ev);
@@ -332,7 +340,7 @@ int salnmf_create(int device, int n_features, int64_t n_samples, int n_signature
     ALLOC(e->X, Np * VMAX);
     ALLOC(e->H, Np * KP);
     ALLOC(e->W, K * V);
-    ALLOC(e->Gpart, (size_t)e->grid * K * V);
+    ALLOC(e->Gpart, (size_t)e->grid * K * VMAX);
     ALLOC(e->Hsumpart, (size_t)e->grid * K);
     ALLOC(e->KLpart, (size_t)e->grid);
     ALLOC(e->red, K * V + K + 2);
@@ -351,6 +359,14 @@ int salnmf_create(int device, int n_features, int64_t n_samples, int n_signature
     }
     if (hipHostMalloc((void**)&e->hpin, 8 * sizeof(double), hipHostMallocDefault) != hipSuccess)
         return cleanup(fail("hipHostMalloc failed"));
+    if (hipMalloc(&e->psync, SYNC_WORDS * sizeof(unsigned)) != hipSuccess) return cleanup(fail("hipMalloc failed"));
+    if (hipHostMalloc((void**)&e->pabort, 64, hipHostMallocDefault) != hipSuccess) return cleanup(fail("hipHostMalloc failed"));
+    *e->pabort = 0;
+    {
+        // measured slower than per-step launches on MI355X: opt-in
+        const char* env = getenv("SALNMF_PERSISTENT");
+        e->persistent = env && env[0] == '1';
+    }
     *out = e;
     return 0;
 }
@@ -395,7 +411,7 @@ static int download_padded(salnmf_engine* e, double* dst, const double* src, int
     HIPCK(hipGetLastError());
     HIPCK(hipMemcpyAsync(dst, e->scratch, (size_t)e->N * cols * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     HIPCK(hipStreamSynchronize(e->stream));
-    return 0;
+    return check_abort(e);
 }
 
 int salnmf_upload_X(salnmf_engine* e, const double* X, int clip) {
@@ -436,7 +452,7 @@ static int download(salnmf_engine* e, double* dst, const double* src, size_t n) 
     HIPCK(hipSetDevice(e->device));
     HIPCK(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     HIPCK(hipStreamSynchronize(e->stream));
-    return 0;
+    return check_abort(e);
 }
 int salnmf_download_W(salnmf_engine* e, double* W) {
     if (!e) return fail("null engine");
@@ -449,11 +465,61 @@ int salnmf_download_H(salnmf_engine* e, double* H) {
     return download_padded(e, H, e->H, e->K, e->KP);
 }
 
+// n joint steps in one persistent launch (fused_kernel<..., PERSIST>): every workgroup must be resident, which the
+// geometry guarantees (grid <= number of CUs, one workgroup per CU by its LDS footprint)
+static int kl_steps_persistent(salnmf_engine* e, int n, int n_given) {
+    FusedParams p = fused_params(e);
+    p.nsteps = n;
+    p.n_given = n_given;
+    p.Wmut = e->W;
+    p.G = e->red;
+    p.sync = e->psync;
+    p.abort_host = e->pabort;
+    HIPCK(hipMemsetAsync(e->psync, 0, SYNC_WORDS * sizeof(unsigned), e->stream));
+    dim3 g(e->grid), b(BLOCK);
+    bool done = false;
+#define SALNMF_CASE(ks, ktm, kr)                                                                                     \
+    if (!done && e->KS == ks && e->KTM == ktm && e->KR == kr) {                                                      \
+        hipLaunchKernelGGL((fused_kernel<ks, ktm, kr, true, true, false, false, true>), g, b, 0, e->stream, p);      \
+        done = true;                                                                                                 \
+    }
+    SALNMF_GEOMETRIES(SALNMF_CASE)
+#undef SALNMF_CASE
+    if (!done) return fail("no kernel instantiation for KS=%d KTM=%d KR=%d", e->KS, e->KTM, e->KR);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+// a persistent launch whose waits gave up leaves the resident state half updated: say so at the next sync point
+static int check_abort(salnmf_engine* e) {
+    if (e->pabort && *e->pabort) {
+        return fail("a wait inside the persistent KL kernel gave up (its workgroups were not all resident: is another process "
+                    "using this GPU?); the engine's W and H are invalid -- upload them again, and set SALNMF_PERSISTENT=0");
+    }
+    return 0;
+}
+
+int salnmf_set_persistent(salnmf_engine* e, int on) {
+    if (!e) return fail("null engine");
+    e->persistent = on != 0;
+    return 0;
+}
+
 int salnmf_kl_step(salnmf_engine* e, int n_steps, int n_given) {
     if (!e) return fail("null engine");
     if (n_given < 0 || n_given > e->K) return fail("n_given out of range");
     HIPCK(hipSetDevice(e->device));
-    for (int i = 0; i < n_steps; ++i) CK(kl_step_once(e, n_given, nullptr));
+    int i = 0;
+    if (e->persistent && !e->comm && !e->wkl && !e->wlh && n_given < e->K && n_steps >= 2) {
+        CK(flush_H_scale(e));  // (after an MvNMF step) the persistent kernel reads H as it is
+        constexpr int kMaxPerLaunch = 64;  // bounds one launch to a few milliseconds
+        while (n_steps - i >= 2) {
+            const int n = std::min(kMaxPerLaunch, n_steps - i);
+            CK(kl_steps_persistent(e, n, n_given));
+            i += n;
+        }
+    }
+    for (; i < n_steps; ++i) CK(kl_step_once(e, n_given, nullptr));
     return 0;
 }
 
@@ -531,6 +597,7 @@ static int objective_to_slot(salnmf_engine* e, const double* W, const double* hs
 static int read_scalars(salnmf_engine* e, int first, int count, double* out) {
     HIPCK(hipMemcpyAsync(e->hpin, e->scal + first, count * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     HIPCK(hipStreamSynchronize(e->stream));
+    CK(check_abort(e));
     for (int i = 0; i < count; ++i) out[i] = e->hpin[i];
     return 0;
 }
@@ -1066,7 +1133,7 @@ int salnmf_sync(salnmf_engine* e) {
     if (!e) return fail("null engine");
     HIPCK(hipSetDevice(e->device));
     HIPCK(hipStreamSynchronize(e->stream));
-    return 0;
+    return check_abort(e);
 }
 
 // ------------------------------------------------------------------------------------ measurement

@@ -114,13 +114,20 @@ struct FusedParams {
     const double* __restrict__ wkl;  // [Np] or null
     const double* __restrict__ wlh;  // [Np] or null
     const double* __restrict__ hscale;  // [KP] or null: H is read as clip(H*hscale) (MvNMF trial)
-    double* __restrict__ Gpart;      // [gridDim.x][K][V]        (DO_G)
+    double* __restrict__ Gpart;      // [gridDim.x][K][VMAX]     (DO_G) per-workgroup partial numerators
     double* __restrict__ Hsumpart;   // [gridDim.x][K]           (DO_STATS) row sums of H
     double* __restrict__ KLpart;     // [gridDim.x]              (DO_STATS) unweighted KL partial
     int64_t N;
     int V;
     int K;
     int64_t ntiles;
+    // persistent multi-step mode (PERSIST instantiation only): the joint update_WH step nsteps times in ONE launch
+    int nsteps;
+    int n_given;
+    double* Wmut;           // = W, written in place by the row owners
+    double* G;              // [K][V] reduced numerator of the last step (what the W tail leaves behind)
+    unsigned* sync;         // device words, zeroed before every launch: [0] slabs published, [32] W rows published, [64] abort
+    unsigned* abort_host;   // pinned host word, set to 1 when a wait gave up
 };
 
 // log(x / p) for positive normal x, p with ONE division and no library call (the objective
@@ -163,9 +170,37 @@ __device__ __forceinline__ double kl_term(double x, double p) {
 // the same for operands that passed log_operand_ok()
 __device__ __forceinline__ double kl_term_fast(double x, double p) { return __builtin_fma(x, log_ratio(x, p), p - x); }
 
+// ---- in-launch synchronisation of the persistent kernel (cdna_hip_programming.md, guideline 16) ----
+// Payloads (G slabs, W rows) are stored write-through (sc1), every storing wave drains its stores
+// (s_waitcnt vmcnt(0)) and joins a workgroup barrier, then ONE lane bumps a monotonic agent-scope counter.
+// Consumers poll that counter with relaxed agent-scope loads from one lane, join a workgroup barrier and then read
+// the payload with sc1 loads only (they bypass this CU's L1).  Every wait is bounded: ~0.25 s on the 100 MHz
+// clock, or another workgroup having given up; on failure the abort words are set and the workgroup exits.
+constexpr int SYNC_SLABS = 0, SYNC_WROWS = 32, SYNC_ABORT = 64, SYNC_WORDS = 128;
+typedef __attribute__((address_space(1))) unsigned gsync_t;
+__device__ __forceinline__ bool wait_counter(unsigned* sync_, int which, unsigned target, unsigned* abort_host) {
+    gsync_t* sync = (gsync_t*)sync_;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (unsigned spins = 1;; ++spins) {
+        if (__hip_atomic_load(sync + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
+        __builtin_amdgcn_s_sleep(1);
+        if ((spins & 63u) == 0) {
+            const bool gave_up = __hip_atomic_load(sync + SYNC_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+            if (gave_up || __builtin_amdgcn_s_memrealtime() - t0 > 25000000ull) {
+                __hip_atomic_store(sync + SYNC_ABORT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store((gsync_t*)abort_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                return false;
+            }
+        }
+    }
+}
+__device__ __forceinline__ void bump_counter(unsigned* sync, int which) {
+    __hip_atomic_fetch_add((gsync_t*)sync + which, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // W -> LDS with the padding described at the top of the file.  All loads in flight together.
-template <int WROWS>
-__device__ __forceinline__ void stage_W(double* Wl, const double* __restrict__ W, int K, int V, int tid) {
+template <int WROWS, bool SC1 = false>
+__device__ __forceinline__ void stage_W(double* Wl, const double* W, int K, int V, int tid) {
     constexpr int WPT = (WROWS * VMAX + BLOCK - 1) / BLOCK;
     constexpr int TOTAL = WPT * BLOCK;
     double wreg[WPT];
@@ -179,7 +214,8 @@ __device__ __forceinline__ void stage_W(double* Wl, const double* __restrict__ W
         int idx = tid + BLOCK * j + rot;
         idx = idx >= TOTAL ? idx - TOTAL : idx;
         int k = idx / VMAX, v = idx - k * VMAX;
-        wreg[j] = W[(k < K ? k : K - 1) * V + (v < V ? v : V - 1)];
+        const double* src = W + (k < K ? k : K - 1) * V + (v < V ? v : V - 1);
+        wreg[j] = SC1 ? __hip_atomic_load((const __attribute__((address_space(1))) double*)src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
     }
 #pragma unroll
     for (int j = 0; j < WPT; ++j) {
@@ -238,6 +274,147 @@ __device__ __forceinline__ double tile_kl(const double (&x)[VT][4], const d4 (&p
 }
 
 // ----------------------------------------------------------------------------------------------
+// W tail arithmetic (_utils_klnmf.py:338-341 / :208-215), shared by tail_kernel and the persistent kernel.
+constexpr int TAIL_PARTS = 8;
+constexpr int TAIL_BLOCK = VMAX * TAIL_PARTS;
+
+// agent-scope relaxed accesses = global_load / global_store ... sc1: they bypass this CU's L1, which is how
+// bytes written by another workgroup of the SAME launch are read (persistent kernel); plain otherwise
+// (address_space(1) makes them global_ instructions; a flat_ access must not carry a hand-off)
+typedef __attribute__((address_space(1))) double gdouble;
+template <bool SC1>
+__device__ __forceinline__ double ld_shared(const double* ptr) {
+    if (SC1) return __hip_atomic_load((const gdouble*)ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *ptr;
+}
+template <bool SC1>
+__device__ __forceinline__ void st_shared(double* ptr, double v) {
+    if (SC1) __hip_atomic_store((gdouble*)ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *ptr = v;
+}
+
+struct TailScratch {
+    double red[TAIL_PARTS][VMAX];
+    double wn[VMAX];
+    double rowsum;
+};
+
+// Row k of the W tail, by NT threads (768 in tail_kernel, 256 inside the persistent kernel): the arithmetic and
+// every summation order are the same for both, so the two paths give the same bits.
+//   work item c = part * VMAX + v:  partial sum over the slabs part, part + 8, part + 16, ... in ascending order
+//   (16 independent loads in flight per item and round), then the 8 parts in order, then W' = W*G, the row sum
+//   sequentially over v, normalise, keep given rows, clip.
+// The slabs are [nslabs][K][VMAX] (row stride VMAX whatever V is).
+template <int NT, bool SC1>
+__device__ __forceinline__ void tail_row(TailScratch& S, int tid, int k, const double* Gpart, int nslabs, double* G, double* W,
+                                         int V, int K, int n_given, int clip_mode, bool do_tail) {
+    constexpr int NC = TAIL_BLOCK / NT;  // work items per thread
+    static_assert(NC * NT == TAIL_BLOCK, "thread count must divide the work items");
+    // loads in flight per item and round: with one item per thread all 32 slabs of a 256-workgroup grid at once
+    // (the tail is a chain of memory round trips: one for the slabs instead of two), the old row beside them
+    constexpr int B = NC == 1 ? 32 : 16;
+    double wold = 0.0;
+    if (do_tail && tid < VMAX && tid < V) wold = ld_shared<SC1>(W + k * V + tid);
+    if (nslabs > 0) {
+        double s[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) s[c] = 0.0;
+        const int64_t slab = (int64_t)K * VMAX;
+        for (int base = 0; base < nslabs; base += TAIL_PARTS * B) {
+            double t[NC][B];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int item = tid + c * NT, part = item / VMAX, v = item - part * VMAX;
+                const double* src = Gpart + (int64_t)k * VMAX + v;
+#pragma unroll
+                for (int j = 0; j < B; ++j) {
+                    const int sl = base + part + j * TAIL_PARTS;
+                    t[c][j] = (v < V && sl < nslabs) ? ld_shared<SC1>(src + sl * slab) : 0.0;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int j = 0; j < B; ++j) s[c] += t[c][j];
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int item = tid + c * NT, part = item / VMAX, v = item - part * VMAX;
+            S.red[part][v] = s[c];
+        }
+        __syncthreads();
+        if (tid < VMAX && tid < V) {
+            double t = 0.0;
+            for (int i = 0; i < TAIL_PARTS; ++i) t += S.red[i][tid];
+            G[k * V + tid] = t;
+            S.red[0][tid] = t;
+        }
+        __syncthreads();
+    } else {
+        if (tid < VMAX && tid < V) S.red[0][tid] = G[k * V + tid];
+        __syncthreads();
+    }
+    if (!do_tail) return;
+    const int v = tid;
+    if (tid < VMAX) S.wn[v] = (v < V) ? wold * S.red[0][v] : 0.0;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int i = 0; i < V; ++i) t += S.wn[i];
+        S.rowsum = t;
+    }
+    __syncthreads();
+    if (tid < VMAX && v < V) {
+        double w = S.wn[v] / S.rowsum;
+        if (k < n_given) {
+            w = wold;
+            if (clip_mode == 0) w = clip_lo(w, kEps);
+        } else {
+            w = clip_lo(w, kEps);
+        }
+        st_shared<SC1>(W + k * V + v, w);
+    }
+}
+
+// End of one step of the persistent kernel (kept out of line: its registers are not the tile loop's; scalar
+// arguments, so that the kernel's parameter block is not copied to the stack).
+// Returns false when a wait gave up (the whole workgroup then exits).
+__device__ __attribute__((noinline)) bool persist_publish_and_tail(unsigned* sync, unsigned* abort_host, const double* Gpart, double* G,
+                                                                   double* W, int K, int V, int n_given, double* lds, int step, int tid) {
+    // publish the slab: every storing wave drains its write-through stores, then one lane counts the workgroup in
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) bump_counter(sync, SYNC_SLABS);
+    // rows of the W tail: the workgroups with the highest indices own them (they have the fewest tiles)
+    bool waited = false;
+    for (int k = (int)gridDim.x - 1 - (int)blockIdx.x; k < K; k += (int)gridDim.x) {
+        if (!waited) {
+            int* okp = reinterpret_cast<int*>(lds + sizeof(TailScratch) / sizeof(double) + 2);
+            if (tid == 0) *okp = wait_counter(sync, SYNC_SLABS, (unsigned)(step + 1) * gridDim.x, abort_host);
+            __syncthreads();
+            if (*okp == 0) return false;
+            waited = true;
+        }
+        tail_row<BLOCK, true>(*reinterpret_cast<TailScratch*>(lds), tid, k, Gpart, (int)gridDim.x, G, W, V, K, n_given, 0, true);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) bump_counter(sync, SYNC_WROWS);
+    }
+    __syncthreads();  // the LDS scratch of the tail is free again
+    return true;
+}
+
+// Start of a step > 0 of the persistent kernel: wait until the K rows of the new W are published.
+__device__ __attribute__((noinline)) bool persist_wait_W(unsigned* sync, unsigned* abort_host, unsigned target, double* lds, int tid) {
+    int* okp = reinterpret_cast<int*>(lds);
+    if (tid == 0) *okp = wait_counter(sync, SYNC_WROWS, target, abort_host);
+    __syncthreads();
+    const bool ok = *okp != 0;
+    __syncthreads();
+    return ok;
+}
+
+// ----------------------------------------------------------------------------------------------
 // Fused update pass.
 //   DO_G     accumulate G = (w_kl * R)^T-contracted numerator for the W update
 //   DO_U     update H in place
@@ -257,8 +434,17 @@ __device__ __forceinline__ double tile_kl(const double (&x)[VT][4], const d4 (&p
 // WTS: the instantiation that honours p.wkl / p.wlh.  The unweighted one has no conditional loads in
 // the tile loop, so hipcc can count vmcnt exactly: with them it falls back to `s_waitcnt vmcnt(0)` at the
 // loop's back edge, which exposes the latency of the H stores of every tile (~1.1 k cycles per tile).
-template <int KS, int KTM, int KR, bool DO_G, bool DO_U, bool DO_STATS, bool WTS = false>
+//
+// PERSIST: p.nsteps joint update_WH steps in ONE launch (requires every workgroup of the grid to be resident: one
+// per CU, grid <= number of CUs).  The workgroups stay on their CUs; per step each publishes its numerator slab,
+// the workgroup that owns signature row k (the ones that run out of tiles first) waits for all slabs, runs the
+// W tail of that row (tail_row: same arithmetic and summation order as tail_kernel) and publishes the new
+// row; everybody waits for the K rows, re-stages W into LDS and goes on.  That replaces two kernel boundaries,
+// the tail launch and the launch ramp per step by two counter hand-offs, and the first tile of the next step is
+// already in flight while a workgroup waits.
+template <int KS, int KTM, int KR, bool DO_G, bool DO_U, bool DO_STATS, bool WTS = false, bool PERSIST = false>
 __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
+    static_assert(!PERSIST || (DO_G && DO_U && !DO_STATS && !WTS), "the persistent mode is the plain joint step");
     using G_ = Geo<KS>;
     constexpr int KT = KTM;  // MFMA tiles on the output side
     constexpr int KP = G_::KP, LS = G_::LS, HV = G_::HV;
@@ -267,7 +453,12 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
     static_assert(KR >= 0 && KR <= 4 && KB + KR <= KP, "remainder columns must fit the padded layout");
     __shared__ __attribute__((aligned(16))) double lds[G_::LDS_DOUBLES + KP];
 
-    const int tid = threadIdx.x;
+    // (persistent mode) everything a step needs is derived inside the step loop from an opaque copy of the thread
+    // index, so that nothing but the step counter is live across the out-of-line synchronisation calls
+    const int nsteps = PERSIST ? p.nsteps : 1;
+    for (int step = 0; step < nsteps; ++step) {
+    int tid = threadIdx.x;
+    if (PERSIST) asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int c16 = lane & 15;
@@ -285,19 +476,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
     if (p.hscale && tid < KP) hsl[tid] = p.hscale[tid];
 
     d4 g[KT][VT];
-    if (DO_G) {
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-            for (int vt = 0; vt < VT; ++vt) g[kt][vt] = (d4){0, 0, 0, 0};
-    }
     double grem[KR > 0 ? KR : 1][VT];  // remainder rows of G: per-lane partials over this lane's sample rows
-    if (DO_G && KR > 0) {
-#pragma unroll
-        for (int j = 0; j < KR; ++j)
-#pragma unroll
-            for (int vt = 0; vt < VT; ++vt) grem[j][vt] = 0.0;
-    }
     double hsum[KT > 0 ? KT : 1];  // column sums of the updated H over this lane's rows (columns 16kt+c16)
     double hsum_rem = 0.0;         // same for the remainder column this lane owns
     double klacc = 0.0;
@@ -307,7 +486,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
     }
 
     const int64_t tstride = (int64_t)gridDim.x * WAVES;
-    int64_t tile = (int64_t)blockIdx.x * WAVES + wave;
+    int64_t tile = 0;
 
     // lane's slice of an H tile: element pair e = 2*lane + 128*j of the contiguous [16][KP] block
     int hrow[HV], hcol[HV];
@@ -575,9 +754,30 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         }
     };
 
-    stage_W<G_::WROWS>(Wl, p.W, K, V, tid);
-    __syncthreads();
-    if (tile < p.ntiles) load_tile(tile);
+    if (DO_G) {
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int vt = 0; vt < VT; ++vt) g[kt][vt] = (d4){0, 0, 0, 0};
+        if (KR > 0) {
+#pragma unroll
+            for (int j = 0; j < KR; ++j)
+#pragma unroll
+                for (int vt = 0; vt < VT; ++vt) grem[j][vt] = 0.0;
+        }
+    }
+    tile = (int64_t)blockIdx.x * WAVES + wave;
+    if (PERSIST) {
+        // the first tile (its H rows were written by this very wave in the previous step) flies during the wait
+        if (tile < p.ntiles) load_tile(tile);
+        if (step > 0 && !persist_wait_W(p.sync, p.abort_host, (unsigned)step * (unsigned)K, lds, tid)) return;
+        stage_W<G_::WROWS, true>(Wl, p.Wmut, K, V, tid);  // sc1 loads: rows published by other workgroups
+        __syncthreads();
+    } else {
+        stage_W<G_::WROWS>(Wl, p.W, K, V, tid);
+        __syncthreads();
+        if (tile < p.ntiles) load_tile(tile);
+    }
     for (; tile < p.ntiles; tile += tstride) process_tile(tile);
 
     // ---- workgroup reductions, fixed order (deterministic)
@@ -602,7 +802,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         auto pbase = [&](int o) constexpr { int b = 0; for (int i = 0; i < o; ++i) b += 3 * owned(i); return b; };
         double* remL = lds + 3 * NT * 256;  // [WAVES][KR][VMAX]
         const int wv = __builtin_amdgcn_readfirstlane(wave);  // provably uniform: scalar branches below
-        double* out = p.Gpart + (int64_t)blockIdx.x * K * V;
+        double* out = p.Gpart + (int64_t)blockIdx.x * K * VMAX;
 #pragma unroll
         for (int half = 0; half < ROUNDS; ++half) {
 #pragma unroll
@@ -651,7 +851,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int k = 16 * kt + q + 4 * r;
-                            if (k < K && v < V) out[k * V + v] = acc[r];
+                            if (k < K && v < V) st_shared<PERSIST>(&out[k * VMAX + v], acc[r]);
                         }
                     }
                 }
@@ -659,11 +859,14 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
                 for (int i = tid; i < KR * VMAX; i += BLOCK) {
                     const int j = i / VMAX, v = i - j * VMAX;
                     const double t = ((remL[j * VMAX + v] + remL[(KR + j) * VMAX + v]) + remL[(2 * KR + j) * VMAX + v]) + remL[(3 * KR + j) * VMAX + v];
-                    if (v < V) out[(KB + j) * V + v] = t;
+                    if (v < V) st_shared<PERSIST>(&out[(KB + j) * VMAX + v], t);
                 }
             }
             if (half + 1 < ROUNDS) __syncthreads();
         }
+    }
+    if (PERSIST) {
+        if (!persist_publish_and_tail(p.sync, p.abort_host, p.Gpart, p.G, p.Wmut, K, V, p.n_given, lds, step, tid)) return;
     }
     if (DO_STATS && DO_U) {
         __syncthreads();
@@ -701,6 +904,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         }
         if (tid == 0) p.KLpart[blockIdx.x] = Ks[0];
     }
+    }  // step
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -868,7 +1072,7 @@ __global__ void __launch_bounds__(BLOCK, (fwd_lds_doubles<KS>() * 8 <= 80 * 1024
 //   stage 1 (nslabs > 0): G[k][:] = sum over the per-workgroup slabs, fixed order
 //   stage 2 (do_tail)   : W' = W*G ; W' /= sum_v W' ; keep given rows ; clip
 struct TailParams {
-    const double* __restrict__ Gpart;  // [nslabs][K][V]
+    const double* __restrict__ Gpart;  // [nslabs][K][VMAX]
     double* __restrict__ G;            // [K][V]
     double* __restrict__ W;            // [K][V] in/out
     int nslabs;
@@ -886,17 +1090,10 @@ struct TailParams {
     int nparts;
 };
 
-constexpr int TAIL_PARTS = 8;
-constexpr int TAIL_BLOCK = VMAX * TAIL_PARTS;
-
 __global__ void __launch_bounds__(TAIL_BLOCK) tail_kernel(TailParams p) {
-    __shared__ double red[TAIL_PARTS][VMAX];
-    __shared__ double wn[VMAX];
-    __shared__ double rowsum;
+    __shared__ TailScratch S;
     const int k = blockIdx.x;
-    const int v = threadIdx.x % VMAX;
-    const int part = threadIdx.x / VMAX;
-    const int V = p.V, K = p.K;
+    const int K = p.K;
     if (p.hsum_part) {  // uniform over the grid
         __shared__ double hred[256];
         for (int which = 0; which < ((k == 0 && p.kl_part) ? 2 : 1); ++which) {
@@ -915,59 +1112,7 @@ __global__ void __launch_bounds__(TAIL_BLOCK) tail_kernel(TailParams p) {
             __syncthreads();
         }
     }
-    if (p.nslabs > 0) {
-        // 16 independent loads in flight per round; the sum order is fixed (slab index ascending)
-        double s = 0.0;
-        if (v < V) {
-            const double* src = p.Gpart + (int64_t)k * V + v;
-            const int64_t slab = (int64_t)K * V;
-            for (int base = part; base < p.nslabs; base += TAIL_PARTS * 16) {
-                double t[16];
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    int sl = base + j * TAIL_PARTS;
-                    t[j] = (sl < p.nslabs) ? src[sl * slab] : 0.0;
-                }
-#pragma unroll
-                for (int j = 0; j < 16; ++j) s += t[j];
-            }
-        }
-        red[part][v] = s;
-        __syncthreads();
-        if (part == 0 && v < V) {
-            double t = 0.0;
-            for (int i = 0; i < TAIL_PARTS; ++i) t += red[i][v];
-            p.G[k * V + v] = t;
-            red[0][v] = t;
-        }
-        __syncthreads();
-    } else {
-        if (part == 0 && v < V) red[0][v] = p.G[k * V + v];
-        __syncthreads();
-    }
-    if (!p.do_tail) return;
-    double wold = 0.0;
-    if (part == 0) {
-        wold = (v < V) ? p.W[k * V + v] : 0.0;
-        wn[v] = (v < V) ? wold * red[0][v] : 0.0;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double s = 0.0;
-        for (int i = 0; i < V; ++i) s += wn[i];
-        rowsum = s;
-    }
-    __syncthreads();
-    if (part == 0 && v < V) {
-        double w = wn[v] / rowsum;
-        if (k < p.n_given) {
-            w = wold;
-            if (p.clip_mode == 0) w = clip_lo(w, kEps);
-        } else {
-            w = clip_lo(w, kEps);
-        }
-        p.W[k * V + v] = w;
-    }
+    tail_row<TAIL_BLOCK, false>(S, threadIdx.x, k, p.Gpart, p.nslabs, p.G, p.W, p.V, K, p.n_given, p.clip_mode, p.do_tail != 0);
 }
 
 // out[j] = sum_i part[i*stride + j], j < width: one workgroup per output, fixed summation order

@@ -97,6 +97,10 @@ class Engine:
     def kl_step(self, n_steps: int = 1, n_given: int = 0):
         _lib.check(self._lib.salnmf_kl_step(self._h, int(n_steps), int(n_given)))
 
+    def set_persistent(self, on: bool = True):
+        """Run multi-step ``kl_step`` calls as one persistent launch (default) or as per-step launches."""
+        _lib.check(self._lib.salnmf_set_persistent(self._h, int(bool(on))))
+
     def update_H(self):
         _lib.check(self._lib.salnmf_update_H(self._h))
 

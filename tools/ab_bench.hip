@@ -32,7 +32,7 @@ int main(int argc, char** argv) {
     for (auto& v : W) v = U(rng) / 50;
     double *dX, *dH, *dH0, *dW, *dW0, *dG, *dGr;
     CK(hipMalloc(&dX, X.size() * 8)); CK(hipMalloc(&dH, H.size() * 8)); CK(hipMalloc(&dH0, H.size() * 8)); CK(hipMalloc(&dW, W.size() * 8)); CK(hipMalloc(&dW0, W.size() * 8));
-    CK(hipMalloc(&dG, (size_t)grid * K * V * 8)); CK(hipMalloc(&dGr, K * V * 8));
+    CK(hipMalloc(&dG, (size_t)grid * K * 96 * 8)); CK(hipMalloc(&dGr, K * V * 8));
     CK(hipMemcpy(dX, X.data(), X.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dH0, H.data(), H.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dW0, W.data(), W.size() * 8, hipMemcpyHostToDevice));
     hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     salnmf_A::FusedParams pa{}; pa.X = dX; pa.H = dH; pa.Hout = dH; pa.hfloor = salnmf_A::kEps; pa.W = dW; pa.Gpart = dG; pa.N = N; pa.V = V; pa.K = K; pa.ntiles = Np / 16;
