@@ -164,6 +164,16 @@ int salnmf_corr_update_sample_embeddings_multi(salnmf_engine* const* engines, in
  * what the reference uses here; status_out has n_signatures ints or is NULL. */
 int salnmf_corr_update_signature_embeddings(salnmf_engine* e, double variance, int maxiter,
                                             int* status_out);
+/* The same solves with the sample-side inputs handed over by the caller: n_all samples (of ALL shards, in
+ * global order) with embeddings U_all (n_all x dim), scalings alpha_all (n_all) and aux_all (n_all x
+ * n_signatures, compact), host pointers.  This is the exchange point of a sample-sharded CorrNMF update
+ * (mmcorrnmf.py:347-396 / corrnmf_det.py:88-113 need sums over all samples): with a communicator attached
+ * salnmf_corr_update_signature_embeddings gathers these three arrays itself over RCCL; this entry point lets a
+ * host-side collective (any torch.distributed backend) do the gather instead.  Result: the engine's
+ * signature embeddings. */
+int salnmf_corr_update_signature_embeddings_from(salnmf_engine* e, int64_t n_all, const double* U_all,
+                                                 const double* alpha_all, const double* aux_all,
+                                                 double variance, int maxiter, int* status_out);
 /* out2[0] = sum of squares of the signature embeddings, out2[1] = of the sample embeddings: what
  * update_variance (corrnmf_det.py:60-69) and the prior terms of elbo_corrnmf
  * (_utils_corrnmf.py:93-98) need from the device-resident embeddings. */
@@ -172,11 +182,15 @@ int salnmf_corr_embedding_sumsq(salnmf_engine* e, double* out2);
 int salnmf_corr_poisson_llh(salnmf_engine* e, double* out);
 
 /* Multi-GPU: one engine per process/GPU, sample axis sharded; the only exchange is an
- * RCCL all-reduce of the (K x V) numerator per W update (+ scalars for objectives).
+ * RCCL all-reduce of the (K x V) numerator per W update (+ scalars for objectives; CorrNMF adds one gather
+ * of the sample-side inputs of the signature-embedding solves per update).
  * Rank 0 obtains an id, the host layer broadcasts it, every rank calls comm_init. */
 #define SALNMF_UNIQUE_ID_BYTES 128
 int salnmf_comm_unique_id(char* out_id /* SALNMF_UNIQUE_ID_BYTES */);
 int salnmf_comm_init(salnmf_engine* e, const char* id, int n_ranks, int rank);
+/* Number of ranks, this engine's rank, and the number of samples over all shards (n_samples of this engine
+ * when no communicator is attached).  Any output may be NULL. */
+int salnmf_comm_info(salnmf_engine* e, int* n_ranks, int* rank, int64_t* n_samples_total);
 
 /* The joint step split at the exchange point, for a caller-side collective
  * (e.g. torch.distributed on a wrapped device pointer):

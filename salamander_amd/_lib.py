@@ -56,10 +56,12 @@ SIGNATURES = {
     "salnmf_corr_update_sample_embeddings": (c_int, [_P, c_double, c_int, POINTER(c_int)]),
     "salnmf_corr_update_sample_embeddings_multi": (c_int, [POINTER(_P), c_int, c_double, c_int, POINTER(c_int)]),
     "salnmf_corr_update_signature_embeddings": (c_int, [_P, c_double, c_int, POINTER(c_int)]),
+    "salnmf_corr_update_signature_embeddings_from": (c_int, [_P, c_int64, _D, _D, _D, c_double, c_int, POINTER(c_int)]),
     "salnmf_corr_embedding_sumsq": (c_int, [_P, _D]),
     "salnmf_corr_poisson_llh": (c_int, [_P, _D]),
     "salnmf_comm_unique_id": (c_int, [ctypes.c_char_p]),
     "salnmf_comm_init": (c_int, [_P, ctypes.c_char_p, c_int, c_int]),
+    "salnmf_comm_info": (c_int, [_P, POINTER(c_int), POINTER(c_int), POINTER(c_int64)]),
     "salnmf_kl_step_partial": (c_int, [_P]),
     "salnmf_kl_step_finish": (c_int, [_P, c_int, c_int]),
     "salnmf_device_ptr": (c_void_p, [_P, c_int]),

@@ -95,6 +95,12 @@ struct salnmf_engine {
     bool persistent = false;     // multi-step kl_step calls run as one persistent launch (opt-in: SALNMF_PERSISTENT=1)
     ncclComm_t comm = nullptr;
     int n_ranks = 1, rank = 0;
+    std::vector<int64_t> shard_N;  // n_samples of every rank's shard (filled by salnmf_comm_init)
+    int64_t N_total = 0;           // sum of shard_N
+    // gathered inputs of the signature-embedding solves (all samples of all shards, compact rows)
+    double *gU = nullptr, *galpha = nullptr, *gaux = nullptr;
+    size_t g_rows = 0;
+    int g_dim = 0;
     std::vector<hipEvent_t> events;
 };
 
@@ -266,7 +272,7 @@ void salnmf_destroy(salnmf_engine* e) {
     if (e->comm) ncclCommDestroy(e->comm);
     double* bufs[] = {e->X, e->H, e->W, e->wkl, e->wlh, e->Gpart, e->Hsumpart, e->KLpart, e->red,
                       e->objpart, e->scal, e->Wunc, e->Wtrial, e->mvA, e->mvB, e->cs, e->scratch, e->Halt,
-                      e->alpha, e->beta, e->Lemb, e->Uemb, e->aux, e->xrowsum, e->corrpart};
+                      e->alpha, e->beta, e->Lemb, e->Uemb, e->aux, e->xrowsum, e->corrpart, e->gU, e->galpha, e->gaux};
     for (double* b : bufs)
         if (b) (void)hipFree(b);
     if (e->hpin) (void)hipHostFree(e->hpin);
@@ -1011,20 +1017,35 @@ int salnmf_corr_update_sample_embeddings_multi(salnmf_engine* const* engines, in
     return sample_embeddings_impl(engines, n_engines, variance, maxiter, status_out);
 }
 
-int salnmf_corr_update_signature_embeddings(salnmf_engine* e, double variance, int maxiter, int* status_out) {
-    CK(corr_ready(e));
-    if (!(variance > 0.0)) return fail("variance must be positive");
-    if (e->n_ranks > 1) return fail("signature-embedding solves need all samples on one engine (sample-sharded engines are not supported)");
+// room for the gathered sample-side inputs of the signature-embedding solves
+static int ensure_gathered(salnmf_engine* e, size_t rows) {
+    if (e->g_rows >= rows && e->g_dim == e->dim) return 0;
+    for (double** b : {&e->gU, &e->galpha, &e->gaux}) {
+        if (*b) HIPCK(hipFree(*b));
+        *b = nullptr;
+    }
+    e->g_rows = 0;
+    HIPCK(hipMalloc(&e->gU, rows * e->dim * sizeof(double)));
+    HIPCK(hipMalloc(&e->galpha, rows * sizeof(double)));
+    HIPCK(hipMalloc(&e->gaux, rows * e->KP * sizeof(double)));
+    e->g_rows = rows;
+    e->g_dim = e->dim;
+    return 0;
+}
+
+// One Newton-CG solve per signature over n_rows samples whose embeddings / scalings / aux rows are at U, alpha, aux
+static int launch_signature_solves(salnmf_engine* e, const double* U, const double* alpha, const double* aux, int64_t n_rows,
+                                   double variance, int maxiter, int* status_out) {
     SignatureEmbeddingParams p;
-    p.aux = e->aux;
-    p.alpha = e->alpha;
+    p.aux = aux;
+    p.alpha = alpha;
     p.beta = e->beta;
-    p.U = e->Uemb;
+    p.U = U;
     p.L = e->Lemb;
     p.status = nullptr;
     p.variance = variance;
-    p.N = e->N;
-    p.Np = e->Np;
+    p.N = n_rows;
+    p.Np = n_rows;
     p.K = e->K;
     p.KP = e->KP;
     p.dim = e->dim;
@@ -1046,6 +1067,55 @@ int salnmf_corr_update_signature_embeddings(salnmf_engine* e, double variance, i
     return rc;
 }
 
+// A signature embedding depends on ALL samples (its objective, gradient and Hessian are sums over samples), and
+// its Newton-CG solve takes data-dependent decisions after every one of them.  With the sample axis sharded, the
+// sample-side inputs of the solves -- U (N x dim), alpha (N) and aux (N x K) -- are gathered ONCE per update
+// (all-gather with per-rank counts = one broadcast per rank inside an RCCL group), after which every rank runs all
+// K solves on identical inputs in the same sample order as an unsharded engine: bit-identical signature embeddings
+// on every rank without any exchange inside the solves.  (The alternative -- an all-reduce of 1 + dim +
+// dim(dim+1)/2 doubles per evaluation -- needs the K solvers advanced in lockstep as resumable state machines and
+// puts hundreds of latency-bound collectives on the critical path; at c5 the gather is 130 MB per update.)
+static int gather_sample_side(salnmf_engine* e) {
+    CK(ensure_gathered(e, (size_t)e->N_total));
+    NCCLCK(ncclGroupStart());
+    int64_t off = 0;
+    for (int r = 0; r < e->n_ranks; ++r) {
+        const size_t n = (size_t)e->shard_N[r];
+        NCCLCK(ncclBroadcast(e->Uemb, e->gU + off * e->dim, n * e->dim, ncclDouble, r, e->comm, e->stream));
+        NCCLCK(ncclBroadcast(e->alpha, e->galpha + off, n, ncclDouble, r, e->comm, e->stream));
+        NCCLCK(ncclBroadcast(e->aux, e->gaux + off * e->KP, n * e->KP, ncclDouble, r, e->comm, e->stream));
+        off += (int64_t)n;
+    }
+    NCCLCK(ncclGroupEnd());
+    return 0;
+}
+
+int salnmf_corr_update_signature_embeddings(salnmf_engine* e, double variance, int maxiter, int* status_out) {
+    CK(corr_ready(e));
+    if (!(variance > 0.0)) return fail("variance must be positive");
+    if (e->comm) {
+        CK(gather_sample_side(e));
+        return launch_signature_solves(e, e->gU, e->galpha, e->gaux, e->N_total, variance, maxiter, status_out);
+    }
+    return launch_signature_solves(e, e->Uemb, e->alpha, e->aux, e->N, variance, maxiter, status_out);
+}
+
+int salnmf_corr_update_signature_embeddings_from(salnmf_engine* e, int64_t n_all, const double* U_all, const double* alpha_all,
+                                                 const double* aux_all, double variance, int maxiter, int* status_out) {
+    CK(corr_ready(e));
+    if (!U_all || !alpha_all || !aux_all) return fail("null argument");
+    if (n_all < 1) return fail("n_all must be positive");
+    if (!(variance > 0.0)) return fail("variance must be positive");
+    CK(ensure_gathered(e, (size_t)n_all));
+    CK(upload(e, e->gU, U_all, (size_t)n_all * e->dim));
+    CK(upload(e, e->galpha, alpha_all, (size_t)n_all));
+    CK(ensure_scratch(e, (size_t)n_all * e->K));
+    CK(upload(e, e->scratch, aux_all, (size_t)n_all * e->K));
+    hipLaunchKernelGGL(pad_kernel, dim3(2048), dim3(256), 0, e->stream, e->gaux, e->scratch, n_all, e->K, n_all, e->KP, 0.0, 0.0, 0.0);
+    HIPCK(hipGetLastError());
+    return launch_signature_solves(e, e->gU, e->galpha, e->gaux, n_all, variance, maxiter, status_out);
+}
+
 int salnmf_corr_embedding_sumsq(salnmf_engine* e, double* out2) {
     CK(corr_ready(e));
     if (!out2) return fail("null argument");
@@ -1056,6 +1126,7 @@ int salnmf_corr_embedding_sumsq(salnmf_engine* e, double* out2) {
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, e->scratch, g, 1, 1, e->scal + 5);
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, e->scratch + g, g, 1, 1, e->scal + 6);
     HIPCK(hipGetLastError());
+    CK(allreduce(e, e->scal + 6, 1));  // the sample embeddings are sharded, the signature embeddings replicated
     return read_scalars(e, 5, 2, out2);
 }
 
@@ -1103,12 +1174,35 @@ int salnmf_comm_unique_id(char* out_id) {
 int salnmf_comm_init(salnmf_engine* e, const char* id_bytes, int n_ranks, int rank) {
     if (!e || !id_bytes) return fail("null argument");
     if (e->comm) return fail("communicator already attached");
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail("rank %d out of range for %d ranks", rank, n_ranks);
     HIPCK(hipSetDevice(e->device));
     ncclUniqueId id;
     memcpy(&id, id_bytes, sizeof id);
     NCCLCK(ncclCommInitRank(&e->comm, n_ranks, id, rank));
     e->n_ranks = n_ranks;
     e->rank = rank;
+    // every rank learns every shard's size (the gathers of the CorrNMF signature solves need the counts)
+    int64_t* dn = nullptr;
+    HIPCK(hipMalloc(&dn, (size_t)(n_ranks + 1) * sizeof(int64_t)));
+    int rc = 0;
+    if (hipMemcpyAsync(dn + n_ranks, &e->N, sizeof(int64_t), hipMemcpyHostToDevice, e->stream) != hipSuccess) rc = fail("hipMemcpy failed");
+    if (!rc && ncclAllGather(dn + n_ranks, dn, 1, ncclInt64, e->comm, e->stream) != ncclSuccess) rc = fail("ncclAllGather of the shard sizes failed");
+    e->shard_N.assign(n_ranks, 0);
+    if (!rc && (hipMemcpyAsync(e->shard_N.data(), dn, (size_t)n_ranks * sizeof(int64_t), hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
+                hipStreamSynchronize(e->stream) != hipSuccess))
+        rc = fail("download of the shard sizes failed");
+    (void)hipFree(dn);
+    if (rc) return rc;
+    e->N_total = 0;
+    for (int64_t n : e->shard_N) e->N_total += n;
+    return 0;
+}
+
+int salnmf_comm_info(salnmf_engine* e, int* n_ranks, int* rank, int64_t* n_samples_total) {
+    if (!e) return fail("null engine");
+    if (n_ranks) *n_ranks = e->n_ranks;
+    if (rank) *rank = e->rank;
+    if (n_samples_total) *n_samples_total = e->comm ? e->N_total : e->N;
     return 0;
 }
 

@@ -55,10 +55,14 @@ def attach_communicator(engine, group=None) -> None:
     engine.comm_init(box[0], world, rank)
 
 
-def broadcast_from_rank0(array: np.ndarray, group=None) -> np.ndarray:
-    """Every rank gets rank 0's copy of ``array`` (bit-identical W at the start of a sharded fit)."""
+def broadcast_from_rank0(value, group=None):
+    """Every rank gets rank 0's copy of ``value`` -- an array or a tuple of arrays / scalars (bit-identical
+    replicated parameters at the start of a sharded fit)."""
     dist = _dist()
-    box = [np.ascontiguousarray(array) if dist.get_rank(group) == 0 else None]
+    if dist.get_rank(group) == 0:
+        box = [np.ascontiguousarray(value) if isinstance(value, np.ndarray) else value]
+    else:
+        box = [None]
     dist.broadcast_object_list(box, src=0, group=group)
     return box[0]
 

@@ -200,6 +200,21 @@ class Engine:
         _lib.check(self._lib.salnmf_corr_update_signature_embeddings(self._h, float(variance), int(maxiter), ptr))
         return status
 
+    def corr_update_signature_embeddings_from(self, U_all, alpha_all, aux_all, variance: float, maxiter: int = 0, return_status: bool = False):
+        """The signature solves on caller-gathered sample-side inputs of ALL shards (global sample order)."""
+        n_all = int(np.shape(alpha_all)[0])
+        U_all = _as_c(U_all, (n_all, self.dim), "U_all")
+        alpha_all = _as_c(alpha_all, (n_all,), "alpha_all")
+        aux_all = _as_c(aux_all, (n_all, self.K), "aux_all")
+        status = np.empty(self.K, dtype=np.int32) if return_status else None
+        ptr = status.ctypes.data_as(POINTER(ctypes.c_int)) if return_status else None
+        _lib.check(
+            self._lib.salnmf_corr_update_signature_embeddings_from(
+                self._h, n_all, _ptr(U_all), _ptr(alpha_all), _ptr(aux_all), float(variance), int(maxiter), ptr
+            )
+        )
+        return status
+
     def corr_embedding_sumsq(self):
         """(sum of squares of the signature embeddings, of the sample embeddings) of the resident state."""
         out = (c_double * 2)()
@@ -222,6 +237,12 @@ class Engine:
         if len(unique_id) != _lib.UNIQUE_ID_BYTES:
             raise ValueError("unique_id has the wrong length")
         _lib.check(self._lib.salnmf_comm_init(self._h, unique_id, int(n_ranks), int(rank)))
+
+    def comm_info(self):
+        """(n_ranks, rank, n_samples over all shards)."""
+        n, r, t = ctypes.c_int(), ctypes.c_int(), ctypes.c_int64()
+        _lib.check(self._lib.salnmf_comm_info(self._h, ctypes.byref(n), ctypes.byref(r), ctypes.byref(t)))
+        return n.value, r.value, t.value
 
     def kl_step_partial(self):
         _lib.check(self._lib.salnmf_kl_step_partial(self._h))

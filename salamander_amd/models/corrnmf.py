@@ -51,8 +51,15 @@ class CorrNMF(SignatureNMF):
         if getattr(e, "dim", None) != self.dim_embeddings:
             e.corr_configure(self.dim_embeddings)
         buffers = (_lib.CORR_SIGNATURE_SCALINGS, _lib.CORR_SAMPLE_SCALINGS, _lib.CORR_SIGNATURE_EMBEDDINGS, _lib.CORR_SAMPLE_EMBEDDINGS)
-        for which, values in zip(buffers, self._factors()):
-            e.corr_upload(which, np.asarray(values, dtype=np.float64))
+        factors = [np.asarray(values, dtype=np.float64) for values in self._factors()]
+        if self.distributed:
+            # the signature-side parameters and the variance are replicated: every rank starts from rank 0's bits
+            from ..distributed import broadcast_from_rank0
+
+            factors[0], factors[2], variance = broadcast_from_rank0((factors[0], factors[2], float(self.variance)))
+            self.variance = variance
+        for which, values in zip(buffers, factors):
+            e.corr_upload(which, values)
 
     # ------------------------------------------------------------------ reference hooks
     def _factors(self):

@@ -105,16 +105,14 @@ class CorrNMFDet(CorrNMF):
         self._sync_from_device()
 
     # ------------------------------------------------------------------ device-resident loop used by fit()
-    def _sync_to_device(self) -> None:
-        if self.distributed:
-            # a signature embedding depends on all samples: every evaluation of its solve would need an exchange
-            raise NotImplementedError("CorrNMFDet does not support sample-sharded (distributed=True) fitting.")
-        super()._sync_to_device()
-
+    # With ``distributed=True`` ``adata`` is this rank's shard of the samples.  The engine then all-reduces the
+    # numerator of the signature update, the two sums of the signature scalings, the Poisson term and the sum of
+    # squares of the sample embeddings, and gathers U / alpha / aux once per update for the signature-embedding
+    # solves (a signature embedding depends on all samples; every rank solves all of them on identical inputs).
     def _resident_variance(self) -> float:
         """update_variance on the resident embeddings (corrnmf_det.py:65-69)."""
         ss_sig, ss_samples = self._engine.corr_embedding_sumsq()
-        count = (self.n_signatures + self.adata.n_obs) * self.dim_embeddings
+        count = (self.n_signatures + self._n_obs_total()) * self.dim_embeddings
         return float(np.clip((ss_sig + ss_samples) / count, EPSILON, None))
 
     def _device_steps(self, n_steps: int, given_parameters) -> None:
@@ -142,7 +140,7 @@ class CorrNMFDet(CorrNMF):
         log_norm = np.log(2 * np.pi * var)
         value = self._engine.corr_poisson_llh()
         value -= 0.5 * dim * self.n_signatures * log_norm + ss_sig / (2 * var)
-        value -= 0.5 * dim * self.adata.n_obs * log_norm + ss_samples / (2 * var)
+        value -= 0.5 * dim * self._n_obs_total() * log_norm + ss_samples / (2 * var)
         return float(value)
 
     def _sync_from_device(self) -> None:

@@ -43,6 +43,7 @@ class MultimodalCorrNMF:
         tol: float = 1e-7,
         *,
         device: int = 0,
+        distributed: bool = False,
     ):
         value_checker("init_method", init_method, INIT_METHODS)
         self.ns_signatures = ns_signatures
@@ -53,7 +54,10 @@ class MultimodalCorrNMF:
         self.conv_test_freq = conv_test_freq
         self.tol = tol
         self.variance = 1.0
+        # ours: which GPU, and whether mdata is this rank's shard of the samples (one communicator per modality)
         self.device = device
+        self.distributed = distributed
+        self._comm_attached: dict[str, bool] = {}
         names = [f"mod{n}" for n in range(1, len(ns_signatures) + 1)]
         self.mdata = MuData({name: AnnData() for name in names})
         self.asignatures = {name: AnnData() for name in names}
@@ -255,8 +259,18 @@ class MultimodalCorrNMF:
         self._sync_from_device()
 
     # ------------------------------------------------------------------ device-resident loop
+    def _n_obs_total(self) -> int:
+        """Samples over all shards when ``distributed`` (``mdata`` is this rank's shard), else ``mdata.n_obs``."""
+        if self.distributed and self._engines and all(self._comm_attached.get(n) for n in self.mod_names):
+            return int(self._engines[self.mod_names[0]].comm_info()[2])
+        return int(self.mdata.n_obs)
+
     def _sync_to_device(self) -> None:
         U = np.ascontiguousarray(self.mdata.obsm["embeddings"], dtype=np.float64)
+        if self.distributed:
+            from ..distributed import attach_communicator, broadcast_from_rank0
+
+            self.variance = broadcast_from_rank0(float(self.variance))
         for name, n_signatures in zip(self.mod_names, self.ns_signatures):
             adata, asigs = self.mdata[name], self.asignatures[name]
             X = np.ascontiguousarray(adata.X, dtype=np.float64)
@@ -266,15 +280,24 @@ class MultimodalCorrNMF:
                 if e is not None:
                     e.close()
                 e = self._engines[name] = Engine(N, V, n_signatures, device=self.device)
+                self._comm_attached[name] = False
             if getattr(e, "dim", None) != self.dim_embeddings:
                 e.corr_configure(self.dim_embeddings)
+            W = np.ascontiguousarray(asigs.X, dtype=np.float64)
+            beta = np.asarray(asigs.obs["scalings"].values, dtype=np.float64)
+            L = np.ascontiguousarray(asigs.obsm["embeddings"], dtype=np.float64)
+            if self.distributed:
+                if not self._comm_attached.get(name):
+                    attach_communicator(e)
+                    self._comm_attached[name] = True
+                W, beta, L = broadcast_from_rank0((W, beta, L))  # replicated parameters: rank 0's bits everywhere
             e.upload_X(X)
-            e.upload_W(np.ascontiguousarray(asigs.X, dtype=np.float64))
+            e.upload_W(W)
             if "exposures" in adata.obsm:
                 e.upload_H(np.ascontiguousarray(adata.obsm["exposures"], dtype=np.float64))
-            e.corr_upload(_lib.CORR_SIGNATURE_SCALINGS, np.asarray(asigs.obs["scalings"].values, dtype=np.float64))
+            e.corr_upload(_lib.CORR_SIGNATURE_SCALINGS, beta)
             e.corr_upload(_lib.CORR_SAMPLE_SCALINGS, np.asarray(adata.obs["scalings"].values, dtype=np.float64))
-            e.corr_upload(_lib.CORR_SIGNATURE_EMBEDDINGS, asigs.obsm["embeddings"])
+            e.corr_upload(_lib.CORR_SIGNATURE_EMBEDDINGS, L)
             e.corr_upload(_lib.CORR_SAMPLE_EMBEDDINGS, U)
 
     def _device_steps(self, n_steps: int, given_parameters) -> None:
@@ -307,7 +330,7 @@ class MultimodalCorrNMF:
 
     def _resident_variance(self) -> float:
         ss_sig, ss_samples = self._resident_sumsq()
-        count = (sum(self.ns_signatures) + self.mdata.n_obs) * self.dim_embeddings
+        count = (sum(self.ns_signatures) + self._n_obs_total()) * self.dim_embeddings
         return float(np.clip((ss_sig + ss_samples) / count, EPSILON, None))
 
     def _device_objective(self) -> float:
@@ -318,7 +341,7 @@ class MultimodalCorrNMF:
             e = self._engines[name]
             value += e.corr_poisson_llh()
             value -= 0.5 * dim * n_signatures * log_norm + e.corr_embedding_sumsq()[0] / (2 * var)
-        value -= 0.5 * dim * self.mdata.n_obs * log_norm + self._resident_sumsq()[1] / (2 * var)
+        value -= 0.5 * dim * self._n_obs_total() * log_norm + self._resident_sumsq()[1] / (2 * var)
         return float(value)
 
     def _sync_from_device(self) -> None:

@@ -173,6 +173,12 @@ class SignatureNMF(ABC):
         self.asignatures.X = self._engine.download_W()
         self.adata.obsm["exposures"] = self._engine.download_H()
 
+    def _n_obs_total(self) -> int:
+        """Samples over all shards (``adata`` is this rank's shard when ``distributed``), else ``adata.n_obs``."""
+        if self.distributed and self._engine is not None and self._comm_attached:
+            return int(self._engine.comm_info()[2])
+        return int(self.adata.n_obs)
+
     @staticmethod
     def _n_given(given_parameters) -> int:
         if given_parameters and "asignatures" in given_parameters:

@@ -103,3 +103,129 @@ class FakeShardEngine(FakeEngine):
 
     def sync(self):
         pass
+
+
+class FakeCorrShardEngine(FakeEngine):
+    """Oracle-backed CorrNMF engine that speaks the engine's sample-sharding protocol over ``torch.distributed``.
+
+    It restates WHERE the C++ engine exchanges data when a communicator is attached (``salnmf.hip``): an
+    all-reduce of the signature-update numerator (``corr_compute_aux``), of the two sums of the signature scalings,
+    of the Poisson term and of the sum of squares of the sample embeddings, and ONE gather of ``U``, ``alpha`` and
+    ``aux`` per update for the signature-embedding solves, which every rank then runs on identical inputs.
+    Without an initialised process group (or before ``comm_init``) it is a plain single-shard engine.
+    """
+
+    def __init__(self, n_samples, n_features, n_signatures, device=0):
+        super().__init__(n_samples, n_features, n_signatures, device)
+        self.world, self.rank, self.n_total = 1, 0, n_samples
+        self._attached = False
+
+    # -- communicator (the unique id is irrelevant here; the process group carries the exchange)
+    @staticmethod
+    def comm_unique_id():
+        return b"\0" * 128
+
+    def comm_init(self, unique_id, n_ranks, rank):
+        import torch
+        import torch.distributed as dist
+
+        self.world, self.rank, self._attached = n_ranks, rank, True
+        t = torch.tensor([self.N], dtype=torch.int64)
+        dist.all_reduce(t)
+        self.n_total = int(t.item())
+
+    def comm_info(self):
+        return self.world, self.rank, self.n_total
+
+    def _allreduce(self, array):
+        if not self._attached:
+            return np.asarray(array, dtype=float)
+        import torch
+        import torch.distributed as dist
+
+        t = torch.from_numpy(np.ascontiguousarray(array, dtype=np.float64).copy())
+        dist.all_reduce(t)
+        return t.numpy()
+
+    def _gather_rows(self, array):
+        if not self._attached:
+            return np.asarray(array)
+        import torch.distributed as dist
+
+        parts = [None] * self.world
+        dist.all_gather_object(parts, np.ascontiguousarray(array))
+        return np.concatenate(parts, axis=0)
+
+    # -- state
+    def corr_configure(self, dim):
+        self.dim = dim
+        self.alpha, self.beta = np.zeros(self.N), np.zeros(self.K)
+        self.L, self.U = np.zeros((self.K, dim)), np.zeros((self.N, dim))
+        self.aux = np.zeros((self.N, self.K))
+
+    def corr_upload(self, which, values):
+        name = ("beta", "alpha", "L", "U", "aux")[which]
+        setattr(self, name, np.array(values, dtype=float))
+
+    def corr_download(self, which):
+        return np.array(getattr(self, ("beta", "alpha", "L", "U", "aux")[which]))
+
+    # -- one update, piece by piece (oracle arithmetic on the local shard + the exchanges)
+    def corr_update_sample_scalings(self):
+        from oracle import corrnmf_oracle as corr
+
+        self.alpha = corr.update_sample_scalings(self.X, self.beta, self.L, self.U)
+
+    def corr_compute_exposures(self):
+        from oracle import corrnmf_oracle as corr
+
+        self.H = corr.compute_exposures(self.beta, self.alpha, self.L, self.U)  # (N, K)
+
+    def corr_compute_aux(self):
+        from oracle import corrnmf_oracle as corr
+
+        aux_kn = corr.compute_aux(self.X, self.W, self.H)  # (K, N)
+        self.aux = aux_kn.T.copy()
+        ratio = self.X / (self.H @ self.W)  # (N, V)
+        self._G = self._allreduce(self.H.T @ ratio)  # (K, V) numerator of update_signatures, all shards
+
+    def corr_update_signature_scalings(self):
+        first = self._allreduce(self.aux.sum(axis=0))
+        second = self._allreduce(np.exp(self.alpha[None, :] + self.L @ self.U.T).sum(axis=1))
+        self.beta = np.log(first) - np.log(second)
+
+    def corr_update_signature_embeddings(self, variance, maxiter=0, return_status=False):
+        from oracle import corrnmf_oracle as corr
+
+        U_all, alpha_all, aux_all = self._gather_rows(self.U), self._gather_rows(self.alpha), self._gather_rows(self.aux)
+        self.L = corr.update_signature_embeddings(aux_all.T, self.L, U_all, self.beta, alpha_all, variance)
+
+    def corr_update_sample_embeddings(self, variance, maxiter=3, return_status=False):
+        from oracle import corrnmf_oracle as corr
+
+        self.U = corr.update_sample_embeddings(self.aux.T, self.L, self.U, self.beta, self.alpha, variance)
+
+    @staticmethod
+    def corr_update_sample_embeddings_multi(engines, variance, maxiter=3, return_status=False):
+        from oracle import corrnmf_oracle as corr
+
+        U = corr.mm_update_sample_embeddings(
+            [e.aux.T for e in engines], [e.L for e in engines], engines[0].U, [e.beta for e in engines], [e.alpha for e in engines], variance
+        )
+        for e in engines:
+            e.U = U.copy()
+
+    def corr_embedding_sumsq(self):
+        return float(np.sum(self.L**2)), float(self._allreduce(np.array([np.sum(self.U**2)]))[0])
+
+    def corr_update_signatures(self, n_given=0):
+        Wn = self.W * self._G
+        Wn = Wn / Wn.sum(axis=1, keepdims=True)
+        Wn[:n_given] = self.W[:n_given]
+        Wn[n_given:] = np.clip(Wn[n_given:], orc.EPSILON, None)  # update_W clips the non-given rows only
+        self.W = Wn
+
+    def corr_poisson_llh(self):
+        from oracle import corrnmf_oracle as corr
+
+        return float(self._allreduce(np.array([corr.poisson_llh(self.X.T, self.W.T, self.H.T)]))[0])

@@ -173,8 +173,10 @@ def test_multimodal_model_setup_checks(mdata):
     assert m.mod_names == ["sbs", "indel"] and m.sample_names == [f"s{i}" for i in range(9)]
 
 
-def test_corrnmf_det_refuses_sample_sharding(adata):
-    m = CorrNMFDet(n_signatures=2, dim_embeddings=2, distributed=True)
-    m.adata = adata
-    with pytest.raises(NotImplementedError, match="sample-sharded"):
-        m._sync_to_device()
+def test_corr_models_accept_the_distributed_flag():
+    from salamander_amd.models import MultimodalCorrNMF
+
+    """Sample-sharded fitting is supported (tests/test_distributed_gloo.py runs it on two ranks): the flag is kept."""
+    assert CorrNMFDet(n_signatures=2, dim_embeddings=2, distributed=True).distributed
+    assert MultimodalCorrNMF([2, 3], dim_embeddings=2, distributed=True).distributed
+    assert not MultimodalCorrNMF([2, 3]).distributed

@@ -299,3 +299,187 @@ def test_joint_solve_matches_reference_executed_vectors():
     for e in engines:
         e.close()
     assert np.allclose(got, U_upd, rtol=1e-6, atol=1e-9)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Config c5 at its real size, and its multi-GPU split (sample-sharded engines)
+
+
+def _c5_engines(N, rng, var, Ks=(40, 40), Vs=(96, 83), dim=40, rows=None):
+    """Engines of the two modalities of a c5-shaped problem (rows = (lo, hi): only that shard of the samples)."""
+    lo, hi = rows if rows is not None else (0, N)
+    U = rng.normal(0, 0.3, (N, dim))
+    engines, state = [], []
+    for m, (K, V) in enumerate(zip(Ks, Vs)):
+        X, W, _ = ko.synthetic_problem(V, N, K, seed=20 + m)
+        beta, L = rng.normal(0, 0.3, K), rng.normal(0, 0.3, (K, dim))
+        e = Engine(hi - lo, V, K)
+        e.upload_X(X[lo:hi])
+        e.upload_W(W)
+        e.corr_configure(dim)
+        e.corr_upload(_lib.CORR_SIGNATURE_SCALINGS, beta)
+        e.corr_upload(_lib.CORR_SIGNATURE_EMBEDDINGS, L)
+        e.corr_upload(_lib.CORR_SAMPLE_EMBEDDINGS, U[lo:hi])
+        engines.append(e)
+        state.append(dict(X=X, W=W, beta=beta, L=L))
+    return engines, state, U
+
+
+def _mm_elbo_resident(engines, var, dim, n_total):
+    """The ELBO of the resident state, as MultimodalCorrNMF._device_objective computes it."""
+    log_norm = np.log(2 * np.pi * var)
+    value = 0.0
+    for e in engines:
+        value += e.corr_poisson_llh()
+        value -= 0.5 * dim * e.K * log_norm + e.corr_embedding_sumsq()[0] / (2 * var)
+    value -= 0.5 * dim * n_total * log_norm + engines[0].corr_embedding_sumsq()[1] / (2 * var)
+    return value
+
+
+def _mm_update(engines, var):
+    for e in engines:
+        e.corr_update_sample_scalings()
+        e.corr_compute_exposures()
+        e.corr_compute_aux()
+        e.corr_update_signature_scalings()
+    for e in engines:
+        e.corr_update_signature_embeddings(var, 0)
+    Engine.corr_update_sample_embeddings_multi(engines, var, 3)
+    ss = [e.corr_embedding_sumsq() for e in engines]
+    count = (sum(e.K for e in engines) + engines[0].N) * engines[0].dim
+    var = float(np.clip((sum(s[0] for s in ss) + ss[0][1]) / count, 1e-7, None))
+    for e in engines:
+        e.corr_update_signatures(0)
+    return var
+
+
+@pytest.mark.parametrize("N", [200000, 50000])
+def test_c5_full_size_update_properties_and_subset_vs_oracle(N):
+    """Config c5 itself -- (96 + 83) x 200 000, ns_signatures = [40, 40], dim 40 -- and its per-GPU share on 4 GPUs
+    (50 000 samples): three full MultimodalCorrNMF updates on one GPU.  Size-independent properties (everything
+    finite, the ELBO increases update over update, unit-sum signatures) and a random subset of the signature and
+    sample solves of the first update against the oracle (the *installed* SciPy's Newton-CG)."""
+    rng = np.random.default_rng(5)
+    var, dim = 0.7, 40
+    engines, state, U = _c5_engines(N, rng, var)
+    # ---- first update piece by piece, keeping what the subset check needs
+    for e in engines:
+        e.corr_update_sample_scalings()
+        e.corr_compute_exposures()
+        e.corr_compute_aux()
+        e.corr_update_signature_scalings()
+    betas = [e.corr_download(_lib.CORR_SIGNATURE_SCALINGS) for e in engines]
+    alphas = [e.corr_download(_lib.CORR_SAMPLE_SCALINGS) for e in engines]
+    auxs = [e.corr_download(_lib.CORR_AUX).T.copy() for e in engines]
+    L_old = [s["L"] for s in state]
+    for e in engines:
+        e.corr_update_signature_embeddings(var, 0)
+    Ls = [e.corr_download(_lib.CORR_SIGNATURE_EMBEDDINGS) for e in engines]
+    for m, k in ((0, 3), (1, 27)):  # one solve per modality against SciPy (each is a pass over all N samples per evaluation)
+        want = co.update_embedding(L_old[m][k], U, betas[m][k], alphas[m], var, auxs[m][k])
+        assert np.allclose(Ls[m][k], want, rtol=1e-5, atol=1e-8)
+    Engine.corr_update_sample_embeddings_multi(engines, var, 3)
+    got = engines[1].corr_download(_lib.CORR_SAMPLE_EMBEDDINGS)
+    L_all, beta_all, aux_all = np.concatenate(Ls), np.concatenate(betas), np.concatenate(auxs)
+    worst = 0.0
+    for n in rng.choice(N, size=60, replace=False):
+        scalings = np.concatenate([np.repeat(alphas[m][n], 40) for m in range(2)])
+        want = co.update_embedding(U[n], L_all, scalings, beta_all, var, aux_all[:, n], options={"maxiter": 3})
+        worst = max(worst, np.abs(got[n] - want).max() / max(np.abs(want).max(), 1e-3))
+    assert worst < 2e-4
+    del auxs, aux_all
+    ss = [e.corr_embedding_sumsq() for e in engines]
+    var = float(np.clip((sum(s[0] for s in ss) + ss[0][1]) / ((80 + N) * dim), 1e-7, None))
+    for e in engines:
+        e.corr_update_signatures(0)
+    # ---- properties over two more full updates
+    elbos = [_mm_elbo_resident(engines, var, dim, N)]
+    for _ in range(2):
+        var = _mm_update(engines, var)
+        elbos.append(_mm_elbo_resident(engines, var, dim, N))
+    assert np.all(np.isfinite(elbos)) and elbos[1] > elbos[0] and elbos[2] > elbos[1], elbos
+    for e in engines:
+        W = e.download_W()
+        assert np.all(np.isfinite(W)) and np.allclose(W.sum(axis=1), 1.0, atol=1e-4)
+        assert np.all(np.isfinite(e.corr_download(_lib.CORR_SIGNATURE_EMBEDDINGS)))
+    Ufin = engines[0].corr_download(_lib.CORR_SAMPLE_EMBEDDINGS)
+    assert np.all(np.isfinite(Ufin)) and np.array_equal(Ufin, engines[1].corr_download(_lib.CORR_SAMPLE_EMBEDDINGS))
+    assert 1e-7 <= var < 10
+    for e in engines:
+        e.close()
+
+
+def test_sharded_signature_solves_equal_unsharded_bitwise():
+    """The exchange point of a sample-sharded CorrNMF update: two engines with half of the samples each, the
+    sample-side inputs of the signature solves gathered (here by the host, as a torch.distributed backend would)
+    and handed to ``corr_update_signature_embeddings_from`` -- every shard's engine ends with the SAME BITS as the
+    engine that holds all samples, because the solves see the same values in the same sample order."""
+    rng = np.random.default_rng(11)
+    N, K, V, dim, var = 6000, 12, 96, 8, 0.8
+    X, W, _ = ko.synthetic_problem(V, N, K, seed=4)
+    beta, L, U = rng.normal(0, 0.3, K), rng.normal(0, 0.4, (K, dim)), rng.normal(0, 0.4, (N, dim))
+
+    def prepared(lo, hi):
+        e = Engine(hi - lo, V, K)
+        e.upload_X(X[lo:hi]), e.upload_W(W)
+        e.corr_configure(dim)
+        e.corr_upload(_lib.CORR_SIGNATURE_SCALINGS, beta)
+        e.corr_upload(_lib.CORR_SIGNATURE_EMBEDDINGS, L)
+        e.corr_upload(_lib.CORR_SAMPLE_EMBEDDINGS, U[lo:hi])
+        e.corr_update_sample_scalings()
+        e.corr_compute_exposures()
+        e.corr_compute_aux()
+        return e
+
+    whole = prepared(0, N)
+    status_whole = whole.corr_update_signature_embeddings(var, 0, return_status=True)
+    want = whole.corr_download(_lib.CORR_SIGNATURE_EMBEDDINGS)
+    shards = [prepared(0, 2992), prepared(2992, N)]  # a 16-aligned split, as shard_bounds produces
+    gathered = [np.concatenate([e.corr_download(which) for e in shards]) for which in (_lib.CORR_SAMPLE_EMBEDDINGS, _lib.CORR_SAMPLE_SCALINGS, _lib.CORR_AUX)]
+    for e in shards:
+        status = e.corr_update_signature_embeddings_from(*gathered, var, 0, return_status=True)
+        assert np.array_equal(e.corr_download(_lib.CORR_SIGNATURE_EMBEDDINGS), want)
+        assert np.array_equal(status, status_whole)
+        e.close()
+    whole.close()
+
+
+def test_distributed_multimodal_model_world_size_one():
+    """MultimodalCorrNMF(distributed=True) on a one-rank process group: communicator per modality, broadcasts, the
+    RCCL gather of U / alpha / aux in front of the signature solves, the all-reduced sums -- the same bits as the
+    single-GPU model."""
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        results = []
+        for distributed in (False, True):
+            c = load_mm_case()
+            m = MultimodalCorrNMF(NS_SIGNATURES, DIM_EMBEDDINGS, distributed=distributed)
+            m.mdata = make_mdata(c)
+            m.asignatures = {}
+            for i in range(2):
+                s = sal.AnnData(c["Ws"][i].copy())
+                s.var_names = m.mdata[f"mod{i}"].var_names
+                s.obs["scalings"] = c["betas"][i].copy()
+                s.obsm["embeddings"] = c["Ls"][i].copy()
+                m.asignatures[f"mod{i}"] = s
+            m.variance = float(c["variance"])
+            m.compute_exposures()
+            m._sync_to_device()
+            m._device_steps(3, None)
+            elbo = m._device_objective()
+            m._sync_from_device()
+            results.append([m.asignatures[f"mod{i}"].X.copy() for i in range(2)] + [m.asignatures[f"mod{i}"].obsm["embeddings"].copy() for i in range(2)]
+                           + [np.asarray(m.mdata.obsm["embeddings"]).copy(), np.array([m.variance, elbo])])
+            for e in m._engines.values():
+                e.close()
+        for a, b in zip(*results):
+            assert np.array_equal(a, b)
+    finally:
+        if created:
+            dist.destroy_process_group()
