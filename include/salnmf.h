@@ -181,6 +181,26 @@ int salnmf_corr_embedding_sumsq(salnmf_engine* e, double* out2);
 /* poisson_llh, _utils_klnmf.py:98-160 (the data term of elbo_corrnmf, _utils_corrnmf.py:92). */
 int salnmf_corr_poisson_llh(salnmf_engine* e, double* out);
 
+/* ---- Initialisation on the device: the deterministic methods of
+ * src/salamander/initialization/methods.py on the resident X, so that a default fit does not spend its time in a
+ * host SVD.  The host layer (salamander_amd/device_init.py) drives them; the signature side (n_features <= 96)
+ * stays on the host.
+ *   init_gram:    gram_out (n_features x n_features) = X^T X and xsum_out = sum of all entries of X (both over ALL
+ *                 shards when a communicator is attached).  The right singular vectors of X are its eigenvectors:
+ *                 what sklearn's _initialize_nmf (methods.py:83) obtains from a randomized SVD.
+ *   init_project: H <- X B^T for B (n_signatures x n_features, host), i.e. the left singular vectors for
+ *                 B = V^T / sigma; posneg_out[0..K) / [K..2K) = squared norms of the positive / negative parts of
+ *                 every column (all shards): all the NNDSVD sign split needs from the left factor.
+ *   init_finish:  H <- clip(fill(threshold(scale_j * part_j(H))) * post_j): the chosen sign part (column 0: |.|),
+ *                 sklearn's `W[W < eps] = 0`, the "nndsvda" fill (0 = none), the exposure scaling of normalize_WH
+ *                 (initialize.py:116) and the EPSILON clip (:117).
+ *   init_flat:    methods.py:58-66 + the same post-processing: H[n][j] = clip(rowsum(X_n) / n_signatures * post_j). */
+int salnmf_init_gram(salnmf_engine* e, double* gram_out, double* xsum_out);
+int salnmf_init_project(salnmf_engine* e, const double* B, double* posneg_out);
+int salnmf_init_finish(salnmf_engine* e, const double* scale, const int* take_neg, const double* post,
+                       double zero_below, double fill);
+int salnmf_init_flat(salnmf_engine* e, const double* post /* n_signatures */);
+
 /* Multi-GPU: one engine per process/GPU, sample axis sharded; the only exchange is an
  * RCCL all-reduce of the (K x V) numerator per W update (+ scalars for objectives; CorrNMF adds one gather
  * of the sample-side inputs of the signature-embedding solves per update).

@@ -5,6 +5,7 @@
 #include "salnmf_kernels.h"
 #include "salnmf_mv_kernels.h"
 #include "salnmf_corr_kernels.h"
+#include "salnmf_init_kernels.h"
 
 #include <rccl/rccl.h>
 
@@ -1156,6 +1157,107 @@ int salnmf_corr_poisson_llh(salnmf_engine* e, double* out) {
     double v;
     CK(read_scalars(e, 6, 1, &v));
     *out = v - e->lgam_sum;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ initialisation (row f3)
+
+int salnmf_init_gram(salnmf_engine* e, double* gram_out, double* xsum_out) {
+    if (!e || !gram_out) return fail("null argument");
+    HIPCK(hipSetDevice(e->device));
+    const int nparts = e->grid * WAVES;
+    CK(ensure_scratch(e, (size_t)nparts * GRAM_PART + nparts + GRAM_PART + 2));
+    double* part = e->scratch;
+    double* xpart = part + (size_t)nparts * GRAM_PART;
+    double* red = xpart + nparts;  // [GRAM_PART | 1]
+    hipLaunchKernelGGL(gram_kernel, dim3(e->grid), dim3(BLOCK), 0, e->stream, e->X, e->ntiles, part, xpart);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(GRAM_PART), dim3(256), 0, e->stream, part, nparts, GRAM_PART, GRAM_PART, red);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, xpart, nparts, 1, 1, red + GRAM_PART);
+    HIPCK(hipGetLastError());
+    CK(allreduce(e, red, (size_t)GRAM_PART + 1));  // sample-sharded engines: the Gram matrix of ALL samples
+    std::vector<double> host((size_t)GRAM_PART + 1);
+    CK(download(e, host.data(), red, host.size()));
+    const int V = e->V;
+    int idx = 0;
+    for (int vt = 0; vt < VT; ++vt)
+        for (int wt = vt; wt < VT; ++wt, ++idx)
+            for (int r = 0; r < 4; ++r)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int i = 16 * vt + (lane >> 4) + 4 * r, j = 16 * wt + (lane & 15);
+                    if (i < V && j < V) {
+                        const double g = host[((size_t)idx * 4 + r) * 64 + lane];
+                        // a diagonal tile holds both triangles; off-diagonal tiles are mirrored
+                        gram_out[(size_t)i * V + j] = g;
+                        if (vt != wt) gram_out[(size_t)j * V + i] = g;
+                    }
+                }
+    if (xsum_out) *xsum_out = host[GRAM_PART];
+    return 0;
+}
+
+int salnmf_init_project(salnmf_engine* e, const double* B, double* posneg_out) {
+    if (!e || !B || !posneg_out) return fail("null argument");
+    HIPCK(hipSetDevice(e->device));
+    const int K = e->K, V = e->V, KP = e->KP;
+    const int pgrid = (int)std::min<int64_t>(1024, e->ntiles);
+    CK(ensure_scratch(e, (size_t)K * V + (size_t)pgrid * 2 * KP + 2 * KP));
+    double* dB = e->scratch;
+    double* part = dB + (size_t)K * V;
+    double* red = part + (size_t)pgrid * 2 * KP;
+    CK(upload(e, dB, B, (size_t)K * V));
+    e->h_pending = false;  // H is overwritten in full
+    const size_t lds = ((size_t)KP * PROJ_LD + 16 * PROJ_LD + 256) * sizeof(double);
+    hipLaunchKernelGGL(init_project_kernel, dim3(pgrid), dim3(256), lds, e->stream, e->X, dB, e->H, e->N, e->ntiles, V, K, KP, part);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(2 * KP), dim3(256), 0, e->stream, part, pgrid, 2 * KP, 2 * KP, red);
+    HIPCK(hipGetLastError());
+    CK(allreduce(e, red, (size_t)2 * KP));
+    std::vector<double> host((size_t)2 * KP);
+    CK(download(e, host.data(), red, host.size()));
+    for (int j = 0; j < K; ++j) {
+        posneg_out[j] = host[j];
+        posneg_out[K + j] = host[KP + j];
+    }
+    return 0;
+}
+
+int salnmf_init_finish(salnmf_engine* e, const double* scale, const int* take_neg, const double* post, double zero_below, double fill) {
+    if (!e || !scale || !take_neg || !post) return fail("null argument");
+    HIPCK(hipSetDevice(e->device));
+    const int K = e->K;
+    CK(ensure_scratch(e, (size_t)3 * K + 8));
+    double* dscale = e->scratch;
+    double* dpost = dscale + K;
+    int* dneg = reinterpret_cast<int*>(dpost + K);
+    CK(upload(e, dscale, scale, (size_t)K));
+    CK(upload(e, dpost, post, (size_t)K));
+    HIPCK(hipMemcpyAsync(dneg, take_neg, (size_t)K * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIPCK(hipStreamSynchronize(e->stream));
+    InitFinishParams p;
+    p.H = e->H;
+    p.scale = dscale;
+    p.take_neg = dneg;
+    p.post = dpost;
+    p.zero_below = zero_below;
+    p.fill = fill;
+    p.N = e->N;
+    p.Np = e->Np;
+    p.K = K;
+    p.KP = e->KP;
+    hipLaunchKernelGGL(init_finish_kernel, dim3(2048), dim3(256), 0, e->stream, p);
+    HIPCK(hipGetLastError());
+    HIPCK(hipStreamSynchronize(e->stream));  // the scratch operands may be reused by the next call
+    return 0;
+}
+
+int salnmf_init_flat(salnmf_engine* e, const double* post) {
+    if (!e || !post) return fail("null argument");
+    HIPCK(hipSetDevice(e->device));
+    e->h_pending = false;
+    CK(ensure_scratch(e, (size_t)e->K));
+    CK(upload(e, e->scratch, post, (size_t)e->K));
+    hipLaunchKernelGGL(init_flat_kernel, dim3(1024), dim3(256), 0, e->stream, e->X, e->H, e->N, e->Np, e->K, e->KP, e->scratch);
+    HIPCK(hipGetLastError());
+    HIPCK(hipStreamSynchronize(e->stream));  // the scratch operand may be reused by the next call
     return 0;
 }
 

@@ -226,6 +226,33 @@ class Engine:
         _lib.check(self._lib.salnmf_corr_poisson_llh(self._h, ctypes.byref(out)))
         return out.value
 
+    # -- initialisation on the device (row f3)
+    def init_gram(self):
+        """(X^T X (V, V), sum of X) of the resident X, over all shards."""
+        G = np.empty((self.V, self.V), dtype=np.float64)
+        total = c_double()
+        _lib.check(self._lib.salnmf_init_gram(self._h, _ptr(G), ctypes.byref(total)))
+        return G, total.value
+
+    def init_project(self, B):
+        """H <- X B^T; returns the squared norms of the positive and of the negative part of every column."""
+        B = _as_c(B, (self.K, self.V), "B")
+        out = np.empty(2 * self.K, dtype=np.float64)
+        _lib.check(self._lib.salnmf_init_project(self._h, _ptr(B), _ptr(out)))
+        return out[: self.K].copy(), out[self.K :].copy()
+
+    def init_finish(self, scale, take_neg, post, zero_below: float, fill: float):
+        scale = _as_c(scale, (self.K,), "scale")
+        post = _as_c(post, (self.K,), "post")
+        neg = np.ascontiguousarray(take_neg, dtype=np.int32)
+        if neg.shape != (self.K,):
+            raise ValueError(f"The shape of 'take_neg' has to be {(self.K,)}.")
+        _lib.check(self._lib.salnmf_init_finish(self._h, _ptr(scale), neg.ctypes.data_as(POINTER(ctypes.c_int)), _ptr(post), float(zero_below), float(fill)))
+
+    def init_flat(self, post):
+        post = _as_c(post, (self.K,), "post")
+        _lib.check(self._lib.salnmf_init_flat(self._h, _ptr(post)))
+
     # -- multi-GPU
     @staticmethod
     def comm_unique_id() -> bytes:

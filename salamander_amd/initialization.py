@@ -123,6 +123,11 @@ def initialize_base(adata, n_signatures, method="nndsvd", given_asignatures=None
         given_mat = np.asarray(given_asignatures.X)
 
     S, E = initialize_mat(np.asarray(adata.X), n_signatures, method, given_mat, **kwargs)
+    return package_signatures(adata, S, n_signatures, given_asignatures), E
+
+
+def package_signatures(adata, S, n_signatures, given_asignatures=None):
+    """The signature matrix as an AnnData with the reference's names and annotations (initialize.py:205-217)."""
     asignatures = AnnData(S)
     asignatures.var_names = adata.var_names
     names = [f"Sig{k + 1}" for k in range(n_signatures)]
@@ -132,7 +137,7 @@ def initialize_base(adata, n_signatures, method="nndsvd", given_asignatures=None
         g = given_asignatures.n_obs
         asignatures.obs_names = list(np.roll(names, g))
         asignatures = concat_rows(given_asignatures, asignatures[g:, :])
-    return asignatures, E
+    return asignatures
 
 
 def initialize_standard_nmf(adata, n_signatures, method="nndsvd", given_parameters: dict[str, Any] | None = None, **kwargs):

@@ -40,6 +40,7 @@ class SignatureNMF(ABC):
         *,
         device: int = 0,
         distributed: bool = False,
+        device_init: bool = True,
     ):
         value_checker("init_method", init_method, INIT_METHODS)
         self.n_signatures = n_signatures
@@ -51,6 +52,9 @@ class SignatureNMF(ABC):
         # ours: which GPU, and whether adata is this rank's shard of the sample axis
         self.device = device
         self.distributed = distributed
+        # ours: run the deterministic initialisation methods (flat, nndsvd, nndsvda) on the GPU (device_init.py)
+        self.device_init = device_init
+        self._resident: set[str] = set()  # what the device already holds from the initialisation: "X", "H"
 
         self.adata = AnnData()
         self.asignatures = AnnData()
@@ -148,25 +152,40 @@ class SignatureNMF(ABC):
         H = np.ascontiguousarray(self.adata.obsm["exposures"], dtype=np.float64)
         return X, W, H
 
-    def _sync_to_device(self) -> None:
-        X, W, H = self._host_state()
-        N, V = X.shape
-        K = W.shape[0]
+    def _ensure_engine(self, N: int, V: int, K: int):
+        """The engine of this problem shape (created on first use), its communicator attached when ``distributed``."""
         e = self._engine
         if e is None or (e.N, e.V, e.K, e.device) != (N, V, K, self.device):
             if e is not None:
                 e.close()
             e = self._engine = Engine(N, V, K, device=self.device)
             self._comm_attached = False
+            self._resident = set()
         if self.distributed and not self._comm_attached:
-            from ..distributed import attach_communicator, broadcast_from_rank0
+            from ..distributed import attach_communicator
 
             attach_communicator(e)
             self._comm_attached = True
+            self._w_broadcast_due = True
+        return e
+
+    def _sync_to_device(self) -> None:
+        X, W, H = self._host_state()
+        N, V = X.shape
+        K = W.shape[0]
+        e = self._ensure_engine(N, V, K)
+        if self.distributed and getattr(self, "_w_broadcast_due", False):
+            from ..distributed import broadcast_from_rank0
+
             W = broadcast_from_rank0(W)  # every rank must start from bit-identical signatures
-        e.upload_X(X)
+            self._w_broadcast_due = False
+        # what a device-side initialisation left resident is not uploaded again (once)
+        if "X" not in self._resident:
+            e.upload_X(X)
         e.upload_W(W)
-        e.upload_H(H)
+        if "H" not in self._resident:
+            e.upload_H(H)
+        self._resident = set()
         e.set_weights(*self._device_weights())
 
     def _sync_from_device(self) -> None:

@@ -8,14 +8,43 @@ from __future__ import annotations
 
 from typing import Any
 
-from ..initialization import initialize_standard_nmf
+import numpy as np
+
+from ..device_init import DEVICE_METHODS, initialize_on_device
+from ..initialization import GIVEN_PARAMETERS_STANDARD_NMF, check_given_asignatures, initialize_standard_nmf, package_signatures
+from ..utils import dict_checker
 from .signature_nmf import SignatureNMF
 
 
 class StandardNMF(SignatureNMF):
     def _initialize(self, given_parameters: dict[str, Any] | None = None, init_kwargs: dict[str, Any] | None = None) -> None:
-        """Initialise signatures and exposures; given signatures are never overwritten later."""
+        """Initialise signatures and exposures; given signatures are never overwritten later.
+
+        The deterministic methods run on the GPU (``device_init.py``: exact SVD through the 96 x 96 Gram matrix
+        instead of sklearn's randomized one) unless ``device_init=False`` or a ``seed`` is passed, which asks for
+        the reference's seeded host computation (``initialize.py:221-255``)."""
         init_kwargs = {} if init_kwargs is None else init_kwargs.copy()
+        if self.device_init and self.init_method in DEVICE_METHODS and "seed" not in init_kwargs:
+            if init_kwargs:
+                raise TypeError(f"init method '{self.init_method}' takes no keyword arguments besides 'seed': {sorted(init_kwargs)}")
+            self._initialize_on_device(given_parameters)
+            return
         self.asignatures = initialize_standard_nmf(
             self.adata, self.n_signatures, self.init_method, given_parameters, **init_kwargs
         )
+
+    def _initialize_on_device(self, given_parameters) -> None:
+        given_parameters = {} if given_parameters is None else given_parameters.copy()
+        dict_checker("given_parameters", given_parameters, GIVEN_PARAMETERS_STANDARD_NMF)
+        given = given_parameters.get("asignatures")
+        given_mat = None
+        if given is not None:
+            check_given_asignatures(given, self.adata, self.n_signatures)
+            given_mat = np.asarray(given.X)
+        X = np.ascontiguousarray(self.adata.X, dtype=np.float64)
+        e = self._ensure_engine(X.shape[0], X.shape[1], self.n_signatures)
+        e.upload_X(X)
+        S = initialize_on_device(e, self.n_signatures, self.init_method, given_mat, self._n_obs_total())
+        self.asignatures = package_signatures(self.adata, S, self.n_signatures, given)
+        self.adata.obsm["exposures"] = e.download_H()
+        self._resident = {"X", "H"}

@@ -76,6 +76,28 @@ class FakeEngine:
         return orc.kl_divergence_penalized(self.X.T, self.W.T, self.H.T, lam, delta)
 
 
+    # -- device-side initialisation primitives (salnmf_init_*), restated in NumPy
+    def init_gram(self):
+        return self.X.T @ self.X, float(self.X.sum())
+
+    def init_project(self, B):
+        self.H = self.X @ np.asarray(B).T
+        return (np.maximum(self.H, 0) ** 2).sum(axis=0), (np.minimum(self.H, 0) ** 2).sum(axis=0)
+
+    def init_finish(self, scale, take_neg, post, zero_below, fill):
+        U = self.H
+        E = np.where(np.asarray(take_neg, dtype=bool)[None, :], np.maximum(-U, 0), np.maximum(U, 0)) * np.asarray(scale)[None, :]
+        E[:, 0] = np.abs(U[:, 0]) * scale[0]
+        E[E < zero_below] = 0
+        if fill != 0.0:
+            E[E == 0] = fill
+        self.H = np.clip(E * np.asarray(post)[None, :], orc.EPSILON, None)
+
+    def init_flat(self, post):
+        e = self.X.sum(axis=1) / self.K
+        self.H = np.clip(e[:, None] * np.asarray(post)[None, :], orc.EPSILON, None)
+
+
 class FakeShardEngine(FakeEngine):
     """Adds the split step (partial / numerator / finish) for the host-collective driver."""
 

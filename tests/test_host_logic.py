@@ -116,6 +116,39 @@ def test_init_methods_match_reference_fixtures(method):
     assert np.allclose(E, np.load(f"{d}/exposures_mat_{suffix}"))
 
 
+@pytest.mark.parametrize("method", ["flat", "nndsvd", "nndsvda"])
+def test_device_init_driver_matches_reference_fixtures(method):
+    """``device_init.initialize_on_device`` (exact SVD through the Gram matrix; here on the NumPy stand-in of the
+    engine primitives) against the reference's fixtures: at 96 x 10, K = 2 the randomized SVD behind them is exact,
+    and NNDSVD does not depend on the signs of the singular vectors, so the entries agree."""
+    from salamander_amd.device_init import initialize_on_device
+
+    d = os.path.join(REF_FIX, "initialization")
+    data = np.load(f"{d}/data_mat.npy")
+    suffix = "flat.npy" if method == "flat" else f"{method}_seed1.npy"
+    e = FakeEngine(data.shape[0], data.shape[1], 2)
+    e.upload_X(data)
+    S = initialize_on_device(e, 2, method)
+    assert np.allclose(S, np.load(f"{d}/signatures_mat_{suffix}"), rtol=1e-7, atol=1e-12)
+    assert np.allclose(e.download_H(), np.load(f"{d}/exposures_mat_{suffix}"), rtol=1e-7, atol=1e-12)
+
+
+def test_model_default_init_runs_on_the_device_unless_seeded(fake_engine, counts):
+    """KLNMF's default nndsvd goes through the engine's init primitives; a seed (or device_init=False) selects the
+    reference's host computation; both leave the same kind of state behind."""
+    host = sal.models.KLNMF(2, "nndsvd", min_iterations=1, max_iterations=1)
+    host.fit(make_adata(counts), init_kwargs={"seed": 1})
+    dev = sal.models.KLNMF(2, "nndsvd", min_iterations=1, max_iterations=1)
+    dev.fit(make_adata(counts))
+    off = sal.models.KLNMF(2, "nndsvd", min_iterations=1, max_iterations=1, device_init=False)
+    np.random.seed(1)
+    off.fit(make_adata(counts))
+    assert rel_l2(dev.asignatures.X, host.asignatures.X) < 1e-6 and rel_l2(off.asignatures.X, host.asignatures.X) < 1e-12
+    assert list(dev.asignatures.obs_names) == ["Sig1", "Sig2"] and dev.adata.obsm["exposures"].shape == (10, 2)
+    with pytest.raises(TypeError):
+        sal.models.KLNMF(2, "flat").fit(make_adata(counts), init_kwargs={"bogus": 1})
+
+
 def test_init_custom_keeps_normalised_input_bitwise():
     """tests/test_initialization.py:56-67: a normalised custom init comes back untouched."""
     data = np.load(os.path.join(REF_FIX, "initialization", "data_mat.npy"))
