@@ -60,8 +60,18 @@ int salnmf_create(int device, int n_features, int64_t n_samples, int n_signature
 void salnmf_destroy(salnmf_engine* e);
 
 /* Upload the count matrix.  clip != 0 applies X.clip(EPSILON) on the way, as
- * SignatureNMF._setup_adata does (src/salamander/models/signature_nmf.py:281). */
+ * SignatureNMF._setup_adata does (src/salamander/models/signature_nmf.py:281).
+ * Ingest is pinned, chunked and overlapped: the caller's array is copied in 32 MB chunks into two pinned staging
+ * buffers by a few host threads, each chunk crosses PCIe by asynchronous DMA and is converted / clipped / padded
+ * into the engine's layout by a kernel while the next chunk is being staged.  The typed entry point takes raw count
+ * matrices as they come (float32 / int32 / int64 / uint16): the conversion to float64 happens on the device. */
+#define SALNMF_F64 0
+#define SALNMF_F32 1
+#define SALNMF_I32 2
+#define SALNMF_I64 3
+#define SALNMF_U16 4
 int salnmf_upload_X(salnmf_engine* e, const double* X, int clip);
+int salnmf_upload_X_typed(salnmf_engine* e, const void* X, int dtype /* SALNMF_F64 ... */, int clip);
 int salnmf_upload_W(salnmf_engine* e, const double* W);
 int salnmf_upload_H(salnmf_engine* e, const double* H);
 /* Per-sample weights (each n_samples long) or NULL to disable

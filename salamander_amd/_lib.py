@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libsalnmf.so")
 
 UNIQUE_ID_BYTES = 128
+DTYPE_CODES = {"float64": 0, "float32": 1, "int32": 2, "int64": 3, "uint16": 4}  # SALNMF_F64 ...
 CLIP_ALL = 0
 CLIP_NON_GIVEN = 1
 BUF_G, BUF_W, BUF_H, BUF_X, BUF_OBJ, BUF_RED = range(6)
@@ -30,6 +31,7 @@ SIGNATURES = {
     "salnmf_create": (c_int, [c_int, c_int, c_int64, c_int, POINTER(_P)]),
     "salnmf_destroy": (None, [_P]),
     "salnmf_upload_X": (c_int, [_P, _D, c_int]),
+    "salnmf_upload_X_typed": (c_int, [_P, c_void_p, c_int, c_int]),
     "salnmf_upload_W": (c_int, [_P, _D]),
     "salnmf_upload_H": (c_int, [_P, _D]),
     "salnmf_set_weights": (c_int, [_P, _D, _D]),

@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace salnmf;
@@ -91,6 +92,10 @@ struct salnmf_engine {
     bool xrowsum_valid = false, lgam_valid = false;
     bool h_pending = false;      // H is to be read as clip(H * cs): the rescale of an accepted MvNMF trial, applied by the next reader
     double lgam_sum = 0.0;       // sum gammaln(1 + X) over the local shard
+    // ingest: two pinned host buffers + two device buffers of STAGE_BYTES each, reused by every upload
+    void* stage_host[2] = {nullptr, nullptr};
+    void* stage_dev[2] = {nullptr, nullptr};
+    hipEvent_t stage_done[2] = {nullptr, nullptr};
     unsigned* psync = nullptr;   // persistent kernel: device sync words (SYNC_WORDS), zeroed before every launch
     unsigned* pabort = nullptr;  // pinned host word the persistent kernel sets when a wait gives up
     bool persistent = false;     // multi-step kl_step calls run as one persistent launch (opt-in: SALNMF_PERSISTENT=1)
@@ -253,6 +258,12 @@ static int kl_step_once(salnmf_engine* e, int n_given, hipEvent_t* ev) {
     return 0;
 }
 
+template <typename T>
+static void launch_pad_rows(salnmf_engine* e, double* dst, const void* src, int64_t rows, int cols, int ld, double fill_cols, double clip_lo) {
+    const int grid = (int)std::min<int64_t>(2048, (rows * ld + 255) / 256);
+    hipLaunchKernelGGL(pad_rows_kernel<T>, dim3(std::max(grid, 1)), dim3(256), 0, e->stream, dst, static_cast<const T*>(src), rows, cols, ld, fill_cols, clip_lo);
+}
+
 // ------------------------------------------------------------------------------------ C ABI
 
 extern "C" {
@@ -277,6 +288,11 @@ void salnmf_destroy(salnmf_engine* e) {
     for (double* b : bufs)
         if (b) (void)hipFree(b);
     if (e->hpin) (void)hipHostFree(e->hpin);
+    for (int i = 0; i < 2; ++i) {
+        if (e->stage_host[i]) (void)hipHostFree(e->stage_host[i]);
+        if (e->stage_dev[i]) (void)hipFree(e->stage_dev[i]);
+        if (e->stage_done[i]) (void)hipEventDestroy(e->stage_done[i]);
+    }
     if (e->psync) (void)hipFree(e->psync);
     if (e->pabort) (void)hipHostFree(e->pabort);
     for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
@@ -396,17 +412,89 @@ static int ensure_scratch(salnmf_engine* e, size_t n) {
     return 0;
 }
 
-// host compact [rows][cols] -> device padded [Np][ld]
+// ---- ingest (row f4): pinned, chunked, overlapped.  The caller's (pageable) array is copied chunk by chunk into
+// one of two pinned staging buffers by a few host threads, each chunk goes to the device with an asynchronous
+// DMA and is converted / clipped / padded into the engine's layout by a kernel on the engine's stream, while the
+// host threads already fill the other buffer.  Element types: the reference hands float64 (after
+// _setup_adata, signature_nmf.py:269-281); raw count matrices may come as float32 / int32 / int64 / uint16 and are
+// converted on the device, which also cuts the bytes that cross PCIe.
+constexpr size_t STAGE_BYTES = (size_t)32 << 20;
+constexpr int STAGE_THREADS = 4;
+
+static size_t dtype_size(int dtype) {
+    switch (dtype) {
+        case SALNMF_F64: return 8;
+        case SALNMF_F32: return 4;
+        case SALNMF_I32: return 4;
+        case SALNMF_I64: return 8;
+        case SALNMF_U16: return 2;
+        default: return 0;
+    }
+}
+
+static int ensure_staging(salnmf_engine* e) {
+    for (int i = 0; i < 2; ++i) {
+        if (!e->stage_host[i]) HIPCK(hipHostMalloc(&e->stage_host[i], STAGE_BYTES, hipHostMallocDefault));
+        if (!e->stage_dev[i]) HIPCK(hipMalloc(&e->stage_dev[i], STAGE_BYTES));
+        if (!e->stage_done[i]) HIPCK(hipEventCreateWithFlags(&e->stage_done[i], hipEventDisableTiming));
+    }
+    return 0;
+}
+
+static void parallel_copy(void* dst, const void* src, size_t bytes) {
+    if (bytes < ((size_t)4 << 20)) {
+        memcpy(dst, src, bytes);
+        return;
+    }
+    std::thread workers[STAGE_THREADS - 1];
+    const size_t piece = (bytes / STAGE_THREADS + 63) & ~(size_t)63;
+    for (int t = 1; t < STAGE_THREADS; ++t) {
+        const size_t off = std::min(bytes, piece * t), len = std::min(bytes, piece * (t + 1)) - off;
+        workers[t - 1] = std::thread([=] { if (len) memcpy((char*)dst + off, (const char*)src + off, len); });
+    }
+    memcpy(dst, src, std::min(bytes, piece));
+    for (auto& w : workers) w.join();
+}
+
+// host compact [N][cols] of element type `dtype` -> device padded double [Np][ld]
+static int upload_rows_staged(salnmf_engine* e, double* dst, const void* src, int dtype, int cols, int ld, double fill_cols, double fill_rows,
+                              double clip_lo) {
+    if (!e || !src) return fail("null argument");
+    const size_t esz = dtype_size(dtype);
+    if (!esz) return fail("unknown element type %d", dtype);
+    HIPCK(hipSetDevice(e->device));
+    CK(ensure_staging(e));
+    const size_t row_bytes = (size_t)cols * esz;
+    const int64_t chunk_rows = std::max<int64_t>(1, (int64_t)(STAGE_BYTES / row_bytes));
+    int slot = 0;
+    for (int64_t r0 = 0; r0 < e->N; r0 += chunk_rows, slot ^= 1) {
+        const int64_t rows = std::min<int64_t>(chunk_rows, e->N - r0);
+        const size_t bytes = (size_t)rows * row_bytes;
+        HIPCK(hipEventSynchronize(e->stage_done[slot]));  // the chunk that used this slot two rounds ago has landed
+        parallel_copy(e->stage_host[slot], (const char*)src + (size_t)r0 * row_bytes, bytes);
+        HIPCK(hipMemcpyAsync(e->stage_dev[slot], e->stage_host[slot], bytes, hipMemcpyHostToDevice, e->stream));
+        double* out = dst + r0 * ld;
+        switch (dtype) {
+            case SALNMF_F64: launch_pad_rows<double>(e, out, e->stage_dev[slot], rows, cols, ld, fill_cols, clip_lo); break;
+            case SALNMF_F32: launch_pad_rows<float>(e, out, e->stage_dev[slot], rows, cols, ld, fill_cols, clip_lo); break;
+            case SALNMF_I32: launch_pad_rows<int32_t>(e, out, e->stage_dev[slot], rows, cols, ld, fill_cols, clip_lo); break;
+            case SALNMF_I64: launch_pad_rows<int64_t>(e, out, e->stage_dev[slot], rows, cols, ld, fill_cols, clip_lo); break;
+            default: launch_pad_rows<uint16_t>(e, out, e->stage_dev[slot], rows, cols, ld, fill_cols, clip_lo); break;
+        }
+        HIPCK(hipGetLastError());
+        HIPCK(hipEventRecord(e->stage_done[slot], e->stream));
+    }
+    if (e->Np > e->N) {
+        hipLaunchKernelGGL(fill_rows_kernel, dim3(4), dim3(256), 0, e->stream, dst, e->N, e->Np, ld, cols, fill_rows, fill_cols);
+        HIPCK(hipGetLastError());
+    }
+    HIPCK(hipStreamSynchronize(e->stream));  // the caller's array is free again (and so are the staging buffers)
+    return 0;
+}
+
 static int upload_padded(salnmf_engine* e, double* dst, const double* src, int cols, int ld, double fill_cols,
                          double fill_rows, double clip_lo) {
-    if (!e || !src) return fail("null argument");
-    HIPCK(hipSetDevice(e->device));
-    CK(ensure_scratch(e, (size_t)e->N * cols));
-    CK(upload(e, e->scratch, src, (size_t)e->N * cols));
-    hipLaunchKernelGGL(pad_kernel, dim3(2048), dim3(256), 0, e->stream, dst, e->scratch, e->N, cols, e->Np, ld,
-                       fill_cols, fill_rows, clip_lo);
-    HIPCK(hipGetLastError());
-    return 0;
+    return upload_rows_staged(e, dst, src, SALNMF_F64, cols, ld, fill_cols, fill_rows, clip_lo);
 }
 
 // device padded [.][ld] -> host compact [N][cols]
@@ -421,11 +509,13 @@ static int download_padded(salnmf_engine* e, double* dst, const double* src, int
     return check_abort(e);
 }
 
-int salnmf_upload_X(salnmf_engine* e, const double* X, int clip) {
-    if (e) e->xrowsum_valid = e->lgam_valid = false;
+int salnmf_upload_X_typed(salnmf_engine* e, const void* X, int dtype, int clip) {
+    if (!e) return fail("null engine");
+    e->xrowsum_valid = e->lgam_valid = false;
     // pad rows / columns are exactly 0 (never clipped): they must contribute X/P = 0
-    return upload_padded(e, e ? e->X : nullptr, X, e ? e->V : 0, VMAX, 0.0, 0.0, clip ? kEps : 0.0);
+    return upload_rows_staged(e, e->X, X, dtype, e->V, VMAX, 0.0, 0.0, clip ? kEps : 0.0);
 }
+int salnmf_upload_X(salnmf_engine* e, const double* X, int clip) { return salnmf_upload_X_typed(e, X, SALNMF_F64, clip); }
 int salnmf_upload_W(salnmf_engine* e, const double* W) {
     if (!e) return fail("null engine");
     return upload(e, e->W, W, (size_t)e->K * e->V);

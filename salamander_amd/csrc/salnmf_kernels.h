@@ -1176,6 +1176,32 @@ __global__ void pad_kernel(double* __restrict__ dst, const double* __restrict__ 
     }
 }
 
+// A block of `rows` compact rows of element type T (row length cols) -> rows [0, rows) of a padded double matrix with
+// leading dimension ld: converts, clips from below (clip_lo > 0) and fills the pad columns.  The ingest pipeline
+// runs it per staged chunk (salnmf.hip: upload_rows_staged), so integer count matrices are converted on the device.
+template <typename T>
+__global__ void pad_rows_kernel(double* __restrict__ dst, const T* __restrict__ src, int64_t rows, int cols, int ld, double fill_cols,
+                                double clip_lo) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < rows * ld; i += stride) {
+        const int64_t r = i / ld;
+        const int c = (int)(i - r * ld);
+        double v = fill_cols;
+        if (c < cols) {
+            v = (double)src[r * cols + c];
+            if (clip_lo > 0.0) v = v < clip_lo ? clip_lo : v;
+        }
+        dst[i] = v;
+    }
+}
+// rows [r0, r1) of a padded matrix <- fill
+__global__ void fill_rows_kernel(double* __restrict__ dst, int64_t r0, int64_t r1, int ld, int cols, double fill_rows, double fill_cols) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + r0 * ld;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < r1 * ld; i += stride) dst[i] = ((int)(i % ld) < cols) ? fill_rows : fill_cols;
+}
+
 // padded [.][ld] -> compact [rows][cols]
 __global__ void unpad_kernel(double* __restrict__ dst, const double* __restrict__ src, int64_t rows, int cols, int ld) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -65,8 +65,16 @@ class Engine:
 
     # -- transfers
     def upload_X(self, X, clip: bool = False):
-        X = _as_c(X, (self.N, self.V), "X")
-        _lib.check(self._lib.salnmf_upload_X(self._h, _ptr(X), int(bool(clip))))
+        """The count matrix; float32 / int32 / int64 / uint16 arrays go over as they are and become float64 on the
+        device, anything else is converted to float64 on the host first."""
+        X = np.asarray(X)
+        code = _lib.DTYPE_CODES.get(X.dtype.name)
+        if code is None:
+            X, code = X.astype(np.float64), 0
+        X = np.ascontiguousarray(X)
+        if X.shape != (self.N, self.V):
+            raise ValueError(f"The shape of 'X' has to be {(self.N, self.V)}.")
+        _lib.check(self._lib.salnmf_upload_X_typed(self._h, X.ctypes.data_as(ctypes.c_void_p), code, int(bool(clip))))
 
     def upload_W(self, W):
         W = _as_c(W, (self.K, self.V), "W")

@@ -275,6 +275,30 @@ def test_upload_clip_matches_setup_adata():
     e.close()
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32", "int32", "int64", "uint16"])
+@pytest.mark.parametrize("N,V", [(100003, 96), (4000, 83)])
+def test_typed_chunked_ingest_equals_host_conversion(dtype, N, V):
+    """Row f4: raw count matrices of any supported element type cross PCIe as they are (several 32 MB chunks at
+    N = 100 003, ragged last tile, V < 96) and are converted, clipped and padded on the device -- the same bits as
+    converting and clipping on the host, as SignatureNMF._setup_adata does (signature_nmf.py:269-281)."""
+    rng = np.random.default_rng(N + V)
+    counts = rng.poisson(rng.gamma(0.6, 10.0, size=(N, V)))  # many zeros: the clip matters
+    raw = counts.astype(dtype)
+    K = 5
+    H0 = rng.uniform(0.5, 2.0, size=(N, K))
+    W0 = rng.dirichlet(np.ones(V), size=K)
+    a, b = Engine(N, V, K), Engine(N, V, K)
+    a.upload_X(raw, clip=True)                                   # typed, converted on the device
+    b.upload_X(raw.astype(np.float64).clip(EPS), clip=False)     # what the reference hands over
+    for e in (a, b):
+        e.upload_W(W0), e.upload_H(H0)
+        e.kl_step(2)
+    assert np.array_equal(a.download_H(), b.download_H()) and np.array_equal(a.download_W(), b.download_W())
+    assert a.objective() == b.objective()
+    assert np.array_equal(a.samplewise_kl(), b.samplewise_kl())
+    a.close(), b.close()
+
+
 # ------------------------------------------------------------------ determinism and split-step (multi-GPU semantics on one GPU)
 def test_bitwise_reproducible():
     X, W0, H0 = orc.synthetic_problem(96, 20000, 50, seed=4)
