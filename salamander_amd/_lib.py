@@ -93,9 +93,13 @@ def _share_torch_hip_runtime() -> None:
     copy first both resolve to it; with the system copy first torch later loads a second runtime, and of two HIP
     runtimes in one process the one that initialises second sees no device.  So torch's ``libamdhip64.so`` is
     opened first, by path and without importing torch (20 ms instead of seconds); a later ``import torch`` finds
-    it loaded.  Only the HIP runtime is preloaded: opening torch's ``librccl.so`` by hand makes the process abort
-    in its destructors at exit, so without torch imported first this library talks to the system RCCL (with
-    torch imported first, as in ``bench.py`` and every ``torch.distributed`` launch, to torch's).
+    it loaded.  Only the HIP runtime is preloaded.  RCCL is not a load-time dependency of ``libsalnmf.so`` at all: the engine
+    binds it when a communicator is first needed (``rccl_bind`` in ``csrc/salnmf.hip``: ``dlopen(RTLD_NOLOAD)`` by
+    SONAME), and by then every ``torch.distributed`` program has imported torch, so the engine and torch's NCCL backend
+    share torch's ``librccl.so`` whatever the import order; a process without torch gets the system library.  (Opening
+    torch's ``librccl.so`` by hand from a process that never initialises torch aborted in that library's static
+    destructors at exit -- nothing here does that any more.)  :func:`mapped_runtime_libraries` reports what is mapped;
+    the tests assert one HIP runtime and at most one RCCL for both import orders.
     ``SALNMF_SHARE_TORCH_RUNTIME=0`` disables the preload; without torch the system libraries are used."""
     import importlib.util
     import sys
@@ -134,6 +138,22 @@ def load():
         fn.argtypes = argtypes
     _lib = lib
     return lib
+
+
+def mapped_runtime_libraries() -> dict:
+    """Paths of the HIP runtime and RCCL copies mapped into this process: ``{"libamdhip64": [...], "librccl": [...]}``."""
+    import re
+
+    found = {"libamdhip64": set(), "librccl": set()}
+    try:
+        with open("/proc/self/maps") as fh:
+            for line in fh:
+                m = re.search(r"(/\S*/(libamdhip64|librccl)\.so\S*)", line)
+                if m:
+                    found[m.group(2)].add(os.path.realpath(m.group(1)))
+    except OSError:
+        pass
+    return {k: sorted(v) for k, v in found.items()}
 
 
 def last_error() -> str:

@@ -7,6 +7,7 @@
 #include "salnmf_corr_kernels.h"
 #include "salnmf_init_kernels.h"
 
+#include <dlfcn.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
@@ -31,6 +32,66 @@ static int fail(const char* fmt, ...) {
     g_err = buf;
     return 1;
 }
+
+// ---- RCCL is bound at first use, not at load time.  The PyTorch-ROCm wheel ships its own librccl.so (SONAME
+// librccl.so.1, requested by libtorch_hip.so under the unversioned name), the system has /opt/rocm/lib/librccl.so.1.
+// A DT_NEEDED entry would pick whichever is visible when THIS library is loaded: loaded before torch, it would pull in
+// the system copy and a later `import torch` a second one -- two RCCLs (built against different HIP runtimes) in one
+// process.  Bound lazily, the choice is made when a communicator is first needed, and by then every torch.distributed
+// program has imported torch: dlopen(RTLD_NOLOAD) finds the copy torch loaded (glibc matches loaded objects by SONAME)
+// and both sides share it.  Only a process without torch falls through to the system library.  Nothing here opens
+// torch's copy by path (doing so from a process that never initialises torch aborted in that copy's static destructors at
+// exit, round 1).
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi g_rccl;
+
+static int rccl_bind() {
+    if (g_rccl.handle) return 0;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);  // the copy already in the process (torch's)
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail("RCCL is not available: %s", dlerror());
+    RcclApi api;
+    api.handle = h;
+    bool ok = true;
+#define SALNMF_BIND(field, name)                                      \
+    *(void**)(&api.field) = dlsym(h, name);                           \
+    ok = ok && api.field != nullptr;
+    SALNMF_BIND(GetUniqueId, "ncclGetUniqueId")
+    SALNMF_BIND(CommInitRank, "ncclCommInitRank")
+    SALNMF_BIND(CommDestroy, "ncclCommDestroy")
+    SALNMF_BIND(AllReduce, "ncclAllReduce")
+    SALNMF_BIND(AllGather, "ncclAllGather")
+    SALNMF_BIND(Broadcast, "ncclBroadcast")
+    SALNMF_BIND(GroupStart, "ncclGroupStart")
+    SALNMF_BIND(GroupEnd, "ncclGroupEnd")
+    SALNMF_BIND(GetErrorString, "ncclGetErrorString")
+#undef SALNMF_BIND
+    if (!ok) return fail("the RCCL library in this process lacks a symbol this engine needs");
+    g_rccl = api;
+    return 0;
+}
+// every use below goes through the bound table (a communicator exists only after rccl_bind succeeded)
+#define ncclGetUniqueId g_rccl.GetUniqueId
+#define ncclCommInitRank g_rccl.CommInitRank
+#define ncclCommDestroy g_rccl.CommDestroy
+#define ncclAllReduce g_rccl.AllReduce
+#define ncclAllGather g_rccl.AllGather
+#define ncclBroadcast g_rccl.Broadcast
+#define ncclGroupStart g_rccl.GroupStart
+#define ncclGroupEnd g_rccl.GroupEnd
+#define ncclGetErrorString g_rccl.GetErrorString
 
 #define HIPCK(call)                                                                              \
     do {                                                                                         \
@@ -1356,6 +1417,7 @@ int salnmf_init_flat(salnmf_engine* e, const double* post) {
 int salnmf_comm_unique_id(char* out_id) {
     if (!out_id) return fail("null argument");
     static_assert(sizeof(ncclUniqueId) <= SALNMF_UNIQUE_ID_BYTES, "id size");
+    CK(rccl_bind());
     ncclUniqueId id;
     NCCLCK(ncclGetUniqueId(&id));
     memset(out_id, 0, SALNMF_UNIQUE_ID_BYTES);
@@ -1368,6 +1430,7 @@ int salnmf_comm_init(salnmf_engine* e, const char* id_bytes, int n_ranks, int ra
     if (e->comm) return fail("communicator already attached");
     if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail("rank %d out of range for %d ranks", rank, n_ranks);
     HIPCK(hipSetDevice(e->device));
+    CK(rccl_bind());
     ncclUniqueId id;
     memcpy(&id, id_bytes, sizeof id);
     NCCLCK(ncclCommInitRank(&e->comm, n_ranks, id, rank));

@@ -75,6 +75,37 @@ def test_null_handle_is_an_error_code_not_a_crash():
         assert _lib.last_error()
 
 
+@pytest.mark.parametrize("order", ["salamander_first", "torch_first"])
+def test_one_hip_runtime_and_one_rccl_whatever_the_import_order(order):
+    """Round 1's hazard: loaded before torch, the engine bound the system RCCL and `import torch` brought a second
+    copy.  RCCL is now bound at first use (dlopen by SONAME, RTLD_NOLOAD first), so both sides share one copy; the
+    child process must also exit cleanly (no abort in a library destructor)."""
+    import subprocess
+    import sys
+
+    code = """
+import ctypes, json, sys
+sys.path.insert(0, %r)
+if %r == "torch_first":
+    import torch
+from salamander_amd import _lib
+lib = _lib.load()
+import torch
+buf = ctypes.create_string_buffer(_lib.UNIQUE_ID_BYTES)
+rc = lib.salnmf_comm_unique_id(buf)   # first RCCL use: binds the library
+print(json.dumps({"rc": rc, "err": _lib.last_error() if rc else "", "libs": _lib.mapped_runtime_libraries()}))
+""" % (ROOT, order)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["rc"] == 0, rec
+    assert len(rec["libs"]["libamdhip64"]) == 1, rec
+    assert len(rec["libs"]["librccl"]) == 1, rec
+    assert "torch" in rec["libs"]["librccl"][0] and "torch" in rec["libs"]["libamdhip64"][0], rec
+
+
 def test_product_never_imports_oracle():
     """The oracle is test infrastructure: nothing under salamander_amd/ may reference it."""
     pkg = os.path.join(ROOT, "salamander_amd")

@@ -451,6 +451,39 @@ def test_engine_and_torch_share_one_hip_runtime_in_either_import_order():
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.returncode, r.stdout[-500:], r.stderr[-2000:])
 
 
+def test_engine_first_then_torch_one_rccl_and_a_working_communicator():
+    """The multi-rank path's library state, in a fresh process with the engine loaded BEFORE torch: after
+    attach_communicator (world size 1, real RCCL communicator inside the engine) exactly one HIP runtime and one RCCL
+    are mapped, a sharded step runs, and the process exits without the destructor abort of round 1."""
+    import subprocess
+    import sys
+
+    code = (
+        "import os, numpy as np\n"
+        "from salamander_amd import Engine, _lib\n"
+        "from salamander_amd.synthetic import synthetic_problem\n"
+        "X, W0, H0 = synthetic_problem(96, 2000, 50, seed=1)\n"
+        "e = Engine(2000, 96, 50)\n"
+        "e.upload_X(X), e.upload_W(W0), e.upload_H(H0)\n"
+        "import torch, torch.distributed as dist\n"
+        "os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29547')\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))\n"
+        "t = torch.ones(4, device='cuda'); dist.all_reduce(t)  # torch's own NCCL backend is live as well\n"
+        "from salamander_amd.distributed import attach_communicator\n"
+        "attach_communicator(e)\n"
+        "e.kl_step(3); W = e.download_W()\n"
+        "assert np.all(np.isfinite(W)) and e.comm_info() == (1, 0, 2000)\n"
+        "libs = _lib.mapped_runtime_libraries()\n"
+        "assert len(libs['libamdhip64']) == 1 and len(libs['librccl']) == 1, libs\n"
+        "e.close(); dist.destroy_process_group()\n"
+        "print('ok')\n"
+    )
+    from conftest import ROOT
+
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+
+
 def test_mvnmf_mixed_call_sequences_match_oracle():
     """State machine check: MvNMF steps leave H lazily rescaled, W / H buffers swapped and (inside a call) the next
     update_H pass possibly pre-computed; every other entry point in between must see the same state as the oracle."""
