@@ -131,6 +131,7 @@ struct salnmf_engine {
     double* Gpart = nullptr;     // [grid][K][VMAX]
     double* Hsumpart = nullptr;  // [grid][K]
     double* KLpart = nullptr;    // [grid]
+    double* KLpart2 = nullptr;   // [grid] KL partials of a speculative update_H pass (the trial's objective)
     double* red = nullptr;       // [K*V | K | 1 | pad]  G, rowsums_H, KL of the local shard (then all-reduced)
     double* objpart = nullptr;   // [grid]
     double* scal = nullptr;      // device scalars: [0]=objective, [1]=f0, [2]=f1, [3]=logdet0, [4]=logdet1
@@ -344,7 +345,7 @@ void salnmf_destroy(salnmf_engine* e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->comm) ncclCommDestroy(e->comm);
     double* bufs[] = {e->X, e->H, e->W, e->wkl, e->wlh, e->Gpart, e->Hsumpart, e->KLpart, e->red,
-                      e->objpart, e->scal, e->Wunc, e->Wtrial, e->mvA, e->mvB, e->cs, e->scratch, e->Halt,
+                      e->objpart, e->scal, e->Wunc, e->Wtrial, e->mvA, e->mvB, e->cs, e->scratch, e->Halt, e->KLpart2,
                       e->alpha, e->beta, e->Lemb, e->Uemb, e->aux, e->xrowsum, e->corrpart, e->gU, e->galpha, e->gaux};
     for (double* b : bufs)
         if (b) (void)hipFree(b);
@@ -829,41 +830,65 @@ static int mv_start_prepare_W(salnmf_engine* e, double delta, bool record_w_even
     return 0;
 }
 
-//   speculate: the caller will run another step right after this one.  While the host waits for the scalars of the
-//            first trial, the GPU already runs that step's update_H pass with the trial as W into a second H buffer;
-//            if the trial is accepted (the common case) the buffers are swapped and *speculated = true tells the caller
-//            to skip its update_H pass, otherwise the result is dropped.  The scalars come back on a side stream.
-static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double delta, double* gamma, bool have_hsum, bool w_ready,
-                            bool speculate = false, bool* speculated = nullptr) {
-    if (speculated) *speculated = false;
-    if (n_given >= e->K) return 0;
-    const int K = e->K, V = e->V;
-    CK(flush_H_scale(e));  // a stand-alone call after an earlier step; inside mv_step the update_H pass consumed it
-    if (!w_ready) CK(mv_start_prepare_W(e, delta, true));
-    // pass over the shard: G = (X/(WH)) @ H.T partials and the KL partial; the rowsums_H partials
-    // come from the preceding update_H pass (have_hsum) or, for a stand-alone _update_W, from a
-    // column-sum kernel over the current H
+// The numerator pass of one MvNMF W update on (W, H): G = (X/(WH)) @ H.T partials and the KL partial, reduced
+// together with the row sums of H (from the preceding update_H pass) by one tail launch and all-reduced.
+static int mv_numerator_pass(salnmf_engine* e, const double* W, const double* H, const double* hscale) {
     FusedParams p = fused_params(e);
     p.wkl = nullptr;  // the MvNMF path is unweighted (mvnmf.py:56)
     p.wlh = nullptr;
+    p.W = W;
+    p.H = const_cast<double*>(H);
+    p.Hout = const_cast<double*>(H);
+    p.hscale = hscale;
     CK((launch_fused<true, false, true>(e, p, e->mv_grid)));
-    // one launch reduces the G slabs, the row sums of H (from the update_H pass) and the KL partials
     CK(launch_tail(e, e->mv_grid, e->red, 0, 0, 0, true));
-    if (!have_hsum) {  // stand-alone _update_W: the row sums come from a column-sum kernel over the current H instead
-        hipLaunchKernelGGL(colsum_kernel, dim3(K), dim3(256), 0, e->stream, e->H, e->N, e->KP, e->red + K * V);
-        HIPCK(hipGetLastError());
+    return 0;
+}
+
+//   speculate: the caller will run another step right after this one.  Everything the NEXT step can do before this
+//            step's line search is decided is queued behind the first trial, assuming it will be accepted (the common
+//            case):
+//              * that step's update_H pass with the trial as W, reading H as clip(H * colsum) on the fly and writing a
+//                second H buffer.  Its P = H' W_trial is exactly what KL(W_trial, H') -- the trial's objective --
+//                needs, so the pass evaluates the trial as well (KL partials from P before the division) and the
+//                separate forward pass over the samples is not run at all;
+//              * its W-only algebra on stream2, and its numerator pass + tail on the main stream.
+//            The scalars come back on a side stream while the numerator pass runs; on acceptance the buffers are
+//            swapped and *speculated = true tells the caller that the next step starts at its closed-form root, otherwise
+//            everything speculative is dropped and the backtracking loop evaluates its trials with the forward kernel.
+//   g_ready:  (in) the numerator pass, tail and all-reduce of THIS step were queued by the previous call's speculation
+static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double delta, double* gamma, bool have_hsum, bool w_ready,
+                            bool speculate = false, bool* speculated = nullptr, bool g_ready = false) {
+    if (speculated) *speculated = false;
+    if (n_given >= e->K) return 0;
+    const int K = e->K, V = e->V;
+    if (!g_ready) {
+        CK(flush_H_scale(e));  // a stand-alone call after an earlier step; inside mv_step the update_H pass consumed it
+        if (!w_ready) CK(mv_start_prepare_W(e, delta, true));
+        // the rowsums_H partials come from the preceding update_H pass (have_hsum) or, for a stand-alone _update_W,
+        // from a column-sum kernel over the current H
+        CK(mv_numerator_pass(e, e->W, e->H, nullptr));
+        if (!have_hsum) {
+            hipLaunchKernelGGL(colsum_kernel, dim3(K), dim3(256), 0, e->stream, e->H, e->N, e->KP, e->red + K * V);
+            HIPCK(hipGetLastError());
+        }
+        CK(allreduce(e, e->red, (size_t)K * V + K + 1));
     }
-    CK(allreduce(e, e->red, (size_t)K * V + K + 1));
     // W_unconstrained from A, B (stream2) and the reduced sums; f0 = KL + lam * logdet(W) -> scal[1]
     HIPCK(hipStreamWaitEvent(e->stream, e->evPrepW, 0));
     hipLaunchKernelGGL(mv_prepare_final_kernel, dim3((K * V + 255) / 256), dim3(256), 0, e->stream, e->W, e->mvA, e->mvB, e->red,
                        e->red + K * V, e->red + K * V + K, e->scal + 3, K, V, n_given, lam, e->Wunc, e->scal + 1);
     HIPCK(hipGetLastError());
     double g = *gamma;
-    bool blend = false;
+    bool blend = false, dropped = false;
     for (;;) {
-        // trial W: normalise + clip and the column sums for H on the main stream; its logdet -> scal[4] on stream2,
-        // beside the forward pass that evaluates KL(W_trial, clip(H * colsum))
+        // a dropped speculation left a W-only kernel on stream2 that reads the trial buffer: the blend must not
+        // overwrite that buffer under it (invariant: Wtrial is rewritten only after every queued reader on stream2)
+        if (dropped) {
+            HIPCK(hipStreamWaitEvent(e->stream, e->evPrepW, 0));
+            dropped = false;
+        }
+        // trial W: normalise + clip and the column sums for H on the main stream; its logdet -> scal[4] on stream2
         hipLaunchKernelGGL(mv_trial_light_kernel, dim3(1), dim3(MV_BLOCK), 0, e->stream, e->W, e->Wunc, blend ? g : 1.0,
                            blend ? 1 : 0, K, V, e->Wtrial, e->cs);
         HIPCK(hipGetLastError());
@@ -872,29 +897,39 @@ static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double de
         hipLaunchKernelGGL(mv_logdet_kernel, dim3(1), dim3(MV_BLOCK), 0, e->stream2, e->Wtrial, K, V, delta, e->scal + 4);
         HIPCK(hipGetLastError());
         HIPCK(hipEventRecord(e->evLogdet, e->stream2));
-        CK(objective_to_slot(e, e->Wtrial, e->cs, false, 2, e->mv_fgrid));
         double v[5];
         const bool spec = speculate && !blend;
         if (spec) {
-            HIPCK(hipEventRecord(e->evObj, e->stream));
             if (!e->Halt) HIPCK(hipMalloc(&e->Halt, (size_t)e->Np * e->KP * sizeof(double)));
+            if (!e->KLpart2) HIPCK(hipMalloc(&e->KLpart2, (size_t)e->grid * sizeof(double)));
+            // the next step's update_H (+ row sums of the new H), which also evaluates this trial: KL(W_trial, H') -> scal[2]
             FusedParams sp = fused_params(e);
             sp.wkl = nullptr;
             sp.wlh = nullptr;
             sp.W = e->Wtrial;
             sp.hscale = e->cs;
             sp.Hout = e->Halt;
-            CK((launch_fused<false, true, true>(e, sp, e->mv_grid)));  // the next step's update_H, assuming acceptance
-            // ... and its W-only algebra, behind the trial's log det on stream2 (A, B of this step are consumed already)
+            sp.KLpart = e->KLpart2;
+            CK((launch_fused<false, true, true>(e, sp, e->mv_grid)));
+            hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, e->KLpart2, e->mv_grid, 1, 1, e->scal + 2);
+            HIPCK(hipGetLastError());
+            CK(allreduce(e, e->scal + 2, 1));
+            HIPCK(hipEventRecord(e->evObj, e->stream));
+            // ... its W-only algebra behind the trial's log det on stream2 (A, B of this step are consumed already) ...
             hipLaunchKernelGGL(mv_prepare_W_kernel, dim3(1), dim3(MV_BLOCK), 0, e->stream2, e->Wtrial, K, V, delta, e->mvA, e->mvB, e->scal + 3);
             HIPCK(hipGetLastError());
             HIPCK(hipEventRecord(e->evPrepW, e->stream2));
+            // ... and its numerator pass (W_trial as W, the new H): it runs while the scalars travel to the host
+            CK(mv_numerator_pass(e, e->Wtrial, e->Halt, nullptr));
+            CK(allreduce(e, e->red, (size_t)K * V + K + 1));
             HIPCK(hipStreamWaitEvent(e->stream3, e->evObj, 0));
             HIPCK(hipStreamWaitEvent(e->stream3, e->evLogdet, 0));
             HIPCK(hipMemcpyAsync(e->hpin, e->scal, 5 * sizeof(double), hipMemcpyDeviceToHost, e->stream3));
             HIPCK(hipStreamSynchronize(e->stream3));
             for (int i = 0; i < 5; ++i) v[i] = e->hpin[i];
         } else {
+            // KL(W_trial, clip(H * colsum)) by the forward pass, beside the log det
+            CK(objective_to_slot(e, e->Wtrial, e->cs, false, 2, e->mv_fgrid));
             HIPCK(hipStreamWaitEvent(e->stream, e->evLogdet, 0));
             CK(read_scalars(e, 0, 5, v));
         }
@@ -902,10 +937,11 @@ static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double de
         if (f1 > f0 && g > 1e-16) {  // mvnmf.py:84
             g *= 0.8;
             blend = true;
+            dropped = spec;  // (a rejected speculation is simply dropped: it wrote scratch buffers only)
             continue;
         }
         if (spec) {
-            // accepted at the first trial: the speculative pass is the next step's update_H
+            // accepted at the first trial: the speculative passes are the first half of the next step
             *gamma = std::min(1.0, 1.2 * g);
             std::swap(e->W, e->Wtrial);
             std::swap(e->H, e->Halt);  // written in full from clip(H * cs): nothing pending
@@ -935,21 +971,23 @@ int salnmf_mv_step(salnmf_engine* e, int n_steps, int n_given, double lam, doubl
     if (!e || !gamma_inout) return fail("null argument");
     if (n_given < 0 || n_given > e->K) return fail("n_given out of range");
     HIPCK(hipSetDevice(e->device));
-    bool have_H = false;  // this step's update_H pass already ran speculatively during the previous step
+    bool ahead = false;  // this step's update_H pass, W-only algebra and numerator pass already ran during the previous step
     for (int i = 0; i < n_steps; ++i) {
         const bool update_W = n_given < e->K;
         if (update_W && i == 0) HIPCK(hipEventRecord(e->evW, e->stream));  // later steps: recorded by the accept
-        if (!have_H) {
+        if (!ahead) {
             FusedParams p = fused_params(e);
             p.wkl = nullptr;  // MvNMF._update_H passes no weights (mvnmf.py:162-165)
             p.wlh = nullptr;
+            p.KLpart = nullptr;  // row sums of the new H only
             CK((launch_fused<false, true, true>(e, p, e->mv_grid)));  // update_H + row sums of the new H
             e->h_pending = false;
         }
         // W-only algebra on stream2, beside the passes; queued after the pass so that the host does not delay it
         // (an accepted speculation ran it already, for exactly this W)
-        if (update_W && !have_H) CK(mv_start_prepare_W(e, delta, false));
-        CK(mv_update_W_impl(e, n_given, lam, delta, gamma_inout, true, true, i + 1 < n_steps, &have_H));
+        if (update_W && !ahead) CK(mv_start_prepare_W(e, delta, false));
+        const bool was_ahead = ahead;
+        CK(mv_update_W_impl(e, n_given, lam, delta, gamma_inout, true, true, i + 1 < n_steps, &ahead, was_ahead));
     }
     return 0;
 }

@@ -116,7 +116,7 @@ struct FusedParams {
     const double* __restrict__ hscale;  // [KP] or null: H is read as clip(H*hscale) (MvNMF trial)
     double* __restrict__ Gpart;      // [gridDim.x][K][VMAX]     (DO_G) per-workgroup partial numerators
     double* __restrict__ Hsumpart;   // [gridDim.x][K]           (DO_STATS) row sums of H
-    double* __restrict__ KLpart;     // [gridDim.x]              (DO_STATS) unweighted KL partial
+    double* __restrict__ KLpart;     // [gridDim.x]              (DO_STATS) unweighted KL partial (DO_U: optional, null = skip)
     int64_t N;
     int V;
     int K;
@@ -568,7 +568,10 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
             }
         }
 
-        if (DO_STATS && DO_G) klacc += tile_kl(x, pr, nullptr, n0, N, V, q, c16);
+        // unweighted KL(X || P) of this tile from P before the division: always with the numerator pass (f0 of the MvNMF
+        // line search), with the update_H pass only when asked (KLpart != null: a speculative pass evaluates the trial
+        // it starts from, which saves the separate forward pass)
+        if (DO_STATS && (DO_G || p.KLpart != nullptr)) klacc += tile_kl(x, pr, nullptr, n0, N, V, q, c16);
         // ---- R = X / P in place (rows n = q + 4r, columns v = 16vt + c16); pads give 0 / P = 0
 #pragma unroll
         for (int vt = 0; vt < VT; ++vt)
@@ -893,7 +896,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
             p.Hsumpart[(int64_t)blockIdx.x * K + tid] = t;
         }
     }
-    if (DO_STATS && DO_G) {
+    if (DO_STATS && (DO_G || p.KLpart != nullptr)) {
         __syncthreads();
         double* Ks = lds;  // [BLOCK], fixed binary tree
         Ks[tid] = klacc;
