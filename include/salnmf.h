@@ -19,6 +19,12 @@
  *   - Host pointers are borrowed for the duration of the call only.  The engine owns
  *     all device memory.  A handle is not re-entrant.
  *   - One engine = one GPU = one shard of the sample axis.
+ *
+ * Limits of this build (the reference has none; every BASELINE.json configuration fits):
+ *   n_features <= 96, n_signatures <= 64, dim_embeddings <= 64, joint sample solves over at most 4 modalities /
+ *   128 signatures.  Anything larger is refused with a message by salnmf_create / salnmf_corr_configure /
+ *   salnmf_corr_update_sample_embeddings_multi -- never silently truncated.  They come from the register / LDS plan
+ *   of the fused kernel.
  */
 #ifndef SALNMF_H
 #define SALNMF_H

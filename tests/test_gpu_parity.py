@@ -264,6 +264,37 @@ def test_errors_are_exceptions_not_aborts():
     e.close()
 
 
+def test_limits_are_refused_with_a_message_and_closed_engines_raise():
+    """The documented limits of this build (include/salnmf.h) and the ADVICE r1 NULL-handle case."""
+    for args, text in (((10, 97, 2), "n_features"), ((10, 96, 65), "n_signatures")):
+        with pytest.raises(RuntimeError, match=text):
+            Engine(*args)
+    e = Engine(10, 96, 2)
+    with pytest.raises(RuntimeError, match="dim_embeddings"):
+        e.corr_configure(65)
+    e.close()
+    for call in (lambda: e.upload_W(np.ones((2, 96))), lambda: e.download_W(), lambda: e.kl_step(1), lambda: e.objective()):
+        with pytest.raises(RuntimeError, match="closed"):
+            call()
+
+
+def test_nan_propagates_as_in_the_reference():
+    """ndarray.clip keeps a NaN (`_utils_klnmf.py:341,347`); so do the engine's clips (fmax would have
+    replaced it by EPSILON and let a poisoned fit look converged).  Same NaN pattern as the oracle, NaN objective."""
+    X, W0, H0 = orc.synthetic_problem(96, 200, 7, seed=12)
+    H0[5, 3] = np.nan
+    e = Engine(200, 96, 7)
+    e.upload_X(X), e.upload_W(W0), e.upload_H(H0)
+    assert np.isnan(e.objective())
+    e.kl_step(1)
+    W, H = e.download_W(), e.download_H()
+    with np.errstate(invalid="ignore"):
+        Wr, Hr = orc.update_WH(X.T, W0.T, H0.T)
+    assert np.array_equal(np.isnan(W), np.isnan(Wr.T)) and np.array_equal(np.isnan(H), np.isnan(Hr.T))
+    assert np.isnan(H[5]).all() and np.isfinite(H[np.arange(200) != 5]).all()
+    e.close()
+
+
 def test_upload_clip_matches_setup_adata():
     X, W0, H0 = orc.synthetic_problem(96, 100, 4, seed=9)
     X[X <= EPS] = 0.0
@@ -297,6 +328,23 @@ def test_typed_chunked_ingest_equals_host_conversion(dtype, N, V):
     assert a.objective() == b.objective()
     assert np.array_equal(a.samplewise_kl(), b.samplewise_kl())
     a.close(), b.close()
+
+
+def test_persistent_multi_step_launch_gives_the_same_bits():
+    """The opt-in persistent kernel (n steps in one launch, in-kernel hand-offs) against per-step
+    launches: bit-identical W, H and objective, incl. given signatures, a grid smaller than the CU count and a step
+    count that is split over several launches."""
+    for N, K, n_given, steps in ((20000, 50, 0, 7), (3000, 50, 7, 70), (100003, 30, 0, 3), (500, 5, 0, 4)):
+        X, W0, H0 = orc.synthetic_problem(96, N, K, seed=N % 97)
+        outs = []
+        for persistent in (False, True):
+            e = Engine(N, 96, K)
+            e.set_persistent(persistent)
+            e.upload_X(X), e.upload_W(W0), e.upload_H(H0)
+            e.kl_step(steps, n_given)
+            outs.append((e.download_W(), e.download_H(), e.objective()))
+            e.close()
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
 
 
 # ------------------------------------------------------------------ determinism and split-step (multi-GPU semantics on one GPU)
