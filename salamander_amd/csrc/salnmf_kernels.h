@@ -105,6 +105,7 @@ struct Geo {
     static constexpr int LDS_DOUBLES = WROWS * WS + WAVES * (HL + RL);
 };
 
+constexpr int COOP_SLAB = 4 * VT * 256 + 4 * VMAX;  // accumulator-layout tiles (<= 4 x 6 of [4][64]) + <= 4 remainder rows
 struct FusedParams {
     const double* __restrict__ X;    // [Np][VMAX]
     double* __restrict__ H;          // [Np][KP]  read; DO_U writes the update to Hout (normally == H)
@@ -121,6 +122,7 @@ struct FusedParams {
     int V;
     int K;
     int64_t ntiles;
+    double* coopslab;       // [gridDim.x][COOP_SLAB]: a workgroup's numerator contribution of its cooperative leftover tile
     // persistent multi-step mode (PERSIST instantiation only): the joint update_WH step nsteps times in ONE launch
     int nsteps;
     int n_given;
@@ -487,6 +489,13 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
 
     const int64_t tstride = (int64_t)gridDim.x * WAVES;
     int64_t tile = 0;
+    // Leftover round.  ntiles = R * (waves of the grid) + L: with 0 < L <= workgroups the L leftover tiles would keep
+    // L waves busy for a whole tile time while the rest of the chip idles (c2: 106 of 1024 waves, 9.6 of 78 us).  In
+    // the plain joint step they are instead worked on by all four waves of workgroup 0 .. L-1 (process_tile_coop below).
+    constexpr bool COOP = DO_G && DO_U && !DO_STATS && !WTS;
+    const int64_t nleft = p.ntiles % tstride;
+    const bool coop = COOP && nleft > 0 && nleft <= (int64_t)gridDim.x && p.hscale == nullptr;
+    const int64_t nfull = coop ? p.ntiles - nleft : p.ntiles;  // tiles of the one-wave-per-tile rounds
 
     // lane's slice of an H tile: element pair e = 2*lane + 128*j of the contiguous [16][KP] block
     int hrow[HV], hcol[HV];
@@ -580,7 +589,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
 
         // prefetch the next tile: X and the staging registers are free from here on, and the loads
         // get the G and U phases to land
-        if (tile + tstride < p.ntiles) load_tile(tile + tstride);
+        if (tile + tstride < nfull) load_tile(tile + tstride);
 
         if (DO_U) {
             // ---- transpose R through LDS: write accumulator layout, read A-operand layout
@@ -769,19 +778,141 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
                 for (int vt = 0; vt < VT; ++vt) grem[j][vt] = 0.0;
         }
     }
+    // ---- one tile by the four waves of a workgroup (leftover round, see above).
+    //   phase A  wave w takes the feature tiles {0,1} / {2,3} / {4} / {5}: P and R = X / P for those columns, their
+    //            share of G (into its own accumulators: G is summed over the waves anyway) and of the remainder rows;
+    //            R goes to a tile in LDS that all waves share (wave 0's), as does the staged H tile
+    //   phase B  wave kt < KT computes U[:, 16 kt .. 16 kt + 15] = R W^T over all 96 features (the same MFMA chain as in
+    //            process_tile: same bits) and updates those columns of H; the next wave takes the KR remainder columns
+    //            (one lane per (sample, column), sequential dot product over the features)
+    // Per entry the arithmetic is the reference's; what differs from process_tile is only which wave's accumulator a
+    // contribution to G lands in and the summation order of the remainder columns of U (rounding level).
+    auto process_tile_coop = [&](int64_t ctile) __attribute__((always_inline)) {
+        const int64_t n0 = ctile * 16;
+        // (indices derived from an opaque copy of the thread index: nothing of this once-per-launch section may be
+        // hoisted above the tile loop, where it would cost registers)
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wave = tid >> 6, c16 = lane & 15, q = lane >> 4;
+        double* Hs = lds + G_::WROWS * WS;  // wave 0's H tile and R tile serve as the shared ones
+        double* cslab = p.coopslab + (int64_t)blockIdx.x * COOP_SLAB;
+        double* Rs = Hs + G_::HL;
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        // loads first (they fly while the slower waves of the workgroup arrive): the H tile, 16 bytes per thread and
+        // round, and this wave's columns of X
+        constexpr int HR = (16 * KP + 2 * BLOCK - 1) / (2 * BLOCK);
+        d2 hst[HR];
+#pragma unroll
+        for (int j = 0; j < HR; ++j) {
+            const int e = 2 * tid + 2 * BLOCK * j;
+            hst[j] = (e < 16 * KP) ? *reinterpret_cast<const d2*>(p.H + n0 * KP + e) : (d2){0, 0};
+        }
+        const int vt0 = wv < 2 ? 2 * wv : wv + 2, nvt = wv < 2 ? 2 : 1;  // {0,1} {2,3} {4} {5}
+        double xx[2][4];
+        {
+            const double* xsrc = p.X + (n0 + q) * VMAX + c16;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xx[i][r] = (i < nvt) ? xsrc[4 * r * VMAX + 16 * (vt0 + i)] : 0.0;
+        }
+        __syncthreads();  // every wave has left its own last tile: wave 0's LDS regions are free
+#pragma unroll
+        for (int j = 0; j < HR; ++j) {
+            const int e = 2 * tid + 2 * BLOCK * j;
+            if (e < 16 * KP) {
+                const int row = e / KP, col = e - row * KP;
+                *reinterpret_cast<d2*>(Hs + row * LS + col) = hst[j];
+            }
+        }
+        __syncthreads();
+        // ---- phase A, one feature tile at a time (compile-time tile index: the accumulators are registers)
+        auto phase_a = [&](auto vtag, const double (&xv)[4]) __attribute__((always_inline)) {
+            constexpr int VTI = decltype(vtag)::value;
+            d4 pp = (d4){0, 0, 0, 0};
+            const double* ha = Hs + c16 * LS + q;
+            const double* wb = Wl + q * WS + 16 * VTI + c16;
+#pragma unroll
+            for (int s2 = 0; s2 < KS; ++s2) pp = mfma(ha[4 * s2], wb[4 * s2 * WS], pp);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pp[r] = div_path(xv[r], pp[r]);
+                Rs[(q + 4 * r) * RS + 16 * VTI + c16] = pp[r];
+            }
+            // this tile's contribution to G goes to the workgroup's cooperative slab (accumulator layout), which the
+            // epilogue adds after the four waves' accumulators: the accumulators themselves are not touched outside the
+            // tile loop (doing so changes hipcc's register assignment inside the loop and costs ~2 % there)
+            d4 gc[KT];
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) gc[kt] = (d4){0, 0, 0, 0};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) gc[kt] = mfma(Hs[(4 * r + q) * LS + 16 * kt + c16], pp[r], gc[kt]);
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int r2 = 0; r2 < 4; ++r2) cslab[((kt * VT + VTI) * 4 + r2) * 64 + lane] = gc[kt][r2];
+            if (KR > 0) {
+#pragma unroll
+                for (int j = 0; j < KR; ++j) {
+                    double t = 0.0;  // this feature column's sum over the 16 samples: 4 rows per lane, then the 4 q groups
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) t = __builtin_fma(Hs[(4 * r + q) * LS + KB + j], pp[r], t);
+                    t += __shfl_xor(t, 16, 64);
+                    t += __shfl_xor(t, 32, 64);
+                    if (q == 0) cslab[4 * VT * 256 + j * VMAX + 16 * VTI + c16] = t;
+                }
+            }
+        };
+        {
+            using std::integral_constant;
+            if (wv == 0) { phase_a(integral_constant<int, 0>{}, xx[0]); phase_a(integral_constant<int, 1>{}, xx[1]); }
+            else if (wv == 1) { phase_a(integral_constant<int, 2>{}, xx[0]); phase_a(integral_constant<int, 3>{}, xx[1]); }
+            else if (wv == 2) phase_a(integral_constant<int, 4>{}, xx[0]);
+            else phase_a(integral_constant<int, 5>{}, xx[0]);
+        }
+        __syncthreads();  // the ratio tile is complete
+        // ---- phase B
+        if (wv < KT) {
+            const int kt = wv;
+            d4 u = (d4){0, 0, 0, 0};
+            const double* ra = Rs + c16 * RS + q;
+            const double* wb = Wl + (16 * kt + c16) * WS + q;
+#pragma unroll
+            for (int s2 = 0; s2 < VSTEPS; ++s2) u = mfma(ra[4 * s2], wb[4 * s2], u);
+            double* hdst = p.Hout + (n0 + q) * KP + 16 * kt + c16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double hn = clip_lo(Hs[(q + 4 * r) * LS + 16 * kt + c16] * u[r], p.hfloor);
+                __builtin_nontemporal_store(hn, &hdst[4 * r * KP]);
+            }
+        } else if (KR > 0 && wv == KT) {
+            const int n = lane & 15, j = lane >> 4;
+            if (j < KR) {
+                const double* rr = Rs + n * RS;
+                const double* wr = Wl + (KB + j) * WS;
+                double dot = 0.0;
+                for (int v = 0; v < VMAX; ++v) dot = __builtin_fma(rr[v], wr[v], dot);
+                p.Hout[(n0 + n) * KP + KB + j] = clip_lo(Hs[n * LS + KB + j] * dot, p.hfloor);
+            }
+        }
+    };
+
     tile = (int64_t)blockIdx.x * WAVES + wave;
     if (PERSIST) {
         // the first tile (its H rows were written by this very wave in the previous step) flies during the wait
-        if (tile < p.ntiles) load_tile(tile);
+        if (tile < nfull) load_tile(tile);
         if (step > 0 && !persist_wait_W(p.sync, p.abort_host, (unsigned)step * (unsigned)K, lds, tid)) return;
         stage_W<G_::WROWS, true>(Wl, p.Wmut, K, V, tid);  // sc1 loads: rows published by other workgroups
         __syncthreads();
     } else {
         stage_W<G_::WROWS>(Wl, p.W, K, V, tid);
         __syncthreads();
-        if (tile < p.ntiles) load_tile(tile);
+        if (tile < nfull) load_tile(tile);
     }
-    for (; tile < p.ntiles; tile += tstride) process_tile(tile);
+    for (; tile < nfull; tile += tstride) process_tile(tile);
+    if (COOP && coop && (int64_t)blockIdx.x < nleft) process_tile_coop(nfull + blockIdx.x);
 
     // ---- workgroup reductions, fixed order (deterministic)
     __syncthreads();  // every wave is done with the LDS copy of W
@@ -850,6 +981,11 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
                                 acc[r] = (w == 0) ? v : acc[r] + v;
                             }
                         }
+                        if (COOP && coop && (int64_t)blockIdx.x < nleft) {
+                            const double* cs = p.coopslab + (int64_t)blockIdx.x * COOP_SLAB + ((kt * VT + vt) * 4) * 64 + lane;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[r] += cs[r * 64];
+                        }
                         const int v = 16 * vt + c16;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -861,7 +997,8 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
             if (KR > 0 && half == 0) {
                 for (int i = tid; i < KR * VMAX; i += BLOCK) {
                     const int j = i / VMAX, v = i - j * VMAX;
-                    const double t = ((remL[j * VMAX + v] + remL[(KR + j) * VMAX + v]) + remL[(2 * KR + j) * VMAX + v]) + remL[(3 * KR + j) * VMAX + v];
+                    double t = ((remL[j * VMAX + v] + remL[(KR + j) * VMAX + v]) + remL[(2 * KR + j) * VMAX + v]) + remL[(3 * KR + j) * VMAX + v];
+                    if (COOP && coop && (int64_t)blockIdx.x < nleft) t += p.coopslab[(int64_t)blockIdx.x * COOP_SLAB + 4 * VT * 256 + j * VMAX + v];
                     if (v < V) st_shared<PERSIST>(&out[(KB + j) * VMAX + v], t);
                 }
             }
