@@ -131,7 +131,6 @@ struct salnmf_engine {
     double* Gpart = nullptr;     // [grid][K][VMAX]
     double* Hsumpart = nullptr;  // [grid][K]
     double* KLpart = nullptr;    // [grid]
-    double* coopslab = nullptr;  // [grid][COOP_SLAB] numerator contributions of the cooperative leftover tiles
     double* KLpart2 = nullptr;   // [grid] KL partials of a speculative update_H pass (the trial's objective)
     double* red = nullptr;       // [K*V | K | 1 | pad]  G, rowsums_H, KL of the local shard (then all-reduced)
     double* objpart = nullptr;   // [grid]
@@ -254,7 +253,6 @@ static FusedParams fused_params(salnmf_engine* e) {
     p.Gpart = e->Gpart;
     p.Hsumpart = e->Hsumpart;
     p.KLpart = e->KLpart;
-    p.coopslab = e->coopslab;
     p.N = e->N;
     p.V = e->V;
     p.K = e->K;
@@ -347,7 +345,7 @@ void salnmf_destroy(salnmf_engine* e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->comm) ncclCommDestroy(e->comm);
     double* bufs[] = {e->X, e->H, e->W, e->wkl, e->wlh, e->Gpart, e->Hsumpart, e->KLpart, e->red,
-                      e->objpart, e->scal, e->Wunc, e->Wtrial, e->mvA, e->mvB, e->cs, e->scratch, e->Halt, e->KLpart2, e->coopslab,
+                      e->objpart, e->scal, e->Wunc, e->Wtrial, e->mvA, e->mvB, e->cs, e->scratch, e->Halt, e->KLpart2,
                       e->alpha, e->beta, e->Lemb, e->Uemb, e->aux, e->xrowsum, e->corrpart, e->gU, e->galpha, e->gaux};
     for (double* b : bufs)
         if (b) (void)hipFree(b);
@@ -430,7 +428,6 @@ int salnmf_create(int device, int n_features, int64_t n_samples, int n_signature
     ALLOC(e->Gpart, (size_t)e->grid * K * VMAX);
     ALLOC(e->Hsumpart, (size_t)e->grid * K);
     ALLOC(e->KLpart, (size_t)e->grid);
-    ALLOC(e->coopslab, (size_t)e->grid * COOP_SLAB);
     ALLOC(e->red, K * V + K + 2);
     ALLOC(e->objpart, (size_t)e->fgrid);
     ALLOC(e->scal, 8);

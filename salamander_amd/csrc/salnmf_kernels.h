@@ -105,7 +105,6 @@ struct Geo {
     static constexpr int LDS_DOUBLES = WROWS * WS + WAVES * (HL + RL);
 };
 
-constexpr int COOP_SLAB = 4 * VT * 256 + 4 * VMAX;  // accumulator-layout tiles (<= 4 x 6 of [4][64]) + <= 4 remainder rows
 struct FusedParams {
     const double* __restrict__ X;    // [Np][VMAX]
     double* __restrict__ H;          // [Np][KP]  read; DO_U writes the update to Hout (normally == H)
@@ -122,7 +121,6 @@ struct FusedParams {
     int V;
     int K;
     int64_t ntiles;
-    double* coopslab;       // [gridDim.x][COOP_SLAB]: a workgroup's numerator contribution of its cooperative leftover tile
     // persistent multi-step mode (PERSIST instantiation only): the joint update_WH step nsteps times in ONE launch
     int nsteps;
     int n_given;
@@ -416,6 +414,19 @@ __device__ __attribute__((noinline)) bool persist_wait_W(unsigned* sync, unsigne
     return ok;
 }
 
+// Epilogue geometry of the fused kernel's numerator reduction, shared with the cooperative tile: ROUNDS feature
+// ranges of VTR tiles; within a round tile t = kt * VTR + h is owned by wave t % 4 (its slot i = t / 4).
+template <int KT, int KR, int LDS_DOUBLES>
+struct EpiGeo {
+    static constexpr int REMD = KR > 0 ? WAVES * KR * VMAX : 0;  // parked remainder rows
+    static constexpr int ROUNDS = (3 * KT * VT * 256 + REMD <= LDS_DOUBLES) ? 1 : 2;
+    static constexpr int VTR = VT / ROUNDS, NT = KT * VTR;
+    static constexpr int MAXI = (NT + WAVES - 1) / WAVES;        // tiles a wave owns per round, at most
+    static constexpr int REM = ROUNDS * NT * 256;                // offset of the remainder rows in the cooperative park
+    static constexpr int COOP_DOUBLES = REM + (KR > 0 ? KR * VMAX : 0);
+    static constexpr int pos(int kt, int vt) { return (vt / VTR) * NT + kt * VTR + (vt % VTR); }
+};
+
 // ----------------------------------------------------------------------------------------------
 // Fused update pass.
 //   DO_G     accumulate G = (w_kl * R)^T-contracted numerator for the W update
@@ -493,6 +504,8 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
     // L waves busy for a whole tile time while the rest of the chip idles (c2: 106 of 1024 waves, 9.6 of 78 us).  In
     // the plain joint step they are instead worked on by all four waves of workgroup 0 .. L-1 (process_tile_coop below).
     constexpr bool COOP = DO_G && DO_U && !DO_STATS && !WTS;
+    using CO_ = EpiGeo<KT, KR, G_::LDS_DOUBLES>;
+    static_assert(CO_::COOP_DOUBLES <= (WAVES - 1) * (G_::HL + G_::RL), "the cooperative tile's numerator park must fit the idle waves' LDS");
     const int64_t nleft = p.ntiles % tstride;
     const bool coop = COOP && nleft > 0 && nleft <= (int64_t)gridDim.x && p.hscale == nullptr;
     const int64_t nfull = coop ? p.ntiles - nleft : p.ntiles;  // tiles of the one-wave-per-tile rounds
@@ -795,7 +808,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         asm volatile("" : "+v"(tid));
         const int lane = tid & 63, wave = tid >> 6, c16 = lane & 15, q = lane >> 4;
         double* Hs = lds + G_::WROWS * WS;  // wave 0's H tile and R tile serve as the shared ones
-        double* cslab = p.coopslab + (int64_t)blockIdx.x * COOP_SLAB;
+        double* cslab = lds + G_::WROWS * WS + (G_::HL + G_::RL);  // the LDS regions of waves 1..3 are free meanwhile
         double* Rs = Hs + G_::HL;
         const int wv = __builtin_amdgcn_readfirstlane(wave);
         // loads first (they fly while the slower waves of the workgroup arrive): the H tile, 16 bytes per thread and
@@ -839,9 +852,10 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
                 pp[r] = div_path(xv[r], pp[r]);
                 Rs[(q + 4 * r) * RS + 16 * VTI + c16] = pp[r];
             }
-            // this tile's contribution to G goes to the workgroup's cooperative slab (accumulator layout), which the
-            // epilogue adds after the four waves' accumulators: the accumulators themselves are not touched outside the
-            // tile loop (doing so changes hipcc's register assignment inside the loop and costs ~2 % there)
+            // this tile's contribution to G is parked in LDS (accumulator layout, indexed like the epilogue's tiles); the
+            // epilogue's owner waves pick it up before they reuse LDS and add it after the four waves' accumulators.  The
+            // accumulators themselves are not touched outside the tile loop (doing so changes hipcc's register assignment
+            // inside the loop and costs ~2 % there).
             d4 gc[KT];
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) gc[kt] = (d4){0, 0, 0, 0};
@@ -852,7 +866,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-                for (int r2 = 0; r2 < 4; ++r2) cslab[((kt * VT + VTI) * 4 + r2) * 64 + lane] = gc[kt][r2];
+                for (int r2 = 0; r2 < 4; ++r2) cslab[((CO_::pos(kt, VTI)) * 4 + r2) * 64 + lane] = gc[kt][r2];
             if (KR > 0) {
 #pragma unroll
                 for (int j = 0; j < KR; ++j) {
@@ -861,7 +875,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
                     for (int r = 0; r < 4; ++r) t = __builtin_fma(Hs[(4 * r + q) * LS + KB + j], pp[r], t);
                     t += __shfl_xor(t, 16, 64);
                     t += __shfl_xor(t, 32, 64);
-                    if (q == 0) cslab[4 * VT * 256 + j * VMAX + 16 * VTI + c16] = t;
+                    if (q == 0) cslab[CO_::REM + j * VMAX + 16 * VTI + c16] = t;
                 }
             }
         };
@@ -928,14 +942,37 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         // conflict-free ds_write per register, no index arithmetic), ONE barrier, then the owner adds the four
         // contributions in the fixed order wave 0 + 1 + 2 + 3 and stores its tiles: 128-byte row segments.
         // ROUNDS = 2 (feature halves) only where the parked tiles do not fit (KT = 4).
-        constexpr int REMD = KR > 0 ? WAVES * KR * VMAX : 0;  // parked remainder rows
-        constexpr int ROUNDS = (3 * KT * VT * 256 + REMD <= G_::LDS_DOUBLES) ? 1 : 2;
-        constexpr int VTR = VT / ROUNDS, NT = KT * VTR;
+        constexpr int REMD = CO_::REMD, ROUNDS = CO_::ROUNDS, VTR = CO_::VTR, NT = CO_::NT;
         static_assert(3 * NT * 256 + REMD <= G_::LDS_DOUBLES, "parked accumulator tiles must fit in LDS");
         auto owned = [](int o) constexpr { return o < NT ? (NT - o + 3) / 4 : 0; };   // tiles owned by wave o
         auto pbase = [&](int o) constexpr { int b = 0; for (int i = 0; i < o; ++i) b += 3 * owned(i); return b; };
         double* remL = lds + 3 * NT * 256;  // [WAVES][KR][VMAX]
         const int wv = __builtin_amdgcn_readfirstlane(wave);  // provably uniform: scalar branches below
+        // a cooperative leftover tile left its numerator contribution in LDS: the owners take theirs into registers
+        // before the parking below reuses that memory
+        const bool coopwg = COOP && coop && (int64_t)blockIdx.x < nleft;
+        double cc[ROUNDS][CO_::MAXI][4];
+        double crem[2] = {0.0, 0.0};
+        if (COOP && coopwg) {
+            const double* cl = lds + G_::WROWS * WS + (G_::HL + G_::RL);
+#pragma unroll
+            for (int half = 0; half < ROUNDS; ++half)
+#pragma unroll
+                for (int i = 0; i < CO_::MAXI; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int t = wv + WAVES * i;
+                        cc[half][i][r] = t < NT ? cl[((half * NT + t) * 4 + r) * 64 + lane] : 0.0;
+                    }
+            if (KR > 0) {
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int i = tid + it * BLOCK;
+                    if (i < KR * VMAX) crem[it] = cl[CO_::REM + i];
+                }
+            }
+            __syncthreads();
+        }
         double* out = p.Gpart + (int64_t)blockIdx.x * K * VMAX;
 #pragma unroll
         for (int half = 0; half < ROUNDS; ++half) {
@@ -981,10 +1018,9 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
                                 acc[r] = (w == 0) ? v : acc[r] + v;
                             }
                         }
-                        if (COOP && coop && (int64_t)blockIdx.x < nleft) {
-                            const double* cs = p.coopslab + (int64_t)blockIdx.x * COOP_SLAB + ((kt * VT + vt) * 4) * 64 + lane;
+                        if (COOP && coopwg) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) acc[r] += cs[r * 64];
+                            for (int r = 0; r < 4; ++r) acc[r] += cc[half][i][r];
                         }
                         const int v = 16 * vt + c16;
 #pragma unroll
@@ -995,11 +1031,15 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
                     }
                 }
             if (KR > 0 && half == 0) {
-                for (int i = tid; i < KR * VMAX; i += BLOCK) {
-                    const int j = i / VMAX, v = i - j * VMAX;
-                    double t = ((remL[j * VMAX + v] + remL[(KR + j) * VMAX + v]) + remL[(2 * KR + j) * VMAX + v]) + remL[(3 * KR + j) * VMAX + v];
-                    if (COOP && coop && (int64_t)blockIdx.x < nleft) t += p.coopslab[(int64_t)blockIdx.x * COOP_SLAB + 4 * VT * 256 + j * VMAX + v];
-                    if (v < V) st_shared<PERSIST>(&out[(KB + j) * VMAX + v], t);
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int i = tid + it * BLOCK;
+                    if (i < KR * VMAX) {
+                        const int j = i / VMAX, v = i - j * VMAX;
+                        double t = ((remL[j * VMAX + v] + remL[(KR + j) * VMAX + v]) + remL[(2 * KR + j) * VMAX + v]) + remL[(3 * KR + j) * VMAX + v];
+                        if (COOP && coopwg) t += crem[it];
+                        if (v < V) st_shared<PERSIST>(&out[(KB + j) * VMAX + v], t);
+                    }
                 }
             }
             if (half + 1 < ROUNDS) __syncthreads();

@@ -39,13 +39,6 @@ int main(int argc, char** argv) {
     salnmf_B::FusedParams pb{}; pb.X = dX; pb.H = dH; pb.Hout = dH; pb.hfloor = salnmf_B::kEps; pb.W = dW; pb.Gpart = dG; pb.N = N; pb.V = V; pb.K = K; pb.ntiles = Np / 16;
     salnmf_A::TailParams ta{}; ta.Gpart = dG; ta.G = dGr; ta.W = dW; ta.nslabs = grid; ta.V = V; ta.K = K; ta.do_tail = 1; ta.nparts = grid;
     salnmf_B::TailParams tb{}; tb.Gpart = dG; tb.G = dGr; tb.W = dW; tb.nslabs = grid; tb.V = V; tb.K = K; tb.do_tail = 1; tb.nparts = grid;
-    double* dCoop; CK(hipMalloc(&dCoop, (size_t)grid * (4 * 6 * 256 + 4 * 96) * 8));  // cooperative-tile slabs (versions that have them)
-#ifdef AB_A_HAS_COOP
-    pa.coopslab = dCoop;
-#endif
-#ifndef AB_B_NO_COOP
-    pb.coopslab = dCoop;
-#endif
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     auto block = [&](int which, int steps) {
         CK(hipMemcpyAsync(dH, dH0, H.size() * 8, hipMemcpyDeviceToDevice, st)); CK(hipMemcpyAsync(dW, dW0, W.size() * 8, hipMemcpyDeviceToDevice, st));

@@ -10,10 +10,10 @@ def rep(anchor, new):
     s = s.replace(anchor, new, 1)
 
 
-rep("    int64_t ntiles;\n};\n\n// log(x / p)", "    int64_t ntiles;\n    unsigned long long* dbg;\n};\n\n// log(x / p)")
+rep("    unsigned* abort_host;   // pinned host word, set to 1 when a wait gave up\n};", "    unsigned* abort_host;   // pinned host word, set to 1 when a wait gave up\n    unsigned long long* dbg;\n};")
 macro = '''#define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t1_; asm volatile("s_memtime %0\\n\\ts_waitcnt lgkmcnt(0)" : "=s"(t1_) :: "memory"); __builtin_amdgcn_sched_barrier(0); ph[i] += t1_ - t0_; t0_ = t1_; } while (0)
 '''
-rep("template <int KS, int KTM, int KR, bool DO_G, bool DO_U, bool DO_STATS, bool WTS = false>\n__global__", macro + "template <int KS, int KTM, int KR, bool DO_G, bool DO_U, bool DO_STATS, bool WTS = false>\n__global__")
+rep("template <int KS, int KTM, int KR, bool DO_G, bool DO_U, bool DO_STATS, bool WTS = false, bool PERSIST = false>\n__global__", macro + "template <int KS, int KTM, int KR, bool DO_G, bool DO_U, bool DO_STATS, bool WTS = false, bool PERSIST = false>\n__global__")
 rep("    d2 hpre[HV];\n    double x[VT][4];\n\n    auto load_tile",
     "    unsigned long long ph[8] = {0,0,0,0,0,0,0,0}; unsigned long long t0_;\n    d2 hpre[HV];\n    double x[VT][4];\n\n    auto load_tile")
 rep("        const int64_t n0 = tile * 16;\n        // ---- stage the H tile", "        const int64_t n0 = tile * 16;\n        STAMP(7);\n        // ---- stage the H tile")

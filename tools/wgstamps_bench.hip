@@ -25,7 +25,7 @@ int main(int argc, char** argv) {
     double *dX, *dH, *dW, *dG, *dGr;
     int grid = 256;
     CK(hipMalloc(&dX, X.size() * 8)); CK(hipMalloc(&dH, H.size() * 8)); CK(hipMalloc(&dW, W.size() * 8));
-    CK(hipMalloc(&dG, (size_t)grid * K * V * 8)); CK(hipMalloc(&dGr, (size_t)K * V * 8));
+    CK(hipMalloc(&dG, (size_t)grid * K * VMAX * 8)); CK(hipMalloc(&dGr, (size_t)K * V * 8));
     CK(hipMemcpy(dX, X.data(), X.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dH, H.data(), H.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dW, W.data(), W.size() * 8, hipMemcpyHostToDevice));
     unsigned long long *dbgF, *dbgT;
     const size_t FS = (size_t)grid * WAVES * 8, TS = 2 * 64;
@@ -48,7 +48,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(F.data(), dbgF, F.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(T.data(), dbgT, T.size() * 8, hipMemcpyDeviceToHost));
     const int NW = grid * WAVES;
     printf("all times in us relative to the first wave's entry into that step's fused kernel (clock tick = 10 ns)\n");
-    printf("step | entry max | W staged avg max | 1st tile done avg | loop done min avg max | wg barrier max | end min avg max | tail start min, end max | next entry min\n");
+    printf("step | entry max | W staged avg max | 1st tile done avg | loop done min avg max | coop tile done max | wg barrier max | end min avg max | tail start min, end max | next entry min\n");
     for (int s = 8; s < STEPS - 1; ++s) {
         const unsigned long long* f = &F[s * FS];
         unsigned long long t0 = ~0ull;
@@ -58,14 +58,14 @@ int main(int argc, char** argv) {
             for (int w = 0; w < NW; ++w) { double v = (double)(long long)(f[w * 8 + i] - t0) * 0.01; mn = std::min(mn, v); mx = std::max(mx, v); av += v; }
             av /= NW;
         };
-        double a[6][3];
-        for (int i = 0; i < 6; ++i) stat(i, a[i][0], a[i][1], a[i][2]);
+        double a[7][3];
+        for (int i = 0; i < 7; ++i) stat(i, a[i][0], a[i][1], a[i][2]);
         double ts = 1e30, te = -1e30;
         for (int k = 0; k < K; ++k) { ts = std::min(ts, (double)(long long)(T[s * TS + 2 * k] - t0) * 0.01); te = std::max(te, (double)(long long)(T[s * TS + 2 * k + 1] - t0) * 0.01); }
         unsigned long long n0 = ~0ull;
         for (int w = 0; w < NW; ++w) n0 = std::min(n0, F[(s + 1) * FS + w * 8]);
-        printf("%4d | %5.2f | %5.2f %5.2f | %5.2f | %6.2f %6.2f %6.2f | %6.2f | %6.2f %6.2f %6.2f | %6.2f %6.2f | %6.2f\n", s, a[0][2], a[1][1], a[1][2], a[2][1],
-               a[3][0], a[3][1], a[3][2], a[4][2], a[5][0], a[5][1], a[5][2], ts, te, (double)(long long)(n0 - t0) * 0.01);
+        printf("%4d | %5.2f | %5.2f %5.2f | %5.2f | %6.2f %6.2f %6.2f | %6.2f | %6.2f | %6.2f %6.2f %6.2f | %6.2f %6.2f | %6.2f\n", s, a[0][2], a[1][1], a[1][2], a[2][1],
+               a[3][0], a[3][1], a[3][2], a[6][2], a[4][2], a[5][0], a[5][1], a[5][2], ts, te, (double)(long long)(n0 - t0) * 0.01);
     }
     // loop-done histogram of the last measured step: waves with 6 vs 7 tiles
     {
