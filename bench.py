@@ -209,6 +209,9 @@ def main():
     ap.add_argument("--weak", action="store_true", help="N > 1: 100 000 samples per GPU instead of 10^6 in total")
     ap.add_argument("--no-one-gpu-reference", action="store_true", help="N > 1: skip rank 0's run of the whole problem on one GPU")
     ap.add_argument("--busy-seconds", type=float, default=2.5, help="repeat the K-step block until the GPU was busy this long")
+    ap.add_argument("--rehearse-sharded", action="store_true",
+                    help="--gpus 1 only: run the N > 1 code path (process group, RCCL communicator in the engine, c3's row blocks, "
+                    "one-GPU reference) at world size 1 -- a rehearsal of what the driver launches on a multi-GPU node")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -224,14 +227,17 @@ def main():
     from salamander_amd.synthetic import synthetic_problem
 
     dist = None
-    if world > 1:
+    sharded = world > 1 or args.rehearse_sharded
+    if sharded:
         import torch.distributed as dist
 
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29555")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    strong = world > 1 and not args.weak
-    if world == 1:
+    strong = sharded and not args.weak
+    if not sharded:
         n_total = args.samples_total or N_C2
         X, W0, H0 = synthetic_problem(V, n_total, K, seed=0)
         n_local = n_total
@@ -239,7 +245,7 @@ def main():
         n_total = args.samples_total or N_C3
         lo, hi = shard_bounds(n_total, world, rank)
         X, H0 = problem_rows(lo, hi)
-        _, W0, _ = synthetic_problem(V, 16, K, seed=0)  # W0 depends on the seed only (drawn after X: same draws need same N)
+        _, W0, _ = synthetic_problem(V, 16, K, seed=0)  # any common start: rank 0's is broadcast below
         n_local = hi - lo
     else:
         n_local = N_C2
@@ -247,7 +253,7 @@ def main():
         X, W0, H0 = synthetic_problem(V, n_local, K, seed=rank)
 
     engine = sal.Engine(n_local, V, K, device=local_rank)
-    if world > 1:
+    if sharded:
         from salamander_amd.distributed import attach_communicator, broadcast_from_rank0
 
         attach_communicator(engine)
@@ -329,7 +335,7 @@ def main():
         if os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc))
-                traffic = rec.get("fused_kernel_hbm_bytes_per_launch")
+                traffic = rec.get("fused_kernel_hbm_bytes_per_launch") if n_local == N_C2 else None  # measured at c2 only
                 traffic_source = (
                     f"NOT measured in this run: profiles/pmc_summary.json ({rec.get('date', 'round 1')}), rocprofv3 --pmc "
                     "FETCH_SIZE / WRITE_SIZE passes of this command at c2 (FETCH x2 gfx950 correction applied)"
@@ -339,7 +345,7 @@ def main():
         steps_per_s = args.steps / median
         line = {
             "metric": "KL-NMF update-steps/sec (96xN, k=50)",
-            "value": steps_per_s * (world if (world > 1 and not strong) else 1),
+            "value": steps_per_s * (world if (sharded and not strong) else 1),
             "unit": "update-steps/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -361,7 +367,7 @@ def main():
                 "n_samples_per_gpu": n_local,
                 "n_samples_total": n_total,
                 "n_signatures": K,
-                "parallelism": f"sample-sharded x{world}; one RCCL all-reduce of {K}x{V} f64 per step" if world > 1 else "single GPU",
+                "parallelism": f"sample-sharded x{world}; one RCCL all-reduce of {K}x{V} f64 per step" if sharded else "single GPU",
                 "global_steps_per_s": steps_per_s,
                 "objective_after_run": objective,
                 "one_gpu_same_problem": one_gpu,
@@ -396,7 +402,7 @@ def main():
             },
         }
         engine.close()
-        if world == 1:
+        if not sharded:
             if not args.no_cpu_baseline:
                 rec, (n_cpu, target, cpu_s) = cpu_baseline(X, W0, H0, args.cpu_steps, args.cpu_budget)
                 line["cpu_baseline"] = rec
