@@ -189,15 +189,19 @@ def initialize_corrnmf(
     method="nndsvd",
     given_parameters: dict[str, Any] | None = None,
     initialize_sample_embeddings: bool = True,
+    base=None,
     **kwargs,
 ):
     """Signatures as for standard NMF; scalings zero; embeddings standard normal from the global RNG;
-    variance 1 -- each unless given (initialize.py:319-384).  Returns ``(asignatures, variance)``."""
+    variance 1 -- each unless given (initialize.py:319-384).  Returns ``(asignatures, variance)``.
+
+    ``base`` (ours): a replacement for :func:`initialize_base` with the same signature -- the models pass the
+    device-side initialisation of the signatures (``device_init.py``) here."""
     if method == "custom":
         raise ValueError("Custom parameter initializations are currently not supported for (multimodal) correlated NMF.")
     given_parameters = {} if given_parameters is None else given_parameters.copy()
     check_given_parameters_corrnmf(adata, n_signatures, dim_embeddings, given_parameters)
-    asignatures, _ = initialize_base(adata, n_signatures, method, given_parameters.get("asignatures"), **kwargs)
+    asignatures, _ = (base or initialize_base)(adata, n_signatures, method, given_parameters.get("asignatures"), **kwargs)
 
     def standard_normal(n):
         return np.random.multivariate_normal(np.zeros(dim_embeddings), np.identity(dim_embeddings), size=n)
@@ -235,7 +239,7 @@ def check_given_parameters_mmcorrnmf(mdata, ns_signatures, dim_embeddings, given
             )
 
 
-def initialize_mmcorrnmf(mdata, ns_signatures, dim_embeddings, method="nndsvd", given_parameters: dict[str, Any] | None = None, **kwargs):
+def initialize_mmcorrnmf(mdata, ns_signatures, dim_embeddings, method="nndsvd", given_parameters: dict[str, Any] | None = None, base=None, **kwargs):
     """One ``initialize_corrnmf`` per modality (without sample embeddings), new signature names prefixed with the
     modality, shared sample embeddings and variance (initialize.py:419-470).  Returns ``(asignatures dict, variance)``."""
     given_parameters = {} if given_parameters is None else given_parameters.copy()
@@ -243,8 +247,9 @@ def initialize_mmcorrnmf(mdata, ns_signatures, dim_embeddings, method="nndsvd", 
     asignatures = {}
     for (mod_name, adata), n_signatures in zip(mdata.mod.items(), ns_signatures):
         given_mod = given_parameters.get(mod_name, {})
+        mod_base = (lambda *a, _name=mod_name, **kw: base(_name, *a, **kw)) if base is not None else None
         asigs, _ = initialize_corrnmf(
-            adata, n_signatures, dim_embeddings, method, given_mod, initialize_sample_embeddings=False, **kwargs
+            adata, n_signatures, dim_embeddings, method, given_mod, initialize_sample_embeddings=False, base=mod_base, **kwargs
         )
         n_given = given_mod["asignatures"].n_obs if "asignatures" in given_mod else 0
         names = list(asigs.obs_names)

@@ -14,7 +14,8 @@ from typing import Any, Literal
 import numpy as np
 
 from .. import _lib
-from ..initialization import initialize_corrnmf
+from ..device_init import DEVICE_METHODS, initialize_on_device
+from ..initialization import check_given_asignatures, initialize_corrnmf, package_signatures
 from ..utils import value_checker
 from . import _utils_corrnmf
 from .signature_nmf import SignatureNMF
@@ -86,10 +87,26 @@ class CorrNMF(SignatureNMF):
     def _initialize(self, given_parameters: dict[str, Any] | None = None, init_kwargs: dict[str, Any] | None = None) -> None:
         """Signatures, scalings, embeddings and variance; then the exposures (corrnmf.py:104-136)."""
         init_kwargs = {} if init_kwargs is None else init_kwargs.copy()
+        base = None
+        if self.device_init and self.init_method in DEVICE_METHODS and "seed" not in init_kwargs:
+            base = self._device_base  # the signatures of the deterministic methods on the GPU (device_init.py)
         self.asignatures, self.variance = initialize_corrnmf(
-            self.adata, self.n_signatures, self.dim_embeddings, self.init_method, given_parameters, **init_kwargs
+            self.adata, self.n_signatures, self.dim_embeddings, self.init_method, given_parameters, base=base, **init_kwargs
         )
         self.compute_exposures()
+
+    def _device_base(self, adata, n_signatures, method, given_asignatures=None):
+        """``initialize_base`` on the engine: X goes up once (and stays for the fit), the signatures come back."""
+        given_mat = None
+        if given_asignatures is not None:
+            check_given_asignatures(given_asignatures, adata, n_signatures)
+            given_mat = np.asarray(given_asignatures.X)
+        X = np.ascontiguousarray(adata.X, dtype=np.float64)
+        e = self._ensure_engine(X.shape[0], X.shape[1], n_signatures)
+        e.upload_X(X)
+        S = initialize_on_device(e, n_signatures, method, given_mat, self._n_obs_total())
+        self._resident = {"X"}
+        return package_signatures(adata, S, n_signatures, given_asignatures), None
 
     def _setup_fitting_parameters(self, fitting_kwargs: dict[str, Any] | None = None) -> None:
         """No fitting parameters (corrnmf.py:138-144)."""

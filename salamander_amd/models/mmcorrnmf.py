@@ -21,7 +21,8 @@ import pandas as pd
 from .. import _lib
 from ..anndata_compat import MUDATA_TYPES, AnnData, MuData
 from ..engine import Engine
-from ..initialization import INIT_METHODS, initialize_mmcorrnmf
+from ..device_init import DEVICE_METHODS, initialize_on_device
+from ..initialization import INIT_METHODS, check_given_asignatures, initialize_mmcorrnmf, package_signatures
 from ..utils import EPSILON, type_checker, value_checker
 from . import _utils_corrnmf
 from ._utils_klnmf import update_W
@@ -44,6 +45,7 @@ class MultimodalCorrNMF:
         *,
         device: int = 0,
         distributed: bool = False,
+        device_init: bool = True,
     ):
         value_checker("init_method", init_method, INIT_METHODS)
         self.ns_signatures = ns_signatures
@@ -57,7 +59,9 @@ class MultimodalCorrNMF:
         # ours: which GPU, and whether mdata is this rank's shard of the samples (one communicator per modality)
         self.device = device
         self.distributed = distributed
+        self.device_init = device_init  # deterministic init methods: the signatures on the GPU (device_init.py)
         self._comm_attached: dict[str, bool] = {}
+        self._x_resident: set[str] = set()  # modalities whose X the device already holds from the initialisation
         names = [f"mod{n}" for n in range(1, len(ns_signatures) + 1)]
         self.mdata = MuData({name: AnnData() for name in names})
         self.asignatures = {name: AnnData() for name in names}
@@ -170,10 +174,43 @@ class MultimodalCorrNMF:
 
     def _initialize(self, given_parameters: dict[str, Any] | None = None, init_kwargs: dict[str, Any] | None = None) -> None:
         init_kwargs = {} if init_kwargs is None else init_kwargs.copy()
+        base = None
+        if self.device_init and self.init_method in DEVICE_METHODS and "seed" not in init_kwargs:
+            base = self._device_base
         self.asignatures, self.variance = initialize_mmcorrnmf(
-            self.mdata, self.ns_signatures, self.dim_embeddings, self.init_method, given_parameters, **init_kwargs
+            self.mdata, self.ns_signatures, self.dim_embeddings, self.init_method, given_parameters, base=base, **init_kwargs
         )
         self.compute_exposures()
+
+    def _engine_for(self, name: str, N: int, V: int, n_signatures: int):
+        """The engine of one modality (created on first use), its communicator attached when ``distributed``."""
+        e = self._engines.get(name)
+        if e is None or (e.N, e.V, e.K, e.device) != (N, V, n_signatures, self.device):
+            if e is not None:
+                e.close()
+            e = self._engines[name] = Engine(N, V, n_signatures, device=self.device)
+            self._comm_attached[name] = False
+            self._x_resident.discard(name)
+        if self.distributed and not self._comm_attached.get(name):
+            from ..distributed import attach_communicator
+
+            attach_communicator(e)
+            self._comm_attached[name] = True
+        return e
+
+    def _device_base(self, name, adata, n_signatures, method, given_asignatures=None):
+        """``initialize_base`` of one modality on its engine (X stays resident for the fit)."""
+        given_mat = None
+        if given_asignatures is not None:
+            check_given_asignatures(given_asignatures, adata, n_signatures)
+            given_mat = np.asarray(given_asignatures.X)
+        X = np.ascontiguousarray(adata.X, dtype=np.float64)
+        e = self._engine_for(name, X.shape[0], X.shape[1], n_signatures)
+        e.upload_X(X)
+        n_total = int(e.comm_info()[2]) if self.distributed else X.shape[0]
+        S = initialize_on_device(e, n_signatures, method, given_mat, n_total)
+        self._x_resident.add(name)
+        return package_signatures(adata, S, n_signatures, given_asignatures), None
 
     def _compute_auxs(self) -> dict[str, np.ndarray]:
         return {
@@ -268,30 +305,24 @@ class MultimodalCorrNMF:
     def _sync_to_device(self) -> None:
         U = np.ascontiguousarray(self.mdata.obsm["embeddings"], dtype=np.float64)
         if self.distributed:
-            from ..distributed import attach_communicator, broadcast_from_rank0
+            from ..distributed import broadcast_from_rank0
 
             self.variance = broadcast_from_rank0(float(self.variance))
         for name, n_signatures in zip(self.mod_names, self.ns_signatures):
             adata, asigs = self.mdata[name], self.asignatures[name]
             X = np.ascontiguousarray(adata.X, dtype=np.float64)
             N, V = X.shape
-            e = self._engines.get(name)
-            if e is None or (e.N, e.V, e.K, e.device) != (N, V, n_signatures, self.device):
-                if e is not None:
-                    e.close()
-                e = self._engines[name] = Engine(N, V, n_signatures, device=self.device)
-                self._comm_attached[name] = False
+            e = self._engine_for(name, N, V, n_signatures)
             if getattr(e, "dim", None) != self.dim_embeddings:
                 e.corr_configure(self.dim_embeddings)
             W = np.ascontiguousarray(asigs.X, dtype=np.float64)
             beta = np.asarray(asigs.obs["scalings"].values, dtype=np.float64)
             L = np.ascontiguousarray(asigs.obsm["embeddings"], dtype=np.float64)
             if self.distributed:
-                if not self._comm_attached.get(name):
-                    attach_communicator(e)
-                    self._comm_attached[name] = True
                 W, beta, L = broadcast_from_rank0((W, beta, L))  # replicated parameters: rank 0's bits everywhere
-            e.upload_X(X)
+            if name not in self._x_resident:
+                e.upload_X(X)
+            self._x_resident.discard(name)
             e.upload_W(W)
             if "exposures" in adata.obsm:
                 e.upload_H(np.ascontiguousarray(adata.obsm["exposures"], dtype=np.float64))

@@ -113,3 +113,40 @@ def test_default_fit_initialises_on_the_device(golden):
     a, b = (f.history["objective_function"][-1] for f in fits)
     assert abs(a - b) / b < 1e-6
     assert rel_l2(fits[0].asignatures.X, fits[1].asignatures.X) < 1e-5
+
+
+def test_corrnmf_models_default_init_on_the_device():
+    """CorrNMFDet / MultimodalCorrNMF with the default nndsvd: the signatures come from the device initialisation
+    (X uploaded once and kept for the fit) and agree with the host path a seed selects (the embeddings are random
+    draws either way, so whole fits are not comparable); the fits run and their ELBO increases."""
+    from salamander_amd.models import CorrNMFDet, MultimodalCorrNMF
+
+    X1, _, _ = orc.synthetic_problem(96, 3000, 6, seed=3)
+    X2, _, _ = orc.synthetic_problem(83, 3000, 4, seed=4)
+    sigs = []
+    for kwargs in (None, {"seed": 1}):
+        m = CorrNMFDet(n_signatures=6, dim_embeddings=3)
+        m._setup_adata(sal.AnnData(X1.copy()))
+        m._initialize(None, kwargs)
+        sigs.append(np.asarray(m.asignatures.X))
+        assert (m._resident == {"X"}) == (kwargs is None)
+    assert rel_l2(sigs[0], sigs[1]) < 1e-3
+    np.random.seed(5)
+    m = CorrNMFDet(n_signatures=6, dim_embeddings=3, min_iterations=30, max_iterations=30)
+    m.fit(sal.AnnData(X1.copy()))
+    hist = m.history["objective_function"]
+    assert np.all(np.isfinite(hist)) and hist[-1] > hist[0] and np.allclose(m.asignatures.X.sum(axis=1), 1.0, atol=1e-4)
+
+    sigs = []
+    for kwargs in (None, {"seed": 1}):
+        mm = MultimodalCorrNMF([6, 4], dim_embeddings=3)
+        mm._setup_mdata(sal.MuData({"sbs": sal.AnnData(X1.copy()), "indel": sal.AnnData(X2.copy())}))
+        mm._initialize(None, kwargs)
+        sigs.append([np.asarray(mm.asignatures[n].X) for n in ("sbs", "indel")])
+        assert list(mm.asignatures["indel"].obs_names)[0] == "indel Sig1"
+    assert rel_l2(sigs[0][0], sigs[1][0]) < 1e-3 and rel_l2(sigs[0][1], sigs[1][1]) < 1e-3
+    np.random.seed(5)
+    mm = MultimodalCorrNMF([6, 4], dim_embeddings=3, min_iterations=30, max_iterations=30)
+    mm.fit(sal.MuData({"sbs": sal.AnnData(X1.copy()), "indel": sal.AnnData(X2.copy())}))
+    hist = mm.history["objective_function"]
+    assert np.all(np.isfinite(hist)) and hist[-1] > hist[0]
