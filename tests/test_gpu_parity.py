@@ -176,7 +176,10 @@ def test_golden_mvnmf_all_steps_in_one_call(golden, tag):
      (96, 999, 30), (96, 333, 33), (96, 1025, 40), (96, 777, 41), (96, 4099, 50), (96, 300, 52), (96, 301, 53),
      (96, 500, 64), (83, 777, 30), (83, 200, 40), (7, 100, 2), (16, 40, 5),
      # more tiles than waves with a short leftover round: the cooperative kernel runs
-     (96, 17190, 50), (96, 17001, 30), (83, 17100, 34), (96, 16500, 64), (96, 16390, 20)],
+     # (leftover tile worked on by the four waves of a workgroup, every output-side geometry: KT = 1..4, KR = 0..4)
+     (96, 17190, 50), (96, 17001, 30), (83, 17100, 34), (96, 16500, 64), (96, 16390, 20),
+     (96, 16450, 1), (96, 16999, 5), (7, 17000, 16), (96, 17010, 17), (96, 16800, 36), (96, 17111, 48), (96, 16777, 53),
+     (96, 16601, 19), (96, 33500, 51)],
 )
 def test_shapes_one_and_five_steps(V, N, K):
     X, W0, H0 = orc.synthetic_problem(V, N, K, seed=V + N + K)
