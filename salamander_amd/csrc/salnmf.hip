@@ -559,14 +559,33 @@ static int upload_padded(salnmf_engine* e, double* dst, const double* src, int c
     return upload_rows_staged(e, dst, src, SALNMF_F64, cols, ld, fill_cols, fill_rows, clip_lo);
 }
 
-// device padded [.][ld] -> host compact [N][cols]
+// device padded [.][ld] -> host compact [N][cols]: the mirror image of the ingest -- per 32 MB chunk an unpad kernel
+// into a device staging buffer, an asynchronous DMA into a pinned buffer, and a multi-threaded host copy into the
+// caller's (pageable) array while the next chunk is on its way
 static int download_padded(salnmf_engine* e, double* dst, const double* src, int cols, int ld) {
     if (!e || !dst) return fail("null argument");
     HIPCK(hipSetDevice(e->device));
-    CK(ensure_scratch(e, (size_t)e->N * cols));
-    hipLaunchKernelGGL(unpad_kernel, dim3(2048), dim3(256), 0, e->stream, e->scratch, src, e->N, cols, ld);
-    HIPCK(hipGetLastError());
-    HIPCK(hipMemcpyAsync(dst, e->scratch, (size_t)e->N * cols * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    CK(ensure_staging(e));
+    const size_t row_bytes = (size_t)cols * sizeof(double);
+    const int64_t chunk_rows = std::max<int64_t>(1, (int64_t)(STAGE_BYTES / row_bytes));
+    const int64_t nchunks = (e->N + chunk_rows - 1) / chunk_rows;
+    auto rows_of = [&](int64_t c) { return std::min<int64_t>(chunk_rows, e->N - c * chunk_rows); };
+    auto issue = [&](int64_t c) -> int {
+        const int slot = (int)(c & 1);
+        const int64_t rows = rows_of(c);
+        hipLaunchKernelGGL(unpad_kernel, dim3(2048), dim3(256), 0, e->stream, static_cast<double*>(e->stage_dev[slot]),
+                           src + c * chunk_rows * ld, rows, cols, ld);
+        HIPCK(hipGetLastError());
+        HIPCK(hipMemcpyAsync(e->stage_host[slot], e->stage_dev[slot], (size_t)rows * row_bytes, hipMemcpyDeviceToHost, e->stream));
+        HIPCK(hipEventRecord(e->stage_done[slot], e->stream));
+        return 0;
+    };
+    if (nchunks > 0) CK(issue(0));
+    for (int64_t c = 0; c < nchunks; ++c) {
+        if (c + 1 < nchunks) CK(issue(c + 1));  // the other slot: its previous content was consumed in the last round
+        HIPCK(hipEventSynchronize(e->stage_done[c & 1]));
+        parallel_copy((char*)dst + (size_t)c * chunk_rows * row_bytes, e->stage_host[c & 1], (size_t)rows_of(c) * row_bytes);
+    }
     HIPCK(hipStreamSynchronize(e->stream));
     return check_abort(e);
 }
