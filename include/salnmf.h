@@ -180,6 +180,12 @@ int salnmf_corr_update_sample_embeddings_multi(salnmf_engine* const* engines, in
  * what the reference uses here; status_out has n_signatures ints or is NULL. */
 int salnmf_corr_update_signature_embeddings(salnmf_engine* e, double variance, int maxiter,
                                             int* status_out);
+/* From 16 384 samples on, the signature solves run in LOCKSTEP (csrc/salnmf_corr_lockstep.h): one evaluation round
+ * per launch over (chunks x signatures) workgroups, the K Newton-CG solvers replayed from their evaluation logs
+ * between rounds -- 3x faster than one workgroup per signature at c5, and shardable: a sample-sharded engine
+ * all-reduces the 1 + dim + dim^2 sums per signature of every round.  0 forces the single-kernel form (also
+ * SALNMF_LOCKSTEP=0); the two agree to rounding of the sums. */
+int salnmf_set_lockstep(salnmf_engine* e, int on);
 /* The same solves with the sample-side inputs handed over by the caller: n_all samples (of ALL shards, in
  * global order) with embeddings U_all (n_all x dim), scalings alpha_all (n_all) and aux_all (n_all x
  * n_signatures, compact), host pointers.  This is the exchange point of a sample-sharded CorrNMF update

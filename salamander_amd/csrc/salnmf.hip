@@ -5,6 +5,7 @@
 #include "salnmf_kernels.h"
 #include "salnmf_mv_kernels.h"
 #include "salnmf_corr_kernels.h"
+#include "salnmf_corr_lockstep.h"
 #include "salnmf_init_kernels.h"
 
 #include <dlfcn.h>
@@ -166,6 +167,12 @@ struct salnmf_engine {
     std::vector<int64_t> shard_N;  // n_samples of every rank's shard (filled by salnmf_comm_init)
     int64_t N_total = 0;           // sum of shard_N
     // gathered inputs of the signature-embedding solves (all samples of all shards, compact rows)
+    // lockstep signature solves (salnmf_corr_lockstep.h): per-signature logs and per-round partial sums, lazily sized
+    double* ls_buf = nullptr;
+    int* ls_int = nullptr;
+    size_t ls_doubles = 0;
+    int ls_S = 0, ls_dim = 0;
+    bool lockstep = true;  // SALNMF_LOCKSTEP=0 forces the single-kernel form
     double *gU = nullptr, *galpha = nullptr, *gaux = nullptr;
     size_t g_rows = 0;
     int g_dim = 0;
@@ -355,6 +362,8 @@ void salnmf_destroy(salnmf_engine* e) {
         if (e->stage_dev[i]) (void)hipFree(e->stage_dev[i]);
         if (e->stage_done[i]) (void)hipEventDestroy(e->stage_done[i]);
     }
+    if (e->ls_buf) (void)hipFree(e->ls_buf);
+    if (e->ls_int) (void)hipFree(e->ls_int);
     if (e->psync) (void)hipFree(e->psync);
     if (e->pabort) (void)hipHostFree(e->pabort);
     for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
@@ -451,6 +460,8 @@ int salnmf_create(int device, int n_features, int64_t n_samples, int n_signature
         // measured slower than per-step launches on MI355X: opt-in
         const char* env = getenv("SALNMF_PERSISTENT");
         e->persistent = env && env[0] == '1';
+        const char* ls = getenv("SALNMF_LOCKSTEP");
+        e->lockstep = !(ls && ls[0] == '0');
     }
     *out = e;
     return 0;
@@ -674,6 +685,12 @@ static int check_abort(salnmf_engine* e) {
         return fail("a wait inside the persistent KL kernel gave up (its workgroups were not all resident: is another process "
                     "using this GPU?); the engine's W and H are invalid -- upload them again, and set SALNMF_PERSISTENT=0");
     }
+    return 0;
+}
+
+int salnmf_set_lockstep(salnmf_engine* e, int on) {
+    if (!e) return fail("null engine");
+    e->lockstep = on != 0;
     return 0;
 }
 
@@ -1242,6 +1259,110 @@ static int ensure_gathered(salnmf_engine* e, size_t rows) {
     return 0;
 }
 
+// ---- lockstep form of the signature solves (salnmf_corr_lockstep.h): evaluation rounds over (chunks x signatures)
+// workgroups, the solvers replayed from their logs between rounds.  `shard`: the rows are this rank's shard and the
+// reduced sums of every round are all-reduced (objective, gradient and Hessian are sums over samples).
+constexpr int64_t LS_MIN_ROWS = 16384;  // below: the single-kernel form (a round costs three launches and one read-back)
+
+static int lockstep_signature_solves(salnmf_engine* e, const double* U, const double* alpha, const double* aux, int64_t n_rows, double variance,
+                                     int maxiter, int* status_out, bool shard) {
+    const int K = e->K, dim = e->dim;
+    hipDeviceProp_t prop;
+    HIPCK(hipGetDeviceProperties(&prop, e->device));
+    const int64_t max_chunks = (n_rows + SIGT - 1) / SIGT;
+    const int S = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(16, prop.multiProcessorCount / K), max_chunks));
+    const int64_t chunk = ((n_rows + S - 1) / S + SIGT - 1) / SIGT * SIGT;
+    // one allocation: [x0 | req | sg] (K x 64 each), part (K S REC), red (K REC), log_y, log_g (K EVAL 64), log_f (K EVAL), log_H (K EVAL dim^2)
+    const size_t nd = (size_t)3 * K * 64 + (size_t)K * S * LS_REC + (size_t)K * LS_REC + (size_t)2 * K * LS_EVAL_MAX * 64 +
+                      (size_t)K * LS_EVAL_MAX + (size_t)K * LS_EVAL_MAX * dim * dim;
+    if (e->ls_doubles < nd || e->ls_S != S || e->ls_dim != dim) {
+        if (e->ls_buf) HIPCK(hipFree(e->ls_buf));
+        e->ls_buf = nullptr;
+        e->ls_doubles = 0;
+        HIPCK(hipMalloc(&e->ls_buf, nd * sizeof(double)));
+        e->ls_doubles = nd;
+        e->ls_S = S;
+        e->ls_dim = dim;
+    }
+    if (!e->ls_int) HIPCK(hipMalloc(&e->ls_int, (size_t)(3 * 64 + 8) * sizeof(int)));
+    LockstepParams q;
+    q.sig.aux = aux;
+    q.sig.alpha = alpha;
+    q.sig.beta = e->beta;
+    q.sig.U = U;
+    q.sig.L = e->Lemb;
+    q.sig.only = nullptr;
+    q.sig.variance = variance;
+    q.sig.N = n_rows;
+    q.sig.Np = n_rows;
+    q.sig.K = K;
+    q.sig.KP = e->KP;
+    q.sig.dim = dim;
+    q.sig.maxiter = maxiter > 0 ? maxiter : 200 * dim;
+    q.S = S;
+    q.chunk = chunk;
+    double* b = e->ls_buf;
+    q.x0 = b; b += (size_t)K * 64;
+    q.req = b; b += (size_t)K * 64;
+    q.sg = b; b += (size_t)K * 64;
+    q.part = b; b += (size_t)K * S * LS_REC;
+    q.red = b; b += (size_t)K * LS_REC;
+    q.log_y = b; b += (size_t)K * LS_EVAL_MAX * 64;
+    q.log_g = b; b += (size_t)K * LS_EVAL_MAX * 64;
+    q.log_f = b; b += (size_t)K * LS_EVAL_MAX;
+    q.log_H = b;
+    q.state = e->ls_int;
+    q.n_evals = e->ls_int + 64;
+    q.sig.status = e->ls_int + 128;
+    q.active = e->ls_int + 192;
+    int* hactive = reinterpret_cast<int*>(e->hpin);
+    const dim3 grid(S, K);
+    // start: sg = sum_n aux[n][k] U[n][:] and the first requests (the start points)
+    hipLaunchKernelGGL(ls_begin_kernel, grid, dim3(SIGT), 0, e->stream, q);
+    hipLaunchKernelGGL(ls_reduce_kernel, dim3(K), dim3(256), 0, e->stream, q.part, q.red, q.state, S, 2, 64, 1);
+    HIPCK(hipGetLastError());
+    if (shard) CK(allreduce(e, q.red, (size_t)K * LS_REC));
+    hipLaunchKernelGGL(ls_copy_sg_kernel, dim3((K * 64 + 255) / 256), dim3(256), 0, e->stream, q.red, q.sg, K);
+    HIPCK(hipGetLastError());
+    const int rec = 66 + dim * dim;
+    bool finished = false;
+    for (int round = 0; round < LS_EVAL_MAX + 2; ++round) {
+        hipLaunchKernelGGL(ls_eval_kernel, grid, dim3(SIGT), 0, e->stream, q);
+        hipLaunchKernelGGL(ls_reduce_kernel, dim3(K), dim3(256), 0, e->stream, q.part, q.red, q.state, S, 0, rec, 0);
+        HIPCK(hipGetLastError());
+        if (shard) CK(allreduce(e, q.red, (size_t)K * LS_REC));
+        HIPCK(hipMemsetAsync(q.active, 0, sizeof(int), e->stream));
+        hipLaunchKernelGGL(ls_advance_kernel, dim3(K), dim3(64), 0, e->stream, q);
+        HIPCK(hipGetLastError());
+        HIPCK(hipMemcpyAsync(hactive, q.active, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+        HIPCK(hipStreamSynchronize(e->stream));
+        if (*hactive == 0) {
+            finished = true;
+            break;
+        }
+    }
+    if (!finished) return fail("lockstep signature solves did not terminate");
+    // runaway solves (log full) are finished by the single-kernel form with its own evaluation budget -- on the rows at hand
+    // (a sharded engine reaches this point on every rank alike, the decisions being identical)
+    std::vector<int> st(64 * 3);
+    HIPCK(hipMemcpyAsync(st.data(), e->ls_int, st.size() * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIPCK(hipStreamSynchronize(e->stream));
+    bool fallback = false;
+    for (int k = 0; k < K; ++k) fallback |= st[k] == LS_FALLBACK;
+    if (fallback) {
+        if (shard) return fail("a signature-embedding solve exceeded %d evaluations on a sample-sharded engine", LS_EVAL_MAX);
+        SignatureEmbeddingParams p = q.sig;
+        p.only = q.state;
+        hipLaunchKernelGGL(corr_signature_embeddings_kernel, dim3(K), dim3(SIGT), 0, e->stream, p);
+        HIPCK(hipGetLastError());
+        HIPCK(hipMemcpyAsync(st.data() + 128, q.sig.status, (size_t)K * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+        HIPCK(hipStreamSynchronize(e->stream));
+    }
+    if (status_out)
+        for (int k = 0; k < K; ++k) status_out[k] = st[128 + k];
+    return 0;
+}
+
 // One Newton-CG solve per signature over n_rows samples whose embeddings / scalings / aux rows are at U, alpha, aux
 static int launch_signature_solves(salnmf_engine* e, const double* U, const double* alpha, const double* aux, int64_t n_rows,
                                    double variance, int maxiter, int* status_out) {
@@ -1252,6 +1373,7 @@ static int launch_signature_solves(salnmf_engine* e, const double* U, const doub
     p.U = U;
     p.L = e->Lemb;
     p.status = nullptr;
+    p.only = nullptr;
     p.variance = variance;
     p.N = n_rows;
     p.Np = n_rows;
@@ -1303,9 +1425,15 @@ int salnmf_corr_update_signature_embeddings(salnmf_engine* e, double variance, i
     CK(corr_ready(e));
     if (!(variance > 0.0)) return fail("variance must be positive");
     if (e->comm) {
+        // sample-sharded: with enough samples the solves run in lockstep on the local rows and the sums of every
+        // evaluation are all-reduced (1 + dim + dim^2 per signature); small problems gather the sample side once
+        // and solve on identical inputs
+        if (e->lockstep && e->N_total >= LS_MIN_ROWS * e->n_ranks)
+            return lockstep_signature_solves(e, e->Uemb, e->alpha, e->aux, e->N, variance, maxiter, status_out, true);
         CK(gather_sample_side(e));
         return launch_signature_solves(e, e->gU, e->galpha, e->gaux, e->N_total, variance, maxiter, status_out);
     }
+    if (e->lockstep && e->N >= LS_MIN_ROWS) return lockstep_signature_solves(e, e->Uemb, e->alpha, e->aux, e->N, variance, maxiter, status_out, false);
     return launch_signature_solves(e, e->Uemb, e->alpha, e->aux, e->N, variance, maxiter, status_out);
 }
 

@@ -394,10 +394,12 @@ struct SignatureEmbeddingParams {
     const double* __restrict__ U;      // [N][dim]
     double* __restrict__ L;            // [K][dim]  in / out
     int* __restrict__ status;          // [K] or null
+    const int* __restrict__ only;      // [K] or null: solve only the signatures with only[k] == ONLY_VALUE (lockstep fallback)
     double variance;
     int64_t N, Np;
     int K, KP, dim, maxiter;
 };
+constexpr int SIG_ONLY_VALUE = 2;
 
 struct SignatureEmbeddingEval {
     const SignatureEmbeddingParams* p;
@@ -414,6 +416,7 @@ struct SignatureEmbeddingEval {
     bool hvalid;    // Al holds the Hessian at hpt
     bool spec;      // Al does not alias the tile buffer: every objective+gradient pass also forms the Hessian
     int k, dim, ldu, DT, tid, lane, wave, budget;
+    int64_t n_begin, n_end;  // the samples this workgroup passes over (all of them, or one chunk: lockstep solves)
 
     __device__ inline void broadcast(double y) {
         __syncthreads();  // previous readers of ybuf are done
@@ -539,11 +542,11 @@ struct SignatureEmbeddingEval {
         --budget;
         if (MODE != 0) broadcast(y);
         double r = 0.0;
-        for (int64_t t0 = 0; t0 < p->N; t0 += SIGT) {
+        for (int64_t t0 = n_begin; t0 < n_end; t0 += SIGT) {
             stage(t0);
             const int64_t n = t0 + tid;
             double w = 0.0;
-            if (n < p->N) w = (MODE == 0) ? p->aux[n * p->KP + k] : exp((c + p->alpha[n]) + row_dot(tid));
+            if (n < n_end) w = (MODE == 0) ? p->aux[n * p->KP + k] : exp((c + p->alpha[n]) + row_dot(tid));
             wt[tid] = w;
             __syncthreads();
             r = tile_weighted(r);
@@ -555,10 +558,10 @@ struct SignatureEmbeddingEval {
         --budget;
         broadcast(y);
         double lin = 0.0, ex = 0.0;
-        for (int64_t t0 = 0; t0 < p->N; t0 += SIGT) {
+        for (int64_t t0 = n_begin; t0 < n_end; t0 += SIGT) {
             stage(t0);
             const int64_t n = t0 + tid;
-            if (n < p->N) {
+            if (n < n_end) {
                 const double s = row_dot(tid);
                 lin = __builtin_fma(s, p->aux[n * p->KP + k], lin);
                 ex += exp((c + p->alpha[n]) + s);
@@ -587,11 +590,11 @@ struct SignatureEmbeddingEval {
         d4 acc[10];
 #pragma unroll
         for (int i = 0; i < 10; ++i) acc[i] = (d4){0, 0, 0, 0};
-        for (int64_t t0 = 0; t0 < p->N; t0 += SIGT) {
+        for (int64_t t0 = n_begin; t0 < n_end; t0 += SIGT) {
             stage(t0);
             const int64_t n = t0 + tid;
             double w = 0.0;
-            if (n < p->N) {
+            if (n < n_end) {
                 const double s = row_dot(tid);
                 lin = __builtin_fma(s, p->aux[n * p->KP + k], lin);
                 w = exp((c + p->alpha[n]) + s);
@@ -622,10 +625,10 @@ struct SignatureEmbeddingEval {
         d4 acc[10];
 #pragma unroll
         for (int i = 0; i < 10; ++i) acc[i] = (d4){0, 0, 0, 0};
-        for (int64_t t0 = 0; t0 < p->N; t0 += SIGT) {
+        for (int64_t t0 = n_begin; t0 < n_end; t0 += SIGT) {
             stage(t0);
             const int64_t n = t0 + tid;
-            wt[tid] = (n < p->N) ? exp((c + p->alpha[n]) + row_dot(tid)) : 0.0;
+            wt[tid] = (n < n_end) ? exp((c + p->alpha[n]) + row_dot(tid)) : 0.0;
             __syncthreads();
             hess_tile(acc);
             __syncthreads();
@@ -651,6 +654,7 @@ constexpr int SIG_POOL = SIGT * 49 + 64 * CORR_LD;
 static_assert(SIG_POOL >= SIGT * CORR_LD, "the widest tile must fit the pool");
 
 __global__ void __launch_bounds__(SIGT) corr_signature_embeddings_kernel(SignatureEmbeddingParams p) {
+    if (p.only && p.only[blockIdx.x] != SIG_ONLY_VALUE) return;  // uniform over the workgroup
     __shared__ double pool[SIG_POOL];
     __shared__ double wt[SIGT], sred[SIGT], ybuf[64], red[4 * 64];
     SignatureEmbeddingEval ev;
@@ -672,6 +676,8 @@ __global__ void __launch_bounds__(SIGT) corr_signature_embeddings_kernel(Signatu
     ev.lane = threadIdx.x & 63;
     ev.wave = threadIdx.x >> 6;
     ev.budget = SIG_BUDGET;
+    ev.n_begin = 0;
+    ev.n_end = p.N;
     ev.hpt = 0.0;
     ev.hvalid = false;
     ev.sg = 0.0;

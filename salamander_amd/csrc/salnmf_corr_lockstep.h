@@ -1,0 +1,295 @@
+// Signature-embedding solves of correlated NMF in LOCKSTEP (mmcorrnmf.py:347-396, corrnmf_det.py:88-113,
+// _utils_corrnmf.py:354-410): all K Newton-CG solves advance together, one objective / gradient / Hessian evaluation
+// per round.
+//
+// The single-kernel form (corr_signature_embeddings_kernel: one workgroup per signature, every evaluation a pass of
+// that workgroup over ALL samples) leaves 5/6 of the chip idle at K = 40 and cannot be sharded: each solve takes
+// data-dependent decisions after every evaluation.  Here an evaluation round is its own launch:
+//
+//   ls_eval_kernel     grid (S chunks, K signatures): every workgroup passes over ITS chunk of the samples for the point
+//                      its signature asked for and leaves partial sums: [lin | ex | sum_n w_n U_n (dim) | Hessian (dim^2)]
+//                      -- the same tile code as the single-kernel form (SignatureEmbeddingEval), Hessian on fp64 MFMA
+//   ls_reduce_kernel   fixed-order sum of the S partials per signature (then an all-reduce over sample shards: exactly
+//                      1 + dim + dim^2 sums per evaluation, as the objective, gradient and Hessian are sums over samples)
+//   ls_advance_kernel  one wavefront per signature: appends the evaluation to that signature's log and RE-RUNS
+//                      ncg::minimize from the start point with an evaluator that answers from the log (ReplayEval).
+//                      The solver is deterministic, so the replay takes the same decisions as before and runs until it
+//                      asks for a point that is not in the log: that is the next request.  No solver state has to be
+//                      saved and ncg::minimize is used unchanged -- the same code that solves the sample embeddings.
+//                      A replay costs the CG iterations again (Hessian-vector products from the logged Hessians, no
+//                      pass over samples): tens of microseconds against a pass of hundreds.
+//
+// The host loops rounds until no signature asks for another evaluation (one 4-byte read-back per round).  Results:
+// objective, gradient and Hessian are the same sums in a different order (chunks), so iterates agree with the
+// single-kernel form to rounding; every rank of a sharded fit sees the same reduced sums and takes the same decisions.
+#pragma once
+#include "salnmf_corr_kernels.h"
+
+namespace salnmf {
+
+constexpr int LS_EVAL_MAX = 192;                    // evaluations per solve kept in the log; beyond: single-kernel fallback
+constexpr int LS_REC = 2 + 64 + 64 * 64;            // doubles per evaluation record: [lin, ex | r (64) | Hessian (dim x dim, compact)]
+constexpr int LS_NEED = 0, LS_DONE = 1, LS_FALLBACK = SIG_ONLY_VALUE;
+
+struct LockstepParams {
+    SignatureEmbeddingParams sig;  // aux, alpha, beta, U, L (in / out), status, variance, N, K, KP, dim, maxiter
+    int S;                         // chunks per signature
+    int64_t chunk;                 // samples per chunk (a multiple of SIGT)
+    double* x0;                    // [K][64] start points
+    double* req;                   // [K][64] requested evaluation points
+    double* sg;                    // [K][64] sum_n aux[n][k] U[n][:]  (constant of a solve)
+    int* state;                    // [K] LS_NEED / LS_DONE / LS_FALLBACK
+    int* n_evals;                  // [K]
+    int* active;                   // [1] signatures that still need an evaluation after this round
+    double* part;                  // [K][S][LS_REC] partial sums of one evaluation round
+    double* red;                   // [K][LS_REC]    reduced (and all-reduced) sums
+    double* log_y;                 // [K][LS_EVAL_MAX][64]
+    double* log_f;                 // [K][LS_EVAL_MAX]
+    double* log_g;                 // [K][LS_EVAL_MAX][64]
+    double* log_H;                 // [K][LS_EVAL_MAX][dim * dim]
+};
+
+__device__ inline void ls_setup_eval(SignatureEmbeddingEval& ev, const LockstepParams& q, double* pool, double* wt, double* sred, double* ybuf,
+                                     double* red, int k, int s) {
+    ev.p = &q.sig;
+    ev.dim = q.sig.dim;
+    ev.DT = (q.sig.dim + 15) / 16;
+    ev.ldu = 16 * ev.DT + 1;
+    ev.spec = ev.DT <= 3;
+    ev.Ut = pool;
+    ev.Al = ev.spec ? pool + SIGT * 49 : pool;
+    ev.wt = wt;
+    ev.ybuf = ybuf;
+    ev.red = red;
+    ev.sred = sred;
+    ev.k = k;
+    ev.c = q.sig.beta[k];
+    ev.variance = q.sig.variance;
+    ev.tid = threadIdx.x;
+    ev.lane = threadIdx.x & 63;
+    ev.wave = threadIdx.x >> 6;
+    ev.budget = 1 << 30;
+    ev.n_begin = (int64_t)s * q.chunk;
+    ev.n_end = ev.n_begin + q.chunk < q.sig.N ? ev.n_begin + q.chunk : q.sig.N;
+    ev.hpt = 0.0;
+    ev.hvalid = false;
+    ev.sg = 0.0;
+}
+
+// start of a solve: start points, first requests, and the per-chunk partials of sg = sum_n aux[n][k] U[n][:]
+__global__ void __launch_bounds__(SIGT) ls_begin_kernel(LockstepParams q) {
+    __shared__ double pool[SIG_POOL];
+    __shared__ double wt[SIGT], sred[SIGT], ybuf[64], red[4 * 64];
+    const int k = blockIdx.y, s = blockIdx.x;
+    SignatureEmbeddingEval ev;
+    ls_setup_eval(ev, q, pool, wt, sred, ybuf, red, k, s);
+    if (s == 0 && threadIdx.x < 64) {
+        const double x = ev.lane < q.sig.dim ? q.sig.L[k * q.sig.dim + ev.lane] : 0.0;
+        q.x0[k * 64 + ev.lane] = x;
+        q.req[k * 64 + ev.lane] = x;
+        if (threadIdx.x == 0) {
+            q.state[k] = LS_NEED;
+            q.n_evals[k] = 0;
+        }
+    }
+    const double t = ev.weighted_sum<0>(0.0);
+    if (ev.wave == 0) q.part[((int64_t)k * q.S + s) * LS_REC + 2 + ev.lane] = t;
+}
+
+// one evaluation round: objective parts, gradient part and Hessian over this workgroup's chunk, at the requested point
+__global__ void __launch_bounds__(SIGT) ls_eval_kernel(LockstepParams q) {
+    const int k = blockIdx.y, s = blockIdx.x;
+    if (q.state[k] != LS_NEED) return;  // uniform over the workgroup
+    __shared__ double pool[SIG_POOL];
+    __shared__ double wt[SIGT], sred[SIGT], ybuf[64], red[4 * 64];
+    SignatureEmbeddingEval ev;
+    ls_setup_eval(ev, q, pool, wt, sred, ybuf, red, k, s);
+    const int dim = q.sig.dim;
+    const double y = ev.lane < dim ? q.req[k * 64 + ev.lane] : 0.0;
+    ev.broadcast(y);
+    double lin = 0.0, ex = 0.0, r = 0.0;
+    d4 acc[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) acc[i] = (d4){0, 0, 0, 0};
+    for (int64_t t0 = ev.n_begin; t0 < ev.n_end; t0 += SIGT) {
+        ev.stage(t0);
+        const int64_t n = t0 + ev.tid;
+        double w = 0.0;
+        if (n < ev.n_end) {
+            const double sdot = ev.row_dot(ev.tid);
+            lin = __builtin_fma(sdot, q.sig.aux[n * q.sig.KP + k], lin);
+            w = exp((ev.c + q.sig.alpha[n]) + sdot);
+            ex += w;
+        }
+        wt[ev.tid] = w;
+        __syncthreads();
+        r = ev.tile_weighted(r);
+        ev.hess_tile(acc);
+        __syncthreads();
+    }
+    const double tot = ev.cross_wave(r);
+    const double vlin = ev.block_sum(lin), vex = ev.block_sum(ex);
+    ev.hess_finish(acc, y);  // the Hessian sum of this chunk in ev.Al [16 DT][CORR_LD]
+    double* out = q.part + ((int64_t)k * q.S + s) * LS_REC;
+    if (ev.tid == 0) {
+        out[0] = vlin;
+        out[1] = vex;
+    }
+    if (ev.wave == 0) out[2 + ev.lane] = tot;
+    for (int i = ev.tid; i < dim * dim; i += SIGT) {
+        const int m = i / dim, j = i - m * dim;
+        out[66 + i] = ev.Al[m * CORR_LD + j];
+    }
+}
+
+// red[k][e] = sum over the S chunk partials, fixed order; only the first `len` entries of a record are live
+__global__ void __launch_bounds__(256) ls_reduce_kernel(const double* __restrict__ part, double* __restrict__ red, const int* __restrict__ state,
+                                                        int S, int first, int len, int all_signatures) {
+    const int k = blockIdx.x;
+    const bool live = all_signatures || state[k] == LS_NEED;
+    for (int e = first + threadIdx.x; e < first + len; e += 256) {
+        double t = 0.0;
+        if (live)
+            for (int s = 0; s < S; ++s) t += part[((int64_t)k * S + s) * LS_REC + e];
+        red[(int64_t)k * LS_REC + e] = t;  // zero for signatures that asked for nothing: the all-reduce covers all K
+    }
+}
+
+__global__ void ls_copy_sg_kernel(const double* __restrict__ red, double* __restrict__ sg, int K) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < K * 64) sg[i] = red[(int64_t)(i / 64) * LS_REC + 2 + (i & 63)];
+}
+
+// The evaluator of the replay: answers from the log of evaluations made so far (by point), asks for the first point it
+// does not know and from then on reports "exhausted", which makes ncg::minimize unwind through its bounded loops.
+struct ReplayEval {
+    const double* ly;  // [n][64]
+    const double* lf;  // [n]
+    const double* lg;  // [n][64]
+    const double* lH;  // [n][dim * dim]
+    int n, dim, lane;
+    int cursor;          // the log is in request order and the replay asks in the same order: next expected entry
+    double variance;
+    bool pending;
+    double req;          // lane m: component of the point asked for
+    double* Hl;          // LDS [64][CORR_LD]: the Hessian sum of the point fixed by prepare_hess
+    bool have_H;
+
+    __device__ inline bool is(int i, double y) const { return __all(lane >= dim || ly[i * 64 + lane] == y); }
+    __device__ inline int lookup(double y) {
+        if (cursor < n && is(cursor, y)) return cursor++;
+        if (cursor > 0 && is(cursor - 1, y)) return cursor - 1;  // the point just evaluated, asked for again (fun, then grad)
+        for (int i = n - 1; i >= 0; --i)
+            if (is(i, y)) return i;
+        return -1;
+    }
+    __device__ inline int find_or_ask(double y) {
+        if (pending) return -1;
+        const int i = lookup(y);
+        if (i < 0) {
+            pending = true;
+            req = y;
+        }
+        return i;
+    }
+    __device__ inline double fun(double y) {
+        const int i = find_or_ask(y);
+        return i < 0 ? 0.0 : lf[i];
+    }
+    __device__ inline double grad(double y) {
+        const int i = find_or_ask(y);
+        return i < 0 ? 0.0 : lg[i * 64 + lane];
+    }
+    __device__ inline void fun_grad(double y, double& f, double& g) {
+        const int i = find_or_ask(y);
+        f = i < 0 ? 0.0 : lf[i];
+        g = i < 0 ? 0.0 : lg[i * 64 + lane];
+    }
+    __device__ inline void prepare_hess(double x) {
+        const int i = find_or_ask(x);
+        have_H = i >= 0;
+        if (!have_H) return;
+        const double* src = lH + (int64_t)i * dim * dim;
+        for (int e = lane; e < dim * dim; e += 64) Hl[(e / dim) * CORR_LD + (e % dim)] = src[e];
+        __builtin_amdgcn_wave_barrier();  // one wave: its LDS operations execute in order
+    }
+    // (Hessian at the fixed point) . v: the logged sum of w_n U_n U_n^T plus the prior's v / variance, in the summation
+    // order of SignatureEmbeddingEval::hessp
+    __device__ inline double hessp(double v) const {
+        if (!have_H) return 0.0;
+        double r = 0.0;
+        const double* row = Hl + (lane < dim ? lane : 0) * CORR_LD;
+        for (int j = 0; j < dim; ++j) r = __builtin_fma(row[j], __shfl(v, j, 64), r);
+        return lane < dim ? r + v / variance : 0.0;
+    }
+    __device__ inline bool exhausted() const { return pending; }
+};
+
+// one wavefront per signature: log the evaluation that has just been reduced, replay the solve, ask or finish
+__global__ void __launch_bounds__(64) ls_advance_kernel(LockstepParams q) {
+    __shared__ double Hl[64 * CORR_LD];
+    const int k = blockIdx.x, lane = threadIdx.x;
+    if (q.state[k] != LS_NEED) return;
+    const int dim = q.sig.dim;
+    const double variance = q.sig.variance;
+    double* ly = q.log_y + (int64_t)k * LS_EVAL_MAX * 64;
+    double* lf = q.log_f + (int64_t)k * LS_EVAL_MAX;
+    double* lg = q.log_g + (int64_t)k * LS_EVAL_MAX * 64;
+    double* lH = q.log_H + (int64_t)k * LS_EVAL_MAX * dim * dim;
+    const double* red = q.red + (int64_t)k * LS_REC;
+    // ---- the evaluation at the requested point (same arithmetic as SignatureEmbeddingEval::fun_grad)
+    const int i = q.n_evals[k];
+    const double y = q.req[k * 64 + lane];
+    {
+        double v = red[0];
+        v -= red[1];
+        v -= ncg::wave_sum(y * y) / (2 * variance);
+        double gg = -red[2 + lane];
+        gg += q.sg[k * 64 + lane];
+        gg -= y / variance;
+        ly[i * 64 + lane] = y;
+        lg[i * 64 + lane] = lane < dim ? -gg : 0.0;
+        if (lane == 0) lf[i] = -v;
+        for (int e = lane; e < dim * dim; e += 64) lH[(int64_t)i * dim * dim + e] = red[66 + e];
+    }
+    __threadfence_block();  // the log entries written above are read back below by other lanes of this wave
+    // ---- replay
+    ReplayEval ev;
+    ev.ly = ly;
+    ev.lf = lf;
+    ev.lg = lg;
+    ev.lH = lH;
+    ev.n = i + 1;
+    ev.dim = dim;
+    ev.lane = lane;
+    ev.variance = variance;
+    ev.cursor = 0;
+    ev.pending = false;
+    ev.req = 0.0;
+    ev.Hl = Hl;
+    ev.have_H = false;
+    double x = q.x0[k * 64 + lane];
+    const int st = ncg::minimize(ev, x, dim, q.sig.maxiter);
+    if (ev.pending) {
+        q.req[k * 64 + lane] = lane < dim ? ev.req : 0.0;
+        if (lane == 0) {
+            q.n_evals[k] = i + 1;
+            if (i + 1 >= LS_EVAL_MAX) {
+                q.state[k] = LS_FALLBACK;  // a runaway solve: the single-kernel form (with its own budget) takes it over
+            } else {
+                atomicAdd(q.active, 1);
+            }
+        }
+        return;
+    }
+    if (x > 0.0 && x < kEps) x = kEps;
+    if (x < 0.0 && x > -kEps) x = -kEps;
+    if (lane < dim) q.sig.L[k * dim + lane] = x;
+    if (lane == 0) {
+        q.n_evals[k] = i + 1;
+        q.state[k] = LS_DONE;
+        if (q.sig.status) q.sig.status[k] = st;
+    }
+}
+
+}  // namespace salnmf

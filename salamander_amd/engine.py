@@ -105,6 +105,10 @@ class Engine:
     def kl_step(self, n_steps: int = 1, n_given: int = 0):
         _lib.check(self._lib.salnmf_kl_step(self._h, int(n_steps), int(n_given)))
 
+    def set_lockstep(self, on: bool = True):
+        """Signature-embedding solves in lockstep rounds (default from 16 384 samples on) or one workgroup per signature."""
+        _lib.check(self._lib.salnmf_set_lockstep(self._h, int(bool(on))))
+
     def set_persistent(self, on: bool = True):
         """Run multi-step ``kl_step`` calls as one persistent launch (default) or as per-step launches."""
         _lib.check(self._lib.salnmf_set_persistent(self._h, int(bool(on))))

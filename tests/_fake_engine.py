@@ -133,7 +133,8 @@ class FakeCorrShardEngine(FakeEngine):
     It restates WHERE the C++ engine exchanges data when a communicator is attached (``salnmf.hip``): an
     all-reduce of the signature-update numerator (``corr_compute_aux``), of the two sums of the signature scalings,
     of the Poisson term and of the sum of squares of the sample embeddings, and ONE gather of ``U``, ``alpha`` and
-    ``aux`` per update for the signature-embedding solves, which every rank then runs on identical inputs.
+    ``aux`` per update for the signature-embedding solves, which every rank then runs on identical inputs (the
+    engine's regime below 16 384 samples per rank; above it all-reduces the sums of every evaluation round instead).
     Without an initialised process group (or before ``comm_init``) it is a plain single-shard engine.
     """
 

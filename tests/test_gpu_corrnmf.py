@@ -8,6 +8,7 @@ geometry class.  fp64 throughout; tolerances are relative 1e-12 unless stated.
 import numpy as np
 import pytest
 
+import salamander_amd as sal
 from oracle import corrnmf_oracle as co
 from oracle import klnmf_oracle as ko
 from salamander_amd import _lib
@@ -560,3 +561,73 @@ def test_embedding_solves_terminate_on_non_finite_input():
     clean = np.ones(40, dtype=bool)
     clean[[5, 7]] = False
     assert np.isfinite(got[clean]).all()
+
+
+@pytest.mark.parametrize("N,K,dim", [(20000, 12, 8), (33000, 40, 40), (17000, 3, 2), (16500, 64, 64)])
+def test_lockstep_signature_solves_agree_with_the_single_kernel_form(N, K, dim):
+    """From 16 384 samples on the signature solves advance in lockstep rounds (evaluation over chunks x signatures, the
+    solvers replayed from their logs).  Same problems, same solver, the sums of an evaluation in a different order:
+    the embeddings agree with the one-workgroup-per-signature kernel far inside the solver's own tolerance and the
+    status codes are the same; two of the solves are checked against SciPy as well."""
+    rng = np.random.default_rng(N + K)
+    X, W, _ = ko.synthetic_problem(96, N, K, seed=K)
+    beta, L, U = rng.normal(0, 0.3, K), rng.normal(0, 0.4, (K, dim)), rng.normal(0, 0.4, (N, dim))
+    out = []
+    for lockstep in (True, False):
+        e = Engine(N, 96, K)
+        e.set_lockstep(lockstep)
+        e.upload_X(X), e.upload_W(W)
+        e.corr_configure(dim)
+        e.corr_upload(_lib.CORR_SIGNATURE_SCALINGS, beta)
+        e.corr_upload(_lib.CORR_SIGNATURE_EMBEDDINGS, L)
+        e.corr_upload(_lib.CORR_SAMPLE_EMBEDDINGS, U)
+        e.corr_update_sample_scalings()
+        e.corr_compute_exposures()
+        e.corr_compute_aux()
+        status = e.corr_update_signature_embeddings(0.8, 0, return_status=True)
+        out.append((e.corr_download(_lib.CORR_SIGNATURE_EMBEDDINGS), status, e.corr_download(_lib.CORR_SAMPLE_SCALINGS), e.corr_download(_lib.CORR_AUX)))
+        e.close()
+    (La, sa, alpha, aux), (Lb, sb, _, _) = out
+    assert np.array_equal(sa, sb)
+    assert np.allclose(La, Lb, rtol=1e-7, atol=1e-10)
+    for k in (0, K - 1):
+        want = co.update_embedding(L[k], U, beta[k], alpha, 0.8, aux[:, k])
+        assert np.allclose(La[k], want, rtol=1e-5, atol=1e-8)
+
+
+def test_lockstep_sharded_path_world_size_one_equals_unsharded():
+    """CorrNMFDet(distributed=True) with enough samples for the lockstep solves: the all-reduce of every round's sums
+    (world size 1) must not change a bit against the single-GPU model."""
+    import os
+
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29543")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        rng = np.random.default_rng(3)
+        N, K, dim = 18000, 6, 3
+        X, W, _ = ko.synthetic_problem(96, N, K, seed=9)
+        res = []
+        for distributed in (False, True):
+            a = sal.AnnData(X.copy())
+            a.obs["scalings"] = np.log(X.sum(axis=1) / K)
+            a.obsm["embeddings"] = np.random.default_rng(4).normal(0, 0.3, (N, dim))
+            sigs = sal.AnnData(W.copy())
+            sigs.obs["scalings"] = np.random.default_rng(5).normal(0, 0.1, K)
+            sigs.obsm["embeddings"] = np.random.default_rng(6).normal(0, 0.3, (K, dim))
+            m = sal.models.CorrNMFDet(n_signatures=K, dim_embeddings=dim, distributed=distributed)
+            m.adata, m.asignatures, m.variance = a, sigs, 0.9
+            m._sync_to_device()
+            m._device_steps(2, None)
+            m._sync_from_device()
+            res.append((sigs.obsm["embeddings"].copy(), np.asarray(sigs.X).copy(), a.obsm["embeddings"].copy(), m.variance))
+            m._engine.close()
+        for x, y in zip(*res):
+            assert np.array_equal(x, y)
+    finally:
+        if created:
+            dist.destroy_process_group()
