@@ -324,7 +324,7 @@ def embedding_problem(N, K, dim, seed):
     "N,K,dim,maxiter",
     [(300, 1, 1, 3), (300, 2, 2, 3), (300, 7, 3, 3), (200, 30, 30, 3), (200, 50, 8, 3), (120, 64, 64, 3), (200, 7, 3, 0), (100, 30, 30, 0)],
 )
-def test_sample_embedding_solves_match_scipy(N, K, dim, maxiter):
+def test_sample_embedding_solves_match_installed_scipy(N, K, dim, maxiter):
     """One device Newton-CG solve per sample against scipy.optimize.minimize(method='Newton-CG') on the
     same problems (the reference's call, ``_utils_corrnmf.py:400-407``), incl. SciPy's status codes.
 
@@ -380,7 +380,7 @@ def test_sample_embeddings_tiny_entries_are_pushed_away_from_zero():
 
 
 @pytest.mark.parametrize("N,K,dim", [(10, 1, 1), (10, 2, 2), (300, 3, 2), (1000, 7, 3), (2000, 30, 30), (3000, 50, 8), (1500, 64, 64)])
-def test_signature_embedding_solves_match_scipy(N, K, dim):
+def test_signature_embedding_solves_match_installed_scipy(N, K, dim):
     """One workgroup per signature, every evaluation a pass over all samples; SciPy's default iteration
     limit as in the reference (corrnmf_det.py:103-113).  Run to convergence, so compared at the solver's
     tolerance; in practice the iterates coincide to ~1e-14."""

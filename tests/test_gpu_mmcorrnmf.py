@@ -189,7 +189,7 @@ class TestGivenParametersMultimodalCorrNMF:
 
 
 @pytest.mark.parametrize("Ks,dim,N", [([7, 5], 3, 300), ([40, 40], 8, 200), ([64, 64], 16, 64), ([3, 4, 5], 2, 150)])
-def test_joint_sample_embedding_solve_matches_scipy(Ks, dim, N):
+def test_joint_sample_embedding_solve_matches_installed_scipy(Ks, dim, N):
     """salnmf_corr_update_sample_embeddings_multi on 2-3 modalities incl. more than 64 signatures in total
     (two terms per lane) against the oracle's SciPy solves."""
     rng = np.random.default_rng(sum(Ks) + dim)
@@ -231,7 +231,7 @@ def test_multi_solve_rejects_mismatched_engines():
     b.close()
 
 
-def test_c5_like_scale_subset_matches_scipy():
+def test_c5_like_scale_subset_matches_installed_scipy():
     """Config c5's shape at a tenth of its samples -- (96 + 83) x 20 000, 40 signatures per modality, dim 40,
     80 terms per sample solve (two per lane) -- checked on a random subset against SciPy."""
     rng = np.random.default_rng(5)
