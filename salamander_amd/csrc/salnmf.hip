@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -56,8 +57,10 @@ struct RcclApi {
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 static RcclApi g_rccl;
+static std::mutex g_rccl_mutex;
 
 static int rccl_bind() {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);  // engines of different host threads may bind concurrently
     if (g_rccl.handle) return 0;
     void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);  // the copy already in the process (torch's)
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
