@@ -915,9 +915,8 @@ static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double de
     }
     // W_unconstrained from A, B (stream2) and the reduced sums; f0 = KL + lam * logdet(W) -> scal[1]
     HIPCK(hipStreamWaitEvent(e->stream, e->evPrepW, 0));
-    hipLaunchKernelGGL(mv_prepare_final_kernel, dim3((K * V + 255) / 256), dim3(256), 0, e->stream, e->W, e->mvA, e->mvB, e->red,
-                       e->red + K * V, e->red + K * V + K, e->scal + 3, K, V, n_given, lam, e->Wunc, e->scal + 1);
-    HIPCK(hipGetLastError());
+    // (evaluated inside the first trial kernel below)
+    const MvRootParams root{e->mvA, e->mvB, e->red, e->red + K * V, e->red + K * V + K, e->scal + 3, e->scal + 1, lam, n_given};
     double g = *gamma;
     bool blend = false, dropped = false;
     for (;;) {
@@ -928,8 +927,12 @@ static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double de
             dropped = false;
         }
         // trial W: normalise + clip and the column sums for H on the main stream; its logdet -> scal[4] on stream2
-        hipLaunchKernelGGL(mv_trial_light_kernel, dim3(1), dim3(MV_BLOCK), 0, e->stream, e->W, e->Wunc, blend ? g : 1.0,
-                           blend ? 1 : 0, K, V, e->Wtrial, e->cs);
+        if (!blend)
+            hipLaunchKernelGGL(mv_trial_light_kernel<true>, dim3(1), dim3(MV_BLOCK), 0, e->stream, e->W, e->Wunc, 1.0, 0, K, V,
+                               e->Wtrial, e->cs, root);
+        else
+            hipLaunchKernelGGL(mv_trial_light_kernel<false>, dim3(1), dim3(MV_BLOCK), 0, e->stream, e->W, e->Wunc, g, 1, K, V,
+                               e->Wtrial, e->cs, root);
         HIPCK(hipGetLastError());
         HIPCK(hipEventRecord(e->evTrial, e->stream));
         HIPCK(hipStreamWaitEvent(e->stream2, e->evTrial, 0));

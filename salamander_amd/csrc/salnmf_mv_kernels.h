@@ -174,35 +174,56 @@ __global__ void __launch_bounds__(MV_BLOCK)
 }
 
 // closed-form root per entry (mvnmf.py:55-65) from A, B, the reduced G, the row sums of H and W; f0 (mvnmf.py:79)
-__global__ void mv_prepare_final_kernel(const double* __restrict__ W, const double* __restrict__ A, const double* __restrict__ B,
-                                        const double* __restrict__ G, const double* __restrict__ hsum,
-                                        const double* __restrict__ kl, const double* __restrict__ logdet, int K, int V,
-                                        int n_given, double lam, double* __restrict__ Wunc, double* __restrict__ f0_out) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx == 0) *f0_out = *kl + lam * *logdet;
-    if (idx >= K * V) return;
-    const int k = idx / V;
-    const double w = W[idx];
-    const double b = hsum[k] - 4.0 * lam * A[idx];
-    const double root = sqrt(b * b + 8.0 * lam * B[idx] * G[idx]);
-    const double wu = w * (root - b) / (4.0 * lam * B[idx]);
-    Wunc[idx] = (k < n_given) ? w : clip_lo(wu, kEps);
-}
+struct MvRootParams {
+    const double *A, *B, *G, *hsum, *kl, *logdet;
+    double* f0_out;
+    double lam;
+    int n_given;
+};
 
-// the part of a line-search trial the forward pass needs (mvnmf.py:80-81, 85-88): blend, row sums, normalise, clip
+// the part of a line-search trial the forward pass needs (mvnmf.py:80-81, 85-88): blend, row sums, normalise, clip.
+// ROOT: the first trial of an update, which also evaluates the closed-form root from MvRootParams and
+// stores it as Wunc -- one kernel boundary less on the serial path of every MvNMF step.
+template <bool ROOT>
 __global__ void __launch_bounds__(MV_BLOCK)
-    mv_trial_light_kernel(const double* __restrict__ W, const double* __restrict__ Wunc, double gamma, int blend, int K, int V,
-                          double* __restrict__ Wtrial, double* __restrict__ cs) {
+    mv_trial_light_kernel(const double* __restrict__ W, double* __restrict__ Wunc, double gamma, int blend, int K, int V,
+                          double* __restrict__ Wtrial, double* __restrict__ cs, MvRootParams r) {
     __shared__ double Wl[MV_KMAX * MV_WS];
     __shared__ double rs[MV_KMAX];
     constexpr int PT = (MV_KMAX * MV_VMAX + MV_BLOCK - 1) / MV_BLOCK;
     double a[PT], b[PT];
     const int total = K * V;
+    if constexpr (ROOT) {
+        if (threadIdx.x == 0) *r.f0_out = *r.kl + r.lam * *r.logdet;
+        double wa[PT], wb[PT], wg[PT];
 #pragma unroll
-    for (int j = 0; j < PT; ++j) {
-        int idx = threadIdx.x + MV_BLOCK * j;
-        a[j] = idx < total ? Wunc[idx] : 0.0;
-        b[j] = (blend && idx < total) ? W[idx] : 0.0;
+        for (int j = 0; j < PT; ++j) {
+            int idx = threadIdx.x + MV_BLOCK * j;
+            const bool in = idx < total;
+            b[j] = in ? W[idx] : 1.0;
+            wa[j] = in ? r.A[idx] : 0.0;
+            wb[j] = in ? r.B[idx] : 1.0;
+            wg[j] = in ? r.G[idx] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < PT; ++j) {
+            int idx = threadIdx.x + MV_BLOCK * j;
+            if (idx < total) {
+                const int k = idx / V;
+                const double bb = r.hsum[k] - 4.0 * r.lam * wa[j];
+                const double root = sqrt(bb * bb + 8.0 * r.lam * wb[j] * wg[j]);
+                const double wu = b[j] * (root - bb) / (4.0 * r.lam * wb[j]);
+                a[j] = (k < r.n_given) ? b[j] : clip_lo(wu, kEps);
+                Wunc[idx] = a[j];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < PT; ++j) {
+            int idx = threadIdx.x + MV_BLOCK * j;
+            a[j] = idx < total ? Wunc[idx] : 0.0;
+            b[j] = (blend && idx < total) ? W[idx] : 0.0;
+        }
     }
 #pragma unroll
     for (int j = 0; j < PT; ++j) {
@@ -210,7 +231,7 @@ __global__ void __launch_bounds__(MV_BLOCK)
         if (idx < total) {
             int k = idx / V, v = idx - k * V;
             double wt = a[j];
-            if (blend) wt = (1 - gamma) * b[j] + gamma * wt;
+            if (!ROOT && blend) wt = (1 - gamma) * b[j] + gamma * wt;
             Wl[k * MV_WS + v] = wt;
         }
     }
