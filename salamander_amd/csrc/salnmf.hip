@@ -9,6 +9,7 @@
 #include "salnmf_init_kernels.h"
 
 #include <dlfcn.h>
+#include <hip/hip_ext.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
@@ -854,6 +855,11 @@ int salnmf_mv_objective(salnmf_engine* e, double lam, double delta, double* out)
     return 0;
 }
 
+// Launch with `ev` bound to the kernel's own completion signal: a hipEventRecord behind the launch would put a
+// barrier packet of its own into the queue, which costs the stream ~7 us per record (profiles/r02/mv_timeline_*.txt).
+#define LAUNCH_WITH_EVENT(kernel, grid, block, stream, ev, ...) \
+    hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, nullptr, ev, 0, __VA_ARGS__)
+
 // MvNMF._update_W (mvnmf.py:190-195) on the current (W, H).
 // Two streams: everything that depends on W alone -- Gram matrix, Cholesky, inverse, A = W Y_minus, B = W |Y|,
 // log det, and later the log det of a trial W -- is single-workgroup latency-bound work and runs on stream2
@@ -863,9 +869,9 @@ int salnmf_mv_objective(salnmf_engine* e, double lam, double delta, double* out)
 static int mv_start_prepare_W(salnmf_engine* e, double delta, bool record_w_event) {
     if (record_w_event) HIPCK(hipEventRecord(e->evW, e->stream));  // else: recorded when W was last written
     HIPCK(hipStreamWaitEvent(e->stream2, e->evW, 0));
-    hipLaunchKernelGGL(mv_prepare_W_kernel, dim3(1), dim3(MV_BLOCK), 0, e->stream2, e->W, e->K, e->V, delta, e->mvA, e->mvB, e->scal + 3);
+    LAUNCH_WITH_EVENT(mv_prepare_W_kernel, dim3(1), dim3(MV_BLOCK), e->stream2, e->evPrepW, e->W, e->K, e->V, delta, e->mvA, e->mvB,
+                      e->scal + 3);
     HIPCK(hipGetLastError());
-    HIPCK(hipEventRecord(e->evPrepW, e->stream2));
     return 0;
 }
 
@@ -928,17 +934,15 @@ static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double de
         }
         // trial W: normalise + clip and the column sums for H on the main stream; its logdet -> scal[4] on stream2
         if (!blend)
-            hipLaunchKernelGGL(mv_trial_light_kernel<true>, dim3(1), dim3(MV_BLOCK), 0, e->stream, e->W, e->Wunc, 1.0, 0, K, V,
-                               e->Wtrial, e->cs, root);
+            LAUNCH_WITH_EVENT(mv_trial_light_kernel<true>, dim3(1), dim3(MV_BLOCK), e->stream, e->evTrial, e->W, e->Wunc, 1.0, 0, K,
+                              V, e->Wtrial, e->cs, root);
         else
-            hipLaunchKernelGGL(mv_trial_light_kernel<false>, dim3(1), dim3(MV_BLOCK), 0, e->stream, e->W, e->Wunc, g, 1, K, V,
-                               e->Wtrial, e->cs, root);
+            LAUNCH_WITH_EVENT(mv_trial_light_kernel<false>, dim3(1), dim3(MV_BLOCK), e->stream, e->evTrial, e->W, e->Wunc, g, 1, K, V,
+                              e->Wtrial, e->cs, root);
         HIPCK(hipGetLastError());
-        HIPCK(hipEventRecord(e->evTrial, e->stream));
         HIPCK(hipStreamWaitEvent(e->stream2, e->evTrial, 0));
-        hipLaunchKernelGGL(mv_logdet_kernel, dim3(1), dim3(MV_BLOCK), 0, e->stream2, e->Wtrial, K, V, delta, e->scal + 4);
+        LAUNCH_WITH_EVENT(mv_logdet_kernel, dim3(1), dim3(MV_BLOCK), e->stream2, e->evLogdet, e->Wtrial, K, V, delta, e->scal + 4);
         HIPCK(hipGetLastError());
-        HIPCK(hipEventRecord(e->evLogdet, e->stream2));
         double v[5];
         const bool spec = speculate && !blend;
         if (spec) {
@@ -953,14 +957,19 @@ static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double de
             sp.Hout = e->Halt;
             sp.KLpart = e->KLpart2;
             CK((launch_fused<false, true, true>(e, sp, e->mv_grid)));
-            hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, e->KLpart2, e->mv_grid, 1, 1, e->scal + 2);
-            HIPCK(hipGetLastError());
-            CK(allreduce(e, e->scal + 2, 1));
-            HIPCK(hipEventRecord(e->evObj, e->stream));
+            if (!e->comm) {
+                LAUNCH_WITH_EVENT(sum_partials_kernel, dim3(1), dim3(256), e->stream, e->evObj, e->KLpart2, e->mv_grid, 1, 1, e->scal + 2);
+                HIPCK(hipGetLastError());
+            } else {
+                hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, e->KLpart2, e->mv_grid, 1, 1, e->scal + 2);
+                HIPCK(hipGetLastError());
+                CK(allreduce(e, e->scal + 2, 1));
+                HIPCK(hipEventRecord(e->evObj, e->stream));
+            }
             // ... its W-only algebra behind the trial's log det on stream2 (A, B of this step are consumed already) ...
-            hipLaunchKernelGGL(mv_prepare_W_kernel, dim3(1), dim3(MV_BLOCK), 0, e->stream2, e->Wtrial, K, V, delta, e->mvA, e->mvB, e->scal + 3);
+            LAUNCH_WITH_EVENT(mv_prepare_W_kernel, dim3(1), dim3(MV_BLOCK), e->stream2, e->evPrepW, e->Wtrial, K, V, delta, e->mvA,
+                              e->mvB, e->scal + 3);
             HIPCK(hipGetLastError());
-            HIPCK(hipEventRecord(e->evPrepW, e->stream2));
             // ... and its numerator pass (W_trial as W, the new H): it runs while the scalars travel to the host
             CK(mv_numerator_pass(e, e->Wtrial, e->Halt, nullptr));
             CK(allreduce(e, e->red, (size_t)K * V + K + 1));
@@ -987,7 +996,7 @@ static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double de
             *gamma = std::min(1.0, 1.2 * g);
             std::swap(e->W, e->Wtrial);
             std::swap(e->H, e->Halt);  // written in full from clip(H * cs): nothing pending
-            HIPCK(hipEventRecord(e->evW, e->stream));
+            // (no evW: the next step's W-only algebra is queued already; a later stand-alone start records its own)
             e->h_pending = false;
             if (speculated) *speculated = true;
             return 0;
