@@ -60,15 +60,14 @@ __device__ __forceinline__ void mfma_agpr(d4& c, double a, double b) {
 // poisoned fit shows up in the objective instead of being masked (fmax would return the bound).
 __device__ __forceinline__ double clip_lo(double x, double lo) { return x < lo ? lo : x; }
 
-// x / p for the path's operands.  Same FMA sequence as hipcc's IEEE fp64 divide (reciprocal, two
-// Newton steps, residual correction) without its range-scaling / fix-up instructions, which only
-// act on operands outside ~[1e-280, 1e280].  Bit-identical to `x / p` on 16.7 M probes covering
-// counts, clipped zeros, 1e-30..1e30 ratios and x = 0 (tools/div_probe.hip); the parity tests pin it.
+// x / p for the path's operands: reciprocal (v_rcp_f64: |r p - 1| < 4.7e-8 measured), ONE Newton step on it
+// (-> ~2^-48), quotient, residual correction of the quotient (-> ~2^-96 before the final rounding).  hipcc's IEEE
+// fp64 divide runs a second Newton step and range-scaling / fix-up instructions that only act on operands outside
+// ~[1e-280, 1e280].  Bit-identical to `x / p` on 16.7 M probes covering counts, clipped zeros, 1e-30..1e30 ratios
+// and x = 0 (tools/div_probe.hip, profiles/r02/div_probe.txt); the parity tests pin it.
 __device__ __forceinline__ double div_path(double x, double p) {
     double r = __builtin_amdgcn_rcp(p);
     double e = __builtin_fma(-p, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-p, r, 1.0);
     r = __builtin_fma(r, e, r);
     double q = x * r;
     double rem = __builtin_fma(-p, q, x);
@@ -567,14 +566,22 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
             for (int vt = 0; vt < VT; ++vt) b[0][vt] = wb[16 * vt];
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
+                // the next k-step's operand reads are spread between this k-step's MFMAs (one LDS instruction behind
+                // each): issued in a clump they queue up behind the other waves' clumps on the CU's one LDS pipe and
+                // hold back the in-order MFMA behind them (tools/phase_probe.hip: 29.7 -> 28.3 ns per MFMA)
+                __builtin_amdgcn_sched_barrier(0);
                 if (s + 1 < KS) {
                     a[(s + 1) & 1] = ha[4 * (s + 1)];
 #pragma unroll
                     for (int vt = 0; vt < VT; ++vt) b[(s + 1) & 1][vt] = wb[4 * (s + 1) * WS + 16 * vt];
                 }
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int vt = 0; vt < VT; ++vt) pr[vt] = mfma(a[s & 1], b[s & 1][vt], pr[vt]);
+#pragma unroll
+                for (int vt = 0; vt < VT; ++vt) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -704,14 +711,19 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
             for (int kt = 0; kt < KT; ++kt) b[0][kt] = wb[16 * kt * WS];
 #pragma unroll
             for (int s = 0; s < VSTEPS; ++s) {
+                __builtin_amdgcn_sched_barrier(0);
                 if (s + 1 < VSTEPS) {
                     a[(s + 1) & 1] = ra[4 * (s + 1)];
 #pragma unroll
                     for (int kt = 0; kt < KT; ++kt) b[(s + 1) & 1][kt] = wb[16 * kt * WS + 4 * (s + 1)];
                 }
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt) u[kt] = mfma(a[s & 1], b[s & 1][kt], u[kt]);
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {  // reads (and the stage's VALU work) spread between the MFMAs, as in the P phase
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (KR > 0) { using std::integral_constant; rs_stage(integral_constant<int, 8>{}, integral_constant<int, NVP>{}); rs_stage(integral_constant<int, 4>{}, integral_constant<int, (NVP / 2 > 1 ? NVP / 2 : 1)>{}); rs_stage(integral_constant<int, 2>{}, integral_constant<int, (NVP / 4 > 1 ? NVP / 4 : 1)>{}); rs_stage(integral_constant<int, 1>{}, integral_constant<int, (NVP / 8 > 1 ? NVP / 8 : 1)>{}); }

@@ -12,6 +12,27 @@ __device__ __forceinline__ double fast_div(double x, double p) {
     double rem = __builtin_fma(-p, q, x);
     return __builtin_fma(rem, r, q);
 }
+// one Newton step on the reciprocal instead of two; the quotient correction supplies the missing bits
+__device__ __forceinline__ double fast_div1(double x, double p) {
+    double r = __builtin_amdgcn_rcp(p);
+    double e = __builtin_fma(-p, r, 1.0); r = __builtin_fma(r, e, r);
+    double q = x * r;
+    double rem = __builtin_fma(-p, q, x);
+    return __builtin_fma(rem, r, q);
+}
+// no Newton step on the reciprocal, two quotient corrections
+__device__ __forceinline__ double fast_div2(double x, double p) {
+    double r = __builtin_amdgcn_rcp(p);
+    double q = x * r;
+    double rem = __builtin_fma(-p, q, x);
+    q = __builtin_fma(rem, r, q);
+    rem = __builtin_fma(-p, q, x);
+    return __builtin_fma(rem, r, q);
+}
+__global__ void k2(const double* x, const double* p, double* b1, double* b2, double* rr, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { b1[i] = fast_div1(x[i], p[i]); b2[i] = fast_div2(x[i], p[i]); rr[i] = __builtin_amdgcn_rcp(p[i]); }
+}
 __global__ void k(const double* x, const double* p, double* a, double* b, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { a[i] = x[i] / p[i]; b[i] = fast_div(x[i], p[i]); }
@@ -37,6 +58,21 @@ int main() {
     for (int i = 0; i < n; ++i) {
         if (a[i] != b[i]) { ++diff; double r = std::fabs(a[i] - b[i]) / std::fabs(a[i]); if (r > maxrel) maxrel = r; }
         if (a[i] != x[i] / p[i]) ++vs_host;
+    }
+    {
+        double *d1, *d2, *dr; hipMalloc(&d1, n * 8); hipMalloc(&d2, n * 8); hipMalloc(&dr, n * 8);
+        k2<<<n / 256, 256>>>(dx, dp, d1, d2, dr, n);
+        std::vector<double> b1(n), b2(n), rr(n);
+        hipMemcpy(b1.data(), d1, n * 8, hipMemcpyDeviceToHost); hipMemcpy(b2.data(), d2, n * 8, hipMemcpyDeviceToHost); hipMemcpy(rr.data(), dr, n * 8, hipMemcpyDeviceToHost);
+        long m1 = 0, m2 = 0; double r1 = 0, r2 = 0, rcperr = 0;
+        for (int i = 0; i < n; ++i) {
+            if (a[i] != b1[i]) { ++m1; r1 = std::fmax(r1, std::fabs(a[i] - b1[i]) / std::fabs(a[i])); }
+            if (a[i] != b2[i]) { ++m2; r2 = std::fmax(r2, std::fabs(a[i] - b2[i]) / std::fabs(a[i])); }
+            rcperr = std::fmax(rcperr, std::fabs(rr[i] * p[i] - 1.0));
+        }
+        printf("v_rcp_f64 max |r p - 1| = %.3g\n", rcperr);
+        printf("one Newton step + correction vs IEEE: %ld of %d differ (max rel %.3g)\n", m1, n, r1);
+        printf("no Newton step, two corrections vs IEEE: %ld of %d differ (max rel %.3g)\n", m2, n, r2);
     }
     printf("fast_div vs device IEEE divide: %ld of %d differ (max rel %.3g); device IEEE vs host divide: %ld differ\n", diff, n, maxrel, vs_host);
     return 0;
