@@ -196,6 +196,33 @@ def problem_rows(start, stop):
     return np.concatenate(Xs), np.concatenate(Hs)
 
 
+def validate_exchange(engine, dist, W0, H0, local_rank, steps=3):
+    """A few steps from the same start through RCCL and through the peer-to-peer exchange: W must agree to rounding
+    (the two add the ranks' numerators in different orders) and, with the exchange, be bit-identical on all ranks."""
+    import torch
+
+    out = {"p2p_valid": False, "validation_steps": steps}
+    rel, digest, good = float("inf"), 0.0, 0.0
+    try:  # (no torch.distributed call inside: a rank that fails must still meet the others in the all-reduce below)
+        W = {}
+        for mode in ("rccl", "p2p"):
+            engine.set_p2p(mode == "p2p")
+            engine.upload_W(W0)
+            engine.upload_H(H0)
+            engine.kl_step(steps)
+            W[mode] = engine.download_W()
+        rel = float(np.linalg.norm(W["p2p"] - W["rccl"]) / np.linalg.norm(W["rccl"]))
+        digest = float(np.frombuffer(W["p2p"].tobytes(), dtype=np.uint32).astype(np.uint64).sum() % (1 << 52))
+        good = 1.0 if rel < 1e-11 else 0.0
+    except RuntimeError as exc:  # e.g. an exchange that gave up waiting for a peer
+        out["error"] = str(exc)
+    t = torch.tensor([digest, -digest, good], dtype=torch.float64, device=f"cuda:{local_rank}")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    same = bool(t[0].item() == -t[1].item())
+    out.update({"p2p_valid": bool(t[2].item() == 1.0 and same), "p2p_vs_rccl_rel_l2_W": rel, "p2p_W_identical_on_all_ranks": same})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -209,10 +236,17 @@ def main():
     ap.add_argument("--weak", action="store_true", help="N > 1: 100 000 samples per GPU instead of 10^6 in total")
     ap.add_argument("--no-one-gpu-reference", action="store_true", help="N > 1: skip rank 0's run of the whole problem on one GPU")
     ap.add_argument("--busy-seconds", type=float, default=2.5, help="repeat the K-step block until the GPU was busy this long")
+    ap.add_argument("--no-p2p", action="store_true", help="N > 1: RCCL all-reduce only, do not try the peer-to-peer exchange")
     ap.add_argument("--rehearse-sharded", action="store_true",
                     help="--gpus 1 only: run the N > 1 code path (process group, RCCL communicator in the engine, c3's row blocks, "
                     "one-GPU reference) at world size 1 -- a rehearsal of what the driver launches on a multi-GPU node")
     args = ap.parse_args()
+
+    # stdout carries the ONE JSON line and nothing else: whatever libraries print there (RCCL's version banner at
+    # communicator creation, for one) goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -261,6 +295,20 @@ def main():
     engine.upload_X(X)
     engine.upload_W(W0)
     engine.upload_H(H0)
+    # N > 1: the K x V all-reduce of every step goes either through RCCL or through the engine's peer-to-peer exchange
+    # (salnmf_p2p_kernels.h).  Both are run; the exchange's result is checked against the RCCL result before it is timed,
+    # and the line reports the faster VALID mode as `value` with both timings under config.exchange.
+    exchange = None
+    if sharded and not args.no_p2p:
+        from salamander_amd.distributed import attach_peer_exchange
+
+        exchange = {"p2p_connected": bool(attach_peer_exchange(engine, n_total, required=False))}
+        if exchange["p2p_connected"]:
+            exchange.update(validate_exchange(engine, dist, W0, H0, local_rank))
+            if not exchange["p2p_valid"]:
+                engine.set_p2p(False)
+            engine.upload_W(W0)
+            engine.upload_H(H0)
 
     def barrier():
         engine.sync()
@@ -286,10 +334,28 @@ def main():
         barrier()
         return max_over_ranks(time.perf_counter() - t0)
 
-    first = timed_block()
-    n_blocks = int(min(1000, max(5, math.ceil(args.busy_seconds / max(first, 1e-6)))))
-    blocks = [timed_block() for _ in range(n_blocks)]
-    median = statistics.median(blocks)
+    def timed_blocks():
+        first = timed_block()
+        n_blocks = int(min(1000, max(5, math.ceil(args.busy_seconds / max(first, 1e-6)))))
+        blocks = [timed_block() for _ in range(n_blocks)]
+        return first, n_blocks, blocks, statistics.median(blocks)
+
+    first, n_blocks, blocks, median = timed_blocks()
+    exchange_mode = "rccl" if sharded else None
+    if exchange is not None and exchange.get("p2p_valid"):
+        # the blocks above ran with the peer-to-peer exchange; the same protocol once more through RCCL
+        exchange["p2p_ms_per_step"] = median / args.steps * 1e3
+        engine.set_p2p(False)
+        engine.kl_step(args.warmup)
+        r_first, r_n, r_blocks, r_median = timed_blocks()
+        exchange["rccl_ms_per_step"] = r_median / args.steps * 1e3
+        if r_median < median:
+            first, n_blocks, blocks, median = r_first, r_n, r_blocks, r_median
+        else:
+            engine.set_p2p(True)
+            exchange_mode = "p2p"
+    if exchange is not None:
+        exchange["used_for_value"] = exchange_mode
 
     # untimed: kernel durations from HIP events around every 2nd step of 200 (100 samples each)
     barrier()
@@ -367,7 +433,13 @@ def main():
                 "n_samples_per_gpu": n_local,
                 "n_samples_total": n_total,
                 "n_signatures": K,
-                "parallelism": f"sample-sharded x{world}; one RCCL all-reduce of {K}x{V} f64 per step" if sharded else "single GPU",
+                "parallelism": (
+                    f"sample-sharded x{world}; one all-reduce of {K}x{V} f64 per step "
+                    + ("by peer-to-peer stores over xGMI (salnmf_p2p_kernels.h)" if exchange_mode == "p2p" else "by RCCL")
+                    if sharded
+                    else "single GPU"
+                ),
+                "exchange": exchange,
                 "global_steps_per_s": steps_per_s,
                 "objective_after_run": objective,
                 "one_gpu_same_problem": one_gpu,
@@ -415,7 +487,8 @@ def main():
                     except Exception as exc:  # an extra must never cost the headline line
                         extra[name] = {"error": f"{type(exc).__name__}: {exc}"}
                 line["extra"] = extra
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     else:
         engine.close()
 

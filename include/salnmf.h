@@ -234,6 +234,21 @@ int salnmf_comm_init(salnmf_engine* e, const char* id, int n_ranks, int rank);
  * when no communicator is attached).  Any output may be NULL. */
 int salnmf_comm_info(salnmf_engine* e, int* n_ranks, int* rank, int64_t* n_samples_total);
 
+/* Peer-to-peer exchange for the small all-reduces (the K x V numerator, the MvNMF line-search sums, objective scalars):
+ * every rank stores its vector straight into an inbox on each peer of the node (hipIpc-mapped uncached memory, xGMI
+ * peer stores) and adds the n vectors in rank order, so all ranks hold bit-identical sums.  It replaces the library
+ * all-reduce where that is pure latency (38 KB at K = 50); larger exchanges keep using RCCL.  One node, <= 8 ranks.
+ *   export : allocates this engine's inbox for vectors of up to max_count doubles (<= 16384) and returns its IPC handle
+ *   connect: maps the peers' inboxes; `handles` = n_ranks * SALNMF_P2P_HANDLE_BYTES in rank order (the host layer
+ *            all-gathers them); n_samples_total = samples over all shards (used when no RCCL communicator is attached)
+ *   set_p2p: switch the exchange off / on again (off: the all-reduces go through RCCL, which must then be attached)
+ * Every rank must issue the same sequence of calls on its engine.  A rank that waits 2 s for a peer gives up: the
+ * next download / objective call on that engine fails.  Destroy the engines only after all ranks are done. */
+#define SALNMF_P2P_HANDLE_BYTES 64
+int salnmf_p2p_export(salnmf_engine* e, int n_ranks, int64_t max_count, char* handle_out /* SALNMF_P2P_HANDLE_BYTES */);
+int salnmf_p2p_connect(salnmf_engine* e, int rank, int n_ranks, const char* handles, int64_t n_samples_total);
+int salnmf_set_p2p(salnmf_engine* e, int on);
+
 /* The joint step split at the exchange point, for a caller-side collective
  * (e.g. torch.distributed on a wrapped device pointer):
  *   partial: fused pass + local reduction -> SALNMF_BUF_G, H updated in place

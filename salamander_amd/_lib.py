@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libsalnmf.so")
 
 UNIQUE_ID_BYTES = 128
+P2P_HANDLE_BYTES = 64
 DTYPE_CODES = {"float64": 0, "float32": 1, "int32": 2, "int64": 3, "uint16": 4}  # SALNMF_F64 ...
 CLIP_ALL = 0
 CLIP_NON_GIVEN = 1
@@ -69,6 +70,9 @@ SIGNATURES = {
     "salnmf_comm_unique_id": (c_int, [ctypes.c_char_p]),
     "salnmf_comm_init": (c_int, [_P, ctypes.c_char_p, c_int, c_int]),
     "salnmf_comm_info": (c_int, [_P, POINTER(c_int), POINTER(c_int), POINTER(c_int64)]),
+    "salnmf_p2p_export": (c_int, [_P, c_int, c_int64, ctypes.c_char_p]),
+    "salnmf_p2p_connect": (c_int, [_P, c_int, c_int, ctypes.c_char_p, c_int64]),
+    "salnmf_set_p2p": (c_int, [_P, c_int]),
     "salnmf_kl_step_partial": (c_int, [_P]),
     "salnmf_kl_step_finish": (c_int, [_P, c_int, c_int]),
     "salnmf_device_ptr": (c_void_p, [_P, c_int]),

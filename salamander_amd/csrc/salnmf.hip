@@ -7,6 +7,7 @@
 #include "salnmf_corr_kernels.h"
 #include "salnmf_corr_lockstep.h"
 #include "salnmf_init_kernels.h"
+#include "salnmf_p2p_kernels.h"
 
 #include <dlfcn.h>
 #include <hip/hip_ext.h>
@@ -168,6 +169,15 @@ struct salnmf_engine {
     bool persistent = false;     // multi-step kl_step calls run as one persistent launch (opt-in: SALNMF_PERSISTENT=1)
     ncclComm_t comm = nullptr;
     int n_ranks = 1, rank = 0;
+    // peer-to-peer exchange of the small all-reduces (salnmf_p2p_kernels.h); RCCL stays for everything larger
+    struct {
+        bool connected = false, on = false;
+        double* local = nullptr;                // this rank's inbox (uncached device memory, exported over hipIpc)
+        double* inbox[P2P_MAX_RANKS] = {};      // every rank's inbox as mapped into this process
+        size_t max_count = 0, slot = 0;
+        int n_ranks = 0;                        // as exported
+        unsigned long long seq = 0;
+    } p2p;
     std::vector<int64_t> shard_N;  // n_samples of every rank's shard (filled by salnmf_comm_init)
     int64_t N_total = 0;           // sum of shard_N
     // gathered inputs of the signature-embedding solves (all samples of all shards, compact rows)
@@ -271,7 +281,7 @@ static FusedParams fused_params(salnmf_engine* e) {
     return p;
 }
 
-static int launch_tail(salnmf_engine* e, int nslabs, double* G, int n_given, int clip_mode, int do_tail, bool with_stats = false) {
+static TailParams tail_params(salnmf_engine* e, int nslabs, double* G, int n_given, int clip_mode, int do_tail, bool with_stats) {
     TailParams t;
     t.Gpart = e->Gpart;
     t.G = G;
@@ -287,15 +297,67 @@ static int launch_tail(salnmf_engine* e, int nslabs, double* G, int n_given, int
     t.kl_part = with_stats ? e->KLpart : nullptr;
     t.kl_out = e->red + (size_t)e->K * e->V + e->K;
     t.nparts = nslabs;
-    hipLaunchKernelGGL(tail_kernel, dim3(e->K), dim3(TAIL_BLOCK), 0, e->stream, t);
+    return t;
+}
+
+static int launch_tail(salnmf_engine* e, int nslabs, double* G, int n_given, int clip_mode, int do_tail, bool with_stats = false) {
+    hipLaunchKernelGGL(tail_kernel, dim3(e->K), dim3(TAIL_BLOCK), 0, e->stream, tail_params(e, nslabs, G, n_given, clip_mode, do_tail, with_stats));
     HIPCK(hipGetLastError());
     return 0;
 }
 
+// the engine holds one shard of the samples: sums over the samples are all-reduced
+static inline bool sharded(const salnmf_engine* e) { return e->comm != nullptr || e->p2p.connected; }
+
+// parameters of the next peer-to-peer exchange (every rank issues the same sequence of exchanges)
+static P2PParams next_exchange(salnmf_engine* e, double* buf, size_t count) {
+    P2PParams q{};
+    q.buf = buf;
+    q.count = (int)count;
+    q.rank = e->rank;
+    q.n_ranks = e->n_ranks;
+    q.seq = ++e->p2p.seq;
+    q.parity = (int)(q.seq & 1);
+    q.slot = e->p2p.slot;
+    q.max_count = e->p2p.max_count;
+    for (int r = 0; r < e->n_ranks; ++r) q.inbox[r] = e->p2p.inbox[r];
+    q.abort_host = e->pabort;
+    return q;
+}
+
+static inline bool p2p_usable(const salnmf_engine* e, size_t count) { return e->p2p.connected && e->p2p.on && count <= e->p2p.max_count; }
+
 static int allreduce(salnmf_engine* e, double* buf, size_t count) {
-    if (!e->comm) return 0;
+    if (p2p_usable(e, count)) {
+        hipLaunchKernelGGL(p2p_allreduce_kernel, dim3(((int)count + P2P_BLOCK - 1) / P2P_BLOCK), dim3(P2P_BLOCK), 0, e->stream,
+                           next_exchange(e, buf, count));
+        HIPCK(hipGetLastError());
+        return 0;
+    }
+    if (!e->comm) {
+        if (e->p2p.connected) return fail("an all-reduce of %zu doubles needs the RCCL communicator (peer-to-peer exchange: %s, limit %zu)", count,
+                                          e->p2p.on ? "on" : "off", e->p2p.max_count);
+        return 0;
+    }
     NCCLCK(ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, e->comm, e->stream));
     return 0;
+}
+
+// W tail of a sharded step: local reduction of the numerator slabs, all-reduce over the ranks, W update.
+// With the peer-to-peer exchange all of it is one launch (tail_p2p_kernel), otherwise reduce launch + RCCL + finish launch.
+static int sharded_tail(salnmf_engine* e, int n_given, int clip_mode) {
+    const size_t count = (size_t)e->K * e->V;
+    if (p2p_usable(e, count) && e->K <= P2P_MAX_WG) {
+        TailP2PParams tp;
+        tp.t = tail_params(e, e->grid, e->red, n_given, clip_mode, 1, false);
+        tp.x = next_exchange(e, e->red, count);
+        hipLaunchKernelGGL(tail_p2p_kernel, dim3(e->K), dim3(TAIL_BLOCK), 0, e->stream, tp);
+        HIPCK(hipGetLastError());
+        return 0;
+    }
+    CK(launch_tail(e, e->grid, e->red, 0, 0, 0));
+    CK(allreduce(e, e->red, count));
+    return launch_tail(e, 0, e->red, n_given, clip_mode, 1);
 }
 
 // materialise a pending rescale of H (needed only by readers that cannot apply it on the fly)
@@ -319,10 +381,8 @@ static int kl_step_once(salnmf_engine* e, int n_given, hipEvent_t* ev) {
     e->h_pending = false;  // the pass wrote H in full
     if (ev) HIPCK(hipEventRecord(ev[1], e->stream));
     if (!all_given) {
-        if (e->comm) {
-            CK(launch_tail(e, e->grid, e->red, 0, 0, 0));
-            CK(allreduce(e, e->red, (size_t)e->K * e->V));
-            CK(launch_tail(e, 0, e->red, n_given, SALNMF_CLIP_ALL, 1));
+        if (sharded(e)) {
+            CK(sharded_tail(e, n_given, SALNMF_CLIP_ALL));
         } else {
             CK(launch_tail(e, e->grid, e->red, n_given, SALNMF_CLIP_ALL, 1));
         }
@@ -355,6 +415,9 @@ void salnmf_destroy(salnmf_engine* e) {
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->comm) ncclCommDestroy(e->comm);
+    for (int r = 0; r < P2P_MAX_RANKS; ++r)
+        if (e->p2p.inbox[r] && e->p2p.inbox[r] != e->p2p.local) (void)hipIpcCloseMemHandle(e->p2p.inbox[r]);
+    if (e->p2p.local) (void)hipFree(e->p2p.local);
     double* bufs[] = {e->X, e->H, e->W, e->wkl, e->wlh, e->Gpart, e->Hsumpart, e->KLpart, e->red,
                       e->objpart, e->scal, e->Wunc, e->Wtrial, e->mvA, e->mvB, e->cs, e->scratch, e->Halt, e->KLpart2,
                       e->alpha, e->beta, e->Lemb, e->Uemb, e->aux, e->xrowsum, e->corrpart, e->gU, e->galpha, e->gaux};
@@ -685,6 +748,10 @@ static int kl_steps_persistent(salnmf_engine* e, int n, int n_given) {
 
 // a persistent launch whose waits gave up leaves the resident state half updated: say so at the next sync point
 static int check_abort(salnmf_engine* e) {
+    if (e->pabort && *e->pabort == 2u) {
+        return fail("a peer-to-peer exchange gave up waiting for another rank (salnmf_p2p_kernels.h: 2 s); the engine's W and H are "
+                    "invalid -- did every rank issue the same calls?");
+    }
     if (e->pabort && *e->pabort) {
         return fail("a wait inside the persistent KL kernel gave up (its workgroups were not all resident: is another process "
                     "using this GPU?); the engine's W and H are invalid -- upload them again, and set SALNMF_PERSISTENT=0");
@@ -709,7 +776,7 @@ int salnmf_kl_step(salnmf_engine* e, int n_steps, int n_given) {
     if (n_given < 0 || n_given > e->K) return fail("n_given out of range");
     HIPCK(hipSetDevice(e->device));
     int i = 0;
-    if (e->persistent && !e->comm && !e->wkl && !e->wlh && n_given < e->K && n_steps >= 2) {
+    if (e->persistent && !sharded(e) && !e->wkl && !e->wlh && n_given < e->K && n_steps >= 2) {
         CK(flush_H_scale(e));  // (after an MvNMF step) the persistent kernel reads H as it is
         constexpr int kMaxPerLaunch = 64;  // bounds one launch to a few milliseconds
         while (n_steps - i >= 2) {
@@ -753,11 +820,7 @@ int salnmf_update_W(salnmf_engine* e, int n_given, int clip_mode) {
     if (n_given >= e->K) return 0;  // _utils_klnmf.py:204-205
     FusedParams p = fused_params(e);
     CK((launch_fused<true, false, false>(e, p)));
-    if (e->comm) {
-        CK(launch_tail(e, e->grid, e->red, 0, 0, 0));
-        CK(allreduce(e, e->red, (size_t)e->K * e->V));
-        return launch_tail(e, 0, e->red, n_given, clip_mode, 1);
-    }
+    if (sharded(e)) return sharded_tail(e, n_given, clip_mode);
     return launch_tail(e, e->grid, e->red, n_given, clip_mode, 1);
 }
 
@@ -957,7 +1020,7 @@ static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double de
             sp.Hout = e->Halt;
             sp.KLpart = e->KLpart2;
             CK((launch_fused<false, true, true>(e, sp, e->mv_grid)));
-            if (!e->comm) {
+            if (!sharded(e)) {
                 LAUNCH_WITH_EVENT(sum_partials_kernel, dim3(1), dim3(256), e->stream, e->evObj, e->KLpart2, e->mv_grid, 1, 1, e->scal + 2);
                 HIPCK(hipGetLastError());
             } else {
@@ -1439,6 +1502,7 @@ static int gather_sample_side(salnmf_engine* e) {
 int salnmf_corr_update_signature_embeddings(salnmf_engine* e, double variance, int maxiter, int* status_out) {
     CK(corr_ready(e));
     if (!(variance > 0.0)) return fail("variance must be positive");
+    if (sharded(e) && !e->comm) return fail("the sharded signature-embedding solves gather through the RCCL communicator: call salnmf_comm_init");
     if (e->comm) {
         // sample-sharded: with enough samples the solves run in lockstep on the local rows and the sums of every
         // evaluation are all-reduced (1 + dim + dim^2 per signature); small problems gather the sample side once
@@ -1657,7 +1721,69 @@ int salnmf_comm_info(salnmf_engine* e, int* n_ranks, int* rank, int64_t* n_sampl
     if (!e) return fail("null engine");
     if (n_ranks) *n_ranks = e->n_ranks;
     if (rank) *rank = e->rank;
-    if (n_samples_total) *n_samples_total = e->comm ? e->N_total : e->N;
+    if (n_samples_total) *n_samples_total = sharded(e) ? e->N_total : e->N;
+    return 0;
+}
+
+int salnmf_p2p_export(salnmf_engine* e, int n_ranks, int64_t max_count, char* handle_out) {
+    if (!e || !handle_out) return fail("null argument");
+    if (e->p2p.local) return fail("the peer-to-peer inbox is exported already");
+    if (n_ranks < 1 || n_ranks > P2P_MAX_RANKS) return fail("peer-to-peer exchange supports 1..%d ranks, not %d", P2P_MAX_RANKS, n_ranks);
+    if (max_count < 1 || max_count > (int64_t)P2P_MAX_WG * P2P_BLOCK) return fail("max_count must be in 1..%d", P2P_MAX_WG * P2P_BLOCK);
+    static_assert(sizeof(hipIpcMemHandle_t) == SALNMF_P2P_HANDLE_BYTES, "handle size");
+    HIPCK(hipSetDevice(e->device));
+    e->p2p.max_count = (size_t)max_count;
+    e->p2p.slot = (size_t)max_count + P2P_MAX_WG;
+    e->p2p.n_ranks = n_ranks;
+    const size_t bytes = 2 * (size_t)n_ranks * e->p2p.slot * sizeof(double);
+    HIPCK(hipExtMallocWithFlags((void**)&e->p2p.local, bytes, hipDeviceMallocUncached));
+    HIPCK(hipMemset(e->p2p.local, 0, bytes));
+    HIPCK(hipDeviceSynchronize());  // the flags are zero before any peer can learn the handle
+    hipIpcMemHandle_t h;
+    HIPCK(hipIpcGetMemHandle(&h, e->p2p.local));
+    memcpy(handle_out, &h, sizeof h);
+    return 0;
+}
+
+int salnmf_p2p_connect(salnmf_engine* e, int rank, int n_ranks, const char* handles, int64_t n_samples_total) {
+    if (!e || !handles) return fail("null argument");
+    if (!e->p2p.local) return fail("salnmf_p2p_export first");
+    if (e->p2p.connected) return fail("peer-to-peer exchange already connected");
+    if (n_ranks != e->p2p.n_ranks || rank < 0 || rank >= n_ranks) return fail("rank %d of %d does not match the exported inbox (%d ranks)", rank, n_ranks, e->p2p.n_ranks);
+    if (e->comm && (e->n_ranks != n_ranks || e->rank != rank)) return fail("rank %d of %d contradicts the RCCL communicator (%d of %d)", rank, n_ranks, e->rank, e->n_ranks);
+    if (n_samples_total < e->N) return fail("n_samples_total %lld is smaller than this shard (%lld)", (long long)n_samples_total, (long long)e->N);
+    HIPCK(hipSetDevice(e->device));
+    for (int r = 0; r < n_ranks; ++r) {
+        if (r == rank) {
+            e->p2p.inbox[r] = e->p2p.local;
+            continue;
+        }
+        hipIpcMemHandle_t h;
+        memcpy(&h, handles + (size_t)r * sizeof h, sizeof h);
+        void* ptr = nullptr;
+        hipError_t rc = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
+        if (rc != hipSuccess) {
+            for (int q = 0; q < r; ++q)
+                if (q != rank && e->p2p.inbox[q]) (void)hipIpcCloseMemHandle(e->p2p.inbox[q]);
+            for (double*& b : e->p2p.inbox) b = nullptr;
+            return fail("hipIpcOpenMemHandle of rank %d's inbox failed: %s", r, hipGetErrorString(rc));
+        }
+        e->p2p.inbox[r] = static_cast<double*>(ptr);
+    }
+    e->n_ranks = n_ranks;
+    e->rank = rank;
+    if (!e->comm) e->N_total = n_samples_total;
+    e->p2p.connected = true;
+    e->p2p.on = true;
+    return 0;
+}
+
+int salnmf_set_p2p(salnmf_engine* e, int on) {
+    if (!e) return fail("null engine");
+    if (on && !e->p2p.connected) return fail("peer-to-peer exchange is not connected");
+    if (!on && e->p2p.connected && !e->comm) return fail("without an RCCL communicator the peer-to-peer exchange cannot be switched off");
+    e->p2p.on = on != 0;
+    if (!on && e->pabort && *e->pabort == 2u) *e->pabort = 0;  // an exchange that gave up: RCCL takes over, the caller re-uploads W and H
     return 0;
 }
 

@@ -80,8 +80,13 @@ __device__ __forceinline__ double div_path(double x, double p) {
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    // every lane of these permutations reads a live lane, so the "old" value is never used: an empty asm hands the
+    // compiler an arbitrary register for it instead of a v_mov 0 per move
+    int olo, ohi;
+    asm volatile("" : "=v"(olo));
+    asm volatile("" : "=v"(ohi));
+    lo = __builtin_amdgcn_update_dpp(olo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(ohi, hi, CTRL, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
 template <int M>

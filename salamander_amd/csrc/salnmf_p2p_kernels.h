@@ -1,0 +1,122 @@
+// All-reduce of a small fp64 vector (the K x V numerator of the W update, the MvNMF line-search sums) over the
+// GPUs of one node by direct peer stores through xGMI -- the exchange step of the sample-sharded update
+// (the reference has no multi-device path; SURVEY.md section 8e specifies one all-reduce of K*V doubles per W update).
+//
+// Why not the RCCL call: the vector is 38 KB at K = 50.  A library all-reduce of that size is pure latency (several
+// kernel-internal ring / tree hops, ~25-40 us on 8 GPUs), which is a third of a c3 step.  Here every rank stores its
+// vector straight into an inbox on each peer (7 links in parallel, < 1 us of wire time), raises one flag per workgroup and
+// peer, waits for the peers' flags in its own inbox and adds the n vectors in rank order -- the same order on every
+// rank, so all ranks end up with bit-identical sums and hence bit-identical W.
+//
+// Memory: the inboxes are uncached device allocations (hipDeviceMallocUncached: remote stores are visible to the home
+// GPU without any cache maintenance there), exported / opened with hipIpc*MemHandle.  Layout per engine:
+//   inbox[parity 0..1][source rank 0..n-1] = { double data[max_count]; uint64 flag[P2P_MAX_WG]; }
+// Two parities: a rank can run at most one exchange ahead of a peer (its exchange s+1 cannot finish before the peer has
+// sent s+1, which the peer does only after it has finished reading s), so the slot of exchange s+2 is free by then.
+// Flags hold the exchange's sequence number (monotonic; never reset).
+// Ordering (cdna_hip_programming.md, guideline 16): payload stores are system-scope write-through stores, every storing
+// wave drains them (s_waitcnt vmcnt(0)) and joins a workgroup barrier, then one lane per peer stores the flag; the reader
+// polls the flags with system-scope loads from one lane per source, joins a barrier and reads the payload with system-scope
+// loads (the inbox is uncached memory: no load is served from a cache).  Every wait is bounded (~2 s of the 100 MHz
+// clock): on expiry the host-visible abort word is set.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "salnmf_kernels.h"
+
+namespace salnmf {
+
+constexpr int P2P_MAX_RANKS = 8;
+constexpr int P2P_BLOCK = 256;
+constexpr int P2P_MAX_WG = 64;  // flags per slot: workgroups of one exchange (max_count <= 16384 doubles), or signature rows
+
+struct P2PParams {
+    double* buf;            // in: this rank's vector, out: the sum over the ranks (p2p_allreduce_kernel)
+    int count;
+    int rank, n_ranks;
+    int parity;
+    unsigned long long seq;
+    size_t slot;            // doubles per (parity, source) slot = max_count + P2P_MAX_WG
+    size_t max_count;
+    double* inbox[P2P_MAX_RANKS];  // base of every rank's inbox as mapped here ([rank] = the local allocation)
+    unsigned* abort_host;
+};
+
+typedef __attribute__((address_space(1))) double gdouble_t;
+typedef __attribute__((address_space(1))) unsigned long long gflag_t;
+
+// One workgroup's part of an exchange: element `idx` of the vector (value v, where `active`), completion flag `flag_idx`
+// of the slot.  Called by every thread of the workgroup; returns the sum over the ranks in rank order (0 where inactive
+// or after a wait gave up, in which case the abort word is set).
+__device__ __forceinline__ double p2p_exchange(const P2PParams& p, int idx, bool active, int flag_idx, double v, int tid) {
+    const size_t mine = ((size_t)p.parity * p.n_ranks + p.rank) * p.slot;
+    if (active) {
+        for (int r = 0; r < p.n_ranks; ++r)
+            __hip_atomic_store((gdouble_t*)(p.inbox[r] + mine + idx), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // every storing wave drains its (write-through, system-scope) stores: they are acknowledged by the destination
+    // before the flag is issued.  No release fence: that would write back this GPU's whole L2 in every workgroup, and
+    // nothing but the uncached inbox is shared with the peers.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid < p.n_ranks) {
+        gflag_t* flag = (gflag_t*)(p.inbox[tid] + mine + p.max_count) + flag_idx;
+        __hip_atomic_store(flag, p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // wait for this workgroup's slice from every source (lane r polls source r)
+    __shared__ int failed;
+    if (tid == 0) failed = 0;
+    __syncthreads();
+    if (tid < p.n_ranks) {
+        const gflag_t* flag = (const gflag_t*)(p.inbox[p.rank] + ((size_t)p.parity * p.n_ranks + tid) * p.slot + p.max_count) + flag_idx;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (unsigned spins = 1;; ++spins) {
+            if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == p.seq) break;
+            __builtin_amdgcn_s_sleep(1);
+            if ((spins & 63u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
+                failed = 1;
+                __hip_atomic_store((__attribute__((address_space(1))) unsigned*)p.abort_host, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    if (failed || !active) return 0.0;
+    double s = 0.0;
+    for (int r = 0; r < p.n_ranks; ++r)
+        s += __hip_atomic_load((const gdouble_t*)(p.inbox[p.rank] + ((size_t)p.parity * p.n_ranks + r) * p.slot + idx), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+    return s;
+}
+
+__global__ void __launch_bounds__(P2P_BLOCK) p2p_allreduce_kernel(P2PParams p) {
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * P2P_BLOCK + tid;
+    const bool active = i < p.count;
+    const double s = p2p_exchange(p, i, active, blockIdx.x, active ? p.buf[i] : 0.0, tid);
+    if (active) p.buf[i] = s;
+}
+
+// The W tail of a sharded joint step with the exchange inside: workgroup k reduces row k of the local numerator slabs,
+// exchanges that row with the peers (flag k of the slot) and finishes row k of W -- one launch where the RCCL path
+// takes a reduce launch, the library all-reduce and a finish launch.  Arithmetic and summation orders of the two
+// tail_row halves are those of tail_kernel.
+struct TailP2PParams {
+    TailParams t;
+    P2PParams x;
+};
+
+__global__ void __launch_bounds__(TAIL_BLOCK) tail_p2p_kernel(TailP2PParams p) {
+    __shared__ TailScratch S;
+    const int k = blockIdx.x, tid = threadIdx.x;
+    const TailParams& t = p.t;
+    tail_row<TAIL_BLOCK, false>(S, tid, k, t.Gpart, t.nslabs, t.G, t.W, t.V, t.K, t.n_given, t.clip_mode, false);
+    const bool active = tid < t.V;  // (tail_row left the row's local sum in S.red[0][v], behind a barrier)
+    const double total = p2p_exchange(p.x, k * t.V + tid, active, k, active ? S.red[0][tid] : 0.0, tid);
+    if (active) t.G[k * t.V + tid] = total;
+    __syncthreads();
+    tail_row<TAIL_BLOCK, false>(S, tid, k, nullptr, 0, t.G, t.W, t.V, t.K, t.n_given, t.clip_mode, true);
+}
+
+}  // namespace salnmf

@@ -55,6 +55,48 @@ def attach_communicator(engine, group=None) -> None:
     engine.comm_init(box[0], world, rank)
 
 
+def attach_peer_exchange(engine, n_samples_total: int | None = None, group=None, required: bool = True) -> bool:
+    """Connect the engines of all ranks of ``group`` (one node) for the peer-to-peer exchange of the small
+    all-reduces (``include/salnmf.h``: ``salnmf_p2p_export`` / ``salnmf_p2p_connect``).  The IPC handles and the shard
+    sizes travel through ``torch.distributed`` (any backend); the exchange itself never touches the host.
+
+    ``required=False``: if any rank cannot export or map an inbox (no peer access between two of the GPUs, more than 8
+    ranks, ...) every rank leaves the exchange off -- the engines then need their RCCL communicator -- and False is
+    returned on all of them instead of an exception on some."""
+    dist = _dist()
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    error = None
+    try:
+        handle = engine.p2p_export(world)
+    except RuntimeError as exc:
+        if required:
+            raise
+        handle, error = None, str(exc)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (handle, engine.N), group=group)
+    ok = all(h is not None for h, _ in gathered)
+    if ok:
+        total = sum(n for _, n in gathered) if n_samples_total is None else int(n_samples_total)
+        try:
+            engine.p2p_connect(rank, [h for h, _ in gathered], total)
+        except RuntimeError as exc:
+            if required:
+                raise
+            ok, error = False, str(exc)
+    # nobody starts exchanging before every rank has mapped every inbox -- and all ranks agree on whether to use it
+    flags = [None] * world
+    dist.all_gather_object(flags, ok, group=group)
+    if not all(flags):
+        if ok:
+            engine.set_p2p(False)
+        if error is not None:
+            import warnings
+
+            warnings.warn(f"peer-to-peer exchange not available on rank {rank}: {error}")
+        return False
+    return True
+
+
 def broadcast_from_rank0(value, group=None):
     """Every rank gets rank 0's copy of ``value`` -- an array or a tuple of arrays / scalars (bit-identical
     replicated parameters at the start of a sharded fit)."""

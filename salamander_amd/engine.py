@@ -283,6 +283,26 @@ class Engine:
         _lib.check(self._lib.salnmf_comm_info(self._h, ctypes.byref(n), ctypes.byref(r), ctypes.byref(t)))
         return n.value, r.value, t.value
 
+    def p2p_export(self, n_ranks: int, max_count: int | None = None) -> bytes:
+        """Allocate this engine's inbox of the peer-to-peer exchange (``include/salnmf.h``) and return its IPC handle.
+
+        ``max_count`` defaults to the largest vector the KL / MvNMF steps all-reduce (K*V + K + 2)."""
+        if max_count is None:
+            max_count = self.K * self.V + self.K + 2
+        buf = ctypes.create_string_buffer(_lib.P2P_HANDLE_BYTES)
+        _lib.check(self._lib.salnmf_p2p_export(self._h, int(n_ranks), int(max_count), buf))
+        return buf.raw
+
+    def p2p_connect(self, rank: int, handles, n_samples_total: int):
+        """Map the peers' inboxes; ``handles``: one ``p2p_export`` result per rank, in rank order."""
+        handles = list(handles)
+        if any(len(h) != _lib.P2P_HANDLE_BYTES for h in handles):
+            raise ValueError("a handle has the wrong length")
+        _lib.check(self._lib.salnmf_p2p_connect(self._h, int(rank), len(handles), b"".join(handles), int(n_samples_total)))
+
+    def set_p2p(self, on: bool):
+        _lib.check(self._lib.salnmf_set_p2p(self._h, int(bool(on))))
+
     def kl_step_partial(self):
         _lib.check(self._lib.salnmf_kl_step_partial(self._h))
 

@@ -1,0 +1,108 @@
+"""The peer-to-peer exchange of the sharded steps (``salnmf_p2p_kernels.h``) with several ranks.
+
+A one-GPU box cannot hold two RCCL ranks, but hipIpc handles work between processes on the same device: the ranks here
+are separate processes with one engine each on ``cuda:0``, connected by ``attach_peer_exchange`` (handles through a
+``gloo`` group), with NO RCCL communicator.  That exercises the whole protocol -- export / map, parity slots, flags,
+rank-ordered sums, the waits -- except the xGMI hop itself.  Compared with the unsharded oracle on the same inputs.
+"""
+
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from conftest import ROOT, rel_l2
+from test_distributed_gloo import _free_port
+
+pytestmark = pytest.mark.gpu
+
+V, N, K = 96, 2500, 50
+LAM, DELTA = 2.0, 0.5
+
+
+def _worker(rank, world, port, out_dir, n_kl, n_mv):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+
+    from oracle import klnmf_oracle as orc
+    from salamander_amd.distributed import attach_peer_exchange, shard_bounds
+    from salamander_amd.engine import Engine
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        X, W0, H0 = orc.synthetic_problem(V, N, K, seed=5)  # sample-major: (N, V), (K, V), (N, K)
+        a, b = shard_bounds(N, world, rank)
+        e = Engine(b - a, V, K)
+        e.upload_X(X[a:b]), e.upload_W(W0), e.upload_H(H0[a:b])
+        attach_peer_exchange(e)
+        assert e.comm_info() == (world, rank, N)
+        e.kl_step(n_kl, 0)
+        Wk, Hk = e.download_W(), e.download_H()
+        obj = e.objective()  # scalar all-reduce through the same exchange
+        gamma = e.mv_step(n_mv, 0, LAM, DELTA, 1.0)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), Wk=Wk, Hk=Hk, obj=obj, Wm=e.download_W(), Hm=e.download_H(), gamma=gamma, a=a, b=b)
+        dist.barrier()  # nobody frees its inbox while a peer may still be inside an exchange
+        e.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_steps_over_peer_exchange_match_unsharded_oracle(tmp_path, world):
+    from oracle import klnmf_oracle as orc
+
+    n_kl, n_mv = 12, 4
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), n_kl, n_mv), nprocs=world, join=True)
+    parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    X, W0, H0 = orc.synthetic_problem(V, N, K, seed=5)
+    W, H = W0.T, H0.T
+    for _ in range(n_kl):
+        W, H = orc.update_WH(X.T, W, H, None, None, 0)
+    for p in parts[1:]:
+        assert np.array_equal(parts[0]["Wk"], p["Wk"])  # rank-ordered sums: the same bits on every rank
+        assert p["obj"] == parts[0]["obj"]
+    assert rel_l2(parts[0]["Wk"], W.T) < 1e-11
+    assert rel_l2(np.concatenate([p["Hk"] for p in parts], axis=0), H.T) < 1e-11
+    assert np.isclose(float(parts[0]["obj"]), orc.kl_divergence(X.T, W, H), rtol=1e-10)
+    gamma = 1.0
+    for _ in range(n_mv):
+        W, H, gamma = orc.mvnmf_step(X.T, W, H, LAM, DELTA, gamma, 0)
+    for p in parts[1:]:
+        assert np.array_equal(parts[0]["Wm"], p["Wm"])
+    assert np.isclose(float(parts[0]["gamma"]), gamma, rtol=1e-12)
+    assert rel_l2(parts[0]["Wm"], W.T) < 1e-8
+    assert rel_l2(np.concatenate([p["Hm"] for p in parts], axis=0), H.T) < 1e-8
+
+
+def test_peer_exchange_argument_checks():
+    from salamander_amd.engine import Engine
+
+    e = Engine(64, 96, 5)
+    with pytest.raises(RuntimeError, match="export first"):
+        e.p2p_connect(0, [b"\0" * 64], 64)
+    with pytest.raises(RuntimeError, match="1..8 ranks"):
+        e.p2p_export(9)
+    with pytest.raises(RuntimeError, match="not connected"):
+        e.set_p2p(True)
+    h = e.p2p_export(1)
+    assert len(h) == 64
+    with pytest.raises(RuntimeError, match="exported already"):
+        e.p2p_export(1)
+    with pytest.raises(RuntimeError, match="does not match"):
+        e.p2p_connect(0, [h, h], 64)
+    # a single rank: the exchange degenerates to a copy through its own inbox
+    X = np.random.default_rng(0).poisson(3.0, (64, 96)).astype(float)
+    W0 = np.random.default_rng(1).random((5, 96)) + 0.1
+    H0 = np.random.default_rng(2).random((64, 5)) + 0.1
+    ref = Engine(64, 96, 5)
+    for eng in (e, ref):
+        eng.upload_X(X), eng.upload_W(W0), eng.upload_H(H0)
+    e.p2p_connect(0, [h], 64)
+    e.kl_step(3, 0), ref.kl_step(3, 0)
+    assert np.array_equal(e.download_W(), ref.download_W()) and np.array_equal(e.download_H(), ref.download_H())
+    with pytest.raises(RuntimeError, match="cannot be switched off"):
+        e.set_p2p(False)
