@@ -162,9 +162,12 @@ class SignatureNMF(ABC):
             self._comm_attached = False
             self._resident = set()
         if self.distributed and not self._comm_attached:
-            from ..distributed import attach_communicator
+            from ..distributed import attach_communicator, attach_peer_exchange
 
             attach_communicator(e)
+            # the K x V all-reduce of every step by peer stores where the GPUs of the node can map each other's
+            # memory (include/salnmf.h: salnmf_p2p_*); otherwise every rank stays on the RCCL all-reduce
+            attach_peer_exchange(e, required=False)
             self._comm_attached = True
             self._w_broadcast_due = True
         return e

@@ -148,6 +148,9 @@ class FakeCorrShardEngine(FakeEngine):
     def comm_unique_id():
         return b"\0" * 128
 
+    def p2p_export(self, n_ranks, max_count=None):
+        raise RuntimeError("no device memory to export (CPU stand-in)")  # attach_peer_exchange(required=False) -> off
+
     def comm_init(self, unique_id, n_ranks, rank):
         import torch
         import torch.distributed as dist
