@@ -242,8 +242,8 @@ int salnmf_comm_info(salnmf_engine* e, int* n_ranks, int* rank, int64_t* n_sampl
  *   connect: maps the peers' inboxes; `handles` = n_ranks * SALNMF_P2P_HANDLE_BYTES in rank order (the host layer
  *            all-gathers them); n_samples_total = samples over all shards (used when no RCCL communicator is attached)
  *   set_p2p: switch the exchange off / on again (off: the all-reduces go through RCCL, which must then be attached)
- * Every rank must issue the same sequence of calls on its engine.  A rank that waits 2 s for a peer gives up: the
- * next download / objective call on that engine fails.  Destroy the engines only after all ranks are done. */
+ * Every rank must issue the same sequence of calls on its engine.  A rank that waits 20 s for a peer gives up: the
+ * next download / objective call on that engine fails, and its later exchanges return at once.  Destroy the engines only after all ranks are done. */
 #define SALNMF_P2P_HANDLE_BYTES 64
 int salnmf_p2p_export(salnmf_engine* e, int n_ranks, int64_t max_count, char* handle_out /* SALNMF_P2P_HANDLE_BYTES */);
 int salnmf_p2p_connect(salnmf_engine* e, int rank, int n_ranks, const char* handles, int64_t n_samples_total);

@@ -177,6 +177,8 @@ struct salnmf_engine {
         size_t max_count = 0, slot = 0;
         int n_ranks = 0;                        // as exported
         unsigned long long seq = 0;
+        unsigned* abort_dev = nullptr;          // device word: an exchange gave up (salnmf_p2p_kernels.h)
+        unsigned long long timeout_ticks = P2P_TIMEOUT_TICKS;
     } p2p;
     std::vector<int64_t> shard_N;  // n_samples of every rank's shard (filled by salnmf_comm_init)
     int64_t N_total = 0;           // sum of shard_N
@@ -322,6 +324,8 @@ static P2PParams next_exchange(salnmf_engine* e, double* buf, size_t count) {
     q.max_count = e->p2p.max_count;
     for (int r = 0; r < e->n_ranks; ++r) q.inbox[r] = e->p2p.inbox[r];
     q.abort_host = e->pabort;
+    q.abort_dev = e->p2p.abort_dev;
+    q.timeout_ticks = e->p2p.timeout_ticks;
     return q;
 }
 
@@ -418,6 +422,7 @@ void salnmf_destroy(salnmf_engine* e) {
     for (int r = 0; r < P2P_MAX_RANKS; ++r)
         if (e->p2p.inbox[r] && e->p2p.inbox[r] != e->p2p.local) (void)hipIpcCloseMemHandle(e->p2p.inbox[r]);
     if (e->p2p.local) (void)hipFree(e->p2p.local);
+    if (e->p2p.abort_dev) (void)hipFree(e->p2p.abort_dev);
     double* bufs[] = {e->X, e->H, e->W, e->wkl, e->wlh, e->Gpart, e->Hsumpart, e->KLpart, e->red,
                       e->objpart, e->scal, e->Wunc, e->Wtrial, e->mvA, e->mvB, e->cs, e->scratch, e->Halt, e->KLpart2,
                       e->alpha, e->beta, e->Lemb, e->Uemb, e->aux, e->xrowsum, e->corrpart, e->gU, e->galpha, e->gaux};
@@ -749,7 +754,7 @@ static int kl_steps_persistent(salnmf_engine* e, int n, int n_given) {
 // a persistent launch whose waits gave up leaves the resident state half updated: say so at the next sync point
 static int check_abort(salnmf_engine* e) {
     if (e->pabort && *e->pabort == 2u) {
-        return fail("a peer-to-peer exchange gave up waiting for another rank (salnmf_p2p_kernels.h: 2 s); the engine's W and H are "
+        return fail("a peer-to-peer exchange gave up waiting for another rank (salnmf_p2p_kernels.h: 20 s); the engine's W and H are "
                     "invalid -- did every rank issue the same calls?");
     }
     if (e->pabort && *e->pabort) {
@@ -1733,11 +1738,17 @@ int salnmf_p2p_export(salnmf_engine* e, int n_ranks, int64_t max_count, char* ha
     static_assert(sizeof(hipIpcMemHandle_t) == SALNMF_P2P_HANDLE_BYTES, "handle size");
     HIPCK(hipSetDevice(e->device));
     e->p2p.max_count = (size_t)max_count;
+    if (const char* ms = getenv("SALNMF_P2P_TIMEOUT_MS")) {
+        const long v = atol(ms);
+        if (v > 0) e->p2p.timeout_ticks = (unsigned long long)v * 100000ull;
+    }
     e->p2p.slot = (size_t)max_count + P2P_MAX_WG;
     e->p2p.n_ranks = n_ranks;
     const size_t bytes = 2 * (size_t)n_ranks * e->p2p.slot * sizeof(double);
     HIPCK(hipExtMallocWithFlags((void**)&e->p2p.local, bytes, hipDeviceMallocUncached));
     HIPCK(hipMemset(e->p2p.local, 0, bytes));
+    HIPCK(hipMalloc(&e->p2p.abort_dev, sizeof(unsigned)));
+    HIPCK(hipMemset(e->p2p.abort_dev, 0, sizeof(unsigned)));
     HIPCK(hipDeviceSynchronize());  // the flags are zero before any peer can learn the handle
     hipIpcMemHandle_t h;
     HIPCK(hipIpcGetMemHandle(&h, e->p2p.local));
@@ -1781,9 +1792,19 @@ int salnmf_p2p_connect(salnmf_engine* e, int rank, int n_ranks, const char* hand
 int salnmf_set_p2p(salnmf_engine* e, int on) {
     if (!e) return fail("null engine");
     if (on && !e->p2p.connected) return fail("peer-to-peer exchange is not connected");
+    if (on && e->p2p.abort_dev) {
+        unsigned gave_up = 0;
+        HIPCK(hipMemcpy(&gave_up, e->p2p.abort_dev, sizeof gave_up, hipMemcpyDeviceToHost));
+        if (gave_up) return fail("the peer-to-peer exchange gave up earlier on this engine and cannot be switched on again");
+    }
     if (!on && e->p2p.connected && !e->comm) return fail("without an RCCL communicator the peer-to-peer exchange cannot be switched off");
     e->p2p.on = on != 0;
-    if (!on && e->pabort && *e->pabort == 2u) *e->pabort = 0;  // an exchange that gave up: RCCL takes over, the caller re-uploads W and H
+    if (!on && e->pabort && *e->pabort == 2u) {
+        // an exchange gave up: RCCL takes over and the caller uploads W and H again.  (The exchange stays unusable on every
+        // rank after that: the ranks' sequence numbers are no longer known to agree.)
+        HIPCK(hipStreamSynchronize(e->stream));
+        *e->pabort = 0;
+    }
     return 0;
 }
 

@@ -17,8 +17,8 @@
 // Ordering (cdna_hip_programming.md, guideline 16): payload stores are system-scope write-through stores, every storing
 // wave drains them (s_waitcnt vmcnt(0)) and joins a workgroup barrier, then one lane per peer stores the flag; the reader
 // polls the flags with system-scope loads from one lane per source, joins a barrier and reads the payload with system-scope
-// loads (the inbox is uncached memory: no load is served from a cache).  Every wait is bounded (~2 s of the 100 MHz
-// clock): on expiry the host-visible abort word is set.
+// loads (the inbox is uncached memory: no load is served from a cache).  Every wait is bounded (20 s of the 100 MHz
+// clock): on expiry the host-visible abort word is set, and a device word that makes the engine's later exchanges return at once.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -29,6 +29,7 @@ namespace salnmf {
 
 constexpr int P2P_MAX_RANKS = 8;
 constexpr int P2P_BLOCK = 256;
+constexpr unsigned long long P2P_TIMEOUT_TICKS = 2000000000ull;  // default: 20 s of the 100 MHz clock (ranks may be that far apart on the host side); SALNMF_P2P_TIMEOUT_MS overrides
 constexpr int P2P_MAX_WG = 64;  // flags per slot: workgroups of one exchange (max_count <= 16384 doubles), or signature rows
 
 struct P2PParams {
@@ -40,7 +41,9 @@ struct P2PParams {
     size_t slot;            // doubles per (parity, source) slot = max_count + P2P_MAX_WG
     size_t max_count;
     double* inbox[P2P_MAX_RANKS];  // base of every rank's inbox as mapped here ([rank] = the local allocation)
-    unsigned* abort_host;
+    unsigned long long timeout_ticks;  // of the 100 MHz clock
+    unsigned* abort_host;   // pinned host word: 2 = an exchange gave up
+    unsigned* abort_dev;    // device word, set with it: later exchanges of this engine return at once instead of waiting again
 };
 
 typedef __attribute__((address_space(1))) double gdouble_t;
@@ -51,6 +54,10 @@ typedef __attribute__((address_space(1))) unsigned long long gflag_t;
 // or after a wait gave up, in which case the abort word is set).
 __device__ __forceinline__ double p2p_exchange(const P2PParams& p, int idx, bool active, int flag_idx, double v, int tid) {
     const size_t mine = ((size_t)p.parity * p.n_ranks + p.rank) * p.slot;
+    __shared__ int failed;
+    if (tid == 0) failed = __hip_atomic_load((__attribute__((address_space(1))) unsigned*)p.abort_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    __syncthreads();
+    if (failed) return 0.0;  // (one lane's reading, so the whole workgroup takes the same way)
     if (active) {
         for (int r = 0; r < p.n_ranks; ++r)
             __hip_atomic_store((gdouble_t*)(p.inbox[r] + mine + idx), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -65,17 +72,15 @@ __device__ __forceinline__ double p2p_exchange(const P2PParams& p, int idx, bool
         __hip_atomic_store(flag, p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     // wait for this workgroup's slice from every source (lane r polls source r)
-    __shared__ int failed;
-    if (tid == 0) failed = 0;
-    __syncthreads();
     if (tid < p.n_ranks) {
         const gflag_t* flag = (const gflag_t*)(p.inbox[p.rank] + ((size_t)p.parity * p.n_ranks + tid) * p.slot + p.max_count) + flag_idx;
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         for (unsigned spins = 1;; ++spins) {
             if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == p.seq) break;
             __builtin_amdgcn_s_sleep(1);
-            if ((spins & 63u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
+            if ((spins & 63u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > p.timeout_ticks) {
                 failed = 1;
+                __hip_atomic_store((__attribute__((address_space(1))) unsigned*)p.abort_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store((__attribute__((address_space(1))) unsigned*)p.abort_host, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }

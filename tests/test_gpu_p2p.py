@@ -78,6 +78,49 @@ def test_sharded_steps_over_peer_exchange_match_unsharded_oracle(tmp_path, world
     assert rel_l2(np.concatenate([p["Hm"] for p in parts], axis=0), H.T) < 1e-8
 
 
+def _stalled_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["SALNMF_P2P_TIMEOUT_MS"] = "300"
+    import torch.distributed as dist
+
+    from oracle import klnmf_oracle as orc
+    from salamander_amd.distributed import attach_peer_exchange, shard_bounds
+    from salamander_amd.engine import Engine
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        X, W0, H0 = orc.synthetic_problem(V, 640, 8, seed=6)
+        a, b = shard_bounds(640, world, rank)
+        e = Engine(b - a, V, 8)
+        e.upload_X(X[a:b]), e.upload_W(W0), e.upload_H(H0[a:b])
+        attach_peer_exchange(e)
+        e.kl_step(2, 0)
+        e.download_W()
+        message = ""
+        if rank == 0:  # rank 1 never joins the third exchange
+            e.kl_step(3, 0)  # three exchanges: one waits 0.3 s, the next two return at once
+            try:
+                e.download_W()
+            except RuntimeError as exc:
+                message = str(exc)
+        open(os.path.join(out_dir, f"msg{rank}.txt"), "w").write(message)
+        dist.barrier()
+        e.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exchange_gives_up_when_a_rank_stays_away(tmp_path):
+    import time
+
+    t0 = time.time()
+    mp.spawn(_stalled_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert "gave up waiting for another rank" in open(os.path.join(tmp_path, "msg0.txt")).read()
+    assert time.time() - t0 < 60
+
+
 def test_peer_exchange_argument_checks():
     from salamander_amd.engine import Engine
 
