@@ -5,6 +5,7 @@
 //       -Iexp/wgstamps tools/wgstamps_bench.hip -o exp/wgstamps/bench && exp/wgstamps/bench [N] [K]
 #include "salnmf_kernels.h"
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <random>
@@ -75,6 +76,32 @@ int main(int argc, char** argv) {
         const int64_t base = ntiles / NW;
         for (int w = 0; w < NW; ++w) { int64_t nt = (ntiles - w + NW - 1) / NW; int c = nt > base ? 1 : 0; cnt[c]++; sum[c] += (double)(long long)(f[w * 8 + 3] - t0) * 0.01; per[c] += (double)(long long)(f[w * 8 + 3] - f[w * 8 + 1]) * 0.01 / nt; }
         for (int c = 0; c < 2; ++c) if (cnt[c]) printf("waves with %lld tiles: %d, loop done avg %.2f us, %.2f us per tile\n", (long long)(base + c), cnt[c], sum[c] / cnt[c], per[c] / cnt[c]);
+    }
+    // who is slow?  workgroup-level loop-done time (max over its 4 waves), averaged over the measured steps: by XCD
+    // (workgroups are dealt round-robin: XCD = blockIdx % 8), its spread, and how persistent a workgroup's rank is
+    {
+        std::vector<double> wg(grid, 0.0), first(grid, 0.0), second(grid, 0.0);
+        int ns = 0;
+        for (int s = 8; s < STEPS - 1; ++s, ++ns) {
+            const unsigned long long* f = &F[s * FS];
+            unsigned long long t0 = ~0ull; for (int w = 0; w < NW; ++w) t0 = std::min(t0, f[w * 8]);
+            for (int b = 0; b < grid; ++b) {
+                double m = 0; for (int w = 0; w < WAVES; ++w) m = std::max(m, (double)(long long)(f[(b * WAVES + w) * 8 + 3] - t0) * 0.01);
+                wg[b] += m; (ns % 2 ? second : first)[b] += m;
+            }
+        }
+        double xs[8] = {0}, all = 0; for (int b = 0; b < grid; ++b) { wg[b] /= ns; xs[b % 8] += wg[b] / (grid / 8); all += wg[b] / grid; }
+        printf("loop done per workgroup (max of its waves), mean over %d steps: all %.2f us; by XCD:", ns, all);
+        for (int x = 0; x < 8; ++x) printf(" %.2f", xs[x]);
+        std::vector<double> sorted(wg); std::sort(sorted.begin(), sorted.end());
+        printf("\n  fastest %.2f, 10%% %.2f, median %.2f, 90%% %.2f, slowest %.2f\n", sorted[0], sorted[grid / 10], sorted[grid / 2], sorted[grid * 9 / 10], sorted[grid - 1]);
+        // persistence: correlation between a workgroup's mean over the even and over the odd measured steps
+        double ma = 0, mb = 0; for (int b = 0; b < grid; ++b) { ma += first[b]; mb += second[b]; } ma /= grid; mb /= grid;
+        double sab = 0, saa = 0, sbb = 0; for (int b = 0; b < grid; ++b) { sab += (first[b] - ma) * (second[b] - mb); saa += (first[b] - ma) * (first[b] - ma); sbb += (second[b] - mb) * (second[b] - mb); }
+        printf("  correlation of a workgroup's loop-done time between even and odd steps: %.3f\n", sab / std::sqrt(saa * sbb));
+        double c0 = 0, c1 = 0; int n0 = 0, n1 = 0; const int64_t nleft = p.ntiles % ((int64_t)grid * WAVES);
+        for (int b = 0; b < grid; ++b) { if (b < nleft) { c0 += wg[b]; ++n0; } else { c1 += wg[b]; ++n1; } }
+        if (n0 && n1) printf("  workgroups with a cooperative tile (blockIdx < %lld): %.2f us; the others: %.2f us\n", (long long)nleft, c0 / n0, c1 / n1);
     }
     return 0;
 }
