@@ -362,9 +362,19 @@ __device__ __forceinline__ void tail_row(TailScratch& S, int tid, int k, const d
     const int v = tid;
     if (tid < VMAX) S.wn[v] = (v < V) ? wold * S.red[0][v] : 0.0;
     __syncthreads();
+    // row sum in a fixed two-level order: 12 groups of 8 consecutive features (sequential inside a group, one thread
+    // each), then the groups in order -- 20 dependent additions on the critical path instead of 96
+    if (tid < VMAX / 8) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += S.wn[8 * tid + i];  // (entries v >= V are 0)
+        S.red[1][tid] = t;
+    }
+    __syncthreads();
     if (tid == 0) {
         double t = 0.0;
-        for (int i = 0; i < V; ++i) t += S.wn[i];
+#pragma unroll
+        for (int i = 0; i < VMAX / 8; ++i) t += S.red[1][i];
         S.rowsum = t;
     }
     __syncthreads();
