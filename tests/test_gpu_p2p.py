@@ -40,11 +40,18 @@ def _worker(rank, world, port, out_dir, n_kl, n_mv):
         e.upload_X(X[a:b]), e.upload_W(W0), e.upload_H(H0[a:b])
         attach_peer_exchange(e)
         assert e.comm_info() == (world, rank, N)
+        # the default initialisation on the shards: Gram matrix and column norms go through the same exchange
+        from salamander_amd.device_init import initialize_on_device
+
+        S_init = initialize_on_device(e, K, "nndsvd", None, N)
+        H_init = e.download_H()
+        e.upload_W(W0), e.upload_H(H0[a:b])
         e.kl_step(n_kl, 0)
         Wk, Hk = e.download_W(), e.download_H()
         obj = e.objective()  # scalar all-reduce through the same exchange
         gamma = e.mv_step(n_mv, 0, LAM, DELTA, 1.0)
-        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), Wk=Wk, Hk=Hk, obj=obj, Wm=e.download_W(), Hm=e.download_H(), gamma=gamma, a=a, b=b)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), Wk=Wk, Hk=Hk, obj=obj, Wm=e.download_W(), Hm=e.download_H(), gamma=gamma, a=a, b=b,
+                 S_init=S_init, H_init=H_init)
         dist.barrier()  # nobody frees its inbox while a peer may still be inside an exchange
         e.close()
     finally:
@@ -68,6 +75,18 @@ def test_sharded_steps_over_peer_exchange_match_unsharded_oracle(tmp_path, world
     assert rel_l2(parts[0]["Wk"], W.T) < 1e-11
     assert rel_l2(np.concatenate([p["Hk"] for p in parts], axis=0), H.T) < 1e-11
     assert np.isclose(float(parts[0]["obj"]), orc.kl_divergence(X.T, W, H), rtol=1e-10)
+    # sharded nndsvd init == the same init on one engine holding all samples (sums in a different order)
+    from salamander_amd.device_init import initialize_on_device
+    from salamander_amd.engine import Engine
+
+    e1 = Engine(N, V, K)
+    e1.upload_X(X)
+    S1 = initialize_on_device(e1, K, "nndsvd", None, N)
+    for p in parts[1:]:
+        assert np.array_equal(parts[0]["S_init"], p["S_init"])
+    assert rel_l2(parts[0]["S_init"], S1) < 1e-9
+    assert rel_l2(np.concatenate([p["H_init"] for p in parts], axis=0), e1.download_H()) < 1e-9
+    e1.close()
     gamma = 1.0
     for _ in range(n_mv):
         W, H, gamma = orc.mvnmf_step(X.T, W, H, LAM, DELTA, gamma, 0)
