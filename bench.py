@@ -50,6 +50,7 @@ N_C2 = 100000        # config c2 (1 GPU)
 N_C3 = 1000000       # config c3 (sharded)
 BLOCK_ROWS = 125000  # generation block of the 10^6 problem (seed = block index)
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix peak (spec); 77.8 measured by tools/mfma_f64_probe.hip
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X fp32 matrix peak (MI355X_MICROARCH.md); only the opt-in fast mode is priced against it
 
 
 def cpu_baseline(X, W0, H0, max_steps=500, budget_s=150.0):
@@ -179,6 +180,42 @@ def extra_default_init_fit(sal, device):
         "init_seconds": init_s,
         "fit_seconds_end_to_end": fit_s,
         "objective_last": float(model.history["objective_function"][-1]),
+    }
+
+
+def extra_fast_mode(sal, device):
+    """The opt-in fp32 fast mode of the KL step at c2 (NOT the headline: `value` and `roofline` are the fp64 path's)."""
+    from salamander_amd.synthetic import synthetic_problem
+
+    X, W0, H0 = synthetic_problem(V, N_C2, K, seed=0)
+    res = {}
+    state = {}
+    for mode in ("f64", "f32"):
+        e = sal.Engine(N_C2, V, K, device=device)
+        e.upload_X(X), e.upload_W(W0), e.upload_H(H0)
+        e.set_precision(mode)
+        e.kl_step(100)
+        state[mode] = (e.download_W(), e.download_H(), e.objective())
+        e.sync()
+        blocks = []
+        for _ in range(7):
+            t0 = time.perf_counter()
+            e.kl_step(200)
+            e.sync()
+            blocks.append((time.perf_counter() - t0) / 200)
+        res[mode] = statistics.median(blocks)
+        e.close()
+    flops = 6.0 * V * K * N_C2
+    rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    return {
+        "workload": f"c2 through Engine.set_precision('f32'): {V}x{N_C2}, k={K}, 7 blocks of 200 steps per kl_step call (median), "
+        "fp32 copies of X and H made / written back inside every call",
+        "us_per_step_f32": res["f32"] * 1e6,
+        "us_per_step_f64_same_protocol": res["f64"] * 1e6,
+        "speedup": res["f64"] / res["f32"],
+        "step_frac_of_fp32_mfma_peak": flops / res["f32"] / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+        "after_100_steps_rel_l2_vs_f64": {"W": rel(state["f32"][0], state["f64"][0]), "H": rel(state["f32"][1], state["f64"][1])},
+        "after_100_steps_objective": {"f32": state["f32"][2], "f64": state["f64"][2]},
     }
 
 
@@ -481,7 +518,7 @@ def main():
                 line["time_to_kl"] = time_to_kl(sal, X, W0, H0, n_cpu, target, cpu_s, local_rank)
             if not args.no_extra:
                 extra = {}
-                for name, fn in (("c4_mvnmf", extra_c4), ("c2_default_init_fit", extra_default_init_fit)):
+                for name, fn in (("c4_mvnmf", extra_c4), ("c2_default_init_fit", extra_default_init_fit), ("c2_fp32_fast_mode", extra_fast_mode)):
                     try:
                         extra[name] = fn(sal, local_rank)
                     except Exception as exc:  # an extra must never cost the headline line

@@ -186,6 +186,15 @@ int salnmf_corr_update_signature_embeddings(salnmf_engine* e, double variance, i
  * all-reduces the 1 + dim + dim^2 sums per signature of every round.  0 forces the single-kernel form (also
  * SALNMF_LOCKSTEP=0); the two agree to rounding of the sums. */
 int salnmf_set_lockstep(salnmf_engine* e, int on);
+
+/* Opt-in fast mode of salnmf_kl_step: the joint update_WH step on the fp32 matrix cores (fp32 copies of X and H are made
+ * on the device; W, the numerator's cross-workgroup sums and the W tail stay fp64; H is converted back at the end of every
+ * salnmf_kl_step call, so every other entry point sees the usual fp64 state).  Unweighted steps only.  Tolerance: W, H
+ * within 1e-5 rel-L2 of the fp64 step after 20 steps, within 1e-3 after 500 (the reference computes in fp64,
+ * _utils_klnmf.py:7-9; the default SALNMF_PRECISION_F64 is the path all parity claims and benchmarks refer to). */
+#define SALNMF_PRECISION_F64 0
+#define SALNMF_PRECISION_F32_FAST 1
+int salnmf_set_precision(salnmf_engine* e, int precision);
 /* The same solves with the sample-side inputs handed over by the caller: n_all samples (of ALL shards, in
  * global order) with embeddings U_all (n_all x dim), scalings alpha_all (n_all) and aux_all (n_all x
  * n_signatures, compact), host pointers.  This is the exchange point of a sample-sharded CorrNMF update

@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libsalnmf.so")
 
 UNIQUE_ID_BYTES = 128
 P2P_HANDLE_BYTES = 64
+PRECISIONS = {"f64": 0, "f32": 1}
 DTYPE_CODES = {"float64": 0, "float32": 1, "int32": 2, "int64": 3, "uint16": 4}  # SALNMF_F64 ...
 CLIP_ALL = 0
 CLIP_NON_GIVEN = 1
@@ -41,6 +42,7 @@ SIGNATURES = {
     "salnmf_kl_step": (c_int, [_P, c_int, c_int]),
     "salnmf_set_persistent": (c_int, [_P, c_int]),
     "salnmf_set_lockstep": (c_int, [_P, c_int]),
+    "salnmf_set_precision": (c_int, [_P, c_int]),
     "salnmf_update_H": (c_int, [_P]),
     "salnmf_update_W": (c_int, [_P, c_int, c_int]),
     "salnmf_objective": (c_int, [_P, _D]),

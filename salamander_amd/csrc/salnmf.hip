@@ -8,6 +8,7 @@
 #include "salnmf_corr_lockstep.h"
 #include "salnmf_init_kernels.h"
 #include "salnmf_p2p_kernels.h"
+#include "salnmf_kernels_f32.h"
 
 #include <dlfcn.h>
 #include <hip/hip_ext.h>
@@ -169,6 +170,9 @@ struct salnmf_engine {
     bool persistent = false;     // multi-step kl_step calls run as one persistent launch (opt-in: SALNMF_PERSISTENT=1)
     ncclComm_t comm = nullptr;
     int n_ranks = 1, rank = 0;
+    // opt-in fp32 fast mode of the KL step (salnmf_kernels_f32.h): fp32 shadow copies of X and H, made when needed
+    bool fast32 = false, x32_valid = false;
+    float *X32 = nullptr, *H32 = nullptr;
     // peer-to-peer exchange of the small all-reduces (salnmf_p2p_kernels.h); RCCL stays for everything larger
     struct {
         bool connected = false, on = false;
@@ -422,6 +426,8 @@ void salnmf_destroy(salnmf_engine* e) {
     for (int r = 0; r < P2P_MAX_RANKS; ++r)
         if (e->p2p.inbox[r] && e->p2p.inbox[r] != e->p2p.local) (void)hipIpcCloseMemHandle(e->p2p.inbox[r]);
     if (e->p2p.local) (void)hipFree(e->p2p.local);
+    if (e->X32) (void)hipFree(e->X32);
+    if (e->H32) (void)hipFree(e->H32);
     if (e->p2p.abort_dev) (void)hipFree(e->p2p.abort_dev);
     double* bufs[] = {e->X, e->H, e->W, e->wkl, e->wlh, e->Gpart, e->Hsumpart, e->KLpart, e->red,
                       e->objpart, e->scal, e->Wunc, e->Wtrial, e->mvA, e->mvB, e->cs, e->scratch, e->Halt, e->KLpart2,
@@ -675,7 +681,7 @@ static int download_padded(salnmf_engine* e, double* dst, const double* src, int
 
 int salnmf_upload_X_typed(salnmf_engine* e, const void* X, int dtype, int clip) {
     if (!e) return fail("null engine");
-    e->xrowsum_valid = e->lgam_valid = false;
+    e->xrowsum_valid = e->lgam_valid = e->x32_valid = false;
     // pad rows / columns are exactly 0 (never clipped): they must contribute X/P = 0
     return upload_rows_staged(e, e->X, X, dtype, e->V, VMAX, 0.0, 0.0, clip ? kEps : 0.0);
 }
@@ -776,10 +782,78 @@ int salnmf_set_persistent(salnmf_engine* e, int on) {
     return 0;
 }
 
+// n joint steps on the fp32 matrix cores (opt-in, salnmf_kernels_f32.h): shadow copies in, steps, H back out
+static int kl_steps_f32(salnmf_engine* e, int n_steps, int n_given) {
+    CK(flush_H_scale(e));
+    const int64_t nx = e->Np * VMAX, nh = e->Np * e->KP;
+    if (!e->X32) {
+        HIPCK(hipMalloc(&e->X32, (size_t)nx * sizeof(float)));
+        e->x32_valid = false;
+    }
+    if (!e->H32) HIPCK(hipMalloc(&e->H32, (size_t)nh * sizeof(float)));
+    if (!e->x32_valid) {
+        hipLaunchKernelGGL(cvt_f64_f32_kernel, dim3(2048), dim3(256), 0, e->stream, e->X32, e->X, nx);
+        HIPCK(hipGetLastError());
+        e->x32_valid = true;
+    }
+    hipLaunchKernelGGL(cvt_f64_f32_kernel, dim3(2048), dim3(256), 0, e->stream, e->H32, e->H, nh);
+    HIPCK(hipGetLastError());
+    Fused32Params p;
+    p.X = e->X32;
+    p.H = e->H32;
+    p.Gpart = e->Gpart;
+    p.N = e->N;
+    p.ntiles = e->ntiles;
+    p.V = e->V;
+    p.K = e->K;
+    p.hfloor = (float)kEps;
+    for (int i = 0; i < n_steps; ++i) {
+        p.W = e->W;
+        dim3 g(e->grid), b(BLOCK);
+#define SALNMF_CASE(ks)                                                          \
+    case ks:                                                                     \
+        hipLaunchKernelGGL((fused_f32_kernel<ks>), g, b, 0, e->stream, p);       \
+        break;
+        switch (e->KS) {
+            SALNMF_CASE(1)
+            SALNMF_CASE(2)
+            SALNMF_CASE(4)
+            SALNMF_CASE(8)
+            SALNMF_CASE(10)
+            SALNMF_CASE(13)
+            SALNMF_CASE(16)
+            default:
+                return fail("no kernel instantiation for KS=%d", e->KS);
+        }
+#undef SALNMF_CASE
+        HIPCK(hipGetLastError());
+        if (n_given < e->K) {  // _utils_klnmf.py:330-331: W untouched when every signature is given
+            if (sharded(e))
+                CK(sharded_tail(e, n_given, SALNMF_CLIP_ALL));
+            else
+                CK(launch_tail(e, e->grid, e->red, n_given, SALNMF_CLIP_ALL, 1));
+        }
+    }
+    hipLaunchKernelGGL(cvt_f32_f64_kernel, dim3(2048), dim3(256), 0, e->stream, e->H, e->H32, nh);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+int salnmf_set_precision(salnmf_engine* e, int precision) {
+    if (!e) return fail("null engine");
+    if (precision != SALNMF_PRECISION_F64 && precision != SALNMF_PRECISION_F32_FAST) return fail("unknown precision %d", precision);
+    e->fast32 = precision == SALNMF_PRECISION_F32_FAST;
+    return 0;
+}
+
 int salnmf_kl_step(salnmf_engine* e, int n_steps, int n_given) {
     if (!e) return fail("null engine");
     if (n_given < 0 || n_given > e->K) return fail("n_given out of range");
     HIPCK(hipSetDevice(e->device));
+    if (e->fast32 && n_steps > 0) {
+        if (e->wkl || e->wlh) return fail("the fp32 fast mode has no weighted step: clear the weights or set SALNMF_PRECISION_F64");
+        return kl_steps_f32(e, n_steps, n_given);
+    }
     int i = 0;
     if (e->persistent && !sharded(e) && !e->wkl && !e->wlh && n_given < e->K && n_steps >= 2) {
         CK(flush_H_scale(e));  // (after an MvNMF step) the persistent kernel reads H as it is

@@ -105,6 +105,13 @@ class Engine:
     def kl_step(self, n_steps: int = 1, n_given: int = 0):
         _lib.check(self._lib.salnmf_kl_step(self._h, int(n_steps), int(n_given)))
 
+    def set_precision(self, precision: str = "f64"):
+        """``"f64"`` (default; the reference's arithmetic) or ``"f32"``: ``kl_step`` on the fp32 matrix cores, an opt-in
+        fast mode with its own tolerance (``include/salnmf.h: salnmf_set_precision``)."""
+        if precision not in _lib.PRECISIONS:
+            raise ValueError(f"precision has to be one of {sorted(_lib.PRECISIONS)}.")
+        _lib.check(self._lib.salnmf_set_precision(self._h, _lib.PRECISIONS[precision]))
+
     def set_lockstep(self, on: bool = True):
         """Signature-embedding solves in lockstep rounds (default from 16 384 samples on) or one workgroup per signature."""
         _lib.check(self._lib.salnmf_set_lockstep(self._h, int(bool(on))))
