@@ -41,6 +41,7 @@ class SignatureNMF(ABC):
         device: int = 0,
         distributed: bool = False,
         device_init: bool = True,
+        precision: str = "f64",
     ):
         value_checker("init_method", init_method, INIT_METHODS)
         self.n_signatures = n_signatures
@@ -54,6 +55,10 @@ class SignatureNMF(ABC):
         self.distributed = distributed
         # ours: run the deterministic initialisation methods (flat, nndsvd, nndsvda) on the GPU (device_init.py)
         self.device_init = device_init
+        # ours: "f32" = the opt-in fast mode of the KL step (Engine.set_precision; unweighted KLNMF fits only); the
+        # default is the reference's fp64 arithmetic
+        value_checker("precision", precision, ("f64", "f32"))
+        self.precision = precision
         self._resident: set[str] = set()  # what the device already holds from the initialisation: "X", "H"
 
         self.adata = AnnData()
@@ -159,6 +164,8 @@ class SignatureNMF(ABC):
             if e is not None:
                 e.close()
             e = self._engine = Engine(N, V, K, device=self.device)
+            if self.precision != "f64":
+                e.set_precision(self.precision)
             self._comm_attached = False
             self._resident = set()
         if self.distributed and not self._comm_attached:

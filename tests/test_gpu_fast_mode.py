@@ -87,3 +87,17 @@ def test_fast_mode_given_signatures_new_data_and_refusals():
     e.set_weights(None, None)
     with pytest.raises(ValueError):
         e.set_precision("bf16")
+
+
+def test_klnmf_model_with_fast_precision_reaches_the_fp64_objective():
+    import salamander_amd as sal
+
+    V, N, K = 96, 2000, 6
+    X, W0, H0 = orc.synthetic_problem(V, N, K, seed=21)
+    fits = {}
+    for precision in ("f64", "f32"):
+        model = sal.models.KLNMF(K, "custom", min_iterations=200, max_iterations=200, precision=precision)
+        model.fit(sal.AnnData(X.copy()), init_kwargs={"signatures_mat": W0, "exposures_mat": H0})
+        fits[precision] = (np.asarray(model.asignatures.X), float(model.history["objective_function"][-1]))
+    assert rel_l2(fits["f32"][0], fits["f64"][0]) < 1e-4
+    assert np.isclose(fits["f32"][1], fits["f64"][1], rtol=1e-7)
