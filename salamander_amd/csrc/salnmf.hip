@@ -507,8 +507,10 @@ int salnmf_create(int device, int n_features, int64_t n_samples, int n_signature
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return cleanup(fail("stream create failed"));
     if (hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess) return cleanup(fail("stream create failed"));
     if (hipStreamCreateWithFlags(&e->stream3, hipStreamNonBlocking) != hipSuccess) return cleanup(fail("stream create failed"));
+    // cross-stream dependencies on ONE device (the host sees results only through explicit copies behind them): no
+    // system-scope fence at the record -- 2 % of an MvNMF step (profiles/r02/ab_step_variants.txt)
     for (hipEvent_t* ev : {&e->evW, &e->evPrepW, &e->evTrial, &e->evLogdet, &e->evObj})
-        if (hipEventCreateWithFlags(ev, hipEventDisableTiming) != hipSuccess) return cleanup(fail("event create failed"));
+        if (hipEventCreateWithFlags(ev, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) return cleanup(fail("event create failed"));
     ALLOC(e->X, Np * VMAX);
     ALLOC(e->H, Np * KP);
     ALLOC(e->W, K * V);
