@@ -164,6 +164,9 @@ def extra_default_init_fit(sal, device):
     from salamander_amd.synthetic import synthetic_problem
 
     X, _, _ = synthetic_problem(V, N_C2, K, seed=0)
+    # once per process, not per fit (pinned staging buffers' first allocation, LAPACK's first eigh): a 2 000-sample fit first
+    warm = sal.models.KLNMF(K, min_iterations=1, max_iterations=1, device=device)
+    warm.fit(sal.AnnData(X[:2000].copy()))
     adata = sal.AnnData(X.copy())
     model = sal.models.KLNMF(K, min_iterations=500, max_iterations=500, device=device)
     t0 = time.perf_counter()
@@ -176,7 +179,8 @@ def extra_default_init_fit(sal, device):
     model.fit(adata)
     fit_s = time.perf_counter() - t0
     return {
-        "workload": f"KLNMF({K}).fit(adata), init_method='{model.init_method}' (the default), {V}x{N_C2}, 500 iterations",
+        "workload": f"KLNMF({K}).fit(adata), init_method='{model.init_method}' (the default), {V}x{N_C2}, 500 iterations; "
+        "after one small warm-up fit in the process",
         "init_seconds": init_s,
         "fit_seconds_end_to_end": fit_s,
         "objective_last": float(model.history["objective_function"][-1]),
