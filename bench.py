@@ -398,7 +398,7 @@ def main():
     if exchange is not None:
         exchange["used_for_value"] = exchange_mode
 
-    # untimed: kernel durations from HIP events around every 2nd step of 200 (100 samples each)
+    # untimed: kernel durations from HIP events bound to the dispatches of every 2nd step of 200 (100 samples each)
     barrier()
     _, fused_ms, tail_ms = engine.profile_kl_steps(200, 0, 2)
     objective = engine.objective()

@@ -270,11 +270,11 @@ void* salnmf_device_ptr(salnmf_engine* e, int which);
 void* salnmf_stream(salnmf_engine* e);
 int salnmf_sync(salnmf_engine* e);
 
-/* Measurement: run n_steps joint steps with HIP events recorded on the engine's stream around
- * the launches of every sample_stride-th step (an event record costs a few microseconds of
- * stream time, so sampling keeps the timed region representative).  Outputs (any may be
- * NULL): total ms over the n_steps (events before the first and after the last launch), and
- * the average duration in ms of the fused update kernel and of the W tail over the samples. */
+/* Measurement: run n_steps joint steps on the engine's stream; every sample_stride-th step carries HIP events bound
+ * to its two dispatches (start / stop of the fused update kernel and of the W tail: the kernels' own durations, the
+ * figure rocprofv3 reports -- events recorded around a launch would add their barrier packets to it).  Outputs (any may
+ * be NULL): total ms over the n_steps (events recorded before the first and after the last launch), and the average
+ * duration in ms of the fused update kernel and of the W tail over the samples. */
 int salnmf_profile_kl_steps(salnmf_engine* e, int n_steps, int n_given, int sample_stride,
                             double* total_ms, double* fused_avg_ms, double* tail_avg_ms);
 /* Same for the forward (W@H) + objective kernel: average duration over n_calls. */

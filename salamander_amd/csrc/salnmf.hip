@@ -219,8 +219,10 @@ static int pick_ks(int K) {
     X(10, 2, 1) X(10, 2, 2) X(10, 2, 3) X(10, 2, 4)                                  \
     X(13, 3, 1) X(13, 3, 2) X(13, 3, 3) X(13, 3, 4)
 
+// ev_start / ev_stop (profiling only): bound to the dispatch itself, so that their elapsed time is the kernel's own
+// duration, as rocprofv3 reports it -- events recorded around the launch add their barrier packets to it
 template <bool DO_G, bool DO_U, bool DO_STATS>
-static int launch_fused(salnmf_engine* e, const FusedParams& p, int grid = 0) {
+static int launch_fused(salnmf_engine* e, const FusedParams& p, int grid = 0, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
     dim3 g(grid > 0 ? grid : e->grid), b(BLOCK);
     bool done = false;
     // per-sample weights select the WTS instantiation (KLNMF only: the MvNMF / CorrNMF passes, which are the
@@ -231,6 +233,7 @@ static int launch_fused(salnmf_engine* e, const FusedParams& p, int grid = 0) {
     if (!done && e->KS == ks && e->KTM == ktm && e->KR == kr) {                                                    \
         if constexpr (!DO_STATS) {                                                                                 \
             if (wts) hipLaunchKernelGGL((fused_kernel<ks, ktm, kr, DO_G, DO_U, false, true>), g, b, 0, e->stream, p);  \
+            else if (ev_stop) hipExtLaunchKernelGGL((fused_kernel<ks, ktm, kr, DO_G, DO_U, false, false>), g, b, 0, e->stream, ev_start, ev_stop, 0, p); \
             else hipLaunchKernelGGL((fused_kernel<ks, ktm, kr, DO_G, DO_U, false, false>), g, b, 0, e->stream, p);     \
         } else {                                                                                                   \
             hipLaunchKernelGGL((fused_kernel<ks, ktm, kr, DO_G, DO_U, DO_STATS, false>), g, b, 0, e->stream, p);   \
@@ -306,8 +309,13 @@ static TailParams tail_params(salnmf_engine* e, int nslabs, double* G, int n_giv
     return t;
 }
 
-static int launch_tail(salnmf_engine* e, int nslabs, double* G, int n_given, int clip_mode, int do_tail, bool with_stats = false) {
-    hipLaunchKernelGGL(tail_kernel, dim3(e->K), dim3(TAIL_BLOCK), 0, e->stream, tail_params(e, nslabs, G, n_given, clip_mode, do_tail, with_stats));
+static int launch_tail(salnmf_engine* e, int nslabs, double* G, int n_given, int clip_mode, int do_tail, bool with_stats = false,
+                       hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
+    if (ev_stop)
+        hipExtLaunchKernelGGL(tail_kernel, dim3(e->K), dim3(TAIL_BLOCK), 0, e->stream, ev_start, ev_stop, 0,
+                              tail_params(e, nslabs, G, n_given, clip_mode, do_tail, with_stats));
+    else
+        hipLaunchKernelGGL(tail_kernel, dim3(e->K), dim3(TAIL_BLOCK), 0, e->stream, tail_params(e, nslabs, G, n_given, clip_mode, do_tail, with_stats));
     HIPCK(hipGetLastError());
     return 0;
 }
@@ -377,25 +385,29 @@ static int flush_H_scale(salnmf_engine* e) {
     return 0;
 }
 
-// one joint step; ev != nullptr records {before fused, after fused, after tail}
+// one joint step; ev != nullptr: {fused start, fused stop, tail start, tail stop} are bound to the two dispatches
+// (a weighted or sharded step, whose tail is more than one launch, falls back to records around the launches)
 static int kl_step_once(salnmf_engine* e, int n_given, hipEvent_t* ev) {
     FusedParams p = fused_params(e);
     const bool all_given = n_given >= e->K;  // _utils_klnmf.py:330-331: W untouched
-    if (ev) HIPCK(hipEventRecord(ev[0], e->stream));
+    const bool bound = ev && !(p.wkl || p.wlh);
+    if (ev && !bound) HIPCK(hipEventRecord(ev[0], e->stream));
     if (all_given)
-        CK((launch_fused<false, true, false>(e, p)));
+        CK((launch_fused<false, true, false>(e, p, 0, bound ? ev[0] : nullptr, bound ? ev[1] : nullptr)));
     else
-        CK((launch_fused<true, true, false>(e, p)));
+        CK((launch_fused<true, true, false>(e, p, 0, bound ? ev[0] : nullptr, bound ? ev[1] : nullptr)));
     e->h_pending = false;  // the pass wrote H in full
-    if (ev) HIPCK(hipEventRecord(ev[1], e->stream));
+    if (ev && !bound) HIPCK(hipEventRecord(ev[1], e->stream));
+    const bool tail_bound = ev && !all_given && !sharded(e);
+    if (ev && !tail_bound) HIPCK(hipEventRecord(ev[2], e->stream));
     if (!all_given) {
         if (sharded(e)) {
             CK(sharded_tail(e, n_given, SALNMF_CLIP_ALL));
         } else {
-            CK(launch_tail(e, e->grid, e->red, n_given, SALNMF_CLIP_ALL, 1));
+            CK(launch_tail(e, e->grid, e->red, n_given, SALNMF_CLIP_ALL, 1, false, tail_bound ? ev[2] : nullptr, tail_bound ? ev[3] : nullptr));
         }
     }
-    if (ev) HIPCK(hipEventRecord(ev[2], e->stream));
+    if (ev && !tail_bound) HIPCK(hipEventRecord(ev[3], e->stream));
     return 0;
 }
 
@@ -1926,12 +1938,12 @@ int salnmf_profile_kl_steps(salnmf_engine* e, int n_steps, int n_given, int samp
     if (sample_stride < 1) sample_stride = 1;
     HIPCK(hipSetDevice(e->device));
     const int n_samples = (n_steps + sample_stride - 1) / sample_stride;
-    CK(ensure_events(e, (size_t)3 * n_samples + 2));
-    hipEvent_t first = e->events[3 * (size_t)n_samples], last = e->events[3 * (size_t)n_samples + 1];
+    CK(ensure_events(e, (size_t)4 * n_samples + 2));
+    hipEvent_t first = e->events[4 * (size_t)n_samples], last = e->events[4 * (size_t)n_samples + 1];
     HIPCK(hipEventRecord(first, e->stream));
     for (int i = 0; i < n_steps; ++i) {
-        // events are recorded around every sample_stride-th step only: each record costs a few us on the stream
-        hipEvent_t* ev = (i % sample_stride == 0) ? &e->events[3 * (size_t)(i / sample_stride)] : nullptr;
+        // every sample_stride-th step carries events (bound to its two dispatches: their own durations)
+        hipEvent_t* ev = (i % sample_stride == 0) ? &e->events[4 * (size_t)(i / sample_stride)] : nullptr;
         CK(kl_step_once(e, n_given, ev));
     }
     HIPCK(hipEventRecord(last, e->stream));
@@ -1939,8 +1951,8 @@ int salnmf_profile_kl_steps(salnmf_engine* e, int n_steps, int n_given, int samp
     double fused = 0, tail = 0;
     for (int i = 0; i < n_samples; ++i) {
         float a = 0, b = 0;
-        HIPCK(hipEventElapsedTime(&a, e->events[3 * (size_t)i], e->events[3 * (size_t)i + 1]));
-        HIPCK(hipEventElapsedTime(&b, e->events[3 * (size_t)i + 1], e->events[3 * (size_t)i + 2]));
+        HIPCK(hipEventElapsedTime(&a, e->events[4 * (size_t)i], e->events[4 * (size_t)i + 1]));
+        HIPCK(hipEventElapsedTime(&b, e->events[4 * (size_t)i + 2], e->events[4 * (size_t)i + 3]));
         fused += a;
         tail += b;
     }
