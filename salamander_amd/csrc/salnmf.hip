@@ -200,6 +200,9 @@ struct salnmf_engine {
 };
 
 static int check_abort(salnmf_engine* e);
+constexpr size_t SMALL_PINNED_BYTES = 4096;  // per-engine pinned block: read-back scalars, the abort word at its middle
+static void release_pinned(void* p, int small_block);
+static hipError_t acquire_pinned(void** out, int small_block);
 
 static const int kKS[] = {1, 2, 4, 8, 10, 13, 16};
 
@@ -248,11 +251,12 @@ static int launch_fused(salnmf_engine* e, const FusedParams& p, int grid = 0, hi
 }
 
 template <int MODE>
-static int launch_forward(salnmf_engine* e, const FwdParams& p, int grid = 0) {
+static int launch_forward(salnmf_engine* e, const FwdParams& p, int grid = 0, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
     dim3 g(grid > 0 ? grid : e->fgrid), b(BLOCK);
-#define SALNMF_CASE(ks)                                                        \
-    case ks:                                                                   \
-        hipLaunchKernelGGL((forward_kernel<ks, MODE>), g, b, 0, e->stream, p); \
+#define SALNMF_CASE(ks)                                                                                                 \
+    case ks:                                                                                                            \
+        if (ev_stop) hipExtLaunchKernelGGL((forward_kernel<ks, MODE>), g, b, 0, e->stream, ev_start, ev_stop, 0, p);    \
+        else hipLaunchKernelGGL((forward_kernel<ks, MODE>), g, b, 0, e->stream, p);                                     \
         break;
     switch (e->KS) {
         SALNMF_CASE(1)
@@ -446,16 +450,15 @@ void salnmf_destroy(salnmf_engine* e) {
                       e->alpha, e->beta, e->Lemb, e->Uemb, e->aux, e->xrowsum, e->corrpart, e->gU, e->galpha, e->gaux};
     for (double* b : bufs)
         if (b) (void)hipFree(b);
-    if (e->hpin) (void)hipHostFree(e->hpin);
+    if (e->hpin) release_pinned(e->hpin, 1);  // (one block: hpin, and the abort word behind it)
     for (int i = 0; i < 2; ++i) {
-        if (e->stage_host[i]) (void)hipHostFree(e->stage_host[i]);
+        if (e->stage_host[i]) release_pinned(e->stage_host[i], 0);  // (the engine's streams are idle: synchronised above)
         if (e->stage_dev[i]) (void)hipFree(e->stage_dev[i]);
         if (e->stage_done[i]) (void)hipEventDestroy(e->stage_done[i]);
     }
     if (e->ls_buf) (void)hipFree(e->ls_buf);
     if (e->ls_int) (void)hipFree(e->ls_int);
     if (e->psync) (void)hipFree(e->psync);
-    if (e->pabort) (void)hipHostFree(e->pabort);
     for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : {e->evW, e->evPrepW, e->evTrial, e->evLogdet, e->evObj})
         if (ev) (void)hipEventDestroy(ev);
@@ -543,10 +546,9 @@ int salnmf_create(int device, int n_features, int64_t n_samples, int n_signature
         if (hipMemcpy(e->cs, ones.data(), KP * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
             return cleanup(fail("hipMemcpy failed"));
     }
-    if (hipHostMalloc((void**)&e->hpin, 8 * sizeof(double), hipHostMallocDefault) != hipSuccess)
-        return cleanup(fail("hipHostMalloc failed"));
+    if (acquire_pinned((void**)&e->hpin, 1) != hipSuccess) return cleanup(fail("hipHostMalloc failed"));
+    e->pabort = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(e->hpin) + SMALL_PINNED_BYTES / 2);
     if (hipMalloc(&e->psync, SYNC_WORDS * sizeof(unsigned)) != hipSuccess) return cleanup(fail("hipMalloc failed"));
-    if (hipHostMalloc((void**)&e->pabort, 64, hipHostMallocDefault) != hipSuccess) return cleanup(fail("hipHostMalloc failed"));
     *e->pabort = 0;
     {
         // measured slower than per-step launches on MI355X: opt-in
@@ -597,9 +599,41 @@ static size_t dtype_size(int dtype) {
     }
 }
 
+// Pinned staging buffers are kept for the life of the process and handed from engine to engine: pinning 32 MB costs
+// 5-80 ms per hipHostMalloc on this platform (rocprofv3 --hip-trace of tools/time_init.py), more than the transfer it serves,
+// and a fit() creates a fresh engine.  At most four are cached (128 MB); never freed at exit (the runtime may be gone).
+// The same for the small per-engine block (scalars read back + the abort word: SMALL_PINNED_BYTES).
+static std::mutex g_pinned_mutex;
+static std::vector<void*> g_pinned_cache[2];  // [0] staging buffers (STAGE_BYTES), [1] small blocks
+
+static hipError_t acquire_pinned(void** out, int small_block) {
+    {
+        std::lock_guard<std::mutex> lock(g_pinned_mutex);
+        auto& c = g_pinned_cache[small_block];
+        if (!c.empty()) {
+            *out = c.back();
+            c.pop_back();
+            return hipSuccess;
+        }
+    }
+    return hipHostMalloc(out, small_block ? SMALL_PINNED_BYTES : STAGE_BYTES, hipHostMallocDefault);
+}
+
+static void release_pinned(void* p, int small_block) {
+    {
+        std::lock_guard<std::mutex> lock(g_pinned_mutex);
+        auto& c = g_pinned_cache[small_block];
+        if (c.size() < (small_block ? 16u : 4u)) {
+            c.push_back(p);
+            return;
+        }
+    }
+    (void)hipHostFree(p);
+}
+
 static int ensure_staging(salnmf_engine* e) {
     for (int i = 0; i < 2; ++i) {
-        if (!e->stage_host[i]) HIPCK(hipHostMalloc(&e->stage_host[i], STAGE_BYTES, hipHostMallocDefault));
+        if (!e->stage_host[i]) HIPCK(acquire_pinned(&e->stage_host[i], 0));
         if (!e->stage_dev[i]) HIPCK(hipMalloc(&e->stage_dev[i], STAGE_BYTES));
         if (!e->stage_done[i]) HIPCK(hipEventCreateWithFlags(&e->stage_done[i], hipEventDisableTiming));
     }
@@ -1980,9 +2014,9 @@ static int profile_forward(salnmf_engine* e, int mode, int n_calls, double* avg_
     }
     int rc = 0;
     for (int i = 0; i < n_calls && !rc; ++i) {
-        if (hipEventRecord(e->events[2 * (size_t)i], e->stream) != hipSuccess) rc = fail("hipEventRecord failed");
-        if (!rc) rc = (mode == 2) ? launch_forward<2>(e, p) : launch_forward<0>(e, p);
-        if (!rc && hipEventRecord(e->events[2 * (size_t)i + 1], e->stream) != hipSuccess) rc = fail("hipEventRecord failed");
+        // (events bound to the dispatch: the kernel's own duration)
+        hipEvent_t a = e->events[2 * (size_t)i], b = e->events[2 * (size_t)i + 1];
+        rc = (mode == 2) ? launch_forward<2>(e, p, 0, a, b) : launch_forward<0>(e, p, 0, a, b);
     }
     if (hipStreamSynchronize(e->stream) != hipSuccess && !rc) rc = fail("hipStreamSynchronize failed");
     double s = 0;
