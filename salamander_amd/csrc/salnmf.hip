@@ -616,19 +616,37 @@ static hipError_t acquire_pinned(void** out, int small_block) {
             return hipSuccess;
         }
     }
-    return hipHostMalloc(out, small_block ? SMALL_PINNED_BYTES : STAGE_BYTES, hipHostMallocDefault);
+    if (!small_block) return hipHostMalloc(out, STAGE_BYTES, hipHostMallocDefault);
+    // small blocks are carved out of one pinned slab of 16 (never returned to the runtime)
+    void* slab = nullptr;
+    const hipError_t rc = hipHostMalloc(&slab, 16 * SMALL_PINNED_BYTES, hipHostMallocDefault);
+    if (rc != hipSuccess) return rc;
+    std::lock_guard<std::mutex> lock(g_pinned_mutex);
+    for (int i = 1; i < 16; ++i) g_pinned_cache[1].push_back(static_cast<char*>(slab) + (size_t)i * SMALL_PINNED_BYTES);
+    *out = slab;
+    return hipSuccess;
 }
 
 static void release_pinned(void* p, int small_block) {
     {
         std::lock_guard<std::mutex> lock(g_pinned_mutex);
         auto& c = g_pinned_cache[small_block];
-        if (c.size() < (small_block ? 16u : 4u)) {
+        if (small_block || c.size() < 4u) {  // (a small block is part of a slab: it always goes back to the list)
             c.push_back(p);
             return;
         }
     }
     (void)hipHostFree(p);
+}
+
+// the pinned halves of the staging pairs are borrowed for the duration of one upload / download (both return with the
+// stream idle), so that engines that are alive at the same time share them
+static void release_staging(salnmf_engine* e) {
+    for (int i = 0; i < 2; ++i)
+        if (e->stage_host[i]) {
+            release_pinned(e->stage_host[i], 0);
+            e->stage_host[i] = nullptr;
+        }
 }
 
 static int ensure_staging(salnmf_engine* e) {
@@ -688,6 +706,7 @@ static int upload_rows_staged(salnmf_engine* e, double* dst, const void* src, in
         HIPCK(hipGetLastError());
     }
     HIPCK(hipStreamSynchronize(e->stream));  // the caller's array is free again (and so are the staging buffers)
+    release_staging(e);
     return 0;
 }
 
@@ -724,6 +743,7 @@ static int download_padded(salnmf_engine* e, double* dst, const double* src, int
         parallel_copy((char*)dst + (size_t)c * chunk_rows * row_bytes, e->stage_host[c & 1], (size_t)rows_of(c) * row_bytes);
     }
     HIPCK(hipStreamSynchronize(e->stream));
+    release_staging(e);
     return check_abort(e);
 }
 

@@ -154,7 +154,9 @@ class SignatureNMF(ABC):
     def _host_state(self):
         X = np.ascontiguousarray(self.adata.X, dtype=np.float64)
         W = np.ascontiguousarray(self.asignatures.X, dtype=np.float64)
-        H = np.ascontiguousarray(self.adata.obsm["exposures"], dtype=np.float64)
+        H = None  # resident on the device only (fit() after a device-side initialisation)
+        if "exposures" in self.adata.obsm or "H" not in self._resident:
+            H = np.ascontiguousarray(self.adata.obsm["exposures"], dtype=np.float64)
         return X, W, H
 
     def _ensure_engine(self, N: int, V: int, K: int):
@@ -226,7 +228,13 @@ class SignatureNMF(ABC):
         verbosity_freq: int = 1000,
     ) -> "SignatureNMF":
         self._setup_adata(adata)
-        self._initialize(given_parameters, init_kwargs)
+        # inside fit() a device-side initialisation leaves the exposures on the device only: they come back once, with
+        # the fitted ones (a 40 MB host array and its page faults less at c2)
+        self._defer_exposures = True
+        try:
+            self._initialize(given_parameters, init_kwargs)
+        finally:
+            self._defer_exposures = False
         self._setup_fitting_parameters(fitting_kwargs)
         self._sync_to_device()
 

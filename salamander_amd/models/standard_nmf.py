@@ -46,5 +46,8 @@ class StandardNMF(SignatureNMF):
         e.upload_X(X)
         S = initialize_on_device(e, self.n_signatures, self.init_method, given_mat, self._n_obs_total())
         self.asignatures = package_signatures(self.adata, S, self.n_signatures, given)
-        self.adata.obsm["exposures"] = e.download_H()
+        if getattr(self, "_defer_exposures", False):
+            self.adata.obsm.pop("exposures", None)  # fit() downloads the fitted exposures at its end
+        else:
+            self.adata.obsm["exposures"] = e.download_H()
         self._resident = {"X", "H"}
