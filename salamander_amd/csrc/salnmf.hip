@@ -520,8 +520,7 @@ int salnmf_create(int device, int n_features, int64_t n_samples, int n_signature
 #define ALLOC(ptr, n)                                                      \
     if (hipMalloc(&(ptr), (n) * sizeof(double)) != hipSuccess) return cleanup(fail("hipMalloc of %zu doubles failed", (size_t)(n)));
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return cleanup(fail("stream create failed"));
-    if (hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess) return cleanup(fail("stream create failed"));
-    if (hipStreamCreateWithFlags(&e->stream3, hipStreamNonBlocking) != hipSuccess) return cleanup(fail("stream create failed"));
+    // (stream2 / stream3 are created by the first MvNMF call: ensure_side_streams)
     // cross-stream dependencies on ONE device (the host sees results only through explicit copies behind them): no
     // system-scope fence at the record -- 2 % of an MvNMF step (profiles/r02/ab_step_variants.txt)
     for (hipEvent_t* ev : {&e->evW, &e->evPrepW, &e->evTrial, &e->evLogdet, &e->evObj})
@@ -1076,7 +1075,16 @@ int salnmf_mv_objective(salnmf_engine* e, double lam, double delta, double* out)
 // while the passes over the samples (which leave one CU free, mv_grid / mv_fgrid) run on the main stream.
 //   w_ready: the caller recorded evW on the main stream after the last write of W and already started
 //            mv_prepare_W on stream2 (mv_step does, so that it also overlaps the update_H pass)
+// The MvNMF side streams exist only in engines that run MvNMF steps (HIP multiplexes a process's streams onto a few
+// hardware queues: an engine that only ever runs KL or CorrNMF steps should not hold three of them).
+static int ensure_side_streams(salnmf_engine* e) {
+    if (!e->stream2) HIPCK(hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking));
+    if (!e->stream3) HIPCK(hipStreamCreateWithFlags(&e->stream3, hipStreamNonBlocking));
+    return 0;
+}
+
 static int mv_start_prepare_W(salnmf_engine* e, double delta, bool record_w_event) {
+    CK(ensure_side_streams(e));
     if (record_w_event) HIPCK(hipEventRecord(e->evW, e->stream));  // else: recorded when W was last written
     HIPCK(hipStreamWaitEvent(e->stream2, e->evW, 0));
     LAUNCH_WITH_EVENT(mv_prepare_W_kernel, dim3(1), dim3(MV_BLOCK), e->stream2, e->evPrepW, e->W, e->K, e->V, delta, e->mvA, e->mvB,
@@ -1116,6 +1124,7 @@ static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double de
                             bool speculate = false, bool* speculated = nullptr, bool g_ready = false) {
     if (speculated) *speculated = false;
     if (n_given >= e->K) return 0;
+    CK(ensure_side_streams(e));
     const int K = e->K, V = e->V;
     if (!g_ready) {
         CK(flush_H_scale(e));  // a stand-alone call after an earlier step; inside mv_step the update_H pass consumed it

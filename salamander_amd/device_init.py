@@ -74,6 +74,16 @@ def nndsvd_signature_side(eigvals, eigvecs, pos2, neg2, n_signatures, x_mean, me
     return H, scale, take_neg, fill
 
 
+def _single_blas_thread():
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:  # pragma: no cover - threadpoolctl comes with scikit-learn
+        import contextlib
+
+        return contextlib.nullcontext()
+    return threadpool_limits(limits=1, user_api="blas")
+
+
 def initialize_on_device(engine, n_signatures, method, given_signatures_mat=None, n_samples_total=None):
     """``initialize_mat`` (``initialize.py:44-119``) for the deterministic methods on the engine's resident ``X``.
 
@@ -90,7 +100,11 @@ def initialize_on_device(engine, n_signatures, method, given_signatures_mat=None
         S = np.full((K, V), 1.0 / V)
     else:
         G, x_sum = engine.init_gram()
-        evals, evecs = np.linalg.eigh(G)
+        # one BLAS thread for the 96 x 96 eigenproblem: a multi-threaded LAPACK call leaves its worker pool spinning on
+        # every host core for a while, which on a busy or small host starves the HIP runtime's threads -- the first
+        # ~100 steps after the initialisation then stall for 30-80 ms (tools/t_bisect.py)
+        with _single_blas_thread():
+            evals, evecs = np.linalg.eigh(G)
         order = np.argsort(evals)[::-1][:K]
         evals, evecs = evals[order], evecs[:, order]
         sigma = np.sqrt(np.maximum(evals, 0.0))
