@@ -615,10 +615,11 @@ static hipError_t acquire_pinned(void** out, int small_block) {
             return hipSuccess;
         }
     }
-    if (!small_block) return hipHostMalloc(out, STAGE_BYTES, hipHostMallocDefault);
+    // (portable: a cached block may be handed to an engine on another device of this process)
+    if (!small_block) return hipHostMalloc(out, STAGE_BYTES, hipHostMallocPortable);
     // small blocks are carved out of one pinned slab of 16 (never returned to the runtime)
     void* slab = nullptr;
-    const hipError_t rc = hipHostMalloc(&slab, 16 * SMALL_PINNED_BYTES, hipHostMallocDefault);
+    const hipError_t rc = hipHostMalloc(&slab, 16 * SMALL_PINNED_BYTES, hipHostMallocPortable);
     if (rc != hipSuccess) return rc;
     std::lock_guard<std::mutex> lock(g_pinned_mutex);
     for (int i = 1; i < 16; ++i) g_pinned_cache[1].push_back(static_cast<char*>(slab) + (size_t)i * SMALL_PINNED_BYTES);
