@@ -1,6 +1,9 @@
+"""Development check (uses the oracle, hence under tests/): 60 random (V, N, K, given) shapes, three KL steps of the fp64
+path and of the fp32 fast mode against the oracle."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from oracle import klnmf_oracle as orc
 from salamander_amd.engine import Engine
