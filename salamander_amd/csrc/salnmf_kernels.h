@@ -164,6 +164,64 @@ __device__ __forceinline__ double log_ratio(double x, double p) {
     return __builtin_fma(kd, 6.93147180369123816490e-01, t);
 }
 
+// log_ratio for M independent operand pairs, stage by stage: the same instruction sequence per pair (same bits), but
+// written so that the M dependent chains (~20 fp64 instructions each) stand next to each other.  hipcc otherwise emits
+// one chain after the other and every dependent instruction waits out the previous one's latency (the divisions of the
+// update pass lost 2.4 % of the kernel that way, profiles/r02/ab_step_variants.txt).
+template <int M>
+__device__ __forceinline__ void log_ratio_n(const double (&x)[M], const double (&p)[M], double (&out)[M]) {
+    double ps[M], kd[M], num[M], den[M], rc[M], e[M], qt[M], s[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        const int hx = __double2hiint(x[i]), hp = __double2hiint(p[i]);
+        const int k = (hx - hp + 0x80000) >> 20;
+        ps[i] = __hiloint2double(hp + (k << 20), __double2loint(p[i]));
+        kd[i] = (double)k;
+    }
+#pragma unroll
+    for (int i = 0; i < M; ++i) num[i] = x[i] - ps[i];
+#pragma unroll
+    for (int i = 0; i < M; ++i) den[i] = x[i] + ps[i];
+    // div_path(num, den)
+#pragma unroll
+    for (int i = 0; i < M; ++i) rc[i] = __builtin_amdgcn_rcp(den[i]);
+#pragma unroll
+    for (int i = 0; i < M; ++i) e[i] = __builtin_fma(-den[i], rc[i], 1.0);
+#pragma unroll
+    for (int i = 0; i < M; ++i) rc[i] = __builtin_fma(rc[i], e[i], rc[i]);
+#pragma unroll
+    for (int i = 0; i < M; ++i) qt[i] = num[i] * rc[i];
+#pragma unroll
+    for (int i = 0; i < M; ++i) e[i] = __builtin_fma(-den[i], qt[i], num[i]);
+#pragma unroll
+    for (int i = 0; i < M; ++i) s[i] = __builtin_fma(e[i], rc[i], qt[i]);
+    double z[M], w[M], t1[M], t2[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) z[i] = s[i] * s[i];
+#pragma unroll
+    for (int i = 0; i < M; ++i) w[i] = z[i] * z[i];
+#pragma unroll
+    for (int i = 0; i < M; ++i) t1[i] = __builtin_fma(w[i], 0.1365426141372305, 0.15389174135906675);
+#pragma unroll
+    for (int i = 0; i < M; ++i) t2[i] = __builtin_fma(w[i], 0.1320375159044889, 0.18181729869745253);
+#pragma unroll
+    for (int i = 0; i < M; ++i) t1[i] = __builtin_fma(w[i], t1[i], 0.22222223148322984);
+#pragma unroll
+    for (int i = 0; i < M; ++i) t2[i] = __builtin_fma(w[i], t2[i], 0.2857142856666864);
+#pragma unroll
+    for (int i = 0; i < M; ++i) t1[i] = __builtin_fma(w[i], t1[i], 0.40000000000009306);
+#pragma unroll
+    for (int i = 0; i < M; ++i) t2[i] = __builtin_fma(w[i], t2[i], 0.6666666666666666);
+#pragma unroll
+    for (int i = 0; i < M; ++i) t1[i] = z[i] * __builtin_fma(z[i], t1[i], t2[i]);  // R
+#pragma unroll
+    for (int i = 0; i < M; ++i) t2[i] = __builtin_fma(kd[i], 1.90821492927058770002e-10, s[i] * t1[i]);
+#pragma unroll
+    for (int i = 0; i < M; ++i) t2[i] = __builtin_fma(2.0, s[i], t2[i]);
+#pragma unroll
+    for (int i = 0; i < M; ++i) out[i] = __builtin_fma(kd[i], 6.93147180369123816490e-01, t2[i]);
+}
+
 // one entry of the generalised KL divergence, any operands (library log)
 __device__ __forceinline__ double kl_term(double x, double p) {
     // _utils_klnmf.py:47-50: entries with X == 0 contribute only WH
@@ -252,11 +310,18 @@ __device__ __forceinline__ double tile_kl(const double (&x)[VT][4], const d4 (&p
         for (int r = 0; r < 4; ++r) {
             const bool nvalid = n0 + q + 4 * r < N;
             double acc = 0.0;
+            double xs[VT], ps[VT], lr[VT];
 #pragma unroll
             for (int vt = 0; vt < VT; ++vt) {
                 const bool valid = nvalid && (16 * vt + c16 < V);
-                const double xs = valid ? x[vt][r] : 1.0, ps = valid ? pr[vt][r] : 1.0;  // pads: harmless operands
-                const double t = kl_term_fast(xs, ps);
+                xs[vt] = valid ? x[vt][r] : 1.0;  // pads: harmless operands
+                ps[vt] = valid ? pr[vt][r] : 1.0;
+            }
+            log_ratio_n<VT>(xs, ps, lr);
+#pragma unroll
+            for (int vt = 0; vt < VT; ++vt) {
+                const bool valid = nvalid && (16 * vt + c16 < V);
+                const double t = __builtin_fma(xs[vt], lr[vt], ps[vt] - xs[vt]);  // kl_term_fast
                 acc += valid ? t : 0.0;
             }
             if (wrow) acc *= wrow[n0 + q + 4 * r];
@@ -617,10 +682,31 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         // it starts from, which saves the separate forward pass)
         if (DO_STATS && (DO_G || p.KLpart != nullptr)) klacc += tile_kl(x, pr, nullptr, n0, N, V, q, c16);
         // ---- R = X / P in place (rows n = q + 4r, columns v = 16vt + c16); pads give 0 / P = 0
+        // (div_path's sequence, six quotients at a time and stage by stage: independent chains next to each other)
 #pragma unroll
-        for (int vt = 0; vt < VT; ++vt)
+        for (int r = 0; r < 4; ++r) {
+            double rc[VT], t0[VT], t1[VT];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) pr[vt][r] = div_path(x[vt][r], pr[vt][r]);
+            for (int vt = 0; vt < VT; ++vt) rc[vt] = __builtin_amdgcn_rcp(pr[vt][r]);
+#pragma unroll
+            for (int vt = 0; vt < VT; ++vt) t0[vt] = __builtin_fma(-pr[vt][r], rc[vt], 1.0);
+#pragma unroll
+            for (int vt = 0; vt < VT; ++vt) rc[vt] = __builtin_fma(rc[vt], t0[vt], rc[vt]);
+#pragma unroll
+            for (int vt = 0; vt < VT; ++vt) t1[vt] = x[vt][r] * rc[vt];
+#pragma unroll
+            for (int vt = 0; vt < VT; ++vt) t0[vt] = __builtin_fma(-pr[vt][r], t1[vt], x[vt][r]);
+#pragma unroll
+            for (int vt = 0; vt < VT; ++vt) pr[vt][r] = __builtin_fma(t0[vt], rc[vt], t1[vt]);
+        }
+        // all 24 divisions before the G phase: left to itself hipcc sinks each division in front of the three MFMAs
+        // that consume it, and a single division is a chain of six dependent fp64 instructions whose latencies are
+        // then exposed 24 times per tile (the MFMAs share the pipe, so nothing is gained by interleaving them).
+        // One empty asm that takes all 24 quotients in and hands them out again pins that.
+        asm volatile("" : "+v"(pr[0][0]), "+v"(pr[0][1]), "+v"(pr[0][2]), "+v"(pr[0][3]), "+v"(pr[1][0]), "+v"(pr[1][1]), "+v"(pr[1][2]),
+                     "+v"(pr[1][3]), "+v"(pr[2][0]), "+v"(pr[2][1]), "+v"(pr[2][2]), "+v"(pr[2][3]), "+v"(pr[3][0]), "+v"(pr[3][1]));
+        asm volatile("" : "+v"(pr[3][2]), "+v"(pr[3][3]), "+v"(pr[4][0]), "+v"(pr[4][1]), "+v"(pr[4][2]), "+v"(pr[4][3]), "+v"(pr[5][0]),
+                     "+v"(pr[5][1]), "+v"(pr[5][2]), "+v"(pr[5][3]));
 
         // prefetch the next tile: X and the staging registers are free from here on, and the loads
         // get the G and U phases to land
@@ -670,19 +756,19 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         if (DO_U && KR > 0) {
 #pragma unroll
             for (int i = 0; i < NVP; ++i) urem[i] = 0.0;
+            // (feature tile outermost: the 4 KR accumulation chains advance side by side; each still adds its six terms
+            // in the order vt = 0..5)
+            double wj[KR > 0 ? KR : 1][VT];
 #pragma unroll
-            for (int j = 0; j < KR; ++j) {
-                double wj[VT];
+            for (int j = 0; j < KR; ++j)
 #pragma unroll
-                for (int vt = 0; vt < VT; ++vt) wj[vt] = Wl[(KB + j) * WS + 16 * vt + c16];
+                for (int vt = 0; vt < VT; ++vt) wj[j][vt] = Wl[(KB + j) * WS + 16 * vt + c16];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    double s = 0.0;
+            for (int vt = 0; vt < VT; ++vt)
 #pragma unroll
-                    for (int vt = 0; vt < VT; ++vt) s = __builtin_fma(pr[vt][r], wj[vt], s);
-                    urem[4 * j + r] = s;
-                }
-            }
+                for (int j = 0; j < KR; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) urem[4 * j + r] = __builtin_fma(pr[vt][r], wj[j][vt], urem[4 * j + r]);
         }
         __builtin_amdgcn_wave_barrier();
 
