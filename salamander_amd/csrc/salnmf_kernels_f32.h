@@ -161,10 +161,16 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_f32_kernel(Fused32Params p) {
             for (int kt = 0; kt < KT; ++kt) ga[r][kt] = ha[16 * kt];
         }
         // ---- R = X / P in place (v_rcp_f32 is good to 1 ulp; pads give 0 * 1/P = 0)
+        // (reciprocals first, products second, and all of it before the G phase: see the fp64 kernel's division chains)
 #pragma unroll
         for (int vt = 0; vt < VT; ++vt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) pr[vt][r] = x[vt][r] * __builtin_amdgcn_rcpf(pr[vt][r]);
+            for (int r = 0; r < 4; ++r) pr[vt][r] = __builtin_amdgcn_rcpf(pr[vt][r]);
+#pragma unroll
+        for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pr[vt][r] *= x[vt][r];
+        asm volatile("" : "+v"(pr[0]), "+v"(pr[1]), "+v"(pr[2]), "+v"(pr[3]), "+v"(pr[4]), "+v"(pr[5]));
         if (tile + tstride < p.ntiles) load_tile(tile + tstride);
         // ---- transpose R through LDS for the U phase
 #pragma unroll
