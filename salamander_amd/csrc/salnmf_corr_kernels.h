@@ -491,20 +491,29 @@ struct SignatureEmbeddingEval {
     __device__ inline void hess_tile(d4 (&acc)[10]) const {
         const int c16 = lane & 15, q = lane >> 4;
         const double* base = Ut + (64 * wave + q) * ldu + c16;
-        for (int sgrp = 0; sgrp < 16; ++sgrp) {  // 4 samples per MFMA step
-            const double wv = wt[64 * wave + 4 * sgrp + q];
-            double a[4], b[4];
+        // operands one step ahead of the MFMAs that use them: the LDS latency of a step's reads used to be exposed in
+        // front of its six MFMAs, sixteen times per tile
+        double wv[2], a[2][4];
+        wv[0] = wt[64 * wave + q];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                a[t] = t < DT ? base[4 * sgrp * ldu + 16 * t] : 0.0;
-                b[t] = wv * a[t];
+        for (int t = 0; t < 4; ++t) a[0][t] = t < DT ? base[16 * t] : 0.0;
+#pragma unroll
+        for (int sgrp = 0; sgrp < 16; ++sgrp) {  // 4 samples per MFMA step
+            const int cur = sgrp & 1, nxt = cur ^ 1;
+            if (sgrp + 1 < 16) {
+                wv[nxt] = wt[64 * wave + 4 * (sgrp + 1) + q];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) a[nxt][t] = t < DT ? base[4 * (sgrp + 1) * ldu + 16 * t] : 0.0;
             }
+            double b[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) b[t] = wv[cur] * a[cur][t];
             int idx = 0;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                 for (int nt = mt; nt < 4; ++nt, ++idx)
-                    if (nt < DT) acc[idx] = mfma(a[mt], b[nt], acc[idx]);  // uniform over the workgroup
+                    if (nt < DT) acc[idx] = mfma(a[cur][mt], b[nt], acc[idx]);  // uniform over the workgroup
         }
     }
     // after the last tile: cross-wave sum in fixed order into Al; the tile buffer is free and serves as staging
