@@ -1505,7 +1505,11 @@ static int lockstep_signature_solves(salnmf_engine* e, const double* U, const do
     hipDeviceProp_t prop;
     HIPCK(hipGetDeviceProperties(&prop, e->device));
     const int64_t max_chunks = (n_rows + SIGT - 1) / SIGT;
-    const int S = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(16, prop.multiProcessorCount / K), max_chunks));
+    // dim <= 48: LS_GROUP signatures share a staged tile of U (salnmf_corr_lockstep.h), so there are fewer, longer rows of
+    // workgroups and more chunks; otherwise one signature per workgroup
+    const bool multi = dim <= 48;
+    const int groups = multi ? (K + LS_GROUP - 1) / LS_GROUP : K;
+    const int S = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(multi ? 32 : 16, prop.multiProcessorCount / groups), max_chunks));
     const int64_t chunk = ((n_rows + S - 1) / S + SIGT - 1) / SIGT * SIGT;
     // one allocation: [x0 | req | sg] (K x 64 each), part (K S REC), red (K REC), log_y, log_g (K EVAL 64), log_f (K EVAL), log_H (K EVAL dim^2)
     const size_t nd = (size_t)3 * K * 64 + (size_t)K * S * LS_REC + (size_t)K * LS_REC + (size_t)2 * K * LS_EVAL_MAX * 64 +
@@ -1551,9 +1555,10 @@ static int lockstep_signature_solves(salnmf_engine* e, const double* U, const do
     q.sig.status = e->ls_int + 128;
     q.active = e->ls_int + 192;
     int* hactive = reinterpret_cast<int*>(e->hpin);
-    const dim3 grid(S, K);
+    const dim3 grid(S, groups);
     // start: sg = sum_n aux[n][k] U[n][:] and the first requests (the start points)
-    hipLaunchKernelGGL(ls_begin_kernel, grid, dim3(SIGT), 0, e->stream, q);
+    if (multi) hipLaunchKernelGGL(ls_begin_multi_kernel, grid, dim3(SIGT), 0, e->stream, q);
+    else hipLaunchKernelGGL(ls_begin_kernel, grid, dim3(SIGT), 0, e->stream, q);
     hipLaunchKernelGGL(ls_reduce_kernel, dim3(K), dim3(256), 0, e->stream, q.part, q.red, q.state, S, 2, 64, 1);
     HIPCK(hipGetLastError());
     if (shard) CK(allreduce(e, q.red, (size_t)K * LS_REC));
@@ -1562,7 +1567,8 @@ static int lockstep_signature_solves(salnmf_engine* e, const double* U, const do
     const int rec = 66 + dim * dim;
     bool finished = false;
     for (int round = 0; round < LS_EVAL_MAX + 2; ++round) {
-        hipLaunchKernelGGL(ls_eval_kernel, grid, dim3(SIGT), 0, e->stream, q);
+        if (multi) hipLaunchKernelGGL(ls_eval_multi_kernel, grid, dim3(SIGT), 0, e->stream, q);
+        else hipLaunchKernelGGL(ls_eval_kernel, grid, dim3(SIGT), 0, e->stream, q);
         hipLaunchKernelGGL(ls_reduce_kernel, dim3(K), dim3(256), 0, e->stream, q.part, q.red, q.state, S, 0, rec, 0);
         HIPCK(hipGetLastError());
         if (shard) CK(allreduce(e, q.red, (size_t)K * LS_REC));

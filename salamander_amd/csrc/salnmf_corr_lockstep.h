@@ -142,6 +142,165 @@ __global__ void __launch_bounds__(SIGT) ls_eval_kernel(LockstepParams q) {
     }
 }
 
+// ---- the same two passes for LS_GROUP signatures per workgroup (dim <= 48).  A pass over the samples is bound by
+// reading U: with one signature per workgroup every signature re-reads all of U (2.6 GB per round at c5: 0.87 of the
+// 1.73 ms of a round, measured by switching the arithmetic off), and aux is read one 8-byte column at a time.  Here a
+// staged tile of U serves LS_GROUP signatures (U traffic / LS_GROUP, aux columns of a group share their cache lines);
+// per signature the arithmetic, its order and the reduction over the chunks are those of the kernels above.
+constexpr int LS_GROUP = 4;
+
+// Hessian tiles of DT <= 3 in a compact array: (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
+__device__ inline void ls_hess_tile3(const SignatureEmbeddingEval& ev, d4 (&acc)[6]) {
+    const int c16 = ev.lane & 15, q = ev.lane >> 4, DT = ev.DT;
+    const double* base = ev.Ut + (64 * ev.wave + q) * ev.ldu + c16;
+    double wv[2], a[2][3];
+    wv[0] = ev.wt[64 * ev.wave + q];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) a[0][t] = t < DT ? base[16 * t] : 0.0;
+#pragma unroll
+    for (int sgrp = 0; sgrp < 16; ++sgrp) {
+        const int cur = sgrp & 1, nxt = cur ^ 1;
+        if (sgrp + 1 < 16) {
+            wv[nxt] = ev.wt[64 * ev.wave + 4 * (sgrp + 1) + q];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) a[nxt][t] = t < DT ? base[4 * (sgrp + 1) * ev.ldu + 16 * t] : 0.0;
+        }
+        double b[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) b[t] = wv[cur] * a[cur][t];
+        acc[0] = mfma(a[cur][0], b[0], acc[0]);
+        if (DT > 1) {  // uniform over the workgroup
+            acc[1] = mfma(a[cur][0], b[1], acc[1]);
+            acc[3] = mfma(a[cur][1], b[1], acc[3]);
+        }
+        if (DT > 2) {
+            acc[2] = mfma(a[cur][0], b[2], acc[2]);
+            acc[4] = mfma(a[cur][1], b[2], acc[4]);
+            acc[5] = mfma(a[cur][2], b[2], acc[5]);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(SIGT) ls_begin_multi_kernel(LockstepParams q) {
+    __shared__ double pool[SIG_POOL];
+    __shared__ double wt[SIGT], sred[SIGT], ybuf[64], red[4 * 64];
+    const int kbase = blockIdx.y * LS_GROUP, s = blockIdx.x;
+    SignatureEmbeddingEval ev;
+    ls_setup_eval(ev, q, pool, wt, sred, ybuf, red, kbase, s);
+    if (s == 0 && threadIdx.x < 64) {
+        for (int g = 0; g < LS_GROUP && kbase + g < q.sig.K; ++g) {
+            const int k = kbase + g;
+            const double x = ev.lane < q.sig.dim ? q.sig.L[k * q.sig.dim + ev.lane] : 0.0;
+            q.x0[k * 64 + ev.lane] = x;
+            q.req[k * 64 + ev.lane] = x;
+            if (threadIdx.x == 0) {
+                q.state[k] = LS_NEED;
+                q.n_evals[k] = 0;
+            }
+        }
+    }
+    double r[LS_GROUP];
+#pragma unroll
+    for (int g = 0; g < LS_GROUP; ++g) r[g] = 0.0;
+    for (int64_t t0 = ev.n_begin; t0 < ev.n_end; t0 += SIGT) {
+        ev.stage(t0);
+        const int64_t n = t0 + ev.tid;
+#pragma unroll
+        for (int g = 0; g < LS_GROUP; ++g) {
+            if (kbase + g >= q.sig.K) continue;  // uniform
+            wt[ev.tid] = n < ev.n_end ? q.sig.aux[n * q.sig.KP + kbase + g] : 0.0;
+            __syncthreads();
+            r[g] = ev.tile_weighted(r[g]);
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < LS_GROUP; ++g) {
+        if (kbase + g >= q.sig.K) continue;
+        const double t = ev.cross_wave(r[g]);
+        if (ev.wave == 0) q.part[((int64_t)(kbase + g) * q.S + s) * LS_REC + 2 + ev.lane] = t;
+    }
+}
+
+__global__ void __launch_bounds__(SIGT) ls_eval_multi_kernel(LockstepParams q) {
+    const int kbase = blockIdx.y * LS_GROUP, s = blockIdx.x;
+    bool live[LS_GROUP], any = false;
+#pragma unroll
+    for (int g = 0; g < LS_GROUP; ++g) {
+        live[g] = kbase + g < q.sig.K && q.state[kbase + g] == LS_NEED;  // uniform over the workgroup
+        any |= live[g];
+    }
+    if (!any) return;
+    __shared__ double pool[SIG_POOL];
+    __shared__ double wt[SIGT], sred[SIGT], ybufs[LS_GROUP][64], red[4 * 64];
+    SignatureEmbeddingEval ev;
+    ls_setup_eval(ev, q, pool, wt, sred, ybufs[0], red, kbase, s);
+    const int dim = q.sig.dim;
+    double cg[LS_GROUP], yg[LS_GROUP];
+#pragma unroll
+    for (int g = 0; g < LS_GROUP; ++g) {
+        const int k = live[g] ? kbase + g : kbase;
+        cg[g] = q.sig.beta[k];
+        yg[g] = (live[g] && ev.lane < dim) ? q.req[k * 64 + ev.lane] : 0.0;
+        if (ev.wave == 0) ybufs[g][ev.lane] = yg[g];
+    }
+    __syncthreads();
+    double lin[LS_GROUP], ex[LS_GROUP], r[LS_GROUP];
+    d4 acc[LS_GROUP][6];
+#pragma unroll
+    for (int g = 0; g < LS_GROUP; ++g) {
+        lin[g] = ex[g] = r[g] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) acc[g][i] = (d4){0, 0, 0, 0};
+    }
+    for (int64_t t0 = ev.n_begin; t0 < ev.n_end; t0 += SIGT) {
+        ev.stage(t0);
+        const int64_t n = t0 + ev.tid;
+        const bool in = n < ev.n_end;
+        const double al = in ? q.sig.alpha[n] : 0.0;
+#pragma unroll
+        for (int g = 0; g < LS_GROUP; ++g) {
+            if (!live[g]) continue;  // uniform
+            double w = 0.0;
+            if (in) {
+                ev.ybuf = ybufs[g];
+                const double sdot = ev.row_dot(ev.tid);
+                lin[g] = __builtin_fma(sdot, q.sig.aux[n * q.sig.KP + kbase + g], lin[g]);
+                w = exp((cg[g] + al) + sdot);
+                ex[g] += w;
+            }
+            wt[ev.tid] = w;
+            __syncthreads();
+            r[g] = ev.tile_weighted(r[g]);
+            ls_hess_tile3(ev, acc[g]);
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < LS_GROUP; ++g) {
+        if (!live[g]) continue;
+        const int k = kbase + g;
+        const double tot = ev.cross_wave(r[g]);
+        const double vlin = ev.block_sum(lin[g]), vex = ev.block_sum(ex[g]);
+        d4 full[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) full[i] = (d4){0, 0, 0, 0};
+        full[0] = acc[g][0], full[1] = acc[g][1], full[2] = acc[g][2], full[4] = acc[g][3], full[5] = acc[g][4], full[7] = acc[g][5];
+        ev.hess_finish(full, yg[g]);  // the Hessian sum of this chunk in ev.Al [16 DT][CORR_LD]
+        double* out = q.part + ((int64_t)k * q.S + s) * LS_REC;
+        if (ev.tid == 0) {
+            out[0] = vlin;
+            out[1] = vex;
+        }
+        if (ev.wave == 0) out[2 + ev.lane] = tot;
+        for (int i = ev.tid; i < dim * dim; i += SIGT) {
+            const int m = i / dim, j = i - m * dim;
+            out[66 + i] = ev.Al[m * CORR_LD + j];
+        }
+        __syncthreads();  // Al / the staging copies are rewritten for the next signature
+    }
+}
+
 // red[k][e] = sum over the S chunk partials, fixed order; only the first `len` entries of a record are live
 __global__ void __launch_bounds__(256) ls_reduce_kernel(const double* __restrict__ part, double* __restrict__ red, const int* __restrict__ state,
                                                         int S, int first, int len, int all_signatures) {

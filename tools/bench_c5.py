@@ -14,7 +14,8 @@ from salamander_amd import synthetic as orc
 from salamander_amd.models import MultimodalCorrNMF
 
 out = []
-for N, dim in [(50000, 40), (200000, 40), (200000, 8)]:
+CONFIGS = [(200000, 40)] if __import__("os").environ.get("C5_ONLY_FULL") else [(50000, 40), (200000, 40), (200000, 8)]
+for N, dim in CONFIGS:
     Xa, _, _ = orc.synthetic_problem(96, N, 40, seed=1)
     Xb, _, _ = orc.synthetic_problem(83, N, 40, seed=2)
     mdata = sal.MuData({"sbs": sal.AnnData(Xa), "indel": sal.AnnData(Xb)})
