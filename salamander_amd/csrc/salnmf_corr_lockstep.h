@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(SIGT) ls_eval_kernel(LockstepParams q) {
 // 1.73 ms of a round, measured by switching the arithmetic off), and aux is read one 8-byte column at a time.  Here a
 // staged tile of U serves LS_GROUP signatures (U traffic / LS_GROUP, aux columns of a group share their cache lines);
 // per signature the arithmetic, its order and the reduction over the chunks are those of the kernels above.
-constexpr int LS_GROUP = 4;
+constexpr int LS_GROUP = 5;
 
 // Hessian tiles of DT <= 3 in a compact array: (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
 __device__ inline void ls_hess_tile3(const SignatureEmbeddingEval& ev, d4 (&acc)[6]) {
