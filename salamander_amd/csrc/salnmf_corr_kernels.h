@@ -221,8 +221,18 @@ struct SampleEmbeddingEval {
             const int i = lane + 64 * t;
             double acc = 0.0;
             if (i < T) {
+                // four partial sums (m mod 4): one chain of dim dependent FMAs would wait out every FMA's latency
                 const double* row = O + i * CORR_LD;
-                for (int m = 0; m < dim; ++m) acc = __builtin_fma(row[m], vbuf[m], acc);
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+                int m = 0;
+                for (; m + 4 <= dim; m += 4) {
+                    a0 = __builtin_fma(row[m], vbuf[m], a0);
+                    a1 = __builtin_fma(row[m + 1], vbuf[m + 1], a1);
+                    a2 = __builtin_fma(row[m + 2], vbuf[m + 2], a2);
+                    a3 = __builtin_fma(row[m + 3], vbuf[m + 3], a3);
+                }
+                for (; m < dim; ++m) a0 = __builtin_fma(row[m], vbuf[m], a0);
+                acc = (a0 + a1) + (a2 + a3);
             }
             s[t] = acc;
         }
@@ -235,8 +245,18 @@ struct SampleEmbeddingEval {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         double r = 0.0;
-        if (lane < dim)
-            for (int i = 0; i < T; ++i) r = __builtin_fma(wbuf[i], O[i * CORR_LD + lane], r);
+        if (lane < dim) {
+            double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;  // (four partial sums, as in products)
+            int i = 0;
+            for (; i + 4 <= T; i += 4) {
+                r0 = __builtin_fma(wbuf[i], O[i * CORR_LD + lane], r0);
+                r1 = __builtin_fma(wbuf[i + 1], O[(i + 1) * CORR_LD + lane], r1);
+                r2 = __builtin_fma(wbuf[i + 2], O[(i + 2) * CORR_LD + lane], r2);
+                r3 = __builtin_fma(wbuf[i + 3], O[(i + 3) * CORR_LD + lane], r3);
+            }
+            for (; i < T; ++i) r0 = __builtin_fma(wbuf[i], O[i * CORR_LD + lane], r0);
+            r = (r0 + r1) + (r2 + r3);
+        }
         __builtin_amdgcn_wave_barrier();
         return r;
     }
