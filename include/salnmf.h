@@ -57,6 +57,10 @@ typedef struct salnmf_engine salnmf_engine;
 
 const char* salnmf_last_error(void);
 int salnmf_version(void);
+/* Optional parts compiled into this library: SALNMF_BUILD_PERSISTENT = the persistent multi-step KL kernel
+ * (a measured negative; only in builds made with SALNMF_WITH_PERSISTENT=1). */
+#define SALNMF_BUILD_PERSISTENT 1
+int salnmf_build_flags(void);
 int salnmf_device_count(void);
 
 /* Create an engine for a shard of n_samples rows on HIP device `device`.
@@ -88,14 +92,15 @@ int salnmf_download_H(salnmf_engine* e, double* H);
 
 /* n_steps joint KLNMF updates, device resident: update_WH, _utils_klnmf.py:281-361.
  * The first n_given rows of W are never changed.
- * Opt-in (salnmf_set_persistent / SALNMF_PERSISTENT=1): with n_steps >= 2, no per-sample weights and no communicator
+ * Opt-in (salnmf_set_persistent, in builds compiled with -DSALNMF_WITH_PERSISTENT): with n_steps >= 2, no per-sample weights and no communicator
  * attached, the steps run in ONE persistent launch (workgroups stay resident; the W tail and its hand-offs happen
  * inside the kernel) -- same bits as step-by-step launches, measured 10 % slower on MI355X, hence off
  * by default.  A wait inside that kernel that gives up (another process holding CUs) is reported by the next
  * synchronising call as an error; the resident state is then invalid. */
 int salnmf_kl_step(salnmf_engine* e, int n_steps, int n_given);
-/* Switch the persistent multi-step launch of salnmf_kl_step on (1) or off (0, the default; the environment
- * variable SALNMF_PERSISTENT=1 changes the default).  Measurement aid. */
+/* Switch the persistent multi-step launch of salnmf_kl_step on (1) or off (0, the default).  Measurement aid: the
+ * default build does not carry that kernel (measured 10 % slower) and refuses on = 1 with an error; build with
+ * SALNMF_WITH_PERSISTENT=1 (__graft_entry__.py) to get it. */
 int salnmf_set_persistent(salnmf_engine* e, int on);
 /* update_H with the current W: _utils_klnmf.py:220-278. */
 int salnmf_update_H(salnmf_engine* e);
@@ -183,8 +188,8 @@ int salnmf_corr_update_signature_embeddings(salnmf_engine* e, double variance, i
 /* From 16 384 samples on, the signature solves run in LOCKSTEP (csrc/salnmf_corr_lockstep.h): one evaluation round
  * per launch over (chunks x signatures) workgroups, the K Newton-CG solvers replayed from their evaluation logs
  * between rounds -- 3x faster than one workgroup per signature at c5, and shardable: a sample-sharded engine
- * all-reduces the 1 + dim + dim^2 sums per signature of every round.  0 forces the single-kernel form (also
- * SALNMF_LOCKSTEP=0); the two agree to rounding of the sums. */
+ * all-reduces the 1 + dim + dim^2 sums per signature of every round.  0 forces the single-kernel form; the two agree
+ * to rounding of the sums. */
 int salnmf_set_lockstep(salnmf_engine* e, int on);
 
 /* Opt-in fast mode of salnmf_kl_step: the joint update_WH step on the fp32 matrix cores (fp32 copies of X and H are made
@@ -251,12 +256,15 @@ int salnmf_comm_info(salnmf_engine* e, int* n_ranks, int* rank, int64_t* n_sampl
  *   connect: maps the peers' inboxes; `handles` = n_ranks * SALNMF_P2P_HANDLE_BYTES in rank order (the host layer
  *            all-gathers them); n_samples_total = samples over all shards (used when no RCCL communicator is attached)
  *   set_p2p: switch the exchange off / on again (off: the all-reduces go through RCCL, which must then be attached)
+ *   set_p2p_timeout_ms: how long a rank waits for a peer inside an exchange before it gives up (default 20 000 ms:
+ *            the ranks' host threads may be that far apart)
  * Every rank must issue the same sequence of calls on its engine.  A rank that waits 20 s for a peer gives up: the
  * next download / objective call on that engine fails, and its later exchanges return at once.  Destroy the engines only after all ranks are done. */
 #define SALNMF_P2P_HANDLE_BYTES 64
 int salnmf_p2p_export(salnmf_engine* e, int n_ranks, int64_t max_count, char* handle_out /* SALNMF_P2P_HANDLE_BYTES */);
 int salnmf_p2p_connect(salnmf_engine* e, int rank, int n_ranks, const char* handles, int64_t n_samples_total);
 int salnmf_set_p2p(salnmf_engine* e, int on);
+int salnmf_set_p2p_timeout_ms(salnmf_engine* e, int64_t timeout_ms);
 
 /* The joint step split at the exchange point, for a caller-side collective
  * (e.g. torch.distributed on a wrapped device pointer):

@@ -29,6 +29,7 @@ _D = POINTER(c_double)
 SIGNATURES = {
     "salnmf_last_error": (c_char_p, []),
     "salnmf_version": (c_int, []),
+    "salnmf_build_flags": (c_int, []),
     "salnmf_device_count": (c_int, []),
     "salnmf_create": (c_int, [c_int, c_int, c_int64, c_int, POINTER(_P)]),
     "salnmf_destroy": (None, [_P]),
@@ -73,6 +74,7 @@ SIGNATURES = {
     "salnmf_comm_init": (c_int, [_P, ctypes.c_char_p, c_int, c_int]),
     "salnmf_comm_info": (c_int, [_P, POINTER(c_int), POINTER(c_int), POINTER(c_int64)]),
     "salnmf_p2p_export": (c_int, [_P, c_int, c_int64, ctypes.c_char_p]),
+    "salnmf_set_p2p_timeout_ms": (c_int, [_P, c_int64]),
     "salnmf_p2p_connect": (c_int, [_P, c_int, c_int, ctypes.c_char_p, c_int64]),
     "salnmf_set_p2p": (c_int, [_P, c_int]),
     "salnmf_kl_step_partial": (c_int, [_P]),
@@ -85,7 +87,11 @@ SIGNATURES = {
     "salnmf_profile_reconstruct": (c_int, [_P, c_int, _D]),
 }
 
+BUILD_PERSISTENT = 1  # salnmf_build_flags(): the library carries the persistent multi-step kernel
+
 _lib = None
+# explicit selector (no environment switch): whether load() opens PyTorch-ROCm's bundled HIP runtime first
+SHARE_TORCH_RUNTIME = True
 
 
 class EngineUnavailable(RuntimeError):
@@ -107,11 +113,12 @@ def _share_torch_hip_runtime() -> None:
     torch's ``librccl.so`` by hand from a process that never initialises torch aborted in that library's static
     destructors at exit -- nothing here does that any more.)  :func:`mapped_runtime_libraries` reports what is mapped;
     the tests assert one HIP runtime and at most one RCCL for both import orders.
-    ``SALNMF_SHARE_TORCH_RUNTIME=0`` disables the preload; without torch the system libraries are used."""
+    ``salamander_amd._lib.SHARE_TORCH_RUNTIME = False`` (set before the first engine is created) disables the preload;
+    without torch the system libraries are used."""
     import importlib.util
     import sys
 
-    if "torch" in sys.modules or os.environ.get("SALNMF_SHARE_TORCH_RUNTIME", "1") == "0":
+    if "torch" in sys.modules or not SHARE_TORCH_RUNTIME:
         return
     try:
         spec = importlib.util.find_spec("torch")

@@ -2,13 +2,12 @@
 // One engine = one GPU = one shard of the sample axis.  All launches go to the
 // engine's own HIP stream; nothing inside a step synchronises with the host.
 #include "../../include/salnmf.h"
-#include "salnmf_kernels.h"
+#include "salnmf_launch.h"
 #include "salnmf_mv_kernels.h"
 #include "salnmf_corr_kernels.h"
 #include "salnmf_corr_lockstep.h"
 #include "salnmf_init_kernels.h"
 #include "salnmf_p2p_kernels.h"
-#include "salnmf_kernels_f32.h"
 
 #include <dlfcn.h>
 #include <hip/hip_ext.h>
@@ -167,7 +166,7 @@ struct salnmf_engine {
     hipEvent_t stage_done[2] = {nullptr, nullptr};
     unsigned* psync = nullptr;   // persistent kernel: device sync words (SYNC_WORDS), zeroed before every launch
     unsigned* pabort = nullptr;  // pinned host word the persistent kernel sets when a wait gives up
-    bool persistent = false;     // multi-step kl_step calls run as one persistent launch (opt-in: SALNMF_PERSISTENT=1)
+    bool persistent = false;     // multi-step kl_step calls run as one persistent launch (opt-in: salnmf_set_persistent)
     ncclComm_t comm = nullptr;
     int n_ranks = 1, rank = 0;
     // opt-in fp32 fast mode of the KL step (salnmf_kernels_f32.h): fp32 shadow copies of X and H, made when needed
@@ -192,7 +191,7 @@ struct salnmf_engine {
     int* ls_int = nullptr;
     size_t ls_doubles = 0;
     int ls_S = 0, ls_dim = 0;
-    bool lockstep = true;  // SALNMF_LOCKSTEP=0 forces the single-kernel form
+    bool lockstep = true;  // salnmf_set_lockstep(e, 0) forces the single-kernel form
     double *gU = nullptr, *galpha = nullptr, *gaux = nullptr;
     size_t g_rows = 0;
     int g_dim = 0;
@@ -215,61 +214,26 @@ static int pick_ks(int K) {
 
 // ------------------------------------------------------------------------------------ launches
 
-// (KS, KTM, KR) combinations that are instantiated; K -> combination in pick_geometry()
-#define SALNMF_GEOMETRIES(X) \
-    X(1, 1, 0) X(2, 1, 0) X(4, 1, 0) X(8, 2, 0) X(10, 3, 0) X(13, 3, 0) X(16, 4, 0) \
-    X(8, 1, 1) X(8, 1, 2) X(8, 1, 3) X(8, 1, 4)                                      \
-    X(10, 2, 1) X(10, 2, 2) X(10, 2, 3) X(10, 2, 4)                                  \
-    X(13, 3, 1) X(13, 3, 2) X(13, 3, 3) X(13, 3, 4)
-
 // ev_start / ev_stop (profiling only): bound to the dispatch itself, so that their elapsed time is the kernel's own
-// duration, as rocprofv3 reports it -- events recorded around the launch add their barrier packets to it
+// duration, as rocprofv3 reports it -- events recorded around the launch add their barrier packets to it.
+// The instantiations live in salnmf_fused_inst.hip / salnmf_forward_inst.hip (salnmf_launch.h).
 template <bool DO_G, bool DO_U, bool DO_STATS>
 static int launch_fused(salnmf_engine* e, const FusedParams& p, int grid = 0, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
-    dim3 g(grid > 0 ? grid : e->grid), b(BLOCK);
-    bool done = false;
     // per-sample weights select the WTS instantiation (KLNMF only: the MvNMF / CorrNMF passes, which are the
     // ones that collect statistics, are unweighted)
     const bool wts = p.wkl || p.wlh;
     if (wts && DO_STATS) return fail("internal: weighted pass with statistics is not instantiated");
-#define SALNMF_CASE(ks, ktm, kr)                                                                                   \
-    if (!done && e->KS == ks && e->KTM == ktm && e->KR == kr) {                                                    \
-        if constexpr (!DO_STATS) {                                                                                 \
-            if (wts) hipLaunchKernelGGL((fused_kernel<ks, ktm, kr, DO_G, DO_U, false, true>), g, b, 0, e->stream, p);  \
-            else if (ev_stop) hipExtLaunchKernelGGL((fused_kernel<ks, ktm, kr, DO_G, DO_U, false, false>), g, b, 0, e->stream, ev_start, ev_stop, 0, p); \
-            else hipLaunchKernelGGL((fused_kernel<ks, ktm, kr, DO_G, DO_U, false, false>), g, b, 0, e->stream, p);     \
-        } else {                                                                                                   \
-            hipLaunchKernelGGL((fused_kernel<ks, ktm, kr, DO_G, DO_U, DO_STATS, false>), g, b, 0, e->stream, p);   \
-        }                                                                                                          \
-        done = true;                                                                                               \
-    }
-    SALNMF_GEOMETRIES(SALNMF_CASE)
-#undef SALNMF_CASE
-    if (!done) return fail("no kernel instantiation for KS=%d KTM=%d KR=%d", e->KS, e->KTM, e->KR);
+    const FusedSel sel{e->KS, e->KTM, e->KR, DO_G, DO_U, DO_STATS, wts, false};
+    if (launch_fused_inst(sel, p, grid > 0 ? grid : e->grid, e->stream, ev_start, ev_stop))
+        return fail("no kernel instantiation for KS=%d KTM=%d KR=%d", e->KS, e->KTM, e->KR);
     HIPCK(hipGetLastError());
     return 0;
 }
 
 template <int MODE>
 static int launch_forward(salnmf_engine* e, const FwdParams& p, int grid = 0, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
-    dim3 g(grid > 0 ? grid : e->fgrid), b(BLOCK);
-#define SALNMF_CASE(ks)                                                                                                 \
-    case ks:                                                                                                            \
-        if (ev_stop) hipExtLaunchKernelGGL((forward_kernel<ks, MODE>), g, b, 0, e->stream, ev_start, ev_stop, 0, p);    \
-        else hipLaunchKernelGGL((forward_kernel<ks, MODE>), g, b, 0, e->stream, p);                                     \
-        break;
-    switch (e->KS) {
-        SALNMF_CASE(1)
-        SALNMF_CASE(2)
-        SALNMF_CASE(4)
-        SALNMF_CASE(8)
-        SALNMF_CASE(10)
-        SALNMF_CASE(13)
-        SALNMF_CASE(16)
-        default:
-            return fail("no kernel instantiation for KS=%d", e->KS);
-    }
-#undef SALNMF_CASE
+    if (launch_forward_inst(e->KS, MODE, p, grid > 0 ? grid : e->fgrid, e->stream, ev_start, ev_stop))
+        return fail("no kernel instantiation for KS=%d", e->KS);
     HIPCK(hipGetLastError());
     return 0;
 }
@@ -427,6 +391,7 @@ extern "C" {
 
 const char* salnmf_last_error(void) { return g_err.c_str(); }
 int salnmf_version(void) { return 100; }
+int salnmf_build_flags(void) { return built_with_persistent() ? SALNMF_BUILD_PERSISTENT : 0; }
 
 int salnmf_device_count(void) {
     int n = 0;
@@ -549,13 +514,6 @@ int salnmf_create(int device, int n_features, int64_t n_samples, int n_signature
     e->pabort = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(e->hpin) + SMALL_PINNED_BYTES / 2);
     if (hipMalloc(&e->psync, SYNC_WORDS * sizeof(unsigned)) != hipSuccess) return cleanup(fail("hipMalloc failed"));
     *e->pabort = 0;
-    {
-        // measured slower than per-step launches on MI355X: opt-in
-        const char* env = getenv("SALNMF_PERSISTENT");
-        e->persistent = env && env[0] == '1';
-        const char* ls = getenv("SALNMF_LOCKSTEP");
-        e->lockstep = !(ls && ls[0] == '0');
-    }
     *out = e;
     return 0;
 }
@@ -811,16 +769,9 @@ static int kl_steps_persistent(salnmf_engine* e, int n, int n_given) {
     p.sync = e->psync;
     p.abort_host = e->pabort;
     HIPCK(hipMemsetAsync(e->psync, 0, SYNC_WORDS * sizeof(unsigned), e->stream));
-    dim3 g(e->grid), b(BLOCK);
-    bool done = false;
-#define SALNMF_CASE(ks, ktm, kr)                                                                                     \
-    if (!done && e->KS == ks && e->KTM == ktm && e->KR == kr) {                                                      \
-        hipLaunchKernelGGL((fused_kernel<ks, ktm, kr, true, true, false, false, true>), g, b, 0, e->stream, p);      \
-        done = true;                                                                                                 \
-    }
-    SALNMF_GEOMETRIES(SALNMF_CASE)
-#undef SALNMF_CASE
-    if (!done) return fail("no kernel instantiation for KS=%d KTM=%d KR=%d", e->KS, e->KTM, e->KR);
+    const FusedSel sel{e->KS, e->KTM, e->KR, true, true, false, false, true};
+    if (launch_fused_inst(sel, p, e->grid, e->stream, nullptr, nullptr))
+        return fail("this build carries no persistent kernel for KS=%d KTM=%d KR=%d (build with SALNMF_WITH_PERSISTENT)", e->KS, e->KTM, e->KR);
     HIPCK(hipGetLastError());
     return 0;
 }
@@ -833,7 +784,7 @@ static int check_abort(salnmf_engine* e) {
     }
     if (e->pabort && *e->pabort) {
         return fail("a wait inside the persistent KL kernel gave up (its workgroups were not all resident: is another process "
-                    "using this GPU?); the engine's W and H are invalid -- upload them again, and set SALNMF_PERSISTENT=0");
+                    "using this GPU?); the engine's W and H are invalid -- upload them again, and call salnmf_set_persistent(e, 0)");
     }
     return 0;
 }
@@ -846,6 +797,7 @@ int salnmf_set_lockstep(salnmf_engine* e, int on) {
 
 int salnmf_set_persistent(salnmf_engine* e, int on) {
     if (!e) return fail("null engine");
+    if (on && !built_with_persistent()) return fail("this build carries no persistent kernel (compile with -DSALNMF_WITH_PERSISTENT)");
     e->persistent = on != 0;
     return 0;
 }
@@ -877,23 +829,7 @@ static int kl_steps_f32(salnmf_engine* e, int n_steps, int n_given) {
     p.hfloor = (float)kEps;
     for (int i = 0; i < n_steps; ++i) {
         p.W = e->W;
-        dim3 g(e->grid), b(BLOCK);
-#define SALNMF_CASE(ks)                                                          \
-    case ks:                                                                     \
-        hipLaunchKernelGGL((fused_f32_kernel<ks>), g, b, 0, e->stream, p);       \
-        break;
-        switch (e->KS) {
-            SALNMF_CASE(1)
-            SALNMF_CASE(2)
-            SALNMF_CASE(4)
-            SALNMF_CASE(8)
-            SALNMF_CASE(10)
-            SALNMF_CASE(13)
-            SALNMF_CASE(16)
-            default:
-                return fail("no kernel instantiation for KS=%d", e->KS);
-        }
-#undef SALNMF_CASE
+        if (launch_fused_f32_inst(e->KS, p, e->grid, e->stream)) return fail("no kernel instantiation for KS=%d", e->KS);
         HIPCK(hipGetLastError());
         if (n_given < e->K) {  // _utils_klnmf.py:330-331: W untouched when every signature is given
             if (sharded(e))
@@ -1896,10 +1832,6 @@ int salnmf_p2p_export(salnmf_engine* e, int n_ranks, int64_t max_count, char* ha
     static_assert(sizeof(hipIpcMemHandle_t) == SALNMF_P2P_HANDLE_BYTES, "handle size");
     HIPCK(hipSetDevice(e->device));
     e->p2p.max_count = (size_t)max_count;
-    if (const char* ms = getenv("SALNMF_P2P_TIMEOUT_MS")) {
-        const long v = atol(ms);
-        if (v > 0) e->p2p.timeout_ticks = (unsigned long long)v * 100000ull;
-    }
     e->p2p.slot = (size_t)max_count + P2P_MAX_WG;
     e->p2p.n_ranks = n_ranks;
     const size_t bytes = 2 * (size_t)n_ranks * e->p2p.slot * sizeof(double);
@@ -1944,6 +1876,13 @@ int salnmf_p2p_connect(salnmf_engine* e, int rank, int n_ranks, const char* hand
     if (!e->comm) e->N_total = n_samples_total;
     e->p2p.connected = true;
     e->p2p.on = true;
+    return 0;
+}
+
+int salnmf_set_p2p_timeout_ms(salnmf_engine* e, int64_t timeout_ms) {
+    if (!e) return fail("null engine");
+    if (timeout_ms < 1) return fail("timeout_ms must be positive");
+    e->p2p.timeout_ticks = (unsigned long long)timeout_ms * 100000ull;  // the exchange kernels count the 100 MHz clock
     return 0;
 }
 

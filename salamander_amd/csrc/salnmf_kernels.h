@@ -1383,6 +1383,7 @@ struct TailParams {
     int nparts;
 };
 
+#ifndef SALNMF_TEMPLATES_ONLY  // the plain kernels below are compiled by salnmf.hip only (salnmf_launch.h)
 __global__ void __launch_bounds__(TAIL_BLOCK) tail_kernel(TailParams p) {
     __shared__ TailScratch S;
     const int k = blockIdx.x;
@@ -1505,5 +1506,7 @@ __global__ void unpad_kernel(double* __restrict__ dst, const double* __restrict_
         dst[i] = src[r * ld + c];
     }
 }
+
+#endif  // SALNMF_TEMPLATES_ONLY
 
 }  // namespace salnmf

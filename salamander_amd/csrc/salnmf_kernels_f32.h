@@ -252,6 +252,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_f32_kernel(Fused32Params p) {
     }
 }
 
+#ifndef SALNMF_TEMPLATES_ONLY
 // fp64 <-> fp32 images of the padded device arrays (X: [Np][VMAX], H: [Np][KP])
 __global__ void cvt_f64_f32_kernel(float* __restrict__ dst, const double* __restrict__ src, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = (float)src[i];
@@ -259,5 +260,7 @@ __global__ void cvt_f64_f32_kernel(float* __restrict__ dst, const double* __rest
 __global__ void cvt_f32_f64_kernel(double* __restrict__ dst, const float* __restrict__ src, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = (double)src[i];
 }
+
+#endif  // SALNMF_TEMPLATES_ONLY
 
 }  // namespace salnmf

@@ -1,0 +1,39 @@
+// Launchers of the heavy template kernels.  The instantiations live in translation units of their own
+// (salnmf_fused_inst.hip, compiled once per geometry set, and salnmf_forward_inst.hip) so that the library builds in
+// parallel: one translation unit with all ~170 instantiations of the fused pass took three minutes.  Every
+// instantiation exists in exactly one translation unit; salnmf.hip only calls these functions.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "salnmf_kernels.h"
+#include "salnmf_kernels_f32.h"
+
+namespace salnmf {
+
+constexpr int FUSED_GEOM_SETS = 6;
+
+struct FusedSel {
+    int KS, KTM, KR;               // geometry (salnmf.hip: pick_ks / salnmf_create)
+    bool G, U, STATS, WTS;         // template switches of fused_kernel
+    bool PERSIST;                  // the persistent multi-step variant (only in builds with SALNMF_WITH_PERSISTENT)
+};
+
+// Return 0 when the kernel was launched (HIP launch errors are left for hipGetLastError), 1 when this build has no
+// such instantiation.  ev_start / ev_stop (may be null) are bound to the dispatch itself (hipExtLaunchKernelGGL).
+int launch_fused_inst(const FusedSel& s, const FusedParams& p, int grid, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop);
+int launch_forward_inst(int KS, int mode, const FwdParams& p, int grid, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop);
+int launch_fused_f32_inst(int KS, const Fused32Params& p, int grid, hipStream_t stream);
+bool built_with_persistent();
+
+// one function per geometry set (salnmf_fused_inst.hip compiled with -DSALNMF_GEOM_SET=i)
+#define SALNMF_DECLARE_SET(i) \
+    int launch_fused_set##i(const FusedSel& s, const FusedParams& p, int grid, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop);
+SALNMF_DECLARE_SET(0)
+SALNMF_DECLARE_SET(1)
+SALNMF_DECLARE_SET(2)
+SALNMF_DECLARE_SET(3)
+SALNMF_DECLARE_SET(4)
+SALNMF_DECLARE_SET(5)
+#undef SALNMF_DECLARE_SET
+
+}  // namespace salnmf

@@ -29,7 +29,7 @@ namespace salnmf {
 
 constexpr int P2P_MAX_RANKS = 8;
 constexpr int P2P_BLOCK = 256;
-constexpr unsigned long long P2P_TIMEOUT_TICKS = 2000000000ull;  // default: 20 s of the 100 MHz clock (ranks may be that far apart on the host side); SALNMF_P2P_TIMEOUT_MS overrides
+constexpr unsigned long long P2P_TIMEOUT_TICKS = 2000000000ull;  // default: 20 s of the 100 MHz clock (ranks may be that far apart on the host side); salnmf_set_p2p_timeout_ms overrides
 constexpr int P2P_MAX_WG = 64;  // flags per slot: workgroups of one exchange (max_count <= 16384 doubles), or signature rows
 
 struct P2PParams {

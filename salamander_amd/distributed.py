@@ -55,19 +55,22 @@ def attach_communicator(engine, group=None) -> None:
     engine.comm_init(box[0], world, rank)
 
 
-def attach_peer_exchange(engine, n_samples_total: int | None = None, group=None, required: bool = True) -> bool:
+def attach_peer_exchange(engine, n_samples_total: int | None = None, group=None, required: bool = True, timeout_ms: int | None = None) -> bool:
     """Connect the engines of all ranks of ``group`` (one node) for the peer-to-peer exchange of the small
     all-reduces (``include/salnmf.h``: ``salnmf_p2p_export`` / ``salnmf_p2p_connect``).  The IPC handles and the shard
     sizes travel through ``torch.distributed`` (any backend); the exchange itself never touches the host.
 
     ``required=False``: if any rank cannot export or map an inbox (no peer access between two of the GPUs, more than 8
     ranks, ...) every rank leaves the exchange off -- the engines then need their RCCL communicator -- and False is
-    returned on all of them instead of an exception on some."""
+    returned on all of them instead of an exception on some.  ``timeout_ms``: how long an exchange waits for a peer
+    before it gives up (default 20 s)."""
     dist = _dist()
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     error = None
     try:
         handle = engine.p2p_export(world)
+        if timeout_ms is not None:
+            engine.set_p2p_timeout(timeout_ms)
     except RuntimeError as exc:
         if required:
             raise

@@ -117,7 +117,8 @@ class Engine:
         _lib.check(self._lib.salnmf_set_lockstep(self._h, int(bool(on))))
 
     def set_persistent(self, on: bool = True):
-        """Run multi-step ``kl_step`` calls as one persistent launch (default) or as per-step launches."""
+        """Run multi-step ``kl_step`` calls as one persistent launch (only in builds with ``SALNMF_WITH_PERSISTENT=1``:
+        measured 10 % slower, so the default library does not carry that kernel) or as per-step launches (default)."""
         _lib.check(self._lib.salnmf_set_persistent(self._h, int(bool(on))))
 
     def update_H(self):
@@ -307,6 +308,10 @@ class Engine:
         if any(len(h) != _lib.P2P_HANDLE_BYTES for h in handles):
             raise ValueError("a handle has the wrong length")
         _lib.check(self._lib.salnmf_p2p_connect(self._h, int(rank), len(handles), b"".join(handles), int(n_samples_total)))
+
+    def set_p2p_timeout(self, timeout_ms: int):
+        """How long an exchange waits for a peer before it gives up (default 20 s)."""
+        _lib.check(self._lib.salnmf_set_p2p_timeout_ms(self._h, int(timeout_ms)))
 
     def set_p2p(self, on: bool):
         _lib.check(self._lib.salnmf_set_p2p(self._h, int(bool(on))))

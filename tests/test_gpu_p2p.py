@@ -100,7 +100,6 @@ def test_sharded_steps_over_peer_exchange_match_unsharded_oracle(tmp_path, world
 def _stalled_worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    os.environ["SALNMF_P2P_TIMEOUT_MS"] = "300"
     import torch.distributed as dist
 
     from oracle import klnmf_oracle as orc
@@ -114,7 +113,7 @@ def _stalled_worker(rank, world, port, out_dir):
         a, b = shard_bounds(640, world, rank)
         e = Engine(b - a, V, 8)
         e.upload_X(X[a:b]), e.upload_W(W0), e.upload_H(H0[a:b])
-        attach_peer_exchange(e)
+        attach_peer_exchange(e, timeout_ms=300)
         e.kl_step(2, 0)
         e.download_W()
         message = ""

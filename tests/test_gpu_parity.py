@@ -336,7 +336,15 @@ def test_typed_chunked_ingest_equals_host_conversion(dtype, N, V):
 def test_persistent_multi_step_launch_gives_the_same_bits():
     """The opt-in persistent kernel (n steps in one launch, in-kernel hand-offs) against per-step
     launches: bit-identical W, H and objective, incl. given signatures, a grid smaller than the CU count and a step
-    count that is split over several launches."""
+    count that is split over several launches.  The default library does not carry that kernel (a measured negative):
+    there the switch must refuse, and the comparison runs only in builds made with SALNMF_WITH_PERSISTENT=1."""
+    if not (_lib.load().salnmf_build_flags() & _lib.BUILD_PERSISTENT):
+        e = Engine(500, 96, 5)
+        with pytest.raises(RuntimeError, match="persistent"):
+            e.set_persistent(True)
+        e.set_persistent(False)
+        e.close()
+        return
     for N, K, n_given, steps in ((20000, 50, 0, 7), (3000, 50, 7, 70), (100003, 30, 0, 3), (500, 5, 0, 4)):
         X, W0, H0 = orc.synthetic_problem(96, N, K, seed=N % 97)
         outs = []
