@@ -140,7 +140,9 @@ struct salnmf_engine {
     double* KLpart2 = nullptr;   // [grid] KL partials of a speculative update_H pass (the trial's objective)
     double* red = nullptr;       // [K*V | K | 1 | pad]  G, rowsums_H, KL of the local shard (then all-reduced)
     double* objpart = nullptr;   // [grid]
-    double* scal = nullptr;      // device scalars: [0]=objective, [1]=f0, [2]=f1, [3]=logdet0, [4]=logdet1
+    double* scal = nullptr;      // device scalars: [0]=objective, [1]=f0, [2]=f1, [3]=logdet0, [4]=logdet1, [5..7] CorrNMF sums, [SCAL_XLX]=sum of xlx
+    double* xlx = nullptr;       // [Np] c_d = sum_v (x log x - x): the x-only part of the KL divergence (tile_kl), lazily computed
+    bool xlx_valid = false;
     double* Wunc = nullptr;      // MvNMF scratch [K][V]
     double* Wtrial = nullptr;    // [K][V]
     double* mvA = nullptr;       // [K][V]  W @ Y_minus
@@ -202,6 +204,8 @@ static int check_abort(salnmf_engine* e);
 constexpr size_t SMALL_PINNED_BYTES = 4096;  // per-engine pinned block: read-back scalars, the abort word at its middle
 static void release_pinned(void* p, int small_block);
 static hipError_t acquire_pinned(void** out, int small_block);
+
+constexpr int SCAL_XLX = 8;  // slot of e->scal that holds the sum over the samples of xlx
 
 static const int kKS[] = {1, 2, 4, 8, 10, 13, 16};
 
@@ -272,6 +276,7 @@ static TailParams tail_params(salnmf_engine* e, int nslabs, double* G, int n_giv
     t.hsum_part = with_stats ? e->Hsumpart : nullptr;
     t.hsum_out = e->red + (size_t)e->K * e->V;
     t.kl_part = with_stats ? e->KLpart : nullptr;
+    t.kl_const = e->scal + SCAL_XLX;
     t.kl_out = e->red + (size_t)e->K * e->V + e->K;
     t.nparts = nslabs;
     return t;
@@ -344,6 +349,18 @@ static int sharded_tail(salnmf_engine* e, int n_given, int clip_mode) {
     return launch_tail(e, 0, e->red, n_given, clip_mode, 1);
 }
 
+// the x-only part of the KL divergence (salnmf_kernels.h: tile_kl), once per upload of X: c_d per sample and their sum
+static int ensure_xlogx(salnmf_engine* e) {
+    if (e->xlx_valid) return 0;
+    if (!e->xlx) HIPCK(hipMalloc(&e->xlx, (size_t)e->Np * sizeof(double)));
+    hipLaunchKernelGGL(xlogx_rowsum_kernel, dim3((unsigned)((e->Np + 15) / 16)), dim3(256), 0, e->stream, e->X, e->Np, e->V, VMAX, e->xlx);
+    HIPCK(hipGetLastError());
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, e->xlx, (int)e->Np, 1, 1, e->scal + SCAL_XLX, nullptr);
+    HIPCK(hipGetLastError());
+    e->xlx_valid = true;
+    return 0;
+}
+
 // materialise a pending rescale of H (needed only by readers that cannot apply it on the fly)
 static int flush_H_scale(salnmf_engine* e) {
     if (!e->h_pending) return 0;
@@ -410,7 +427,7 @@ void salnmf_destroy(salnmf_engine* e) {
     if (e->X32) (void)hipFree(e->X32);
     if (e->H32) (void)hipFree(e->H32);
     if (e->p2p.abort_dev) (void)hipFree(e->p2p.abort_dev);
-    double* bufs[] = {e->X, e->H, e->W, e->wkl, e->wlh, e->Gpart, e->Hsumpart, e->KLpart, e->red,
+    double* bufs[] = {e->xlx, e->X, e->H, e->W, e->wkl, e->wlh, e->Gpart, e->Hsumpart, e->KLpart, e->red,
                       e->objpart, e->scal, e->Wunc, e->Wtrial, e->mvA, e->mvB, e->cs, e->scratch, e->Halt, e->KLpart2,
                       e->alpha, e->beta, e->Lemb, e->Uemb, e->aux, e->xrowsum, e->corrpart, e->gU, e->galpha, e->gaux};
     for (double* b : bufs)
@@ -498,7 +515,7 @@ int salnmf_create(int device, int n_features, int64_t n_samples, int n_signature
     ALLOC(e->KLpart, (size_t)e->grid);
     ALLOC(e->red, K * V + K + 2);
     ALLOC(e->objpart, (size_t)e->fgrid);
-    ALLOC(e->scal, 8);
+    ALLOC(e->scal, 16);
     ALLOC(e->Wunc, K * V);
     ALLOC(e->Wtrial, K * V);
     ALLOC(e->mvA, K * V);
@@ -707,7 +724,7 @@ static int download_padded(salnmf_engine* e, double* dst, const double* src, int
 
 int salnmf_upload_X_typed(salnmf_engine* e, const void* X, int dtype, int clip) {
     if (!e) return fail("null engine");
-    e->xrowsum_valid = e->lgam_valid = e->x32_valid = false;
+    e->xrowsum_valid = e->lgam_valid = e->x32_valid = e->xlx_valid = false;
     // pad rows / columns are exactly 0 (never clipped): they must contribute X/P = 0
     return upload_rows_staged(e, e->X, X, dtype, e->V, VMAX, 0.0, 0.0, clip ? kEps : 0.0);
 }
@@ -908,12 +925,14 @@ int salnmf_update_W(salnmf_engine* e, int n_given, int clip_mode) {
 }
 
 static int fwd_params(salnmf_engine* e, FwdParams& p) {
+    CK(ensure_xlogx(e));  // (mode 0 reads them; computed once per upload of X)
     p.X = e->X;
     p.H = e->H;
     p.W = e->W;
     p.wkl = e->wkl;
     p.wlh = e->wlh;
     p.hscale = e->h_pending ? e->cs : nullptr;
+    p.xlx = e->xlx;
     p.out = e->objpart;
     p.N = e->N;
     p.V = e->V;
@@ -925,7 +944,7 @@ static int fwd_params(salnmf_engine* e, FwdParams& p) {
 // objective of (W, H[, hscale]) -> device scalar e->scal[slot] (all-reduced), no host sync
 static int objective_to_slot(salnmf_engine* e, const double* W, const double* hscale, bool weighted, int slot, int grid = 0) {
     FwdParams p;
-    fwd_params(e, p);
+    CK(fwd_params(e, p));
     p.W = W;
     if (hscale) p.hscale = hscale;  // else: the pending rescale, if any
     if (!weighted) {
@@ -958,9 +977,9 @@ int salnmf_samplewise_kl(salnmf_engine* e, double* out) {
     if (!e || !out) return fail("null argument");
     HIPCK(hipSetDevice(e->device));
     double* dev = nullptr;
-    HIPCK(hipMalloc(&dev, (size_t)e->Np * sizeof(double)));
     FwdParams p;
-    fwd_params(e, p);
+    CK(fwd_params(e, p));
+    HIPCK(hipMalloc(&dev, (size_t)e->Np * sizeof(double)));
     p.out = dev;
     int rc = launch_forward<1>(e, p);
     if (!rc) rc = download(e, out, dev, (size_t)e->N);
@@ -972,9 +991,9 @@ int salnmf_reconstruct(salnmf_engine* e, double* out) {
     if (!e || !out) return fail("null argument");
     HIPCK(hipSetDevice(e->device));
     double* dev = nullptr;
-    HIPCK(hipMalloc(&dev, (size_t)e->Np * VMAX * sizeof(double)));
     FwdParams p;
-    fwd_params(e, p);
+    CK(fwd_params(e, p));
+    HIPCK(hipMalloc(&dev, (size_t)e->Np * VMAX * sizeof(double)));
     p.out = dev;
     int rc = launch_forward<2>(e, p);
     if (!rc) rc = download_padded(e, out, dev, e->V, VMAX);
@@ -1033,6 +1052,7 @@ static int mv_start_prepare_W(salnmf_engine* e, double delta, bool record_w_even
 // The numerator pass of one MvNMF W update on (W, H): G = (X/(WH)) @ H.T partials and the KL partial, reduced
 // together with the row sums of H (from the preceding update_H pass) by one tail launch and all-reduced.
 static int mv_numerator_pass(salnmf_engine* e, const double* W, const double* H, const double* hscale) {
+    CK(ensure_xlogx(e));
     FusedParams p = fused_params(e);
     p.wkl = nullptr;  // the MvNMF path is unweighted (mvnmf.py:56)
     p.wlh = nullptr;
@@ -1114,10 +1134,10 @@ static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double de
             sp.KLpart = e->KLpart2;
             CK((launch_fused<false, true, true>(e, sp, e->mv_grid)));
             if (!sharded(e)) {
-                LAUNCH_WITH_EVENT(sum_partials_kernel, dim3(1), dim3(256), e->stream, e->evObj, e->KLpart2, e->mv_grid, 1, 1, e->scal + 2);
+                LAUNCH_WITH_EVENT(sum_partials_kernel, dim3(1), dim3(256), e->stream, e->evObj, e->KLpart2, e->mv_grid, 1, 1, e->scal + 2, e->scal + SCAL_XLX);
                 HIPCK(hipGetLastError());
             } else {
-                hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, e->KLpart2, e->mv_grid, 1, 1, e->scal + 2);
+                hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, e->KLpart2, e->mv_grid, 1, 1, e->scal + 2, (const double*)(e->scal + SCAL_XLX));
                 HIPCK(hipGetLastError());
                 CK(allreduce(e, e->scal + 2, 1));
                 HIPCK(hipEventRecord(e->evObj, e->stream));
@@ -1661,7 +1681,7 @@ int salnmf_corr_poisson_llh(salnmf_engine* e, double* out) {
         e->lgam_valid = true;
     }
     FwdParams p;
-    fwd_params(e, p);
+    CK(fwd_params(e, p));
     p.wkl = nullptr;
     p.wlh = nullptr;
     CK(launch_forward<3>(e, p));
@@ -1981,7 +2001,7 @@ static int profile_forward(salnmf_engine* e, int mode, int n_calls, double* avg_
     HIPCK(hipSetDevice(e->device));
     CK(ensure_events(e, (size_t)2 * n_calls));
     FwdParams p;
-    fwd_params(e, p);
+    CK(fwd_params(e, p));
     double* recon = nullptr;
     if (mode == 2) {
         HIPCK(hipMalloc(&recon, (size_t)e->Np * VMAX * sizeof(double)));

@@ -33,6 +33,8 @@
 
 #include <type_traits>
 
+#include "salnmf_logtab.h"
+
 namespace salnmf {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -120,7 +122,8 @@ struct FusedParams {
     const double* __restrict__ hscale;  // [KP] or null: H is read as clip(H*hscale) (MvNMF trial)
     double* __restrict__ Gpart;      // [gridDim.x][K][VMAX]     (DO_G) per-workgroup partial numerators
     double* __restrict__ Hsumpart;   // [gridDim.x][K]           (DO_STATS) row sums of H
-    double* __restrict__ KLpart;     // [gridDim.x]              (DO_STATS) unweighted KL partial (DO_U: optional, null = skip)
+    double* __restrict__ KLpart;     // [gridDim.x]              (DO_STATS) unweighted partial of sum (p - x log p): the KL divergence minus
+                                     //                          the x-only constant (tile_kl) (DO_U: optional, null = skip)
     int64_t N;
     int V;
     int K;
@@ -142,7 +145,8 @@ struct FusedParams {
 //   log(x/p) = k ln2 + log((1+s)/(1-s)) = k ln2 + 2s + s R(s^2), R fitted for this range
 // Measured against a long-double reference (tools/log_probe.hip): abs error <= 2e-14 over
 // |log| <= 460, relative error <= 1e-15 away from ratio = 1 and better than log(fl(x/p)) near it.
-// Callers guarantee the operands are in range with log_operand_ok().
+// Callers guarantee the operands are in range with log_operand_ok().  Used by the per-sample KL (forward mode 1); the
+// objectives use log_pos below.
 __device__ __forceinline__ bool log_operand_ok(double v) {
     // positive, normal, and far enough from the ends of the exponent range for the p * 2^k trick
     return (unsigned)(__double2hiint(v) - 0x03D00000) < (unsigned)(0x7C200000 - 0x03D00000);
@@ -164,73 +168,70 @@ __device__ __forceinline__ double log_ratio(double x, double p) {
     return __builtin_fma(kd, 6.93147180369123816490e-01, t);
 }
 
-// log_ratio for M independent operand pairs, stage by stage: the same instruction sequence per pair (same bits), but
-// written so that the M dependent chains (~20 fp64 instructions each) stand next to each other.  hipcc otherwise emits
-// one chain after the other and every dependent instruction waits out the previous one's latency (the divisions of the
-// update pass lost 2.4 % of the kernel that way, profiles/r02/ab_step_variants.txt).
+// ---- log(p) for the objective terms, table driven (no division): p = 2^e m, m in [1, 2); entry i = top 8 mantissa
+// bits holds inv_i ~ 1 / c_i (c_i the centre of the i-th mantissa interval) and lc_i = -log(inv_i);
+//   r = m inv_i - 1 (one fma, |r| <= 2^-9),  log p = e ln2 + lc_i + (r - r^2/2 + r^3/3 - r^4/4 + r^5/5)
+// (the next term is < 1e-17).  5 integer + 9 fp64 instructions and one 16-byte LDS read per logarithm against 26 fp64
+// instructions (one of them a division chain) for log_ratio: the objective terms are fp64 VALU work on the pipe the
+// MFMAs use.  Error <= 2.5e-16 max(|log p|, 0.5) (tools/gen_logtab.py on the host, tools/log_probe.hip on the device).
+// The KL divergence is evaluated as  sum_d w_d [ c_d + sum_v (p - x log p) ],  c_d = sum_v (x log x - x)  (0 where
+// x = 0): the x-only part is computed once per upload of X (xlogx_rowsum_kernel, library log), so an objective costs ONE
+// logarithm per entry, of p alone.  _utils_klnmf.py:41-53: same value to rounding (entries with x = 0 contribute p).
+constexpr int LOGTAB_DOUBLES = 2 * LOGTAB_N;
+__device__ __forceinline__ void stage_logtab(double* tab, int tid) {
+    static_assert(LOGTAB_N == BLOCK, "one table entry per thread");
+    reinterpret_cast<d2*>(tab)[tid] = reinterpret_cast<const d2*>(kLogTab)[tid];
+}
+// positive, normal, finite
+__device__ __forceinline__ bool log_pos_ok(double v) { return (unsigned)(__double2hiint(v) - 0x00100000) < 0x7FE00000u; }
+
+// M independent logarithms, stage by stage (the M dependent chains stand next to each other, as in log_ratio_n)
 template <int M>
-__device__ __forceinline__ void log_ratio_n(const double (&x)[M], const double (&p)[M], double (&out)[M]) {
-    double ps[M], kd[M], num[M], den[M], rc[M], e[M], qt[M], s[M];
+__device__ __forceinline__ void log_pos_n(const double (&p)[M], const double* __restrict__ tab, double (&out)[M]) {
+    double kd[M], m[M], r[M], r2[M], h[M];
+    d2 te[M];
 #pragma unroll
     for (int i = 0; i < M; ++i) {
-        const int hx = __double2hiint(x[i]), hp = __double2hiint(p[i]);
-        const int k = (hx - hp + 0x80000) >> 20;
-        ps[i] = __hiloint2double(hp + (k << 20), __double2loint(p[i]));
-        kd[i] = (double)k;
+        const int hi = __double2hiint(p[i]);
+        te[i] = *reinterpret_cast<const d2*>(tab + 2 * ((hi >> 12) & 0xFF));
+        kd[i] = (double)((hi >> 20) - 1023);
+        m[i] = __hiloint2double((hi & 0x000FFFFF) | 0x3FF00000, __double2loint(p[i]));
     }
 #pragma unroll
-    for (int i = 0; i < M; ++i) num[i] = x[i] - ps[i];
+    for (int i = 0; i < M; ++i) r[i] = __builtin_fma(m[i], te[i][0], -1.0);
 #pragma unroll
-    for (int i = 0; i < M; ++i) den[i] = x[i] + ps[i];
-    // div_path(num, den)
+    for (int i = 0; i < M; ++i) r2[i] = r[i] * r[i];
 #pragma unroll
-    for (int i = 0; i < M; ++i) rc[i] = __builtin_amdgcn_rcp(den[i]);
+    for (int i = 0; i < M; ++i) h[i] = __builtin_fma(r[i], 0.2, -0.25);
 #pragma unroll
-    for (int i = 0; i < M; ++i) e[i] = __builtin_fma(-den[i], rc[i], 1.0);
+    for (int i = 0; i < M; ++i) h[i] = __builtin_fma(r[i], h[i], 0.33333333333333331);
 #pragma unroll
-    for (int i = 0; i < M; ++i) rc[i] = __builtin_fma(rc[i], e[i], rc[i]);
+    for (int i = 0; i < M; ++i) h[i] = __builtin_fma(r[i], h[i], -0.5);
 #pragma unroll
-    for (int i = 0; i < M; ++i) qt[i] = num[i] * rc[i];
+    for (int i = 0; i < M; ++i) h[i] = __builtin_fma(r2[i], h[i], r[i]);                          // log1p(r)
 #pragma unroll
-    for (int i = 0; i < M; ++i) e[i] = __builtin_fma(-den[i], qt[i], num[i]);
+    for (int i = 0; i < M; ++i) r[i] = __builtin_fma(kd[i], 6.93147180369123816490e-01, te[i][1]);  // e ln2_hi + lc (product exact)
 #pragma unroll
-    for (int i = 0; i < M; ++i) s[i] = __builtin_fma(e[i], rc[i], qt[i]);
-    double z[M], w[M], t1[M], t2[M];
+    for (int i = 0; i < M; ++i) h[i] = __builtin_fma(kd[i], 1.90821492927058770002e-10, h[i]);
 #pragma unroll
-    for (int i = 0; i < M; ++i) z[i] = s[i] * s[i];
-#pragma unroll
-    for (int i = 0; i < M; ++i) w[i] = z[i] * z[i];
-#pragma unroll
-    for (int i = 0; i < M; ++i) t1[i] = __builtin_fma(w[i], 0.1365426141372305, 0.15389174135906675);
-#pragma unroll
-    for (int i = 0; i < M; ++i) t2[i] = __builtin_fma(w[i], 0.1320375159044889, 0.18181729869745253);
-#pragma unroll
-    for (int i = 0; i < M; ++i) t1[i] = __builtin_fma(w[i], t1[i], 0.22222223148322984);
-#pragma unroll
-    for (int i = 0; i < M; ++i) t2[i] = __builtin_fma(w[i], t2[i], 0.2857142856666864);
-#pragma unroll
-    for (int i = 0; i < M; ++i) t1[i] = __builtin_fma(w[i], t1[i], 0.40000000000009306);
-#pragma unroll
-    for (int i = 0; i < M; ++i) t2[i] = __builtin_fma(w[i], t2[i], 0.6666666666666666);
-#pragma unroll
-    for (int i = 0; i < M; ++i) t1[i] = z[i] * __builtin_fma(z[i], t1[i], t2[i]);  // R
-#pragma unroll
-    for (int i = 0; i < M; ++i) t2[i] = __builtin_fma(kd[i], 1.90821492927058770002e-10, s[i] * t1[i]);
-#pragma unroll
-    for (int i = 0; i < M; ++i) t2[i] = __builtin_fma(2.0, s[i], t2[i]);
-#pragma unroll
-    for (int i = 0; i < M; ++i) out[i] = __builtin_fma(kd[i], 6.93147180369123816490e-01, t2[i]);
+    for (int i = 0; i < M; ++i) out[i] = r[i] + h[i];
+}
+__device__ __forceinline__ double log_pos(double p, const double* __restrict__ tab) {
+    const double pp[1] = {p};
+    double o[1];
+    log_pos_n<1>(pp, tab, o);
+    return o[0];
 }
 
-// one entry of the generalised KL divergence, any operands (library log)
-__device__ __forceinline__ double kl_term(double x, double p) {
-    // _utils_klnmf.py:47-50: entries with X == 0 contribute only WH
+// x-free part of one entry of the generalised KL divergence for any operands (library log): p - x log p, and p alone
+// where x == 0 (_utils_klnmf.py:47-50: such entries contribute only WH)
+__device__ __forceinline__ double kl_term_p(double x, double p) {
     double t = p;
-    if (x != 0.0) t += x * log(x / p) - x;
+    if (x != 0.0) t -= x * log(p);
     return t;
 }
-// the same for operands that passed log_operand_ok()
-__device__ __forceinline__ double kl_term_fast(double x, double p) { return __builtin_fma(x, log_ratio(x, p), p - x); }
+// the x-only part of an entry: x log x - x, 0 where x == 0
+__device__ __forceinline__ double kl_term_x(double x) { return x != 0.0 ? x * log(x) - x : 0.0; }
 
 // ---- in-launch synchronisation of the persistent kernel (cdna_hip_programming.md, guideline 16) ----
 // Payloads (G slabs, W rows) are stored write-through (sc1), every storing wave drains its stores
@@ -289,39 +290,40 @@ __device__ __forceinline__ void stage_W(double* Wl, const double* W, int K, int 
     }
 }
 
-// Sum over one tile (accumulator layout: rows n = q+4r, columns v = 16vt+c16) of the per-sample
-// weighted KL terms.  Entries outside [0,N) x [0,V) are skipped.  If every valid operand of the
-// wave passes log_operand_ok() -- always the case inside fit(), where X >= EPS -- the terms go
-// through the division-fused log_ratio; otherwise (zeros in X through the function-level API,
-// denormals) the whole tile takes the library path.
+// Sum over one tile (accumulator layout: rows n = q+4r, columns v = 16vt+c16) of the per-sample weighted
+//   [c16 == 0 ? c_d : 0] + sum_v (p - x log p)
+// i.e. the tile's share of the KL divergence (see log_pos above); with crow == null the x-only constants c_d are left
+// to the caller (the fused passes add their sum once, in the reduction).  Entries outside [0,N) x [0,V) are skipped.
+// If every valid P of the wave is a positive normal number -- always the case inside fit() -- the logarithms go through
+// the table; otherwise (an all-zero row of H or W through the function-level API) the whole tile takes the library path.
 __device__ __forceinline__ double tile_kl(const double (&x)[VT][4], const d4 (&pr)[VT], const double* __restrict__ wrow,
-                                          int64_t n0, int64_t N, int V, int q, int c16) {
+                                          const double* __restrict__ crow, const double* __restrict__ tab, int64_t n0, int64_t N, int V,
+                                          int q, int c16) {
     bool ok = true;
 #pragma unroll
     for (int vt = 0; vt < VT; ++vt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const bool valid = (n0 + q + 4 * r < N) && (16 * vt + c16 < V);
-            ok &= !valid || (log_operand_ok(x[vt][r]) && log_operand_ok(pr[vt][r]));
+            ok &= !valid || log_pos_ok(pr[vt][r]);
         }
     double total = 0.0;
     if (__all(ok)) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const bool nvalid = n0 + q + 4 * r < N;
-            double acc = 0.0;
-            double xs[VT], ps[VT], lr[VT];
+            double acc = (crow && nvalid && c16 == 0) ? crow[n0 + q + 4 * r] : 0.0;
+            double ps[VT], lp[VT];
 #pragma unroll
             for (int vt = 0; vt < VT; ++vt) {
                 const bool valid = nvalid && (16 * vt + c16 < V);
-                xs[vt] = valid ? x[vt][r] : 1.0;  // pads: harmless operands
-                ps[vt] = valid ? pr[vt][r] : 1.0;
+                ps[vt] = valid ? pr[vt][r] : 1.0;  // pads: a harmless operand
             }
-            log_ratio_n<VT>(xs, ps, lr);
+            log_pos_n<VT>(ps, tab, lp);
 #pragma unroll
             for (int vt = 0; vt < VT; ++vt) {
                 const bool valid = nvalid && (16 * vt + c16 < V);
-                const double t = __builtin_fma(xs[vt], lr[vt], ps[vt] - xs[vt]);  // kl_term_fast
+                const double t = __builtin_fma(-x[vt][r], lp[vt], ps[vt]);
                 acc += valid ? t : 0.0;
             }
             if (wrow) acc *= wrow[n0 + q + 4 * r];
@@ -331,10 +333,10 @@ __device__ __forceinline__ double tile_kl(const double (&x)[VT][4], const d4 (&p
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const bool nvalid = n0 + q + 4 * r < N;
-            double acc = 0.0;
+            double acc = (crow && nvalid && c16 == 0) ? crow[n0 + q + 4 * r] : 0.0;
 #pragma unroll
             for (int vt = 0; vt < VT; ++vt)
-                if (nvalid && 16 * vt + c16 < V) acc += kl_term(x[vt][r], pr[vt][r]);
+                if (nvalid && 16 * vt + c16 < V) acc += kl_term_p(x[vt][r], pr[vt][r]);
             if (wrow) acc *= wrow[n0 + q + 4 * r];
             total += acc;
         }
@@ -543,7 +545,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
     constexpr int KB = 16 * KTM;                                   // first remainder column
     constexpr int NVP = KR == 0 ? 0 : (KR == 1 ? 4 : (KR == 2 ? 8 : 16));  // 4*KR values, padded to a power of two
     static_assert(KR >= 0 && KR <= 4 && KB + KR <= KP, "remainder columns must fit the padded layout");
-    __shared__ __attribute__((aligned(16))) double lds[G_::LDS_DOUBLES + KP];
+    __shared__ __attribute__((aligned(16))) double lds[G_::LDS_DOUBLES + KP + (DO_STATS ? LOGTAB_DOUBLES : 0)];
 
     // (persistent mode) everything a step needs is derived inside the step loop from an opaque copy of the thread
     // index, so that nothing but the step counter is live across the out-of-line synchronisation calls
@@ -566,6 +568,8 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
 
     double* hsl = lds + G_::LDS_DOUBLES;  // [KP] copy of hscale
     if (p.hscale && tid < KP) hsl[tid] = p.hscale[tid];
+    double* ltab = hsl + KP;              // (DO_STATS) table of log_pos
+    if (DO_STATS) stage_logtab(ltab, tid);
 
     d4 g[KT][VT];
     double grem[KR > 0 ? KR : 1][VT];  // remainder rows of G: per-lane partials over this lane's sample rows
@@ -680,7 +684,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         // unweighted KL(X || P) of this tile from P before the division: always with the numerator pass (f0 of the MvNMF
         // line search), with the update_H pass only when asked (KLpart != null: a speculative pass evaluates the trial
         // it starts from, which saves the separate forward pass)
-        if (DO_STATS && (DO_G || p.KLpart != nullptr)) klacc += tile_kl(x, pr, nullptr, n0, N, V, q, c16);
+        if (DO_STATS && (DO_G || p.KLpart != nullptr)) klacc += tile_kl(x, pr, nullptr, nullptr, ltab, n0, N, V, q, c16);
         // ---- R = X / P in place (rows n = q + 4r, columns v = 16vt + c16); pads give 0 / P = 0
         // (div_path's sequence, six quotients at a time and stage by stage: independent chains next to each other)
 #pragma unroll
@@ -1213,6 +1217,7 @@ struct FwdParams {
     const double* __restrict__ wkl;     // [Np] or null
     const double* __restrict__ wlh;     // [Np] or null
     const double* __restrict__ hscale;  // [KP] or null: H read as clip(H*hscale)
+    const double* __restrict__ xlx;     // [Np] mode 0: c_d = sum_v (x log x - x) of every sample (xlogx_rowsum_kernel)
     double* __restrict__ out;           // mode 0: [gridDim.x]; mode 1: [Np]; mode 2: [Np][VMAX]
     int64_t N;
     int V;
@@ -1224,7 +1229,7 @@ struct FwdParams {
 // are not software-pipelined here, so the second wave hides the first one's memory latency.
 // Only the 4*KS rows of W that the contraction touches are staged, which keeps LDS <= 80 KB.
 template <int KS>
-constexpr int fwd_lds_doubles() { return 4 * KS * WS + WAVES * Geo<KS>::HL + BLOCK + Geo<KS>::KP; }
+constexpr int fwd_lds_doubles() { return 4 * KS * WS + WAVES * Geo<KS>::HL + BLOCK + Geo<KS>::KP + LOGTAB_DOUBLES; }
 
 template <int KS, int MODE>
 __global__ void __launch_bounds__(BLOCK, (fwd_lds_doubles<KS>() * 8 <= 80 * 1024 ? 2 : 1)) forward_kernel(FwdParams p) {
@@ -1246,6 +1251,8 @@ __global__ void __launch_bounds__(BLOCK, (fwd_lds_doubles<KS>() * 8 <= 80 * 1024
     double* red = lds + FROWS * WS + WAVES * G_::HL;
     double* hsl = red + BLOCK;  // [KP] copy of hscale
     if (p.hscale && tid < KP) hsl[tid] = p.hscale[tid];
+    double* ltab = hsl + KP;    // table of log_pos
+    if (MODE == 0 || MODE == 3) stage_logtab(ltab, tid);
 
     stage_W<FROWS>(Wl, p.W, K, V, tid);
     __syncthreads();
@@ -1307,7 +1314,7 @@ __global__ void __launch_bounds__(BLOCK, (fwd_lds_doubles<KS>() * 8 <= 80 * 1024
         }
 
         if (MODE == 0) {
-            total += pen + tile_kl(x, pr, p.wkl, n0, N, V, q, c16);
+            total += pen + tile_kl(x, pr, p.wkl, p.xlx, ltab, n0, N, V, q, c16);
         } else if (MODE == 1) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -1329,16 +1336,35 @@ __global__ void __launch_bounds__(BLOCK, (fwd_lds_doubles<KS>() * 8 <= 80 * 1024
         } else if (MODE == 3) {
             // Poisson log-likelihood without the factorial term (_utils_klnmf.py:98-133):
             // sum over the valid entries of (P != 0 ? X log P : 0) - P
+            bool ok = true;
 #pragma unroll
             for (int vt = 0; vt < VT; ++vt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (n0 + q + 4 * r < N && 16 * vt + c16 < V) {
-                        const double xv = x[vt][r], pv = pr[vt][r];
-                        double t = 0.0;
-                        if (pv != 0.0) t = xv * (log_operand_ok(pv) ? log_ratio(pv, 1.0) : log(pv));
-                        total += t - pv;
-                    }
+                for (int r = 0; r < 4; ++r) ok &= !(n0 + q + 4 * r < N && 16 * vt + c16 < V) || log_pos_ok(pr[vt][r]);
+            if (__all(ok)) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool nvalid = n0 + q + 4 * r < N;
+                    double ps[VT], lp[VT];
+#pragma unroll
+                    for (int vt = 0; vt < VT; ++vt) ps[vt] = (nvalid && 16 * vt + c16 < V) ? pr[vt][r] : 1.0;
+                    log_pos_n<VT>(ps, ltab, lp);
+#pragma unroll
+                    for (int vt = 0; vt < VT; ++vt)
+                        if (nvalid && 16 * vt + c16 < V) total += x[vt][r] * lp[vt] - ps[vt];
+                }
+            } else {
+#pragma unroll
+                for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n0 + q + 4 * r < N && 16 * vt + c16 < V) {
+                            const double xv = x[vt][r], pv = pr[vt][r];
+                            double t = 0.0;
+                            if (pv != 0.0) t = xv * log(pv);
+                            total += t - pv;
+                        }
+            }
         } else {
             double* dst = p.out + (n0 + q) * VMAX + c16;
 #pragma unroll
@@ -1378,7 +1404,8 @@ struct TailParams {
     // summation order of sum_partials_kernel
     const double* __restrict__ hsum_part;  // [nparts][K] or null
     double* __restrict__ hsum_out;         // [K]
-    const double* __restrict__ kl_part;    // [nparts] or null
+    const double* __restrict__ kl_part;    // [nparts] or null: partials of sum (p - x log p) (tile_kl)
+    const double* __restrict__ kl_const;   // [1] sum over the samples of c_d = sum_v (x log x - x), added to the reduced partials
     double* __restrict__ kl_out;           // [1]
     int nparts;
 };
@@ -1402,7 +1429,7 @@ __global__ void __launch_bounds__(TAIL_BLOCK) tail_kernel(TailParams p) {
                 if ((int)threadIdx.x < h) hred[threadIdx.x] += hred[threadIdx.x + h];
                 __syncthreads();
             }
-            if (threadIdx.x == 0) (which == 0 ? p.hsum_out[k] : p.kl_out[0]) = hred[0];
+            if (threadIdx.x == 0) (which == 0 ? p.hsum_out[k] : p.kl_out[0]) = which == 0 ? hred[0] : hred[0] + p.kl_const[0];
             __syncthreads();
         }
     }
@@ -1412,7 +1439,7 @@ __global__ void __launch_bounds__(TAIL_BLOCK) tail_kernel(TailParams p) {
 // out[j] = sum_i part[i*stride + j], j < width: one workgroup per output, fixed summation order
 // (thread t adds rows t, t+256, ... in order; then a fixed binary tree over the 256 threads)
 __global__ void __launch_bounds__(256) sum_partials_kernel(const double* __restrict__ part, int n, int stride, int width,
-                                                           double* __restrict__ out) {
+                                                           double* __restrict__ out, const double* __restrict__ addend = nullptr) {
     __shared__ double red[256];
     const int j = blockIdx.x;
     if (j >= width) return;
@@ -1424,7 +1451,20 @@ __global__ void __launch_bounds__(256) sum_partials_kernel(const double* __restr
         if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[j] = red[0];
+    if (threadIdx.x == 0) out[j] = addend ? red[0] + addend[0] : red[0];
+}
+
+// c[n] = sum_v (x log x - x) over the features of sample n (0 where x == 0): the x-only part of the KL divergence
+// (tile_kl), once per upload of X.  Library log: any x the reference accepts.  X is [Np][ldx], pad rows are 0.
+__global__ void __launch_bounds__(256) xlogx_rowsum_kernel(const double* __restrict__ X, int64_t Np, int V, int ldx, double* __restrict__ c) {
+    const int64_t n = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int l = threadIdx.x & 15;
+    if (n >= Np) return;
+    double s = 0.0;
+    for (int v = l; v < V; v += 16) s += kl_term_x(X[n * ldx + v]);
+    // fixed order over the 16 lanes of a row
+    for (int m = 8; m > 0; m >>= 1) s += __shfl_xor(s, m, 64);
+    if (l == 0) c[n] = s;
 }
 
 // out[k] = sum over rows n < N of H[n][k] (padded layout, leading dimension ldh): one workgroup per

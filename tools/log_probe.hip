@@ -9,6 +9,14 @@ __global__ void k(const double* x, const double* p, double* a, double* b, int n)
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { a[i] = (salnmf::log_operand_ok(x[i]) && salnmf::log_operand_ok(p[i])) ? salnmf::log_ratio(x[i], p[i]) : log(x[i] / p[i]); b[i] = log(x[i] / p[i]); }
 }
+// log_pos (table driven, the objectives' logarithm) against the library log and a long-double reference
+__global__ void kpos(const double* p, double* a, double* b, int n) {
+    __shared__ double tab[salnmf::LOGTAB_DOUBLES];
+    salnmf::stage_logtab(tab, threadIdx.x);
+    __syncthreads();
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { a[i] = salnmf::log_pos_ok(p[i]) ? salnmf::log_pos(p[i], tab) : log(p[i]); b[i] = log(p[i]); }
+}
 int main() {
     int n = 1 << 22;
     std::vector<double> x(n), p(n), a(n), b(n);
@@ -38,5 +46,26 @@ int main() {
         double aa = std::fabs((double)((long double)a[i] - ref)); if (aa > mabs_a[m]) mabs_a[m] = aa;
     }
     for (int m = 0; m < 5; ++m) { int i = worst[m]; printf("mode %d: log_ratio max rel err %.3g (abs %.3g) | ocml log(x/p) max rel err %.3g | worst x=%.17g p=%.17g got %.17g ref %.17Lg\n", m, mrel_a[m], mabs_a[m], mrel_b[m], x[i], p[i], a[i], logl((long double)x[i] / (long double)p[i])); }
+    // ---- log_pos
+    for (int i = 0; i < n; ++i) {
+        int mode = i % 5;
+        if (mode == 0) p[i] = U(rng) * 500 + 1e-3;
+        else if (mode == 1) p[i] = std::exp(U(rng) * 1400 - 700);
+        else if (mode == 2) p[i] = 1 + (U(rng) - 0.5) * 1e-6;
+        else if (mode == 3) p[i] = std::ldexp(1 + std::floor(U(rng) * 257) / 256.0, (int)(U(rng) * 40) - 20) * (1 + (U(rng) - 0.5) * 1e-12);  // table seams
+        else p[i] = 1.1920928955078125e-07 * (1 + U(rng));
+    }
+    hipMemcpy(dp, p.data(), n * 8, hipMemcpyHostToDevice);
+    kpos<<<n / 256, 256>>>(dp, da, db, n);
+    hipMemcpy(a.data(), da, n * 8, hipMemcpyDeviceToHost); hipMemcpy(b.data(), db, n * 8, hipMemcpyDeviceToHost);
+    double ea[5] = {0}, eb[5] = {0};
+    for (int i = 0; i < n; ++i) {
+        long double ref = logl((long double)p[i]);
+        long double sc = std::max(fabsl(ref), (long double)0.5);
+        int m = i % 5;
+        ea[m] = std::max(ea[m], (double)(fabsl((long double)a[i] - ref) / sc));
+        eb[m] = std::max(eb[m], (double)(fabsl((long double)b[i] - ref) / sc));
+    }
+    for (int m = 0; m < 5; ++m) printf("log_pos mode %d: max |err| / max(|log p|, 0.5) = %.3g | ocml log %.3g\n", m, ea[m], eb[m]);
     return 0;
 }
