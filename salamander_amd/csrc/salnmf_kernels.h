@@ -168,10 +168,11 @@ __device__ __forceinline__ double log_ratio(double x, double p) {
     return __builtin_fma(kd, 6.93147180369123816490e-01, t);
 }
 
-// ---- log(p) for the objective terms, table driven (no division): p = 2^e m, m in [1, 2); entry i = top 8 mantissa
-// bits holds inv_i ~ 1 / c_i (c_i the centre of the i-th mantissa interval) and lc_i = -log(inv_i);
+// ---- log(p) for the objective terms, table driven (no division): p = 2^e m, m in [0.5, 1) (v_frexp_exp_i32_f64,
+// v_frexp_mant_f64); entry i = top 8 mantissa bits holds inv_i ~ 1 / c_i (c_i the centre of the i-th mantissa interval)
+// and lc_i = -log(inv_i);
 //   r = m inv_i - 1 (one fma, |r| <= 2^-9),  log p = e ln2 + lc_i + (r - r^2/2 + r^3/3 - r^4/4 + r^5/5)
-// (the next term is < 1e-17).  5 integer + 9 fp64 instructions and one 16-byte LDS read per logarithm against 26 fp64
+// (the next term is < 1e-17).  3 integer + 12 fp64-rate instructions and one 16-byte LDS read per logarithm against 26 fp64
 // instructions (one of them a division chain) for log_ratio: the objective terms are fp64 VALU work on the pipe the
 // MFMAs use.  Error <= 2.5e-16 max(|log p|, 0.5) (tools/gen_logtab.py on the host, tools/log_probe.hip on the device).
 // The KL divergence is evaluated as  sum_d w_d [ c_d + sum_v (p - x log p) ],  c_d = sum_v (x log x - x)  (0 where
@@ -194,8 +195,8 @@ __device__ __forceinline__ void log_pos_n(const double (&p)[M], const double* __
     for (int i = 0; i < M; ++i) {
         const int hi = __double2hiint(p[i]);
         te[i] = *reinterpret_cast<const d2*>(tab + 2 * ((hi >> 12) & 0xFF));
-        kd[i] = (double)((hi >> 20) - 1023);
-        m[i] = __hiloint2double((hi & 0x000FFFFF) | 0x3FF00000, __double2loint(p[i]));
+        kd[i] = (double)__builtin_amdgcn_frexp_exp(p[i]);
+        m[i] = __builtin_amdgcn_frexp_mant(p[i]);
     }
 #pragma unroll
     for (int i = 0; i < M; ++i) r[i] = __builtin_fma(m[i], te[i][0], -1.0);
@@ -292,13 +293,44 @@ __device__ __forceinline__ void stage_W(double* Wl, const double* W, int K, int 
 
 // Sum over one tile (accumulator layout: rows n = q+4r, columns v = 16vt+c16) of the per-sample weighted
 //   [c16 == 0 ? c_d : 0] + sum_v (p - x log p)
-// i.e. the tile's share of the KL divergence (see log_pos above); with crow == null the x-only constants c_d are left
-// to the caller (the fused passes add their sum once, in the reduction).  Entries outside [0,N) x [0,V) are skipped.
-// If every valid P of the wave is a positive normal number -- always the case inside fit() -- the logarithms go through
-// the table; otherwise (an all-zero row of H or W through the function-level API) the whole tile takes the library path.
-__device__ __forceinline__ double tile_kl(const double (&x)[VT][4], const d4 (&pr)[VT], const double* __restrict__ wrow,
-                                          const double* __restrict__ crow, const double* __restrict__ tab, int64_t n0, int64_t N, int V,
-                                          int q, int c16) {
+// i.e. the tile's share of the KL divergence (see log_pos above).  ROWS: wv[r] / cv[r] are the weight and the x-only
+// constant c_d of sample n0 + q + 4r (loaded by the caller with the tile's other loads); without ROWS the sum is
+// unweighted and the constants are left to the caller (the fused passes add their sum once, in the reduction).
+// Entries outside [0,N) x [0,V) are skipped.  The objective terms are VALU-issue bound, so the common case -- a full
+// tile of a 96-feature problem whose P are all positive normal numbers, always the case inside fit() -- runs without a
+// single select: the range check is two min3/max3 chains over the high words.  Partial tiles and V < 96 take the masked
+// form; a P that is zero, denormal or not finite (an all-zero row of H or W through the function-level API) sends the
+// whole tile to the library path.
+template <bool ROWS>
+__device__ __forceinline__ double tile_kl(const double (&x)[VT][4], const d4 (&pr)[VT], const double (&wv)[4], const double (&cv)[4],
+                                          const double* __restrict__ tab, int64_t n0, int64_t N, int V, int q, int c16) {
+    if (n0 + 16 <= N && V == VMAX) {  // (wave-uniform)
+        unsigned lo = 0xFFFFFFFFu, hi = 0u;
+#pragma unroll
+        for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned h = (unsigned)__double2hiint(pr[vt][r]);
+                lo = h < lo ? h : lo;
+                hi = h > hi ? h : hi;
+            }
+        if (__all(lo >= 0x00100000u && hi < 0x7FF00000u)) {
+            double total = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double ps[VT], lp[VT];
+#pragma unroll
+                for (int vt = 0; vt < VT; ++vt) ps[vt] = pr[vt][r];
+                log_pos_n<VT>(ps, tab, lp);
+                double acc = (ROWS && c16 == 0) ? cv[r] : 0.0;
+#pragma unroll
+                for (int vt = 0; vt < VT; ++vt) acc += __builtin_fma(-x[vt][r], lp[vt], ps[vt]);
+                if (ROWS) acc *= wv[r];
+                total += acc;
+            }
+            return total;
+        }
+    }
     bool ok = true;
 #pragma unroll
     for (int vt = 0; vt < VT; ++vt)
@@ -312,7 +344,7 @@ __device__ __forceinline__ double tile_kl(const double (&x)[VT][4], const d4 (&p
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const bool nvalid = n0 + q + 4 * r < N;
-            double acc = (crow && nvalid && c16 == 0) ? crow[n0 + q + 4 * r] : 0.0;
+            double acc = (ROWS && nvalid && c16 == 0) ? cv[r] : 0.0;
             double ps[VT], lp[VT];
 #pragma unroll
             for (int vt = 0; vt < VT; ++vt) {
@@ -326,18 +358,18 @@ __device__ __forceinline__ double tile_kl(const double (&x)[VT][4], const d4 (&p
                 const double t = __builtin_fma(-x[vt][r], lp[vt], ps[vt]);
                 acc += valid ? t : 0.0;
             }
-            if (wrow) acc *= wrow[n0 + q + 4 * r];
+            if (ROWS) acc *= wv[r];
             total += acc;
         }
     } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const bool nvalid = n0 + q + 4 * r < N;
-            double acc = (crow && nvalid && c16 == 0) ? crow[n0 + q + 4 * r] : 0.0;
+            double acc = (ROWS && nvalid && c16 == 0) ? cv[r] : 0.0;
 #pragma unroll
             for (int vt = 0; vt < VT; ++vt)
                 if (nvalid && 16 * vt + c16 < V) acc += kl_term_p(x[vt][r], pr[vt][r]);
-            if (wrow) acc *= wrow[n0 + q + 4 * r];
+            if (ROWS) acc *= wv[r];
             total += acc;
         }
     }
@@ -684,7 +716,10 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         // unweighted KL(X || P) of this tile from P before the division: always with the numerator pass (f0 of the MvNMF
         // line search), with the update_H pass only when asked (KLpart != null: a speculative pass evaluates the trial
         // it starts from, which saves the separate forward pass)
-        if (DO_STATS && (DO_G || p.KLpart != nullptr)) klacc += tile_kl(x, pr, nullptr, nullptr, ltab, n0, N, V, q, c16);
+        if (DO_STATS && (DO_G || p.KLpart != nullptr)) {
+            const double none[4] = {0.0, 0.0, 0.0, 0.0};
+            klacc += tile_kl<false>(x, pr, none, none, ltab, n0, N, V, q, c16);
+        }
         // ---- R = X / P in place (rows n = q + 4r, columns v = 16vt + c16); pads give 0 / P = 0
         // (div_path's sequence, six quotients at a time and stage by stage: independent chains next to each other)
 #pragma unroll
@@ -1282,6 +1317,14 @@ __global__ void __launch_bounds__(BLOCK, (fwd_lds_doubles<KS>() * 8 <= 80 * 1024
 #pragma unroll
                 for (int r = 0; r < 4; ++r) x[vt][r] = xsrc[4 * r * VMAX + 16 * vt];
         }
+        double wv[4] = {1.0, 1.0, 1.0, 1.0}, cv[4] = {0.0, 0.0, 0.0, 0.0};  // mode 0: weight and x-only constant of this lane's rows
+        if (MODE == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                cv[r] = p.xlx[n0 + q + 4 * r];
+                if (p.wkl) wv[r] = p.wkl[n0 + q + 4 * r];
+            }
+        }
         double pen = 0.0;
 #pragma unroll
         for (int j = 0; j < HV; ++j) {
@@ -1314,7 +1357,7 @@ __global__ void __launch_bounds__(BLOCK, (fwd_lds_doubles<KS>() * 8 <= 80 * 1024
         }
 
         if (MODE == 0) {
-            total += pen + tile_kl(x, pr, p.wkl, p.xlx, ltab, n0, N, V, q, c16);
+            total += pen + tile_kl<true>(x, pr, wv, cv, ltab, n0, N, V, q, c16);
         } else if (MODE == 1) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
