@@ -125,6 +125,7 @@ struct salnmf_engine {
     int KR = 0;    // remainder columns (K - 16*KTM, <= 4) done on the VALU; 0 = none
     double* scratch = nullptr;  // compact staging buffer for layout conversion (lazily sized)
     size_t scratch_n = 0;
+    int cus = 0;    // compute units of the device
     int grid = 0;   // workgroups of the fused kernel (one per CU)
     int fgrid = 0;  // workgroups of the forward kernels (two per CU)
     hipStream_t stream = nullptr;
@@ -141,6 +142,7 @@ struct salnmf_engine {
     double* red = nullptr;       // [K*V | K | 1 | pad]  G, rowsums_H, KL of the local shard (then all-reduced)
     double* objpart = nullptr;   // [grid]
     double* scal = nullptr;      // device scalars: [0]=objective, [1]=f0, [2]=f1, [3]=logdet0, [4]=logdet1, [5..7] CorrNMF sums, [SCAL_XLX]=sum of xlx
+    unsigned* klcnt = nullptr;   // arrival counter of the in-launch KL sum of the MvNMF update_H pass (zero between launches)
     double* xlx = nullptr;       // [Np] c_d = sum_v (x log x - x): the x-only part of the KL divergence (tile_kl), lazily computed
     bool xlx_valid = false;
     double* Wunc = nullptr;      // MvNMF scratch [K][V]
@@ -243,7 +245,7 @@ static int launch_forward(salnmf_engine* e, const FwdParams& p, int grid = 0, hi
 }
 
 static FusedParams fused_params(salnmf_engine* e) {
-    FusedParams p;
+    FusedParams p{};  // (the optional parts -- MvNMF side workgroup, in-launch KL sum, persistent mode -- are off)
     p.X = e->X;
     p.H = e->H;
     p.Hout = e->H;
@@ -262,7 +264,7 @@ static FusedParams fused_params(salnmf_engine* e) {
     return p;
 }
 
-static TailParams tail_params(salnmf_engine* e, int nslabs, double* G, int n_given, int clip_mode, int do_tail, bool with_stats) {
+static TailParams tail_params(salnmf_engine* e, int nslabs, double* G, int n_given, int clip_mode, int do_tail, bool with_stats, int hsum_parts = 0) {
     TailParams t;
     t.Gpart = e->Gpart;
     t.G = G;
@@ -279,16 +281,17 @@ static TailParams tail_params(salnmf_engine* e, int nslabs, double* G, int n_giv
     t.kl_const = e->scal + SCAL_XLX;
     t.kl_out = e->red + (size_t)e->K * e->V + e->K;
     t.nparts = nslabs;
+    t.nparts_h = hsum_parts > 0 ? hsum_parts : nslabs;
     return t;
 }
 
 static int launch_tail(salnmf_engine* e, int nslabs, double* G, int n_given, int clip_mode, int do_tail, bool with_stats = false,
-                       hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
+                       hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, int hsum_parts = 0) {
     if (ev_stop)
         hipExtLaunchKernelGGL(tail_kernel, dim3(e->K), dim3(TAIL_BLOCK), 0, e->stream, ev_start, ev_stop, 0,
-                              tail_params(e, nslabs, G, n_given, clip_mode, do_tail, with_stats));
+                              tail_params(e, nslabs, G, n_given, clip_mode, do_tail, with_stats, hsum_parts));
     else
-        hipLaunchKernelGGL(tail_kernel, dim3(e->K), dim3(TAIL_BLOCK), 0, e->stream, tail_params(e, nslabs, G, n_given, clip_mode, do_tail, with_stats));
+        hipLaunchKernelGGL(tail_kernel, dim3(e->K), dim3(TAIL_BLOCK), 0, e->stream, tail_params(e, nslabs, G, n_given, clip_mode, do_tail, with_stats, hsum_parts));
     HIPCK(hipGetLastError());
     return 0;
 }
@@ -441,6 +444,7 @@ void salnmf_destroy(salnmf_engine* e) {
     if (e->ls_buf) (void)hipFree(e->ls_buf);
     if (e->ls_int) (void)hipFree(e->ls_int);
     if (e->psync) (void)hipFree(e->psync);
+    if (e->klcnt) (void)hipFree(e->klcnt);
     for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : {e->evW, e->evPrepW, e->evTrial, e->evLogdet, e->evObj})
         if (ev) (void)hipEventDestroy(ev);
@@ -490,7 +494,7 @@ int salnmf_create(int device, int n_features, int64_t n_samples, int n_signature
     // MvNMF overlaps single-workgroup kernels on a second stream with the passes over the samples.  Workgroups are
     // dealt round-robin to the 8 XCDs and a one-workgroup kernel lands on the first XCD, whichever kernel is
     // dispatched first: leaving one CU per XCD free (3 % of the pass) guarantees it a place
-    const int cus = prop.multiProcessorCount;
+    const int cus = e->cus = prop.multiProcessorCount;
     const int spare = (cus % 8 == 0 && cus >= 64) ? 8 : 1;
     e->mv_grid = (e->grid >= cus && e->grid > spare) ? e->grid - spare : e->grid;
     e->mv_fgrid = (e->fgrid >= 2 * cus && e->fgrid > 2 * spare) ? e->fgrid - 2 * spare : e->fgrid;
@@ -530,6 +534,7 @@ int salnmf_create(int device, int n_features, int64_t n_samples, int n_signature
     if (acquire_pinned((void**)&e->hpin, 1) != hipSuccess) return cleanup(fail("hipHostMalloc failed"));
     e->pabort = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(e->hpin) + SMALL_PINNED_BYTES / 2);
     if (hipMalloc(&e->psync, SYNC_WORDS * sizeof(unsigned)) != hipSuccess) return cleanup(fail("hipMalloc failed"));
+    if (hipMalloc(&e->klcnt, 16) != hipSuccess || hipMemset(e->klcnt, 0, 16) != hipSuccess) return cleanup(fail("hipMalloc failed"));
     *e->pabort = 0;
     *out = e;
     return 0;
@@ -1039,6 +1044,18 @@ static int ensure_side_streams(salnmf_engine* e) {
     return 0;
 }
 
+// An MvNMF update_H pass whose last workgroup runs the W-only algebra (fused_kernel<!G, U, STATS>: sideW): `total`
+// workgroups are launched, `total - 1` of them process tiles.  One per CU at most, so that the side workgroup starts at once.
+static inline int mv_side_total(const salnmf_engine* e) { return std::min(e->cus, e->grid + 1); }
+
+static void mv_side_params(salnmf_engine* e, FusedParams& p, const double* W, double delta) {
+    p.sideW = W;
+    p.sideDelta = delta;
+    p.sideA = e->mvA;
+    p.sideB = e->mvB;
+    p.sideLogdet = e->scal + 3;
+}
+
 static int mv_start_prepare_W(salnmf_engine* e, double delta, bool record_w_event) {
     CK(ensure_side_streams(e));
     if (record_w_event) HIPCK(hipEventRecord(e->evW, e->stream));  // else: recorded when W was last written
@@ -1051,7 +1068,10 @@ static int mv_start_prepare_W(salnmf_engine* e, double delta, bool record_w_even
 
 // The numerator pass of one MvNMF W update on (W, H): G = (X/(WH)) @ H.T partials and the KL partial, reduced
 // together with the row sums of H (from the preceding update_H pass) by one tail launch and all-reduced.
-static int mv_numerator_pass(salnmf_engine* e, const double* W, const double* H, const double* hscale) {
+//   grid: e->mv_grid leaves one CU per XCD to the side stream's kernels; the steady state of mv_step has nothing on the
+//   side stream and uses the whole chip (e->grid)
+//   hsum_parts: workgroups of the preceding update_H pass (rows of Hsumpart)
+static int mv_numerator_pass(salnmf_engine* e, const double* W, const double* H, const double* hscale, int grid, int hsum_parts) {
     CK(ensure_xlogx(e));
     FusedParams p = fused_params(e);
     p.wkl = nullptr;  // the MvNMF path is unweighted (mvnmf.py:56)
@@ -1060,8 +1080,8 @@ static int mv_numerator_pass(salnmf_engine* e, const double* W, const double* H,
     p.H = const_cast<double*>(H);
     p.Hout = const_cast<double*>(H);
     p.hscale = hscale;
-    CK((launch_fused<true, false, true>(e, p, e->mv_grid)));
-    CK(launch_tail(e, e->mv_grid, e->red, 0, 0, 0, true));
+    CK((launch_fused<true, false, true>(e, p, grid)));
+    CK(launch_tail(e, grid, e->red, 0, 0, 0, true, nullptr, nullptr, hsum_parts));
     return 0;
 }
 
@@ -1076,6 +1096,8 @@ static int mv_numerator_pass(salnmf_engine* e, const double* W, const double* H,
 //            The scalars come back on a side stream while the numerator pass runs; on acceptance the buffers are
 //            swapped and *speculated = true tells the caller that the next step starts at its closed-form root, otherwise
 //            everything speculative is dropped and the backtracking loop evaluates its trials with the forward kernel.
+//   w_ready:  A, B and the log det of the current W are produced on the MAIN stream already (the side workgroup of the
+//            preceding update_H pass); otherwise mv_prepare_W_kernel is started on stream2 here and waited for
 //   g_ready:  (in) the numerator pass, tail and all-reduce of THIS step were queued by the previous call's speculation
 static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double delta, double* gamma, bool have_hsum, bool w_ready,
                             bool speculate = false, bool* speculated = nullptr, bool g_ready = false) {
@@ -1087,44 +1109,48 @@ static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double de
         CK(flush_H_scale(e));  // a stand-alone call after an earlier step; inside mv_step the update_H pass consumed it
         if (!w_ready) CK(mv_start_prepare_W(e, delta, true));
         // the rowsums_H partials come from the preceding update_H pass (have_hsum) or, for a stand-alone _update_W,
-        // from a column-sum kernel over the current H
-        CK(mv_numerator_pass(e, e->W, e->H, nullptr));
+        // from a column-sum kernel over the current H.  Inside mv_step (w_ready: the W-only algebra ran in that pass's
+        // side workgroup, on this stream) the numerator pass has the whole chip, as the speculative one has: the same
+        // slab order, hence the same bits of W, whether the steps come in one call or one by one; a stand-alone call
+        // leaves one CU per XCD to the W-only kernel on stream2.
+        if (w_ready)
+            CK(mv_numerator_pass(e, e->W, e->H, nullptr, e->grid, mv_side_total(e) - 1));
+        else
+            CK(mv_numerator_pass(e, e->W, e->H, nullptr, e->mv_grid, e->mv_grid));
         if (!have_hsum) {
             hipLaunchKernelGGL(colsum_kernel, dim3(K), dim3(256), 0, e->stream, e->H, e->N, e->KP, e->red + K * V);
             HIPCK(hipGetLastError());
         }
         CK(allreduce(e, e->red, (size_t)K * V + K + 1));
     }
-    // W_unconstrained from A, B (stream2) and the reduced sums; f0 = KL + lam * logdet(W) -> scal[1]
-    HIPCK(hipStreamWaitEvent(e->stream, e->evPrepW, 0));
+    // W_unconstrained from A, B and the reduced sums; f0 = KL + lam * logdet(W) -> scal[1].  A, B and the log det come
+    // from stream2 (mv_prepare_W_kernel) unless the previous call's speculation produced them on this stream
+    if (!g_ready && !w_ready) HIPCK(hipStreamWaitEvent(e->stream, e->evPrepW, 0));
     // (evaluated inside the first trial kernel below)
     const MvRootParams root{e->mvA, e->mvB, e->red, e->red + K * V, e->red + K * V + K, e->scal + 3, e->scal + 1, lam, n_given};
     double g = *gamma;
-    bool blend = false, dropped = false;
+    bool blend = false;
     for (;;) {
-        // a dropped speculation left a W-only kernel on stream2 that reads the trial buffer: the blend must not
-        // overwrite that buffer under it (invariant: Wtrial is rewritten only after every queued reader on stream2)
-        if (dropped) {
-            HIPCK(hipStreamWaitEvent(e->stream, e->evPrepW, 0));
-            dropped = false;
-        }
-        // trial W: normalise + clip and the column sums for H on the main stream; its logdet -> scal[4] on stream2
-        if (!blend)
+        const bool spec = speculate && !blend;
+        // trial W: normalise + clip and the column sums for H on the main stream
+        if (spec)
+            hipLaunchKernelGGL(mv_trial_light_kernel<true>, dim3(1), dim3(MV_BLOCK), 0, e->stream, e->W, e->Wunc, 1.0, 0, K, V, e->Wtrial, e->cs, root);
+        else if (!blend)
             LAUNCH_WITH_EVENT(mv_trial_light_kernel<true>, dim3(1), dim3(MV_BLOCK), e->stream, e->evTrial, e->W, e->Wunc, 1.0, 0, K,
                               V, e->Wtrial, e->cs, root);
         else
             LAUNCH_WITH_EVENT(mv_trial_light_kernel<false>, dim3(1), dim3(MV_BLOCK), e->stream, e->evTrial, e->W, e->Wunc, g, 1, K, V,
                               e->Wtrial, e->cs, root);
         HIPCK(hipGetLastError());
-        HIPCK(hipStreamWaitEvent(e->stream2, e->evTrial, 0));
-        LAUNCH_WITH_EVENT(mv_logdet_kernel, dim3(1), dim3(MV_BLOCK), e->stream2, e->evLogdet, e->Wtrial, K, V, delta, e->scal + 4);
-        HIPCK(hipGetLastError());
         double v[5];
-        const bool spec = speculate && !blend;
         if (spec) {
             if (!e->Halt) HIPCK(hipMalloc(&e->Halt, (size_t)e->Np * e->KP * sizeof(double)));
             if (!e->KLpart2) HIPCK(hipMalloc(&e->KLpart2, (size_t)e->grid * sizeof(double)));
-            // the next step's update_H (+ row sums of the new H), which also evaluates this trial: KL(W_trial, H') -> scal[2]
+            // The next step's update_H (+ row sums of the new H), which also evaluates this trial: KL(W_trial, H') -> scal[2],
+            // summed inside the launch by the workgroup that finishes last.  The grid's last workgroup does no tiles: it
+            // runs the next step's W-only algebra on the trial (A, B; its log det -> scal[3] is this trial's log det as
+            // well) -- nothing of the steady state is left on a second stream, so nothing here waits for another queue.
+            const int total = mv_side_total(e), nwg = total - 1;
             FusedParams sp = fused_params(e);
             sp.wkl = nullptr;
             sp.wlh = nullptr;
@@ -1132,39 +1158,43 @@ static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double de
             sp.hscale = e->cs;
             sp.Hout = e->Halt;
             sp.KLpart = e->KLpart2;
-            CK((launch_fused<false, true, true>(e, sp, e->mv_grid)));
+            mv_side_params(e, sp, e->Wtrial, delta);
             if (!sharded(e)) {
-                LAUNCH_WITH_EVENT(sum_partials_kernel, dim3(1), dim3(256), e->stream, e->evObj, e->KLpart2, e->mv_grid, 1, 1, e->scal + 2, e->scal + SCAL_XLX);
-                HIPCK(hipGetLastError());
+                sp.kl_out = e->scal + 2;
+                sp.kl_const = e->scal + SCAL_XLX;
+                sp.kl_counter = e->klcnt;
+                CK((launch_fused<false, true, true>(e, sp, total, nullptr, e->evObj)));  // evObj = the pass's own completion signal
             } else {
-                hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, e->KLpart2, e->mv_grid, 1, 1, e->scal + 2, (const double*)(e->scal + SCAL_XLX));
+                CK((launch_fused<false, true, true>(e, sp, total)));
+                hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, e->KLpart2, nwg, 1, 1, e->scal + 2, (const double*)(e->scal + SCAL_XLX));
                 HIPCK(hipGetLastError());
                 CK(allreduce(e, e->scal + 2, 1));
                 HIPCK(hipEventRecord(e->evObj, e->stream));
             }
-            // ... its W-only algebra behind the trial's log det on stream2 (A, B of this step are consumed already) ...
-            LAUNCH_WITH_EVENT(mv_prepare_W_kernel, dim3(1), dim3(MV_BLOCK), e->stream2, e->evPrepW, e->Wtrial, K, V, delta, e->mvA,
-                              e->mvB, e->scal + 3);
-            HIPCK(hipGetLastError());
-            // ... and its numerator pass (W_trial as W, the new H): it runs while the scalars travel to the host
-            CK(mv_numerator_pass(e, e->Wtrial, e->Halt, nullptr));
+            // ... and its numerator pass (W_trial as W, the new H) on the whole chip: it runs while the scalars travel to the host
+            CK(mv_numerator_pass(e, e->Wtrial, e->Halt, nullptr, e->grid, nwg));
             CK(allreduce(e, e->red, (size_t)K * V + K + 1));
             HIPCK(hipStreamWaitEvent(e->stream3, e->evObj, 0));
-            HIPCK(hipStreamWaitEvent(e->stream3, e->evLogdet, 0));
             HIPCK(hipMemcpyAsync(e->hpin, e->scal, 5 * sizeof(double), hipMemcpyDeviceToHost, e->stream3));
             HIPCK(hipStreamSynchronize(e->stream3));
             for (int i = 0; i < 5; ++i) v[i] = e->hpin[i];
+            v[4] = v[3];  // the trial's log det came from the side workgroup
         } else {
-            // KL(W_trial, clip(H * colsum)) by the forward pass, beside the log det
+            // the trial's log det -> scal[4] on stream2, beside KL(W_trial, clip(H * colsum)) by the forward pass
+            HIPCK(hipStreamWaitEvent(e->stream2, e->evTrial, 0));
+            LAUNCH_WITH_EVENT(mv_logdet_kernel, dim3(1), dim3(MV_BLOCK), e->stream2, e->evLogdet, e->Wtrial, K, V, delta, e->scal + 4);
+            HIPCK(hipGetLastError());
             CK(objective_to_slot(e, e->Wtrial, e->cs, false, 2, e->mv_fgrid));
             HIPCK(hipStreamWaitEvent(e->stream, e->evLogdet, 0));
             CK(read_scalars(e, 0, 5, v));
         }
         const double f0 = v[1], f1 = v[2] + lam * v[4];
         if (f1 > f0 && g > 1e-16) {  // mvnmf.py:84
+            // (a rejected speculation is simply dropped: it wrote scratch buffers only -- Halt, the numerator slabs, A, B
+            // and scal[3], which the next non-speculative step recomputes for the W it starts from -- and everything that
+            // read the trial buffer ran on this stream, ahead of the blend that overwrites it)
             g *= 0.8;
             blend = true;
-            dropped = spec;  // (a rejected speculation is simply dropped: it wrote scratch buffers only)
             continue;
         }
         if (spec) {
@@ -1172,7 +1202,7 @@ static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double de
             *gamma = std::min(1.0, 1.2 * g);
             std::swap(e->W, e->Wtrial);
             std::swap(e->H, e->Halt);  // written in full from clip(H * cs): nothing pending
-            // (no evW: the next step's W-only algebra is queued already; a later stand-alone start records its own)
+            // (no evW: the next step's W-only algebra ran already; a later stand-alone start records its own)
             e->h_pending = false;
             if (speculated) *speculated = true;
             return 0;
@@ -1201,18 +1231,21 @@ int salnmf_mv_step(salnmf_engine* e, int n_steps, int n_given, double lam, doubl
     bool ahead = false;  // this step's update_H pass, W-only algebra and numerator pass already ran during the previous step
     for (int i = 0; i < n_steps; ++i) {
         const bool update_W = n_given < e->K;
-        if (update_W && i == 0) HIPCK(hipEventRecord(e->evW, e->stream));  // later steps: recorded by the accept
         if (!ahead) {
             FusedParams p = fused_params(e);
             p.wkl = nullptr;  // MvNMF._update_H passes no weights (mvnmf.py:162-165)
             p.wlh = nullptr;
             p.KLpart = nullptr;  // row sums of the new H only
-            CK((launch_fused<false, true, true>(e, p, e->mv_grid)));  // update_H + row sums of the new H
+            // update_H + row sums of the new H; the pass's last workgroup runs the W-only algebra of the W step beside
+            // it (an accepted speculation ran both already, for exactly this W)
+            if (update_W) {
+                mv_side_params(e, p, e->W, delta);
+                CK((launch_fused<false, true, true>(e, p, mv_side_total(e))));
+            } else {
+                CK((launch_fused<false, true, true>(e, p)));
+            }
             e->h_pending = false;
         }
-        // W-only algebra on stream2, beside the passes; queued after the pass so that the host does not delay it
-        // (an accepted speculation ran it already, for exactly this W)
-        if (update_W && !ahead) CK(mv_start_prepare_W(e, delta, false));
         const bool was_ahead = ahead;
         CK(mv_update_W_impl(e, n_given, lam, delta, gamma_inout, true, true, i + 1 < n_steps, &ahead, was_ahead));
     }

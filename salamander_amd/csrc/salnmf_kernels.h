@@ -34,6 +34,7 @@
 #include <type_traits>
 
 #include "salnmf_logtab.h"
+#include "salnmf_mv_device.h"
 
 namespace salnmf {
 
@@ -128,6 +129,21 @@ struct FusedParams {
     int V;
     int K;
     int64_t ntiles;
+    // MvNMF update_H pass only (fused_kernel<!DO_G, DO_U, DO_STATS>), both optional:
+    //  * sideW != null: the LAST workgroup of the grid processes no tiles; it runs the W-only algebra of the W step
+    //    (mv_prepare_W_body: A = W Y_minus, B = W |Y|, log det(W W^T + delta I), mvnmf.py:19-24,48-54) on sideW beside the
+    //    pass -- the latency chain that used to need a second stream and an event wait on this one;
+    //  * kl_out != null (with KLpart): the workgroup that finishes last sums the KL partials in the order of
+    //    sum_partials_kernel and stores kl_out[0] = sum + kl_const[0] -- one kernel and one boundary less per MvNMF step.
+    //    kl_counter: arrival counter, zero between launches (the last arriver resets it).
+    const double* sideW;
+    double sideDelta;
+    double* sideA;
+    double* sideB;
+    double* sideLogdet;
+    double* kl_out;
+    const double* kl_const;
+    unsigned* kl_counter;
     // persistent multi-step mode (PERSIST instantiation only): the joint update_WH step nsteps times in ONE launch
     int nsteps;
     int n_given;
@@ -579,6 +595,18 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
     static_assert(KR >= 0 && KR <= 4 && KB + KR <= KP, "remainder columns must fit the padded layout");
     __shared__ __attribute__((aligned(16))) double lds[G_::LDS_DOUBLES + KP + (DO_STATS ? LOGTAB_DOUBLES : 0)];
 
+    // MvNMF update_H pass: the grid's last workgroup may be the one that does the W-only algebra instead of tiles
+    constexpr bool MVU = DO_U && DO_STATS && !DO_G;
+    const int nwg = (int)gridDim.x - ((MVU && p.sideW != nullptr) ? 1 : 0);  // workgroups that process tiles
+    if (MVU && p.sideW != nullptr && (int)blockIdx.x == nwg) {
+        static_assert(!MVU || KP * (MV_WS + 2 * MV_LD + 1) + 1 <= G_::LDS_DOUBLES, "the W-only algebra must fit this geometry's LDS");
+        const int K = p.K;  // <= KP: the three matrices are packed by K rows
+        double* Wl = lds;
+        double* S = Wl + K * MV_WS;
+        double* T = S + K * MV_LD;
+        mv_prepare_W_body<BLOCK>(p.sideW, K, p.V, p.sideDelta, p.sideA, p.sideB, p.sideLogdet, Wl, S, T, T + K * MV_LD);
+        return;
+    }
     // (persistent mode) everything a step needs is derived inside the step loop from an opaque copy of the thread
     // index, so that nothing but the step counter is live across the out-of-line synchronisation calls
     const int nsteps = PERSIST ? p.nsteps : 1;
@@ -613,7 +641,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         for (int kt = 0; kt < KT; ++kt) hsum[kt] = 0.0;
     }
 
-    const int64_t tstride = (int64_t)gridDim.x * WAVES;
+    const int64_t tstride = (int64_t)(MVU ? nwg : (int)gridDim.x) * WAVES;
     int64_t tile = 0;
     // Leftover round.  ntiles = R * (waves of the grid) + L: with 0 < L <= workgroups the L leftover tiles would keep
     // L waves busy for a whole tile time while the rest of the chip idles (c2: 106 of 1024 waves, 9.6 of 78 us).  In
@@ -1234,7 +1262,37 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
             if (tid < h) Ks[tid] += Ks[tid + h];
             __syncthreads();
         }
-        if (tid == 0) p.KLpart[blockIdx.x] = Ks[0];
+        if (!(MVU && p.kl_out != nullptr)) {
+            if (tid == 0) p.KLpart[blockIdx.x] = Ks[0];
+        } else {
+            // in-launch final sum (cdna_hip_programming.md, guideline 16, counter form): the partial is published by a
+            // write-through store of ONE lane, which drains it and draws a ticket; whoever draws the last ticket reads
+            // all partials with sc1 loads and adds them in the order of sum_partials_kernel (same bits)
+            if (tid == 0) {
+                __hip_atomic_store((gdouble*)(p.KLpart + blockIdx.x), Ks[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned ticket = __hip_atomic_fetch_add((gsync_t*)p.kl_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                Ks[1] = (ticket == (unsigned)nwg - 1u) ? 1.0 : 0.0;
+            }
+            __syncthreads();
+            const bool last = Ks[1] != 0.0;  // (uniform)
+            __syncthreads();
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // (no instruction: keeps the loads below the ticket)
+                double sum = 0.0;
+                for (int i = tid; i < nwg; i += BLOCK) sum += ld_shared<true>(p.KLpart + i);
+                Ks[tid] = sum;
+                __syncthreads();
+                for (int h = BLOCK / 2; h > 0; h >>= 1) {
+                    if (tid < h) Ks[tid] += Ks[tid + h];
+                    __syncthreads();
+                }
+                if (tid == 0) {
+                    p.kl_out[0] = Ks[0] + p.kl_const[0];
+                    __hip_atomic_store((gsync_t*)p.kl_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
     }
     }  // step
 }
@@ -1450,7 +1508,8 @@ struct TailParams {
     const double* __restrict__ kl_part;    // [nparts] or null: partials of sum (p - x log p) (tile_kl)
     const double* __restrict__ kl_const;   // [1] sum over the samples of c_d = sum_v (x log x - x), added to the reduced partials
     double* __restrict__ kl_out;           // [1]
-    int nparts;
+    int nparts;    // KL partials (workgroups of the numerator pass)
+    int nparts_h;  // row-sum partials (workgroups of the preceding update_H pass)
 };
 
 #ifndef SALNMF_TEMPLATES_ONLY  // the plain kernels below are compiled by salnmf.hip only (salnmf_launch.h)
@@ -1463,9 +1522,10 @@ __global__ void __launch_bounds__(TAIL_BLOCK) tail_kernel(TailParams p) {
         for (int which = 0; which < ((k == 0 && p.kl_part) ? 2 : 1); ++which) {
             const double* part = which == 0 ? p.hsum_part + k : p.kl_part;
             const int stride = which == 0 ? K : 1;
+            const int nparts = which == 0 ? p.nparts_h : p.nparts;
             double s = 0.0;
             if (threadIdx.x < 256)
-                for (int i = threadIdx.x; i < p.nparts; i += 256) s += part[(int64_t)i * stride];
+                for (int i = threadIdx.x; i < nparts; i += 256) s += part[(int64_t)i * stride];
             if (threadIdx.x < 256) hred[threadIdx.x] = s;
             __syncthreads();
             for (int h = 128; h > 0; h >>= 1) {
