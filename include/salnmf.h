@@ -98,6 +98,12 @@ int salnmf_download_H(salnmf_engine* e, double* H);
  * by default.  A wait inside that kernel that gives up (another process holding CUs) is reported by the next
  * synchronising call as an error; the resident state is then invalid. */
 int salnmf_kl_step(salnmf_engine* e, int n_steps, int n_given);
+/* salnmf_kl_step that keeps the state it starts from: the first step writes the new H / W into second buffers (no
+ * copy), which then change roles.  salnmf_kl_rollback returns to the kept state (once, until the next _keep call); the
+ * steps it discards may still be running.  For a caller that queues the next block of steps BEFORE it has read the
+ * objective that decides convergence (signature_nmf.py:373-380): the decision's host round trip hides behind the block. */
+int salnmf_kl_step_keep(salnmf_engine* e, int n_steps, int n_given);
+int salnmf_kl_rollback(salnmf_engine* e);
 /* Switch the persistent multi-step launch of salnmf_kl_step on (1) or off (0, the default).  Measurement aid: the
  * default build does not carry that kernel (measured 10 % slower) and refuses on = 1 with an error; build with
  * SALNMF_WITH_PERSISTENT=1 (__graft_entry__.py) to get it. */
@@ -111,6 +117,14 @@ int salnmf_update_W(salnmf_engine* e, int n_given, int clip_mode);
  * klnmf.py:64-80 and _utils_klnmf.py:11-55.  With a communicator attached the value
  * is all-reduced over the shards. */
 int salnmf_objective(salnmf_engine* e, double* out);
+/* The same without a host round trip: queue the objective of the resident state into slot `slot` of a device ring
+ * (SALNMF_OBJECTIVE_SLOTS entries, pinned host memory the reducing kernel writes directly), read a range of slots later:
+ * the read waits for those objectives only, not for work queued behind them.
+ * SignatureNMF.fit evaluates the objective every conv_test_freq iterations (signature_nmf.py:373-383) but cannot stop
+ * before min_iterations: until then the values are only queued and come back in one read. */
+#define SALNMF_OBJECTIVE_SLOTS 256
+int salnmf_objective_async(salnmf_engine* e, int slot);
+int salnmf_objective_read(salnmf_engine* e, int first, int count, double* out);
 /* samplewise_kl_divergence, _utils_klnmf.py:58-97 (unweighted); out has n_samples. */
 int salnmf_samplewise_kl(salnmf_engine* e, double* out);
 /* H @ W (n_samples x n_features): SignatureNMF.compute_reconstruction,

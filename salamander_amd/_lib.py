@@ -47,6 +47,10 @@ SIGNATURES = {
     "salnmf_update_H": (c_int, [_P]),
     "salnmf_update_W": (c_int, [_P, c_int, c_int]),
     "salnmf_objective": (c_int, [_P, _D]),
+    "salnmf_objective_async": (c_int, [_P, c_int]),
+    "salnmf_objective_read": (c_int, [_P, c_int, c_int, _D]),
+    "salnmf_kl_step_keep": (c_int, [_P, c_int, c_int]),
+    "salnmf_kl_rollback": (c_int, [_P]),
     "salnmf_samplewise_kl": (c_int, [_P, _D]),
     "salnmf_reconstruct": (c_int, [_P, _D]),
     "salnmf_mv_step": (c_int, [_P, c_int, c_int, c_double, c_double, _D]),
@@ -87,6 +91,7 @@ SIGNATURES = {
     "salnmf_profile_reconstruct": (c_int, [_P, c_int, _D]),
 }
 
+OBJECTIVE_SLOTS = 256  # SALNMF_OBJECTIVE_SLOTS
 BUILD_PERSISTENT = 1  # salnmf_build_flags(): the library carries the persistent multi-step kernel
 
 _lib = None

@@ -132,7 +132,13 @@ struct salnmf_engine {
     hipStream_t stream2 = nullptr;  // MvNMF: the small W-only kernels run here, beside the passes over the samples
     hipStream_t stream3 = nullptr;  // MvNMF: read-back of the line-search scalars past a speculative pass on the main stream
     hipEvent_t evW = nullptr, evPrepW = nullptr, evTrial = nullptr, evLogdet = nullptr, evObj = nullptr;
-    double* Halt = nullptr;      // [Np][KP] second H buffer of the speculative update_H pass (lazily allocated)
+    double* Halt = nullptr;      // [Np][KP] second H buffer: the speculative update_H pass of MvNMF; the state kept by salnmf_kl_step_keep (lazily allocated)
+    double* Wkeep = nullptr;     // [K][V] W of the state kept by salnmf_kl_step_keep (lazily allocated)
+    double* Wdst = nullptr;      // where the next W tail writes its result (null = in place); set for one step by a kept block
+    bool keep_valid = false, keep_has_W = false;
+    double* objring = nullptr;   // [SALNMF_OBJECTIVE_SLOTS] device copies of the queued objectives (sharded engines: all-reduced in place)
+    double* objpin = nullptr;    // [SALNMF_OBJECTIVE_SLOTS] pinned host ring the queued objectives land in (salnmf_objective_async)
+    std::vector<hipEvent_t> objev;  // per slot: completion of the kernel that wrote it
     int mv_grid = 0, mv_fgrid = 0;  // grids that leave one CU free for stream2
     double *X = nullptr, *H = nullptr, *W = nullptr, *wkl = nullptr, *wlh = nullptr;
     double* Gpart = nullptr;     // [grid][K][VMAX]
@@ -269,6 +275,7 @@ static TailParams tail_params(salnmf_engine* e, int nslabs, double* G, int n_giv
     t.Gpart = e->Gpart;
     t.G = G;
     t.W = e->W;
+    t.Wout = e->Wdst ? e->Wdst : e->W;
     t.nslabs = nslabs;
     t.V = e->V;
     t.K = e->K;
@@ -375,9 +382,15 @@ static int flush_H_scale(salnmf_engine* e) {
 
 // one joint step; ev != nullptr: {fused start, fused stop, tail start, tail stop} are bound to the two dispatches
 // (a weighted or sharded step, whose tail is more than one launch, falls back to records around the launches)
-static int kl_step_once(salnmf_engine* e, int n_given, hipEvent_t* ev) {
+//   keep: this step leaves the state it starts from untouched -- the new H goes to the second H buffer, the new W to
+//   Wkeep -- and the buffers change roles afterwards (salnmf_kl_step_keep)
+static int kl_step_once(salnmf_engine* e, int n_given, hipEvent_t* ev, bool keep = false) {
     FusedParams p = fused_params(e);
     const bool all_given = n_given >= e->K;  // _utils_klnmf.py:330-331: W untouched
+    if (keep) {
+        p.Hout = e->Halt;
+        e->Wdst = all_given ? nullptr : e->Wkeep;
+    }
     const bool bound = ev && !(p.wkl || p.wlh);
     if (ev && !bound) HIPCK(hipEventRecord(ev[0], e->stream));
     if (all_given)
@@ -396,6 +409,12 @@ static int kl_step_once(salnmf_engine* e, int n_given, hipEvent_t* ev) {
         }
     }
     if (ev && !tail_bound) HIPCK(hipEventRecord(ev[3], e->stream));
+    if (keep) {
+        std::swap(e->H, e->Halt);
+        if (!all_given) std::swap(e->W, e->Wkeep);
+        e->Wdst = nullptr;
+        e->keep_has_W = !all_given;
+    }
     return 0;
 }
 
@@ -431,11 +450,14 @@ void salnmf_destroy(salnmf_engine* e) {
     if (e->H32) (void)hipFree(e->H32);
     if (e->p2p.abort_dev) (void)hipFree(e->p2p.abort_dev);
     double* bufs[] = {e->xlx, e->X, e->H, e->W, e->wkl, e->wlh, e->Gpart, e->Hsumpart, e->KLpart, e->red,
-                      e->objpart, e->scal, e->Wunc, e->Wtrial, e->mvA, e->mvB, e->cs, e->scratch, e->Halt, e->KLpart2,
+                      e->objpart, e->scal, e->Wunc, e->Wtrial, e->mvA, e->mvB, e->cs, e->scratch, e->Halt, e->KLpart2, e->Wkeep, e->objring,
                       e->alpha, e->beta, e->Lemb, e->Uemb, e->aux, e->xrowsum, e->corrpart, e->gU, e->galpha, e->gaux};
     for (double* b : bufs)
         if (b) (void)hipFree(b);
     if (e->hpin) release_pinned(e->hpin, 1);  // (one block: hpin, and the abort word behind it)
+    if (e->objpin) release_pinned(e->objpin, 1);
+    for (hipEvent_t ev : e->objev)
+        if (ev) (void)hipEventDestroy(ev);
     for (int i = 0; i < 2; ++i) {
         if (e->stage_host[i]) release_pinned(e->stage_host[i], 0);  // (the engine's streams are idle: synchronised above)
         if (e->stage_dev[i]) (void)hipFree(e->stage_dev[i]);
@@ -565,7 +587,7 @@ static int ensure_scratch(salnmf_engine* e, size_t n) {
 // _setup_adata, signature_nmf.py:269-281); raw count matrices may come as float32 / int32 / int64 / uint16 and are
 // converted on the device, which also cuts the bytes that cross PCIe.
 constexpr size_t STAGE_BYTES = (size_t)32 << 20;
-constexpr int STAGE_THREADS = 4;
+constexpr int STAGE_THREADS = 8;
 
 static size_t dtype_size(int dtype) {
     switch (dtype) {
@@ -736,10 +758,11 @@ int salnmf_upload_X_typed(salnmf_engine* e, const void* X, int dtype, int clip) 
 int salnmf_upload_X(salnmf_engine* e, const double* X, int clip) { return salnmf_upload_X_typed(e, X, SALNMF_F64, clip); }
 int salnmf_upload_W(salnmf_engine* e, const double* W) {
     if (!e) return fail("null engine");
+    e->keep_valid = false;
     return upload(e, e->W, W, (size_t)e->K * e->V);
 }
 int salnmf_upload_H(salnmf_engine* e, const double* H) {
-    if (e) e->h_pending = false;
+    if (e) e->h_pending = e->keep_valid = false;
     // pad columns 0, pad rows 1: finite, and positive in the rows so that P > 0 there
     return upload_padded(e, e ? e->H : nullptr, H, e ? e->K : 0, e ? e->KP : 0, 0.0, 1.0, 0.0);
 }
@@ -894,6 +917,40 @@ int salnmf_kl_step(salnmf_engine* e, int n_steps, int n_given) {
     return 0;
 }
 
+int salnmf_kl_step_keep(salnmf_engine* e, int n_steps, int n_given) {
+    if (!e) return fail("null engine");
+    if (n_given < 0 || n_given > e->K) return fail("n_given out of range");
+    if (n_steps < 1) return fail("n_steps must be positive");
+    HIPCK(hipSetDevice(e->device));
+    if (!e->Halt) HIPCK(hipMalloc(&e->Halt, (size_t)e->Np * e->KP * sizeof(double)));
+    if (!e->Wkeep) HIPCK(hipMalloc(&e->Wkeep, (size_t)e->K * e->V * sizeof(double)));
+    e->keep_valid = false;
+    CK(flush_H_scale(e));
+    if (e->fast32 || e->persistent) {
+        // the fp32 fast mode and the persistent kernel update the state in place: keep a copy instead
+        HIPCK(hipMemcpyAsync(e->Halt, e->H, (size_t)e->Np * e->KP * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+        HIPCK(hipMemcpyAsync(e->Wkeep, e->W, (size_t)e->K * e->V * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+        CK(salnmf_kl_step(e, n_steps, n_given));
+        e->keep_has_W = true;  // H / W hold the new state, Halt / Wkeep the copy of the old one: the same roles as below
+    } else {
+        CK(kl_step_once(e, n_given, nullptr, true));
+        for (int i = 1; i < n_steps; ++i) CK(kl_step_once(e, n_given, nullptr));
+    }
+    e->keep_valid = true;
+    return 0;
+}
+
+int salnmf_kl_rollback(salnmf_engine* e) {
+    if (!e) return fail("null engine");
+    if (!e->keep_valid) return fail("no kept state: salnmf_kl_rollback undoes the last salnmf_kl_step_keep, once");
+    // (the discarded steps may still be running: they write the buffers that become scratch, in stream order)
+    std::swap(e->H, e->Halt);
+    if (e->keep_has_W) std::swap(e->W, e->Wkeep);
+    e->h_pending = false;
+    e->keep_valid = false;
+    return 0;
+}
+
 int salnmf_update_H(salnmf_engine* e) {
     if (!e) return fail("null engine");
     HIPCK(hipSetDevice(e->device));
@@ -947,7 +1004,7 @@ static int fwd_params(salnmf_engine* e, FwdParams& p) {
 }
 
 // objective of (W, H[, hscale]) -> device scalar e->scal[slot] (all-reduced), no host sync
-static int objective_to_slot(salnmf_engine* e, const double* W, const double* hscale, bool weighted, int slot, int grid = 0) {
+static int objective_to_ptr(salnmf_engine* e, const double* W, const double* hscale, bool weighted, double* out, int grid = 0) {
     FwdParams p;
     CK(fwd_params(e, p));
     p.W = W;
@@ -958,9 +1015,12 @@ static int objective_to_slot(salnmf_engine* e, const double* W, const double* hs
     }
     const int fgrid = grid > 0 ? grid : e->fgrid;
     CK(launch_forward<0>(e, p, fgrid));
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, e->objpart, fgrid, 1, 1, e->scal + slot);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, e->objpart, fgrid, 1, 1, out);
     HIPCK(hipGetLastError());
-    return allreduce(e, e->scal + slot, 1);
+    return allreduce(e, out, 1);
+}
+static int objective_to_slot(salnmf_engine* e, const double* W, const double* hscale, bool weighted, int slot, int grid = 0) {
+    return objective_to_ptr(e, W, hscale, weighted, e->scal + slot, grid);
 }
 
 static int read_scalars(salnmf_engine* e, int first, int count, double* out) {
@@ -976,6 +1036,49 @@ int salnmf_objective(salnmf_engine* e, double* out) {
     HIPCK(hipSetDevice(e->device));
     CK(objective_to_slot(e, e->W, nullptr, true, 0));
     return read_scalars(e, 0, 1, out);
+}
+
+int salnmf_objective_async(salnmf_engine* e, int slot) {
+    if (!e) return fail("null engine");
+    if (slot < 0 || slot >= SALNMF_OBJECTIVE_SLOTS) return fail("slot must be in [0, %d)", SALNMF_OBJECTIVE_SLOTS);
+    HIPCK(hipSetDevice(e->device));
+    static_assert(SALNMF_OBJECTIVE_SLOTS * sizeof(double) <= SMALL_PINNED_BYTES, "the ring lives in one small pinned block");
+    if (!e->objpin) HIPCK(acquire_pinned((void**)&e->objpin, 1));
+    if (e->objev.empty()) e->objev.assign(SALNMF_OBJECTIVE_SLOTS, nullptr);
+    // (with the system-scope fence: the host reads the slot once the event has completed)
+    if (!e->objev[slot]) HIPCK(hipEventCreateWithFlags(&e->objev[slot], hipEventDisableTiming));
+    // The value lands in pinned host memory straight from the reducing kernel, and the slot's event is that kernel's own
+    // completion signal: the reader waits for THIS objective only, not for whatever was queued behind it (the next
+    // block of steps), and no copy packet sits in the stream.  A sharded engine all-reduces the device copy first.
+    FwdParams p;
+    CK(fwd_params(e, p));
+    CK(launch_forward<0>(e, p, e->fgrid));
+    if (!sharded(e)) {
+        hipExtLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, nullptr, e->objev[slot], 0, e->objpart, e->fgrid, 1, 1,
+                              e->objpin + slot, (const double*)nullptr);
+        HIPCK(hipGetLastError());
+        return 0;
+    }
+    if (!e->objring) HIPCK(hipMalloc(&e->objring, SALNMF_OBJECTIVE_SLOTS * sizeof(double)));
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, e->objpart, e->fgrid, 1, 1, e->objring + slot, (const double*)nullptr);
+    HIPCK(hipGetLastError());
+    CK(allreduce(e, e->objring + slot, 1));
+    hipExtLaunchKernelGGL(copy_scalar_kernel, dim3(1), dim3(1), 0, e->stream, nullptr, e->objev[slot], 0, e->objpin + slot, (const double*)(e->objring + slot));
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+int salnmf_objective_read(salnmf_engine* e, int first, int count, double* out) {
+    if (!e || !out) return fail("null argument");
+    if (first < 0 || count < 0 || first + count > SALNMF_OBJECTIVE_SLOTS) return fail("slots out of range");
+    if (count == 0) return 0;
+    HIPCK(hipSetDevice(e->device));
+    for (int i = first; i < first + count; ++i)
+        if (e->objev.empty() || !e->objev[i]) return fail("slot %d has never been queued", i);
+    // slots are filled in stream order: the caller reads ranges in the order it queued them, so the last one decides
+    for (int i = first; i < first + count; ++i) HIPCK(hipEventSynchronize(e->objev[i]));
+    for (int i = 0; i < count; ++i) out[i] = e->objpin[first + i];
+    return check_abort(e);
 }
 
 int salnmf_samplewise_kl(salnmf_engine* e, double* out) {
@@ -1220,6 +1323,7 @@ static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double de
 
 int salnmf_mv_update_W(salnmf_engine* e, int n_given, double lam, double delta, double* gamma_inout) {
     if (!e || !gamma_inout) return fail("null argument");
+    e->keep_valid = false;  // (the MvNMF steps use the second H buffer themselves)
     HIPCK(hipSetDevice(e->device));
     return mv_update_W_impl(e, n_given, lam, delta, gamma_inout, false, false);
 }
@@ -1228,6 +1332,7 @@ int salnmf_mv_step(salnmf_engine* e, int n_steps, int n_given, double lam, doubl
     if (!e || !gamma_inout) return fail("null argument");
     if (n_given < 0 || n_given > e->K) return fail("n_given out of range");
     HIPCK(hipSetDevice(e->device));
+    e->keep_valid = false;  // (the MvNMF steps use the second H buffer themselves)
     bool ahead = false;  // this step's update_H pass, W-only algebra and numerator pass already ran during the previous step
     for (int i = 0; i < n_steps; ++i) {
         const bool update_W = n_given < e->K;

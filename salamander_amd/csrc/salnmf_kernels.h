@@ -424,9 +424,10 @@ struct TailScratch {
 //   (16 independent loads in flight per item and round), then the 8 parts in order, then W' = W*G, the row sum
 //   sequentially over v, normalise, keep given rows, clip.
 // The slabs are [nslabs][K][VMAX] (row stride VMAX whatever V is).
+//   Wout: where the new row goes (normally W itself; the first step of a kept block writes a second buffer)
 template <int NT, bool SC1>
-__device__ __forceinline__ void tail_row(TailScratch& S, int tid, int k, const double* Gpart, int nslabs, double* G, double* W,
-                                         int V, int K, int n_given, int clip_mode, bool do_tail) {
+__device__ __forceinline__ void tail_row(TailScratch& S, int tid, int k, const double* Gpart, int nslabs, double* G, const double* W,
+                                         double* Wout, int V, int K, int n_given, int clip_mode, bool do_tail) {
     constexpr int NC = TAIL_BLOCK / NT;  // work items per thread
     static_assert(NC * NT == TAIL_BLOCK, "thread count must divide the work items");
     // loads in flight per item and round: with one item per thread all 32 slabs of a 256-workgroup grid at once
@@ -501,7 +502,7 @@ __device__ __forceinline__ void tail_row(TailScratch& S, int tid, int k, const d
         } else {
             w = clip_lo(w, kEps);
         }
-        st_shared<SC1>(W + k * V + v, w);
+        st_shared<SC1>(Wout + k * V + v, w);
     }
 }
 
@@ -524,7 +525,7 @@ __device__ __attribute__((noinline)) bool persist_publish_and_tail(unsigned* syn
             if (*okp == 0) return false;
             waited = true;
         }
-        tail_row<BLOCK, true>(*reinterpret_cast<TailScratch*>(lds), tid, k, Gpart, (int)gridDim.x, G, W, V, K, n_given, 0, true);
+        tail_row<BLOCK, true>(*reinterpret_cast<TailScratch*>(lds), tid, k, Gpart, (int)gridDim.x, G, W, W, V, K, n_given, 0, true);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) bump_counter(sync, SYNC_WROWS);
@@ -1494,7 +1495,8 @@ __global__ void __launch_bounds__(BLOCK, (fwd_lds_doubles<KS>() * 8 <= 80 * 1024
 struct TailParams {
     const double* __restrict__ Gpart;  // [nslabs][K][VMAX]
     double* __restrict__ G;            // [K][V]
-    double* __restrict__ W;            // [K][V] in/out
+    const double* W;                   // [K][V] in
+    double* Wout;                      // [K][V] out (normally == W)
     int nslabs;
     int V;
     int K;
@@ -1536,7 +1538,7 @@ __global__ void __launch_bounds__(TAIL_BLOCK) tail_kernel(TailParams p) {
             __syncthreads();
         }
     }
-    tail_row<TAIL_BLOCK, false>(S, threadIdx.x, k, p.Gpart, p.nslabs, p.G, p.W, p.V, K, p.n_given, p.clip_mode, p.do_tail != 0);
+    tail_row<TAIL_BLOCK, false>(S, threadIdx.x, k, p.Gpart, p.nslabs, p.G, p.W, p.Wout, p.V, K, p.n_given, p.clip_mode, p.do_tail != 0);
 }
 
 // out[j] = sum_i part[i*stride + j], j < width: one workgroup per output, fixed summation order
@@ -1556,6 +1558,9 @@ __global__ void __launch_bounds__(256) sum_partials_kernel(const double* __restr
     }
     if (threadIdx.x == 0) out[j] = addend ? red[0] + addend[0] : red[0];
 }
+
+// one double, device -> (pinned) host, as a kernel: its completion signal carries the event the reader waits for
+__global__ void copy_scalar_kernel(double* __restrict__ dst, const double* __restrict__ src) { *dst = *src; }
 
 // c[n] = sum_v (x log x - x) over the features of sample n (0 where x == 0): the x-only part of the KL divergence
 // (tile_kl), once per upload of X.  Library log: any x the reference accepts.  X is [Np][ldx], pad rows are 0.

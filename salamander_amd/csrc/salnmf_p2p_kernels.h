@@ -116,12 +116,12 @@ __global__ void __launch_bounds__(TAIL_BLOCK) tail_p2p_kernel(TailP2PParams p) {
     __shared__ TailScratch S;
     const int k = blockIdx.x, tid = threadIdx.x;
     const TailParams& t = p.t;
-    tail_row<TAIL_BLOCK, false>(S, tid, k, t.Gpart, t.nslabs, t.G, t.W, t.V, t.K, t.n_given, t.clip_mode, false);
+    tail_row<TAIL_BLOCK, false>(S, tid, k, t.Gpart, t.nslabs, t.G, t.W, t.Wout, t.V, t.K, t.n_given, t.clip_mode, false);
     const bool active = tid < t.V;  // (tail_row left the row's local sum in S.red[0][v], behind a barrier)
     const double total = p2p_exchange(p.x, k * t.V + tid, active, k, active ? S.red[0][tid] : 0.0, tid);
     if (active) t.G[k * t.V + tid] = total;
     __syncthreads();
-    tail_row<TAIL_BLOCK, false>(S, tid, k, nullptr, 0, t.G, t.W, t.V, t.K, t.n_given, t.clip_mode, true);
+    tail_row<TAIL_BLOCK, false>(S, tid, k, nullptr, 0, t.G, t.W, t.Wout, t.V, t.K, t.n_given, t.clip_mode, true);
 }
 
 }  // namespace salnmf

@@ -96,10 +96,15 @@ class Engine:
         _lib.check(self._lib.salnmf_download_W(self._h, _ptr(W)))
         return W
 
-    def download_H(self) -> np.ndarray:
-        H = np.empty((self.N, self.K), dtype=np.float64)
-        _lib.check(self._lib.salnmf_download_H(self._h, _ptr(H)))
-        return H
+    def download_H(self, out: np.ndarray | None = None) -> np.ndarray:
+        """The exposures; ``out``: a C-contiguous float64 ``(N, K)`` array to fill (e.g. one whose pages were touched
+        beforehand: a fresh 400 MB array costs more in page faults than its transfer)."""
+        if out is None:
+            out = np.empty((self.N, self.K), dtype=np.float64)
+        elif out.shape != (self.N, self.K) or out.dtype != np.float64 or not out.flags.c_contiguous:
+            raise ValueError(f"'out' has to be a C-contiguous float64 array of shape {(self.N, self.K)}.")
+        _lib.check(self._lib.salnmf_download_H(self._h, _ptr(out)))
+        return out
 
     # -- KLNMF
     def kl_step(self, n_steps: int = 1, n_given: int = 0):
@@ -131,6 +136,23 @@ class Engine:
         out = c_double()
         _lib.check(self._lib.salnmf_objective(self._h, ctypes.byref(out)))
         return out.value
+
+    def objective_async(self, slot: int):
+        """Queue the objective of the resident state into slot ``slot`` of the device ring (no host round trip)."""
+        _lib.check(self._lib.salnmf_objective_async(self._h, int(slot)))
+
+    def objective_read(self, first: int, count: int) -> np.ndarray:
+        """The values of ``count`` slots from ``first`` on (blocks until everything queued has finished)."""
+        out = np.empty(int(count), dtype=np.float64)
+        _lib.check(self._lib.salnmf_objective_read(self._h, int(first), int(count), _ptr(out)))
+        return out
+
+    def kl_step_keep(self, n_steps: int = 1, n_given: int = 0):
+        """``kl_step`` that keeps the state it starts from; :meth:`kl_rollback` returns to it."""
+        _lib.check(self._lib.salnmf_kl_step_keep(self._h, int(n_steps), int(n_given)))
+
+    def kl_rollback(self):
+        _lib.check(self._lib.salnmf_kl_rollback(self._h))
 
     def samplewise_kl(self) -> np.ndarray:
         out = np.empty(self.N, dtype=np.float64)

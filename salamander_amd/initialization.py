@@ -99,9 +99,14 @@ def initialize_mat(data_mat, n_signatures, method="nndsvd", given_signatures_mat
             raise ValueError("The given signature matrix contains too many signatures.")
         S[:g, :] = given_signatures_mat.copy()
 
-    W, H = normalize_WH(S.T, E.T)
-    W, H = W.clip(EPSILON), H.clip(EPSILON)
-    return W.T, H.T
+    # normalize_WH + clip (initialize.py:116-118; utils.py:155-158), with the exposures kept in their (N, K) storage
+    # layout: the same products entry by entry (H[k, n] * colsum[k]), but one pass over a C-contiguous array that the
+    # upload can take as it is, instead of a (K, N) temporary, its clipped copy and a transposing copy at c2's 40 MB
+    colsum = S.T.sum(axis=0)
+    W = (S.T / colsum).clip(EPSILON)
+    E = E * colsum[None, :]
+    np.clip(E, EPSILON, None, out=E)
+    return W.T, E
 
 
 def check_given_asignatures(given_asignatures, adata, n_signatures) -> None:

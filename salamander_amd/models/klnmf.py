@@ -64,6 +64,20 @@ class KLNMF(StandardNMF):
     def _device_objective(self) -> float:
         return self._engine.objective()
 
+    def _device_objective_async(self, slot: int) -> bool:
+        self._engine.objective_async(slot)
+        return True
+
+    def _device_objectives_read(self, first: int, count: int):
+        return self._engine.objective_read(first, count)
+
+    def _device_steps_keep(self, n_steps: int, given_parameters) -> bool:
+        self._engine.kl_step_keep(n_steps, self._n_given(given_parameters))
+        return True
+
+    def _device_rollback(self) -> None:
+        self._engine.kl_rollback()
+
     # -- fitting kwargs: per-sample loss weights and l-half penalty weights
     def _weight_vector(self, name: str, value):
         """Normalise one fitting kwarg to ``None`` or a non-negative ``ndarray (n_obs,)``.

@@ -16,6 +16,7 @@ dimensionality-reduction helpers.
 
 from __future__ import annotations
 
+import threading
 from abc import ABC, abstractmethod
 from typing import Any, Literal
 
@@ -29,6 +30,10 @@ from ..utils import EPSILON, type_checker, value_checker
 
 
 class SignatureNMF(ABC):
+    # fit() may clip the caller's X in a worker thread while the device starts from the raw matrix (models whose
+    # _initialize calls _finish_setup() before any host code reads adata.X)
+    _background_setup = False
+
     def __init__(
         self,
         n_signatures: int = 1,
@@ -120,11 +125,60 @@ class SignatureNMF(ABC):
         ...
 
     # ------------------------------------------------------------------ hooks
-    def _setup_adata(self, adata) -> None:
-        """Type check, keep a reference (no copy), clip the caller's X (signature_nmf.py:269-281)."""
+    def _setup_adata(self, adata, background: bool = False) -> None:
+        """Type check, keep a reference (no copy), clip the caller's X (signature_nmf.py:269-281).
+
+        ``background`` (``fit`` only): the clipped copy the reference hands back in ``adata.X`` is made by a worker
+        thread while the device already works from the raw matrix, which it clips itself on upload
+        (``salnmf_upload_X_typed(clip=1)``: the same values); ``_finish_setup`` joins the thread and sets ``adata.X``
+        -- before any host code reads it, and before ``fit`` returns at the latest.  The thread also touches the
+        pages of the array the fitted exposures will be downloaded into."""
         type_checker("adata", adata, ANNDATA_TYPES)
         self.adata = adata
-        self.adata.X = np.asarray(self.adata.X).clip(EPSILON)
+        if not background:
+            self.adata.X = np.asarray(self.adata.X).clip(EPSILON)
+            return
+        raw = np.asarray(self.adata.X)
+        box: dict[str, Any] = {}
+        n_sigs = self.n_signatures
+
+        def work():
+            import time
+
+            try:
+                t0 = time.perf_counter()
+                box["X"] = raw.clip(EPSILON)
+                t1 = time.perf_counter()
+                if raw.ndim == 2 and isinstance(n_sigs, int) and n_sigs > 0:
+                    out = np.empty((raw.shape[0], n_sigs), dtype=np.float64)
+                    np.copyto(out, 0.0)  # first touch here (the GIL is released), not inside the download at the end of the fit
+                    box["H"] = out
+                box["seconds"] = (t0, t1, time.perf_counter())  # (development aid: tools/time_fit_custom.py)
+            except BaseException as exc:  # re-raised by _finish_setup
+                box["error"] = exc
+
+        self._raw_X = raw
+        self._setup_box = box
+        self._setup_thread = threading.Thread(target=work, name="salnmf-setup", daemon=True)
+        self._setup_thread.start()
+
+    def _finish_setup(self) -> None:
+        """Join the worker of ``_setup_adata(background=True)``: ``adata.X`` becomes the clipped matrix."""
+        thread = getattr(self, "_setup_thread", None)
+        if thread is None:
+            return
+        thread.join()
+        box = self._setup_box
+        self._setup_thread = None
+        raw, self._raw_X = self._raw_X, None
+        if "error" in box:
+            raise box["error"]
+        self.adata.X = box["X"]
+        self._exposures_out = box.get("H")
+        # adata.X just let go of the caller's unclipped matrix; if that was its last reference, returning 77 MB (c2) to the
+        # system costs ~5 ms: a helper thread holds the array for a moment longer and lets go of it off this thread
+        threading.Thread(target=lambda a: None, args=(raw,), name="salnmf-release", daemon=True).start()
+        del raw
 
     @abstractmethod
     def _initialize(self, given_parameters=None, init_kwargs=None) -> None:
@@ -151,8 +205,17 @@ class SignatureNMF(ABC):
         return None, None
 
     # ------------------------------------------------------------------ host <-> device state
+    def _upload_X(self, e) -> None:
+        """X to the device: the raw matrix, clipped there, while the background clip of ``fit`` is still running."""
+        raw = getattr(self, "_raw_X", None)
+        if raw is not None:
+            e.upload_X(raw, clip=True)
+        else:
+            e.upload_X(np.ascontiguousarray(self.adata.X, dtype=np.float64))
+
     def _host_state(self):
-        X = np.ascontiguousarray(self.adata.X, dtype=np.float64)
+        raw = getattr(self, "_raw_X", None)
+        X = raw if raw is not None else np.ascontiguousarray(self.adata.X, dtype=np.float64)
         W = np.ascontiguousarray(self.asignatures.X, dtype=np.float64)
         H = None  # resident on the device only (fit() after a device-side initialisation)
         if "exposures" in self.adata.obsm or "H" not in self._resident:
@@ -193,7 +256,7 @@ class SignatureNMF(ABC):
             self._w_broadcast_due = False
         # what a device-side initialisation left resident is not uploaded again (once)
         if "X" not in self._resident:
-            e.upload_X(X)
+            self._upload_X(e)
         e.upload_W(W)
         if "H" not in self._resident:
             e.upload_H(H)
@@ -202,7 +265,25 @@ class SignatureNMF(ABC):
 
     def _sync_from_device(self) -> None:
         self.asignatures.X = self._engine.download_W()
-        self.adata.obsm["exposures"] = self._engine.download_H()
+        out = getattr(self, "_exposures_out", None)  # (fit: an array whose pages are touched already)
+        self._exposures_out = None
+        if out is not None and out.shape != (self._engine.N, self._engine.K):
+            out = None
+        self.adata.obsm["exposures"] = self._engine.download_H(out)
+
+    # asynchronous objectives (fit): models whose objective can be queued without a host round trip override these
+    def _device_objective_async(self, slot: int) -> bool:
+        return False
+
+    def _device_objectives_read(self, first: int, count: int):
+        raise NotImplementedError
+
+    def _device_steps_keep(self, n_steps: int, given_parameters) -> bool:
+        """Queue ``n_steps`` updates that can be undone by ``_device_rollback`` (False: not supported)."""
+        return False
+
+    def _device_rollback(self) -> None:
+        raise NotImplementedError
 
     def _n_obs_total(self) -> int:
         """Samples over all shards (``adata`` is this rank's shard when ``distributed``), else ``adata.n_obs``."""
@@ -227,17 +308,41 @@ class SignatureNMF(ABC):
         verbose: Literal[0, 1] = 0,
         verbosity_freq: int = 1000,
     ) -> "SignatureNMF":
-        self._setup_adata(adata)
-        # inside fit() a device-side initialisation leaves the exposures on the device only: they come back once, with
-        # the fitted ones (a 40 MB host array and its page faults less at c2)
-        self._defer_exposures = True
+        self._setup_adata(adata, background=self._background_setup)
         try:
-            self._initialize(given_parameters, init_kwargs)
+            # inside fit() a device-side initialisation leaves the exposures on the device only: they come back once,
+            # with the fitted ones (a 40 MB host array and its page faults less at c2)
+            self._defer_exposures = True
+            try:
+                self._initialize(given_parameters, init_kwargs)
+            finally:
+                self._defer_exposures = False
+            self._setup_fitting_parameters(fitting_kwargs)
+            self._sync_to_device()
+            if not verbose and self._device_objective_async(0):
+                of_values, n_iteration = self._fit_loop_queued(given_parameters)
+            else:
+                of_values, n_iteration = self._fit_loop_blocking(given_parameters, verbose, verbosity_freq)
         finally:
-            self._defer_exposures = False
-        self._setup_fitting_parameters(fitting_kwargs)
-        self._sync_to_device()
+            self._finish_setup()  # adata.X is the clipped matrix from here on (signature_nmf.py:281)
+        self._sync_from_device()
+        self.n_iterations_ = n_iteration
+        if history:
+            self.history["objective_function"] = of_values[1:]
+        return self
 
+    def _next_stop(self, n_iteration: int) -> int:
+        """The next iteration at which the reference would look at the model: a convergence test or the iteration cap
+        (the reference tests ``n_iteration >= max_iterations`` after every single update: the cap is the next iteration
+        at the latest, and ``max_iterations <= 0`` still runs exactly one update)."""
+        freq = self.conv_test_freq
+        stop = (n_iteration // freq + 1) * freq
+        stop = min(stop, max(self.max_iterations, n_iteration + 1))
+        return max(stop, n_iteration + 1)
+
+    def _fit_loop_blocking(self, given_parameters, verbose, verbosity_freq):
+        """The loop of signature_nmf.py:358-385 with one host round trip per objective (verbose fits, and models whose
+        objective cannot be queued)."""
         of_values = [self._device_objective()]
         n_iteration = 0
         converged = False
@@ -248,10 +353,7 @@ class SignatureNMF(ABC):
             if verbose and (n_iteration + 1) % verbosity_freq == 0:
                 # printed before the update of that iteration, with the latest known objective
                 print(f"iteration: {n_iteration + 1}; objective: {of_values[-1]:.2f}")
-            stop = (n_iteration // freq + 1) * freq
-            # the reference tests `n_iteration >= max_iterations` after every single update: the cap is the next
-            # iteration at the latest (max_iterations <= 0 still runs exactly one update)
-            stop = min(stop, max(self.max_iterations, n_iteration + 1))
+            stop = self._next_stop(n_iteration)
             if verbose:
                 next_print = ((n_iteration + 1) // verbosity_freq + 1) * verbosity_freq
                 stop = min(stop, next_print - 1)
@@ -265,12 +367,62 @@ class SignatureNMF(ABC):
                 rel_change = np.abs(prev - of_values[-1]) / np.abs(prev)
                 converged = bool(rel_change < self.tol and n_iteration >= self.min_iterations)
             converged |= n_iteration >= self.max_iterations
+        return of_values, n_iteration
 
-        self._sync_from_device()
-        self.n_iterations_ = n_iteration
-        if history:
-            self.history["objective_function"] = of_values[1:]
-        return self
+    def _fit_loop_queued(self, given_parameters):
+        """The same loop with the host out of the way (same objectives, same stopping iteration).
+
+        * Before ``min_iterations`` the convergence test cannot stop the fit (signature_nmf.py:373-380): objectives are
+          only QUEUED into the device's ring of slots and the steps keep being launched; the values are read in one go
+          when a decision first needs them.
+        * From ``min_iterations`` on every test needs its objective, so the next block of steps is queued BEFORE the
+          value is read -- as steps that keep the state they start from (``salnmf_kl_step_keep``: no copy) -- and the
+          read's round trip hides behind it; if the test says "converged" the block is rolled back.
+        The initial objective is in slot 0 already (queued by ``fit``)."""
+        from .. import _lib
+
+        ring = _lib.OBJECTIVE_SLOTS
+        freq = self.conv_test_freq
+        of_values: list[float] = []
+        first_slot, pending = 0, 1  # slots [first_slot, first_slot + pending) hold queued, unread objectives
+
+        def read_pending():
+            nonlocal first_slot, pending
+            while pending:
+                n = min(pending, ring - first_slot)
+                of_values.extend(float(v) for v in self._device_objectives_read(first_slot, n))
+                first_slot = (first_slot + n) % ring
+                pending -= n
+
+        n_iteration = 0  # the iteration the decisions below are about
+        n_queued = 0     # updates launched so far (ahead of n_iteration by one kept block at most)
+        while True:
+            stop = self._next_stop(n_iteration)
+            if n_queued < stop:
+                self._device_steps(stop - n_queued, given_parameters)
+                n_queued = stop
+            n_iteration = stop
+            check = n_iteration % freq == 0
+            if check:
+                if pending == ring:
+                    read_pending()
+                self._device_objective_async((first_slot + pending) % ring)
+                pending += 1
+            if n_iteration >= self.max_iterations:
+                break
+            if check and n_iteration >= self.min_iterations:
+                nxt = self._next_stop(n_iteration)
+                kept = self._device_steps_keep(nxt - n_iteration, given_parameters)
+                if kept:
+                    n_queued = nxt
+                read_pending()
+                prev, cur = of_values[-2], of_values[-1]
+                if np.abs(prev - cur) / np.abs(prev) < self.tol:
+                    if kept:
+                        self._device_rollback()
+                    break
+        read_pending()
+        return of_values, n_iteration
 
     # ------------------------------------------------------------------ out of scope
     def _out_of_scope(self, *args, **kwargs):

@@ -17,6 +17,8 @@ from .signature_nmf import SignatureNMF
 
 
 class StandardNMF(SignatureNMF):
+    _background_setup = True  # _initialize below joins the background clip before host code reads adata.X
+
     def _initialize(self, given_parameters: dict[str, Any] | None = None, init_kwargs: dict[str, Any] | None = None) -> None:
         """Initialise signatures and exposures; given signatures are never overwritten later.
 
@@ -29,6 +31,8 @@ class StandardNMF(SignatureNMF):
                 raise TypeError(f"init method '{self.init_method}' takes no keyword arguments besides 'seed': {sorted(init_kwargs)}")
             self._initialize_on_device(given_parameters)
             return
+        if self.init_method != "custom":  # ("custom" looks at the shape of X only)
+            self._finish_setup()  # the host methods read the clipped adata.X
         self.asignatures = initialize_standard_nmf(
             self.adata, self.n_signatures, self.init_method, given_parameters, **init_kwargs
         )
@@ -41,9 +45,9 @@ class StandardNMF(SignatureNMF):
         if given is not None:
             check_given_asignatures(given, self.adata, self.n_signatures)
             given_mat = np.asarray(given.X)
-        X = np.ascontiguousarray(self.adata.X, dtype=np.float64)
-        e = self._ensure_engine(X.shape[0], X.shape[1], self.n_signatures)
-        e.upload_X(X)
+        n_obs, n_vars = np.shape(self.adata.X)
+        e = self._ensure_engine(n_obs, n_vars, self.n_signatures)
+        self._upload_X(e)  # (inside fit: the raw matrix, clipped on the device, while the host's clipped copy is being made)
         S = initialize_on_device(e, self.n_signatures, self.init_method, given_mat, self._n_obs_total())
         self.asignatures = package_signatures(self.adata, S, self.n_signatures, given)
         if getattr(self, "_defer_exposures", False):

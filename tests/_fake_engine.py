@@ -38,8 +38,11 @@ class FakeEngine:
     def download_W(self):
         return self.W.copy()
 
-    def download_H(self):
-        return self.H.copy()
+    def download_H(self, out=None):
+        if out is None:
+            return self.H.copy()
+        out[...] = self.H
+        return out
 
     def kl_step(self, n_steps=1, n_given=0):
         self.steps_log.append(n_steps)
@@ -48,7 +51,29 @@ class FakeEngine:
             self.W, self.H = W.T.copy(), H.T.copy()
 
     def objective(self):
+        self.blocking_objectives = getattr(self, "blocking_objectives", 0) + 1
         return orc.klnmf_objective(self.X.T, self.W.T, self.H.T, self.wkl, self.wlh)
+
+    # -- the queued forms (salnmf_objective_async / _read, salnmf_kl_step_keep / _rollback)
+    def objective_async(self, slot):
+        if not hasattr(self, "ring"):
+            self.ring = np.full(256, np.nan)
+        self.ring[slot] = orc.klnmf_objective(self.X.T, self.W.T, self.H.T, self.wkl, self.wlh)
+
+    def objective_read(self, first, count):
+        self.reads = getattr(self, "reads", [])
+        self.reads.append((first, count))
+        return self.ring[first : first + count].copy()
+
+    def kl_step_keep(self, n_steps=1, n_given=0):
+        self._kept = (self.W.copy(), self.H.copy())
+        self.kl_step(n_steps, n_given)
+        self.steps_log[-1] = ("keep", n_steps)
+
+    def kl_rollback(self):
+        self.W, self.H = self._kept
+        self._kept = None
+        self.steps_log.append("rollback")
 
     def update_H(self):
         self.H = orc.update_H(self.X.T, self.W.T, self.H.T, self.wkl, self.wlh).T.copy()

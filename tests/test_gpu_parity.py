@@ -358,6 +358,62 @@ def test_persistent_multi_step_launch_gives_the_same_bits():
         assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
 
 
+@pytest.mark.parametrize(
+    "N,K,n_given,weights,precision",
+    [(20000, 50, 0, False, "f64"), (3000, 50, 7, False, "f64"), (1000, 30, 0, True, "f64"), (500, 5, 5, False, "f64"), (4000, 16, 0, False, "f32")],
+)
+def test_kept_block_rollback_and_queued_objectives(N, K, n_given, weights, precision):
+    """``kl_step_keep`` = ``kl_step`` bit for bit, ``kl_rollback`` returns to the state the kept block started from
+    (incl. all signatures given, per-sample weights, the fp32 fast mode), and the queued objectives are the blocking
+    ones -- what lets ``fit`` launch the next block before it has read the deciding objective."""
+    X, W0, H0 = orc.synthetic_problem(96, N, K, seed=N % 89)
+    rng = np.random.default_rng(3)
+    wk, wl = (rng.uniform(0.5, 2.0, N), rng.uniform(0.0, 0.3, N)) if weights else (None, None)
+    engines = []
+    for _ in range(2):
+        e = Engine(N, 96, K)
+        e.upload_X(X), e.upload_W(W0), e.upload_H(H0)
+        e.set_weights(wk, wl)
+        e.set_precision(precision)
+        e.kl_step(3, n_given)
+        engines.append(e)
+    a, b = engines
+    W3, H3, o3 = a.download_W(), a.download_H(), a.objective()
+    a.kl_step(7, n_given)
+    b.objective_async(5)
+    b.kl_step_keep(7, n_given)
+    b.objective_async(6)
+    assert np.array_equal(b.download_W(), a.download_W()) and np.array_equal(b.download_H(), a.download_H())
+    b.kl_rollback()
+    assert np.array_equal(b.download_W(), W3) and np.array_equal(b.download_H(), H3)
+    with pytest.raises(RuntimeError, match="kept"):
+        b.kl_rollback()
+    b.kl_step_keep(7, n_given)  # again from the restored state: the same seven steps
+    b.objective_async(7)
+    assert np.array_equal(b.download_W(), a.download_W()) and np.array_equal(b.download_H(), a.download_H())
+    vals = b.objective_read(5, 3)
+    assert vals[0] == o3 and vals[1] == a.objective() and vals[2] == vals[1]
+    a.close(), b.close()
+
+
+def test_model_fit_queued_loop_equals_blocking_loop_on_the_device():
+    """``KLNMF.fit`` with the host out of the loop (queued objectives, speculative kept blocks) against the blocking loop
+    (verbose): same stopping iteration, history and bits of W and H -- with a tolerance stop, i.e. through a rollback."""
+    X, W0, H0 = orc.synthetic_problem(96, 2000, 8, seed=12)
+    fits = []
+    for verbose in (0, 1):
+        m = sal.models.KLNMF(8, "custom", min_iterations=30, max_iterations=3000, conv_test_freq=10, tol=1e-5)
+        m.fit(sal.AnnData(X.copy()), init_kwargs={"signatures_mat": W0.copy(), "exposures_mat": H0.copy()}, verbose=verbose, verbosity_freq=10**9)
+        fits.append(m)
+    q, b = fits
+    assert 30 < q.n_iterations_ < 3000 and q.n_iterations_ == b.n_iterations_
+    assert q.history["objective_function"] == b.history["objective_function"]
+    assert np.array_equal(q.asignatures.X, b.asignatures.X) and np.array_equal(q.adata.obsm["exposures"], b.adata.obsm["exposures"])
+    W, H, it, hist = orc.fit_klnmf(X.T, W0.T, H0.T, min_iterations=30, max_iterations=3000, conv_test_freq=10, tol=1e-5)
+    assert it == q.n_iterations_ and np.allclose(q.history["objective_function"], hist, rtol=1e-11)
+    assert rel_l2(q.asignatures.X, W.T) < 1e-8 and rel_l2(q.adata.obsm["exposures"], H.T) < 1e-8
+
+
 # ------------------------------------------------------------------ determinism and split-step (multi-GPU semantics on one GPU)
 def test_bitwise_reproducible():
     X, W0, H0 = orc.synthetic_problem(96, 20000, 50, seed=4)

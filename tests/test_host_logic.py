@@ -271,6 +271,41 @@ def test_fit_equals_oracle_fit_including_convergence_stop(fake_engine, counts):
     assert rel_l2(m.asignatures.X, W.T) < 1e-13 and rel_l2(m.adata.obsm["exposures"], H.T) < 1e-13
 
 
+def test_fit_queues_objectives_until_min_iterations_then_speculates(fake_engine, counts):
+    """The host is out of the loop: before ``min_iterations`` no objective is read back -- they are
+    queued into the ring and fetched in one read; from then on the next block is launched (as a kept block) before the
+    deciding objective is read, and rolled back when the test says "converged".  Same history, stopping iteration and
+    final state as the blocking loop (which verbose fits still use)."""
+    X = counts.T.values.astype(float)
+    S0, E0 = init.initialize_mat(X.clip(utils.EPSILON), 2, "random", seed=2)
+    kw = dict(min_iterations=40, max_iterations=400, conv_test_freq=10, tol=1e-4)
+    init_kw = lambda: {"signatures_mat": S0.copy(), "exposures_mat": E0.copy()}
+    q = sal.models.KLNMF(2, "custom", **kw)
+    q.fit(make_adata(counts), init_kwargs=init_kw())
+    e = q._engine
+    assert getattr(e, "blocking_objectives", 0) == 0
+    # steps up to min_iterations are plain launches, every block after a decision point is a kept one, and the last
+    # kept block was discarded
+    assert e.steps_log[:4] == [10, 10, 10, 10] and all(s == ("keep", 10) for s in e.steps_log[4:-1]) and e.steps_log[-1] == "rollback"
+    # one read fetched everything queued before the first decision (initial objective + 4 checks); then one per decision
+    assert e.reads[0] == (0, 5) and all(c == 1 for _, c in e.reads[1:])
+    assert q.n_iterations_ < 400 and q.n_iterations_ == 10 * (len(e.steps_log) - 2)
+    b = sal.models.KLNMF(2, "custom", **kw)
+    b.fit(make_adata(counts), init_kwargs=init_kw(), verbose=1, verbosity_freq=10**9)
+    assert b._engine.blocking_objectives == len(b.history["objective_function"]) + 1
+    assert q.n_iterations_ == b.n_iterations_ and q.history["objective_function"] == b.history["objective_function"]
+    assert np.array_equal(q.asignatures.X, b.asignatures.X) and np.array_equal(q.adata.obsm["exposures"], b.adata.obsm["exposures"])
+
+
+def test_fit_objective_ring_wraps(fake_engine, counts):
+    """More queued objectives than the device ring has slots (256): the loop drains the ring when it is full."""
+    m = sal.models.KLNMF(2, "flat", min_iterations=1100, max_iterations=1100, conv_test_freq=1)
+    m.fit(make_adata(counts))
+    hist = m.history["objective_function"]
+    assert len(hist) == 1100 and np.all(np.isfinite(hist)) and np.all(np.diff(hist) <= 1e-9 * np.abs(hist[:-1]))
+    assert m._engine.reads[0] == (0, 256) and sum(c for _, c in m._engine.reads) == 1101
+
+
 def test_verbose_prints_at_the_reference_iterations(fake_engine, counts, capsys):
     m = sal.models.KLNMF(2, "flat", min_iterations=25, max_iterations=25)
     m.fit(make_adata(counts), verbose=1, verbosity_freq=7)

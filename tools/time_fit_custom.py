@@ -1,0 +1,33 @@
+"""Development aid: where the wall-clock of KLNMF(50, "custom").fit goes at c2 (500 iterations), piece by piece
+(the bench's time_to_kl.gpu_fit_seconds_end_to_end), with the background setup of fit() on and off."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import salamander_amd as sal
+from salamander_amd.synthetic import synthetic_problem
+from salamander_amd.models import signature_nmf, standard_nmf
+
+V, N, K = 96, 100000, 50
+X, W0, H0 = synthetic_problem(V, N, K, seed=0)
+
+
+def stamp(fn, name, log):
+    def wrapped(*a, **k):
+        t0 = time.perf_counter(); r = fn(*a, **k); log.append((name, time.perf_counter() - t0)); return r
+    return wrapped
+
+
+for background in (True, False, True, False, True):
+    standard_nmf.StandardNMF._background_setup = background
+    m = sal.models.KLNMF(K, "custom", min_iterations=500, max_iterations=500)
+    log = []
+    for name in ("_setup_adata", "_initialize", "_sync_to_device", "_fit_loop_queued", "_finish_setup", "_sync_from_device"):
+        setattr(m, name, stamp(getattr(m, name), name, log))
+    adata = sal.AnnData(X.copy())
+    t0 = time.perf_counter()
+    m.fit(adata, init_kwargs={"signatures_mat": W0.copy(), "exposures_mat": H0.copy()})
+    t = time.perf_counter() - t0
+    if background:
+        w = m._setup_box.get("seconds")
+        print(f"   worker: started {1e3*(w[0]-t0):.1f} ms after fit began, clip {1e3*(w[1]-w[0]):.1f} ms, touch {1e3*(w[2]-w[1]):.1f} ms", flush=True)
+    print(f"background={background}: fit {t*1e3:.1f} ms | " + ", ".join(f"{n} {1e3*d:.1f}" for n, d in log), flush=True)
