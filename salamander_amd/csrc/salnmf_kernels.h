@@ -425,16 +425,18 @@ struct TailScratch {
 //   sequentially over v, normalise, keep given rows, clip.
 // The slabs are [nslabs][K][VMAX] (row stride VMAX whatever V is).
 //   Wout: where the new row goes (normally W itself; the first step of a kept block writes a second buffer)
+//   nslabs: > 0 sum the slabs into G; 0 take the reduced row from G; < 0 it is in S.red[0] already (wold_in = the old
+//   row of W, loaded by the caller beside its other loads)
 template <int NT, bool SC1>
 __device__ __forceinline__ void tail_row(TailScratch& S, int tid, int k, const double* Gpart, int nslabs, double* G, const double* W,
-                                         double* Wout, int V, int K, int n_given, int clip_mode, bool do_tail) {
+                                         double* Wout, int V, int K, int n_given, int clip_mode, bool do_tail, double wold_in = 0.0) {
     constexpr int NC = TAIL_BLOCK / NT;  // work items per thread
     static_assert(NC * NT == TAIL_BLOCK, "thread count must divide the work items");
     // loads in flight per item and round: with one item per thread all 32 slabs of a 256-workgroup grid at once
     // (the tail is a chain of memory round trips: one for the slabs instead of two), the old row beside them
     constexpr int B = NC == 1 ? 32 : 16;
-    double wold = 0.0;
-    if (do_tail && tid < VMAX && tid < V) wold = ld_shared<SC1>(W + k * V + tid);
+    double wold = wold_in;
+    if (do_tail && nslabs >= 0 && tid < VMAX && tid < V) wold = ld_shared<SC1>(W + k * V + tid);
     if (nslabs > 0) {
         double s[NC];
 #pragma unroll
@@ -470,7 +472,7 @@ __device__ __forceinline__ void tail_row(TailScratch& S, int tid, int k, const d
             S.red[0][tid] = t;
         }
         __syncthreads();
-    } else {
+    } else if (nslabs == 0) {
         if (tid < VMAX && tid < V) S.red[0][tid] = G[k * V + tid];
         __syncthreads();
     }

@@ -5,8 +5,8 @@
 // Why not the RCCL call: the vector is 38 KB at K = 50.  A library all-reduce of that size is pure latency (several
 // kernel-internal ring / tree hops, ~25-40 us on 8 GPUs), which is a third of a c3 step.  Here every rank stores its
 // vector straight into an inbox on each peer (7 links in parallel, < 1 us of wire time), raises one flag per workgroup and
-// peer, waits for the peers' flags in its own inbox and adds the n vectors in rank order -- the same order on every
-// rank, so all ranks end up with bit-identical sums and hence bit-identical W.
+// peer, waits for the peers' flags in its own inbox and adds the n vectors in rank order (its own term from the register
+// it still holds) -- the same order on every rank, so all ranks end up with bit-identical sums and hence bit-identical W.
 //
 // Memory: the inboxes are uncached device allocations (hipDeviceMallocUncached: remote stores are visible to the home
 // GPU without any cache maintenance there), exported / opened with hipIpc*MemHandle.  Layout per engine:
@@ -52,27 +52,35 @@ typedef __attribute__((address_space(1))) unsigned long long gflag_t;
 // One workgroup's part of an exchange: element `idx` of the vector (value v, where `active`), completion flag `flag_idx`
 // of the slot.  Called by every thread of the workgroup; returns the sum over the ranks in rank order (0 where inactive
 // or after a wait gave up, in which case the abort word is set).
-__device__ __forceinline__ double p2p_exchange(const P2PParams& p, int idx, bool active, int flag_idx, double v, int tid) {
+// The engine's "an earlier exchange gave up" word, read by lane 0 (0 elsewhere).  A kernel that has other work before its
+// exchange issues this load first, so that its round trip is not on the exchange's critical path.
+__device__ __forceinline__ unsigned p2p_abort_word(const P2PParams& p, int tid) {
+    return tid == 0 ? __hip_atomic_load((__attribute__((address_space(1))) unsigned*)p.abort_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+}
+
+//   abort_word: p2p_abort_word(p, tid)
+__device__ __forceinline__ double p2p_exchange(const P2PParams& p, int idx, bool active, int flag_idx, double v, int tid, unsigned abort_word) {
     const size_t mine = ((size_t)p.parity * p.n_ranks + p.rank) * p.slot;
     __shared__ int failed;
-    if (tid == 0) failed = __hip_atomic_load((__attribute__((address_space(1))) unsigned*)p.abort_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    if (tid == 0) failed = abort_word != 0;
     __syncthreads();
     if (failed) return 0.0;  // (one lane's reading, so the whole workgroup takes the same way)
+    // (this rank's own contribution stays in its register: no round trip through its own uncached inbox)
     if (active) {
         for (int r = 0; r < p.n_ranks; ++r)
-            __hip_atomic_store((gdouble_t*)(p.inbox[r] + mine + idx), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (r != p.rank) __hip_atomic_store((gdouble_t*)(p.inbox[r] + mine + idx), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     // every storing wave drains its (write-through, system-scope) stores: they are acknowledged by the destination
     // before the flag is issued.  No release fence: that would write back this GPU's whole L2 in every workgroup, and
     // nothing but the uncached inbox is shared with the peers.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid < p.n_ranks) {
+    if (tid < p.n_ranks && tid != p.rank) {
         gflag_t* flag = (gflag_t*)(p.inbox[tid] + mine + p.max_count) + flag_idx;
         __hip_atomic_store(flag, p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    // wait for this workgroup's slice from every source (lane r polls source r)
-    if (tid < p.n_ranks) {
+    // wait for this workgroup's slice from every other source (lane r polls source r)
+    if (tid < p.n_ranks && tid != p.rank) {
         const gflag_t* flag = (const gflag_t*)(p.inbox[p.rank] + ((size_t)p.parity * p.n_ranks + tid) * p.slot + p.max_count) + flag_idx;
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         for (unsigned spins = 1;; ++spins) {
@@ -88,10 +96,18 @@ __device__ __forceinline__ double p2p_exchange(const P2PParams& p, int idx, bool
     }
     __syncthreads();
     if (failed || !active) return 0.0;
+    // all peers' values in flight together, then the sum in rank order (this rank's own term from the register)
+    double t[P2P_MAX_RANKS];
+#pragma unroll
+    for (int r = 0; r < P2P_MAX_RANKS; ++r)
+        t[r] = (r < p.n_ranks && r != p.rank)
+                   ? __hip_atomic_load((const gdouble_t*)(p.inbox[p.rank] + ((size_t)p.parity * p.n_ranks + r) * p.slot + idx), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_SYSTEM)
+                   : 0.0;
     double s = 0.0;
-    for (int r = 0; r < p.n_ranks; ++r)
-        s += __hip_atomic_load((const gdouble_t*)(p.inbox[p.rank] + ((size_t)p.parity * p.n_ranks + r) * p.slot + idx), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+    for (int r = 0; r < P2P_MAX_RANKS; ++r)
+        if (r < p.n_ranks) s += (r == p.rank) ? v : t[r];
     return s;
 }
 
@@ -99,7 +115,8 @@ __global__ void __launch_bounds__(P2P_BLOCK) p2p_allreduce_kernel(P2PParams p) {
     const int tid = threadIdx.x;
     const int i = blockIdx.x * P2P_BLOCK + tid;
     const bool active = i < p.count;
-    const double s = p2p_exchange(p, i, active, blockIdx.x, active ? p.buf[i] : 0.0, tid);
+    const unsigned ab = p2p_abort_word(p, tid);
+    const double s = p2p_exchange(p, i, active, blockIdx.x, active ? p.buf[i] : 0.0, tid, ab);
     if (active) p.buf[i] = s;
 }
 
@@ -116,12 +133,19 @@ __global__ void __launch_bounds__(TAIL_BLOCK) tail_p2p_kernel(TailP2PParams p) {
     __shared__ TailScratch S;
     const int k = blockIdx.x, tid = threadIdx.x;
     const TailParams& t = p.t;
+    const unsigned ab = p2p_abort_word(p.x, tid);  // (in flight beside the slab loads)
+    const double wold = (tid < t.V) ? t.W[k * t.V + tid] : 0.0;  // old row of W, for the second half: likewise
     tail_row<TAIL_BLOCK, false>(S, tid, k, t.Gpart, t.nslabs, t.G, t.W, t.Wout, t.V, t.K, t.n_given, t.clip_mode, false);
     const bool active = tid < t.V;  // (tail_row left the row's local sum in S.red[0][v], behind a barrier)
-    const double total = p2p_exchange(p.x, k * t.V + tid, active, k, active ? S.red[0][tid] : 0.0, tid);
-    if (active) t.G[k * t.V + tid] = total;
+    const double total = p2p_exchange(p.x, k * t.V + tid, active, k, active ? S.red[0][tid] : 0.0, tid, ab);
+    // the reduced row goes to G (the engine's buffer) and, through LDS, straight into the W update: no store -> load
+    // round trip through global memory in between
+    if (active) {
+        t.G[k * t.V + tid] = total;
+        S.red[0][tid] = total;
+    }
     __syncthreads();
-    tail_row<TAIL_BLOCK, false>(S, tid, k, nullptr, 0, t.G, t.W, t.Wout, t.V, t.K, t.n_given, t.clip_mode, true);
+    tail_row<TAIL_BLOCK, false>(S, tid, k, nullptr, -1, t.G, t.W, t.Wout, t.V, t.K, t.n_given, t.clip_mode, true, wold);
 }
 
 }  // namespace salnmf
