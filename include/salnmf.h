@@ -250,6 +250,11 @@ int salnmf_init_project(salnmf_engine* e, const double* B, double* posneg_out);
 int salnmf_init_finish(salnmf_engine* e, const double* scale, const int* take_neg, const double* post,
                        double zero_below, double fill);
 int salnmf_init_flat(salnmf_engine* e, const double* post /* n_signatures */);
+/* separableNMF (methods.py:112-135), the signature side: n_select rounds of successive projection on the resident X
+ * (every sample normalised to sum 1; argmax of the squared norms with np.argmax's tie rule; rank-1 deflation) ->
+ * chosen_out[n_select] = the selected sample indices in selection order.  The exposures of that method come from the
+ * host's legacy RNG (methods.py:133) and stay with the host layer.  Unsharded engines only. */
+int salnmf_init_separable(salnmf_engine* e, int n_select, int64_t* chosen_out);
 
 /* Multi-GPU: one engine per process/GPU, sample axis sharded; the only exchange is an
  * RCCL all-reduce of the (K x V) numerator per W update (+ scalars for objectives; CorrNMF adds one gather

@@ -161,4 +161,117 @@ __global__ void init_flat_kernel(const double* __restrict__ X, double* __restric
     }
 }
 
+// ---- separableNMF (successive projection, Gillis & Vavasis 2013): the signature side of
+// src/salamander/initialization/methods.py:112-135.  R = X^T with every sample normalised to sum 1; K rounds of
+//   j = argmax_n |R_n|^2 (lowest index on ties, as np.argmax),  u = R_j,  R_n <- R_n - (u <u, R_n>) / |u|^2
+// The reference forms the V x V projector's action through a V x N temporary per round (seconds at c2, in front of a
+// 39 ms loop); here a round is ONE pass over the resident R (deflation by the previous round's u fused with the next
+// round's norms and per-workgroup argmax) and a one-workgroup selection kernel.  16 lanes per sample row: coalesced
+// 128-byte row segments, reductions over the 16 lanes by shuffles.
+constexpr int SEP_BLOCK = 256;  // 16 samples x 16 lanes
+constexpr int SEP_STATE = 128;  // doubles: u[96] | |u|^2 at [96]
+
+template <bool INIT>
+__global__ void __launch_bounds__(SEP_BLOCK) sep_pass_kernel(const double* __restrict__ X, double* __restrict__ R, int64_t N, int V,
+                                                              const double* __restrict__ state, double* __restrict__ pval,
+                                                              long long* __restrict__ pidx) {
+    __shared__ double bval[16];
+    __shared__ long long bidx[16];
+    const int slot = threadIdx.x >> 4, c = threadIdx.x & 15;
+    double u[VT], un = 1.0;
+    if (!INIT) {
+#pragma unroll
+        for (int t = 0; t < VT; ++t) u[t] = state[c + 16 * t];
+        un = state[VMAX];
+    }
+    double best = -1.0;
+    long long besti = 0x7fffffffffffffffll;
+    for (int64_t n = (int64_t)blockIdx.x * 16 + slot; n < N; n += (int64_t)gridDim.x * 16) {
+        double r[VT];
+        const double* src = (INIT ? X : R) + n * VMAX + c;
+#pragma unroll
+        for (int t = 0; t < VT; ++t) r[t] = (c + 16 * t < V) ? src[16 * t] : 0.0;
+        double acc = 0.0;
+        if (INIT) {
+#pragma unroll
+            for (int t = 0; t < VT; ++t) acc += r[t];
+        } else {
+#pragma unroll
+            for (int t = 0; t < VT; ++t) acc = __builtin_fma(u[t], r[t], acc);
+        }
+#pragma unroll
+        for (int m = 8; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 16);
+        if (INIT) {
+#pragma unroll
+            for (int t = 0; t < VT; ++t) r[t] = r[t] / acc;               // data_mat.T / data_mat.T.sum(axis=0)
+        } else {
+#pragma unroll
+            for (int t = 0; t < VT; ++t) r[t] = r[t] - (u[t] * acc) / un;  // R - np.outer(u, u @ R) / norms[j]
+        }
+        double nrm = 0.0;
+#pragma unroll
+        for (int t = 0; t < VT; ++t) {
+            R[n * VMAX + c + 16 * t] = r[t];
+            nrm = __builtin_fma(r[t], r[t], nrm);
+        }
+#pragma unroll
+        for (int m = 8; m > 0; m >>= 1) nrm += __shfl_xor(nrm, m, 16);
+        if (nrm > best) {  // (n increases: a later equal norm does not replace an earlier one)
+            best = nrm;
+            besti = n;
+        }
+    }
+    if (c == 0) {
+        bval[slot] = best;
+        bidx[slot] = besti;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double b = bval[0];
+        long long bi = bidx[0];
+        for (int i = 1; i < 16; ++i)
+            if (bval[i] > b || (bval[i] == b && bidx[i] < bi)) {
+                b = bval[i];
+                bi = bidx[i];
+            }
+        pval[blockIdx.x] = b;
+        pidx[blockIdx.x] = bi;
+    }
+}
+
+// one workgroup: the global argmax of the per-workgroup candidates (lowest index on ties), u <- R_j, |u|^2, chosen[round] <- j
+__global__ void __launch_bounds__(256) sep_select_kernel(const double* __restrict__ R, const double* __restrict__ pval,
+                                                         const long long* __restrict__ pidx, int nparts, double* __restrict__ state,
+                                                         long long* __restrict__ chosen, int round) {
+    __shared__ double bval[256];
+    __shared__ long long bidx[256];
+    double b = -1.0;
+    long long bi = 0x7fffffffffffffffll;
+    for (int i = threadIdx.x; i < nparts; i += 256)
+        if (pval[i] > b || (pval[i] == b && pidx[i] < bi)) {
+            b = pval[i];
+            bi = pidx[i];
+        }
+    bval[threadIdx.x] = b;
+    bidx[threadIdx.x] = bi;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) {
+            const double o = bval[threadIdx.x + h];
+            const long long oi = bidx[threadIdx.x + h];
+            if (o > bval[threadIdx.x] || (o == bval[threadIdx.x] && oi < bidx[threadIdx.x])) {
+                bval[threadIdx.x] = o;
+                bidx[threadIdx.x] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    const long long j = bidx[0];
+    if (threadIdx.x < VMAX) state[threadIdx.x] = R[j * VMAX + threadIdx.x];
+    if (threadIdx.x == 0) {
+        state[VMAX] = bval[0];
+        chosen[round] = j;
+    }
+}
+
 }  // namespace salnmf

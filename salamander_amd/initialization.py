@@ -60,16 +60,22 @@ def init_nndsvd(data_mat, n_signatures, method="nndsvd", seed=None):
     return S, E
 
 
-def init_separableNMF(data_mat, n_signatures, seed=None):
-    """Successive projection (Gillis & Vavasis 2013) for signatures + random exposures (methods.py:112-135)."""
-    R = data_mat.T / data_mat.T.sum(axis=0)
-    chosen = np.empty(n_signatures, dtype=int)
-    for k in range(n_signatures):
-        norms = (R**2).sum(axis=0)
-        j = int(np.argmax(norms))
-        u = R[:, j]
-        R = R - np.outer(u, u @ R) / norms[j]
-        chosen[k] = j
+def init_separableNMF(data_mat, n_signatures, seed=None, chosen=None):
+    """Successive projection (Gillis & Vavasis 2013) for signatures + random exposures (methods.py:112-135).
+
+    ``chosen``: the selected sample indices when the selection already ran on the device
+    (``Engine.init_separable``: the same K rounds as one pass over the resident matrix each); the deflation below, K
+    products with a V x N temporary, is then skipped."""
+    if chosen is None:
+        R = data_mat.T / data_mat.T.sum(axis=0)
+        chosen = np.empty(n_signatures, dtype=int)
+        for k in range(n_signatures):
+            norms = (R**2).sum(axis=0)
+            j = int(np.argmax(norms))
+            u = R[:, j]
+            R = R - np.outer(u, u @ R) / norms[j]
+            chosen[k] = j
+    chosen = np.asarray(chosen, dtype=int)
     S = data_mat[chosen, :].astype(float)
     S /= S.sum(axis=1, keepdims=True)
     _, E = init_random(data_mat, n_signatures, seed=seed)

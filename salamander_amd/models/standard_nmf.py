@@ -31,6 +31,14 @@ class StandardNMF(SignatureNMF):
                 raise TypeError(f"init method '{self.init_method}' takes no keyword arguments besides 'seed': {sorted(init_kwargs)}")
             self._initialize_on_device(given_parameters)
             return
+        if self.device_init and self.init_method == "separableNMF" and not self.distributed and "chosen" not in init_kwargs:
+            # the K deflation rounds of the signature selection on the device (deterministic: the same indices with or
+            # without a seed); the exposures are the host's legacy-RNG draw, as in the reference (methods.py:133)
+            n_obs, n_vars = np.shape(self.adata.X)
+            e = self._ensure_engine(n_obs, n_vars, self.n_signatures)
+            self._upload_X(e)
+            init_kwargs["chosen"] = e.init_separable(self.n_signatures)
+            self._resident = {"X"}
         if self.init_method != "custom":  # ("custom" looks at the shape of X only)
             self._finish_setup()  # the host methods read the clipped adata.X
         self.asignatures = initialize_standard_nmf(

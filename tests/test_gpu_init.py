@@ -150,3 +150,63 @@ def test_corrnmf_models_default_init_on_the_device():
     mm.fit(sal.MuData({"sbs": sal.AnnData(X1.copy()), "indel": sal.AnnData(X2.copy())}))
     hist = mm.history["objective_function"]
     assert np.all(np.isfinite(hist)) and hist[-1] > hist[0]
+
+
+# ---------------------------------------------------------------- separableNMF: the K deflation rounds on the device
+def _host_selection(X, K):
+    """The reference's loop (methods.py:112-135), as ``initialization.init_separableNMF`` restates it."""
+    R = X.T / X.T.sum(axis=0)
+    chosen = []
+    for _ in range(K):
+        norms = (R**2).sum(axis=0)
+        j = int(np.argmax(norms))
+        u = R[:, j]
+        R = R - np.outer(u, u @ R) / norms[j]
+        chosen.append(j)
+    return np.array(chosen)
+
+
+def test_separable_selection_matches_reference_fixture_index_for_index():
+    """The reference's separableNMF fixture (tests/test_initialization.py:28-53; seed 1, K = 2): the device selects the
+    same samples in the same order, and the initialisation built on its indices equals the fixture."""
+    d = os.path.join(REF_FIX, "initialization")
+    data = np.load(f"{d}/data_mat.npy")
+    e = Engine(data.shape[0], data.shape[1], 2)
+    e.upload_X(data)
+    chosen = e.init_separable(2)
+    e.close()
+    assert chosen.tolist() == _host_selection(data, 2).tolist()
+    S, E = init.initialize_mat(data, 2, "separableNMF", seed=1, chosen=chosen)
+    assert np.allclose(S, np.load(f"{d}/signatures_mat_separableNMF_seed1.npy"))
+    assert np.allclose(E, np.load(f"{d}/exposures_mat_separableNMF_seed1.npy"))
+
+
+@pytest.mark.parametrize("N,V,K", [(3000, 96, 50), (777, 83, 12), (20001, 96, 30), (40, 7, 5)])
+def test_separable_selection_equals_the_host_loop(N, V, K):
+    """Synthetic counts (incl. ragged N, V < 96, zeros clipped to EPSILON as fit() hands them over): the same K indices
+    as the host's deflation loop, whose norms differ from the device's only in summation order."""
+    X, _, _ = orc.synthetic_problem(V, N, min(K, 8), seed=N)
+    e = Engine(N, V, K)
+    e.upload_X(X)
+    chosen = e.init_separable(K)
+    e.close()
+    assert chosen.tolist() == _host_selection(X, K).tolist()
+    assert len(set(chosen.tolist())) == K
+
+
+def test_model_separable_init_uses_the_device_and_equals_the_host_path():
+    """``init_method="separableNMF"``: the model takes the indices from the device (X stays resident for the fit) and the
+    exposures from the host's seeded RNG -- the same initial state as the reference's host computation, bit for bit."""
+    X, _, _ = orc.synthetic_problem(96, 5000, 6, seed=3)
+    states = []
+    for device_init in (True, False):
+        m = sal.models.KLNMF(20, "separableNMF", min_iterations=0, max_iterations=0, device_init=device_init)
+        m._setup_adata(sal.AnnData(X.copy()))
+        m._initialize(None, {"seed": 7})
+        states.append((np.array(m.asignatures.X), np.array(m.adata.obsm["exposures"]), set(m._resident)))
+    assert np.array_equal(states[0][0], states[1][0]) and np.array_equal(states[0][1], states[1][1])
+    assert states[0][2] == {"X"} and states[1][2] == set()
+    m = sal.models.KLNMF(20, "separableNMF", min_iterations=20, max_iterations=20)
+    m.fit(sal.AnnData(X.copy()), init_kwargs={"seed": 7})
+    W, H, _, hist = orc.fit_klnmf(X.T, states[1][0].T, states[1][1].T, min_iterations=20, max_iterations=20)
+    assert rel_l2(m.asignatures.X, W.T) < 1e-10 and np.allclose(m.history["objective_function"], hist, rtol=1e-11)
