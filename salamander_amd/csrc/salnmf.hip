@@ -1661,7 +1661,9 @@ static int lockstep_signature_solves(salnmf_engine* e, const double* U, const do
     const int rec = 66 + dim * dim;
     bool finished = false;
     for (int round = 0; round < LS_EVAL_MAX + 2; ++round) {
-        if (multi) hipLaunchKernelGGL(ls_eval_multi_kernel, grid, dim3(SIGT), 0, e->stream, q);
+        // (dim % 16 != 0: the padded tile has room for the column of ones that makes the Hessian product yield the gradient too)
+        if (multi && dim % 16 != 0) hipLaunchKernelGGL(ls_eval_multi_kernel<true>, grid, dim3(SIGT), 0, e->stream, q);
+        else if (multi) hipLaunchKernelGGL(ls_eval_multi_kernel<false>, grid, dim3(SIGT), 0, e->stream, q);
         else hipLaunchKernelGGL(ls_eval_kernel, grid, dim3(SIGT), 0, e->stream, q);
         hipLaunchKernelGGL(ls_reduce_kernel, dim3(K), dim3(256), 0, e->stream, q.part, q.red, q.state, S, 0, rec, 0);
         HIPCK(hipGetLastError());

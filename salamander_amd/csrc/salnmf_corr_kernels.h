@@ -202,8 +202,6 @@ template <int TPL>
 struct SampleEmbeddingEval {
     const double* O;   // LDS [terms][CORR_LD]: the signature embeddings of all modalities
     const double* so;  // LDS [terms]: signature scalings
-    double* vbuf;      // LDS, wave private [64]: a vector to broadcast
-    double* wbuf;      // LDS, wave private [64 * TPL]: per-term weights
     double c[TPL];     // sample scaling of the modality of this lane's term(s)
     double a[TPL];     // aux of this lane's term(s) for this sample
     double hw[TPL];    // exp(c + so + <L_i, x>) at the point the Hessian is fixed
@@ -211,54 +209,62 @@ struct SampleEmbeddingEval {
     double variance;
     int T, dim, lane;  // T = number of terms
 
+    // component m of a vector held one component per lane (wave-uniform m): two v_readlane_b32 instead of a broadcast
+    // read from LDS.  The kernel is bound by the LDS pipe (profiles/r03/c5_roofline.md: LDS busy 13 of 16.9 ms per call,
+    // VALU 5); a broadcast read costs the pipe as much as any other 512-byte wave read, a readlane costs it nothing.
+    // Same summation orders as before (four partial sums by index mod 4): same bits.
+    // Measured and NOT adopted on top of this (profiles/r03/c5_roofline.md): combine's column of L in registers (48 terms:
+    // the 256 registers that two waves per SIMD leave each wave hold no more without spilling) -- 15.1 instead of
+    // 11.2 ms per call; a dense per-sample Hessian formed on the MFMA units once per Newton iteration -- 18.9 ms (its
+    // LDS staging halves the occupancy, and the Gram product costs more than the few CG iterations it serves).
+    static __device__ __forceinline__ double lane_value(double v, int m) {
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), m), __builtin_amdgcn_readlane(__double2loint(v), m));
+    }
     // <L_i, y> for this lane's term(s)
     __device__ __forceinline__ void products(double y, double (&s)[TPL]) {
-        vbuf[lane] = y;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        const double* row[TPL];
 #pragma unroll
-        for (int t = 0; t < TPL; ++t) {
-            const int i = lane + 64 * t;
-            double acc = 0.0;
-            if (i < T) {
-                // four partial sums (m mod 4): one chain of dim dependent FMAs would wait out every FMA's latency
-                const double* row = O + i * CORR_LD;
-                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-                int m = 0;
-                for (; m + 4 <= dim; m += 4) {
-                    a0 = __builtin_fma(row[m], vbuf[m], a0);
-                    a1 = __builtin_fma(row[m + 1], vbuf[m + 1], a1);
-                    a2 = __builtin_fma(row[m + 2], vbuf[m + 2], a2);
-                    a3 = __builtin_fma(row[m + 3], vbuf[m + 3], a3);
-                }
-                for (; m < dim; ++m) a0 = __builtin_fma(row[m], vbuf[m], a0);
-                acc = (a0 + a1) + (a2 + a3);
-            }
-            s[t] = acc;
+        for (int t = 0; t < TPL; ++t) row[t] = O + ((lane + 64 * t < T) ? lane + 64 * t : 0) * CORR_LD;
+        // four partial sums (m mod 4) per term: one chain of dim dependent FMAs would wait out every FMA's latency
+        double a[TPL][4];
+#pragma unroll
+        for (int t = 0; t < TPL; ++t) a[t][0] = a[t][1] = a[t][2] = a[t][3] = 0.0;
+        int m = 0;
+        for (; m + 4 <= dim; m += 4) {
+            double yv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) yv[u] = lane_value(y, m + u);
+#pragma unroll
+            for (int t = 0; t < TPL; ++t)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a[t][u] = __builtin_fma(row[t][m + u], yv[u], a[t][u]);
         }
-        __builtin_amdgcn_wave_barrier();
+        for (; m < dim; ++m) {
+            const double yv = lane_value(y, m);
+#pragma unroll
+            for (int t = 0; t < TPL; ++t) a[t][0] = __builtin_fma(row[t][m], yv, a[t][0]);
+        }
+#pragma unroll
+        for (int t = 0; t < TPL; ++t) s[t] = (lane + 64 * t < T) ? (a[t][0] + a[t][1]) + (a[t][2] + a[t][3]) : 0.0;
     }
     // lane m: sum_i w_i L[i][m]
     __device__ __forceinline__ double combine(const double (&w)[TPL]) {
+        const double* col = O + (lane < dim ? lane : 0);
+        double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;  // (four partial sums, as in products)
 #pragma unroll
-        for (int t = 0; t < TPL; ++t) wbuf[lane + 64 * t] = w[t];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        double r = 0.0;
-        if (lane < dim) {
-            double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;  // (four partial sums, as in products)
+        for (int t = 0; t < TPL; ++t) {
+            const int n = T - 64 * t < 64 ? T - 64 * t : 64;  // terms held by this register of the lanes
+            const double* c = col + 64 * t * CORR_LD;
             int i = 0;
-            for (; i + 4 <= T; i += 4) {
-                r0 = __builtin_fma(wbuf[i], O[i * CORR_LD + lane], r0);
-                r1 = __builtin_fma(wbuf[i + 1], O[(i + 1) * CORR_LD + lane], r1);
-                r2 = __builtin_fma(wbuf[i + 2], O[(i + 2) * CORR_LD + lane], r2);
-                r3 = __builtin_fma(wbuf[i + 3], O[(i + 3) * CORR_LD + lane], r3);
+            for (; i + 4 <= n; i += 4) {
+                r0 = __builtin_fma(lane_value(w[t], i), c[i * CORR_LD], r0);
+                r1 = __builtin_fma(lane_value(w[t], i + 1), c[(i + 1) * CORR_LD], r1);
+                r2 = __builtin_fma(lane_value(w[t], i + 2), c[(i + 2) * CORR_LD], r2);
+                r3 = __builtin_fma(lane_value(w[t], i + 3), c[(i + 3) * CORR_LD], r3);
             }
-            for (; i < T; ++i) r0 = __builtin_fma(wbuf[i], O[i * CORR_LD + lane], r0);
-            r = (r0 + r1) + (r2 + r3);
+            for (; i < n; ++i) r0 = __builtin_fma(lane_value(w[t], i), c[i * CORR_LD], r0);
         }
-        __builtin_amdgcn_wave_barrier();
-        return r;
+        return lane < dim ? (r0 + r1) + (r2 + r3) : 0.0;
     }
     __device__ __forceinline__ double rate(int t, double s) const {
         const int i = lane + 64 * t;
@@ -343,7 +349,6 @@ __global__ void __launch_bounds__(CORR_BLOCK) corr_sample_embeddings_kernel(Samp
     __shared__ double Ll[64 * TPL * CORR_LD];
     __shared__ double bl[64 * TPL];
     __shared__ int tmod[64 * TPL], tk[64 * TPL];  // term -> (modality, signature)
-    __shared__ double vb[4][64], wb[4][64 * TPL];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int dim = p.dim;
     int T = 0;
@@ -366,8 +371,6 @@ __global__ void __launch_bounds__(CORR_BLOCK) corr_sample_embeddings_kernel(Samp
         SampleEmbeddingEval<TPL> ev;
         ev.O = Ll;
         ev.so = bl;
-        ev.vbuf = vb[wave];
-        ev.wbuf = wb[wave];
         ev.variance = p.variance;
         ev.T = T;
         ev.dim = dim;

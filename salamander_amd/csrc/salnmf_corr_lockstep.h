@@ -222,6 +222,23 @@ __global__ void __launch_bounds__(SIGT) ls_begin_multi_kernel(LockstepParams q) 
     }
 }
 
+// component m of a vector held one component per lane (wave-uniform m): v_readlane instead of a broadcast read from LDS
+__device__ __forceinline__ double ls_lane_value(double v, int m) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), m), __builtin_amdgcn_readlane(__double2loint(v), m));
+}
+
+// AUG (dim not a multiple of 16, i.e. the 16-padded tile has a free component column): the staged tile carries a column of
+// ones at component `dim`, so the weighted Gram product that forms the Hessian,  sum_n w_n [U_n 1]^T [U_n 1],  also yields
+// the gradient part  sum_n w_n U_n  (column dim) and  sum_n w_n  (entry [dim][dim]) -- on the MFMAs that run anyway.
+// With that every wave works on ITS 64 samples of a tile from the logits to the Hessian with no workgroup barrier in
+// between, and the per-signature passes over the tile that were chains of dependent LDS reads are gone:
+//   * logits of the LS_GROUP signatures in ONE sweep over the sample's row (one LDS read per component, the requested
+//     points come from registers by v_readlane; per signature the FMA chain of row_dot, same bits) instead of LS_GROUP
+//     sweeps of two reads per FMA (5.2 k cycles each, measured: profiles/r03/c5_roofline.md);
+//   * no tile_weighted pass (2.6 k cycles per signature and tile) and no cross-wave sum of its result.
+// What differs from the single-kernel form: the gradient part and sum_n w_n are summed in the MFMA's order (rounding
+// level; same on every rank of a sharded solve).  !AUG keeps those two sums on the VALU (two barriers per signature).
+template <bool AUG>
 __global__ void __launch_bounds__(SIGT) ls_eval_multi_kernel(LockstepParams q) {
     const int kbase = blockIdx.y * LS_GROUP, s = blockIdx.x;
     bool live[LS_GROUP], any = false;
@@ -242,9 +259,7 @@ __global__ void __launch_bounds__(SIGT) ls_eval_multi_kernel(LockstepParams q) {
         const int k = live[g] ? kbase + g : kbase;
         cg[g] = q.sig.beta[k];
         yg[g] = (live[g] && ev.lane < dim) ? q.req[k * 64 + ev.lane] : 0.0;
-        if (ev.wave == 0) ybufs[g][ev.lane] = yg[g];
     }
-    __syncthreads();
     double lin[LS_GROUP], ex[LS_GROUP], r[LS_GROUP];
     d4 acc[LS_GROUP][6];
 #pragma unroll
@@ -254,45 +269,78 @@ __global__ void __launch_bounds__(SIGT) ls_eval_multi_kernel(LockstepParams q) {
         for (int i = 0; i < 6; ++i) acc[g][i] = (d4){0, 0, 0, 0};
     }
     for (int64_t t0 = ev.n_begin; t0 < ev.n_end; t0 += SIGT) {
-        ev.stage(t0);
+        ev.stage(t0);  // (ends with a workgroup barrier; rows 64 wave .. 64 wave + 63 are this wave's samples)
         const int64_t n = t0 + ev.tid;
         const bool in = n < ev.n_end;
         const double al = in ? q.sig.alpha[n] : 0.0;
+        double* myrow = ev.Ut + ev.tid * ev.ldu;
+        if (AUG) myrow[dim] = 1.0;
+        // <U_n, y_g> for the group's signatures in one sweep over the row (per signature: row_dot's FMA chain)
+        double sd[LS_GROUP];
+#pragma unroll
+        for (int g = 0; g < LS_GROUP; ++g) sd[g] = 0.0;
+        int m = 0;
+        for (; m + 4 <= dim; m += 4) {
+            double x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[u] = myrow[m + u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int g = 0; g < LS_GROUP; ++g) sd[g] = __builtin_fma(x[u], ls_lane_value(yg[g], m + u), sd[g]);
+        }
+        for (; m < dim; ++m) {
+            const double x = myrow[m];
+#pragma unroll
+            for (int g = 0; g < LS_GROUP; ++g) sd[g] = __builtin_fma(x, ls_lane_value(yg[g], m), sd[g]);
+        }
+        double auxv[LS_GROUP];
+#pragma unroll
+        for (int g = 0; g < LS_GROUP; ++g) auxv[g] = (in && live[g]) ? q.sig.aux[n * q.sig.KP + kbase + g] : 0.0;
 #pragma unroll
         for (int g = 0; g < LS_GROUP; ++g) {
             if (!live[g]) continue;  // uniform
             double w = 0.0;
             if (in) {
-                ev.ybuf = ybufs[g];
-                const double sdot = ev.row_dot(ev.tid);
-                lin[g] = __builtin_fma(sdot, q.sig.aux[n * q.sig.KP + kbase + g], lin[g]);
-                w = exp((cg[g] + al) + sdot);
-                ex[g] += w;
+                lin[g] = __builtin_fma(sd[g], auxv[g], lin[g]);
+                w = exp((cg[g] + al) + sd[g]);
+                if (!AUG) ex[g] += w;
             }
             wt[ev.tid] = w;
-            __syncthreads();
-            r[g] = ev.tile_weighted(r[g]);
-            ls_hess_tile3(ev, acc[g]);
-            __syncthreads();
+            if (AUG) {
+                __builtin_amdgcn_wave_barrier();  // (LDS operations of one wave execute in order: its own 64 weights)
+                ls_hess_tile3(ev, acc[g]);
+                __builtin_amdgcn_wave_barrier();
+            } else {
+                __syncthreads();
+                r[g] = ev.tile_weighted(r[g]);
+                ls_hess_tile3(ev, acc[g]);
+                __syncthreads();
+            }
         }
+        if (AUG) __syncthreads();  // every wave is done with the tile before the next one is staged over it
     }
 #pragma unroll
     for (int g = 0; g < LS_GROUP; ++g) {
         if (!live[g]) continue;
         const int k = kbase + g;
-        const double tot = ev.cross_wave(r[g]);
-        const double vlin = ev.block_sum(lin[g]), vex = ev.block_sum(ex[g]);
+        double tot = 0.0, vex = 0.0;
+        if (!AUG) {
+            tot = ev.cross_wave(r[g]);
+            vex = ev.block_sum(ex[g]);
+        }
+        const double vlin = ev.block_sum(lin[g]);
         d4 full[10];
 #pragma unroll
         for (int i = 0; i < 10; ++i) full[i] = (d4){0, 0, 0, 0};
         full[0] = acc[g][0], full[1] = acc[g][1], full[2] = acc[g][2], full[4] = acc[g][3], full[5] = acc[g][4], full[7] = acc[g][5];
-        ev.hess_finish(full, yg[g]);  // the Hessian sum of this chunk in ev.Al [16 DT][CORR_LD]
+        ev.hess_finish(full, yg[g]);  // the (augmented) Hessian sum of this chunk in ev.Al [16 DT][CORR_LD]
         double* out = q.part + ((int64_t)k * q.S + s) * LS_REC;
         if (ev.tid == 0) {
             out[0] = vlin;
-            out[1] = vex;
+            out[1] = AUG ? ev.Al[dim * CORR_LD + dim] : vex;
         }
-        if (ev.wave == 0) out[2 + ev.lane] = tot;
+        if (ev.wave == 0) out[2 + ev.lane] = AUG ? (ev.lane < dim ? ev.Al[ev.lane * CORR_LD + dim] : 0.0) : tot;
         for (int i = ev.tid; i < dim * dim; i += SIGT) {
             const int m = i / dim, j = i - m * dim;
             out[66 + i] = ev.Al[m * CORR_LD + j];
