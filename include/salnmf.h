@@ -64,7 +64,12 @@ int salnmf_build_flags(void);
 int salnmf_device_count(void);
 
 /* Create an engine for a shard of n_samples rows on HIP device `device`.
- * Limits of this build: n_features <= 96, n_signatures <= 64. */
+ * Limits of this build: n_signatures <= 64; n_features <= 3072.  Up to 96 features (every BASELINE configuration) the
+ * whole API is available.  Wider catalogues (SBS-288, SBS-1536, ...) run the KLNMF entry points -- upload / download,
+ * salnmf_kl_step (both halves from the old state, as update_WH), salnmf_update_H / _W, the objectives (blocking and
+ * queued), salnmf_samplewise_kl, salnmf_reconstruct, per-sample weights -- one 96-feature block of X and W per launch
+ * (U = R W^T accumulated over the blocks); MvNMF, CorrNMF, the device-side initialisation, the fp32 fast mode and
+ * sample sharding answer with an error there. */
 int salnmf_create(int device, int n_features, int64_t n_samples, int n_signatures,
                   salnmf_engine** out);
 void salnmf_destroy(salnmf_engine* e);

@@ -118,6 +118,9 @@ static int rccl_bind() {
 struct salnmf_engine {
     int device = 0;
     int V = 0, K = 0;
+    int NB = 1;    // 96-feature blocks of X and W: 1 unless n_features > 96 (then only the KLNMF entry points are available)
+    double* Gblk = nullptr;  // [NB][K][96] reduced numerators of the feature blocks (NB > 1)
+    double* Uacc = nullptr;  // [Np][KP] running sum of U = R W^T over the feature blocks (NB > 1)
     int64_t N = 0, Np = 0, ntiles = 0;  // Np = 16 * ntiles: rows of the padded device layout
     int KS = 0;    // instantiated contraction depth (k-steps of 4) covering K
     int KP = 0;    // leading dimension of H on the device = 16 * ceil(KS / 4)
@@ -134,6 +137,7 @@ struct salnmf_engine {
     hipEvent_t evW = nullptr, evPrepW = nullptr, evTrial = nullptr, evLogdet = nullptr, evObj = nullptr;
     double* Halt = nullptr;      // [Np][KP] second H buffer: the speculative update_H pass of MvNMF; the state kept by salnmf_kl_step_keep (lazily allocated)
     double* Wkeep = nullptr;     // [K][V] W of the state kept by salnmf_kl_step_keep (lazily allocated)
+    double* Hkeep = nullptr;     // [Np][KP] H of the kept state of an engine with feature blocks (its steps use Halt themselves)
     double* Wdst = nullptr;      // where the next W tail writes its result (null = in place); set for one step by a kept block
     bool keep_valid = false, keep_has_W = false;
     double* objring = nullptr;   // [SALNMF_OBJECTIVE_SLOTS] device copies of the queued objectives (sharded engines: all-reduced in place)
@@ -213,6 +217,7 @@ constexpr size_t SMALL_PINNED_BYTES = 4096;  // per-engine pinned block: read-ba
 static void release_pinned(void* p, int small_block);
 static hipError_t acquire_pinned(void** out, int small_block);
 
+constexpr int NB_MAX = 32;  // feature blocks of 96: n_features <= 3072 (SBS-1536 needs 16)
 constexpr int SCAL_XLX = 8;  // slot of e->scal that holds the sum over the samples of xlx
 
 static const int kKS[] = {1, 2, 4, 8, 10, 13, 16};
@@ -265,9 +270,23 @@ static FusedParams fused_params(salnmf_engine* e) {
     p.KLpart = e->KLpart;
     p.N = e->N;
     p.V = e->V;
+    p.ldw = e->V;
     p.K = e->K;
     p.ntiles = e->ntiles;
     return p;
+}
+
+// ---- feature blocks (n_features > 96): block b of X, the matching 96 columns of W
+static inline int block_width(const salnmf_engine* e, int b) { return std::min(VMAX, e->V - VMAX * b); }
+static void to_block(const salnmf_engine* e, FusedParams& p, int b) {
+    p.X = e->X + (size_t)b * e->Np * VMAX;
+    p.W = e->W + (size_t)VMAX * b;
+    p.V = block_width(e, b);
+    p.ldw = e->V;
+}
+static int single_block(const salnmf_engine* e, const char* what) {
+    if (e->NB > 1) return fail("%s is not available for n_features > %d (this engine has %d): only the KLNMF entry points are", what, VMAX, e->V);
+    return 0;
 }
 
 static TailParams tail_params(salnmf_engine* e, int nslabs, double* G, int n_given, int clip_mode, int do_tail, bool with_stats, int hsum_parts = 0) {
@@ -362,9 +381,12 @@ static int sharded_tail(salnmf_engine* e, int n_given, int clip_mode) {
 // the x-only part of the KL divergence (salnmf_kernels.h: tile_kl), once per upload of X: c_d per sample and their sum
 static int ensure_xlogx(salnmf_engine* e) {
     if (e->xlx_valid) return 0;
-    if (!e->xlx) HIPCK(hipMalloc(&e->xlx, (size_t)e->Np * sizeof(double)));
-    hipLaunchKernelGGL(xlogx_rowsum_kernel, dim3((unsigned)((e->Np + 15) / 16)), dim3(256), 0, e->stream, e->X, e->Np, e->V, VMAX, e->xlx);
-    HIPCK(hipGetLastError());
+    if (!e->xlx) HIPCK(hipMalloc(&e->xlx, (size_t)e->NB * e->Np * sizeof(double)));
+    for (int b = 0; b < e->NB; ++b) {  // (feature blocks: the constants of every block's own features)
+        hipLaunchKernelGGL(xlogx_rowsum_kernel, dim3((unsigned)((e->Np + 15) / 16)), dim3(256), 0, e->stream, e->X + (size_t)b * e->Np * VMAX, e->Np,
+                           block_width(e, b), VMAX, e->xlx + (size_t)b * e->Np);
+        HIPCK(hipGetLastError());
+    }
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, e->xlx, (int)e->Np, 1, 1, e->scal + SCAL_XLX, nullptr);
     HIPCK(hipGetLastError());
     e->xlx_valid = true;
@@ -449,8 +471,8 @@ void salnmf_destroy(salnmf_engine* e) {
     if (e->X32) (void)hipFree(e->X32);
     if (e->H32) (void)hipFree(e->H32);
     if (e->p2p.abort_dev) (void)hipFree(e->p2p.abort_dev);
-    double* bufs[] = {e->xlx, e->X, e->H, e->W, e->wkl, e->wlh, e->Gpart, e->Hsumpart, e->KLpart, e->red,
-                      e->objpart, e->scal, e->Wunc, e->Wtrial, e->mvA, e->mvB, e->cs, e->scratch, e->Halt, e->KLpart2, e->Wkeep, e->objring,
+    double* bufs[] = {e->Gblk, e->Uacc, e->xlx, e->X, e->H, e->W, e->wkl, e->wlh, e->Gpart, e->Hsumpart, e->KLpart, e->red,
+                      e->objpart, e->scal, e->Wunc, e->Wtrial, e->mvA, e->mvB, e->cs, e->scratch, e->Halt, e->KLpart2, e->Wkeep, e->Hkeep, e->objring,
                       e->alpha, e->beta, e->Lemb, e->Uemb, e->aux, e->xrowsum, e->corrpart, e->gU, e->galpha, e->gaux};
     for (double* b : bufs)
         if (b) (void)hipFree(b);
@@ -482,7 +504,7 @@ void salnmf_destroy(salnmf_engine* e) {
 int salnmf_create(int device, int n_features, int64_t n_samples, int n_signatures, salnmf_engine** out) {
     if (!out) return fail("out is null");
     *out = nullptr;
-    if (n_features < 1 || n_features > VMAX) return fail("n_features must be in [1, %d], got %d", VMAX, n_features);
+    if (n_features < 1 || n_features > VMAX * NB_MAX) return fail("n_features must be in [1, %d], got %d", VMAX * NB_MAX, n_features);
     if (n_signatures < 1 || n_signatures > 64) return fail("n_signatures must be in [1, 64], got %d", n_signatures);
     if (n_samples < 1) return fail("n_samples must be positive");
     int ndev = 0;
@@ -501,6 +523,7 @@ int salnmf_create(int device, int n_features, int64_t n_samples, int n_signature
     e->N = n_samples;
     e->ntiles = (n_samples + 15) / 16;
     e->Np = e->ntiles * 16;
+    e->NB = (n_features + VMAX - 1) / VMAX;
     e->KS = pick_ks(n_signatures);
     e->KP = 16 * ((e->KS + 3) / 4);
     // output-side split: full MFMA tiles + up to 4 remainder columns on the VALU (K >= 17 only)
@@ -533,14 +556,18 @@ int salnmf_create(int device, int n_features, int64_t n_samples, int n_signature
     // system-scope fence at the record -- 2 % of an MvNMF step (profiles/r02/ab_step_variants.txt)
     for (hipEvent_t* ev : {&e->evW, &e->evPrepW, &e->evTrial, &e->evLogdet, &e->evObj})
         if (hipEventCreateWithFlags(ev, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) return cleanup(fail("event create failed"));
-    ALLOC(e->X, Np * VMAX);
+    ALLOC(e->X, (size_t)e->NB * Np * VMAX);
     ALLOC(e->H, Np * KP);
     ALLOC(e->W, K * V);
     ALLOC(e->Gpart, (size_t)e->grid * K * VMAX);
     ALLOC(e->Hsumpart, (size_t)e->grid * K);
     ALLOC(e->KLpart, (size_t)e->grid);
     ALLOC(e->red, K * V + K + 2);
-    ALLOC(e->objpart, (size_t)e->fgrid);
+    ALLOC(e->objpart, (size_t)e->NB * e->fgrid);
+    if (e->NB > 1) {
+        ALLOC(e->Gblk, (size_t)e->NB * K * VMAX);
+        ALLOC(e->Uacc, Np * KP);
+    }
     ALLOC(e->scal, 16);
     ALLOC(e->Wunc, K * V);
     ALLOC(e->Wtrial, K * V);
@@ -676,8 +703,10 @@ static void parallel_copy(void* dst, const void* src, size_t bytes) {
 }
 
 // host compact [N][cols] of element type `dtype` -> device padded double [Np][ld]
+//   nb > 1 (X of an engine with more than 96 features): the rows are scattered into nb blocks of 96 columns, block b at
+//   dst + b * Np * 96 (pad_rows_blocked_kernel); ld, fill_cols and fill_rows are then 96, 0, 0
 static int upload_rows_staged(salnmf_engine* e, double* dst, const void* src, int dtype, int cols, int ld, double fill_cols, double fill_rows,
-                              double clip_lo) {
+                              double clip_lo, int nb = 1) {
     if (!e || !src) return fail("null argument");
     const size_t esz = dtype_size(dtype);
     if (!esz) return fail("unknown element type %d", dtype);
@@ -693,6 +722,17 @@ static int upload_rows_staged(salnmf_engine* e, double* dst, const void* src, in
         parallel_copy(e->stage_host[slot], (const char*)src + (size_t)r0 * row_bytes, bytes);
         HIPCK(hipMemcpyAsync(e->stage_dev[slot], e->stage_host[slot], bytes, hipMemcpyHostToDevice, e->stream));
         double* out = dst + r0 * ld;
+        if (nb > 1) {
+            const int g = (int)std::min<int64_t>(2048, (rows * nb * VMAX + 255) / 256);
+            const int64_t bs = (int64_t)e->Np * VMAX;
+            switch (dtype) {
+                case SALNMF_F64: hipLaunchKernelGGL(pad_rows_blocked_kernel<double>, dim3(g), dim3(256), 0, e->stream, out, static_cast<const double*>(e->stage_dev[slot]), rows, cols, nb, bs, clip_lo); break;
+                case SALNMF_F32: hipLaunchKernelGGL(pad_rows_blocked_kernel<float>, dim3(g), dim3(256), 0, e->stream, out, static_cast<const float*>(e->stage_dev[slot]), rows, cols, nb, bs, clip_lo); break;
+                case SALNMF_I32: hipLaunchKernelGGL(pad_rows_blocked_kernel<int32_t>, dim3(g), dim3(256), 0, e->stream, out, static_cast<const int32_t*>(e->stage_dev[slot]), rows, cols, nb, bs, clip_lo); break;
+                case SALNMF_I64: hipLaunchKernelGGL(pad_rows_blocked_kernel<int64_t>, dim3(g), dim3(256), 0, e->stream, out, static_cast<const int64_t*>(e->stage_dev[slot]), rows, cols, nb, bs, clip_lo); break;
+                default: hipLaunchKernelGGL(pad_rows_blocked_kernel<uint16_t>, dim3(g), dim3(256), 0, e->stream, out, static_cast<const uint16_t*>(e->stage_dev[slot]), rows, cols, nb, bs, clip_lo); break;
+            }
+        } else
         switch (dtype) {
             case SALNMF_F64: launch_pad_rows<double>(e, out, e->stage_dev[slot], rows, cols, ld, fill_cols, clip_lo); break;
             case SALNMF_F32: launch_pad_rows<float>(e, out, e->stage_dev[slot], rows, cols, ld, fill_cols, clip_lo); break;
@@ -704,8 +744,11 @@ static int upload_rows_staged(salnmf_engine* e, double* dst, const void* src, in
         HIPCK(hipEventRecord(e->stage_done[slot], e->stream));
     }
     if (e->Np > e->N) {
-        hipLaunchKernelGGL(fill_rows_kernel, dim3(4), dim3(256), 0, e->stream, dst, e->N, e->Np, ld, cols, fill_rows, fill_cols);
-        HIPCK(hipGetLastError());
+        for (int b = 0; b < nb; ++b) {
+            hipLaunchKernelGGL(fill_rows_kernel, dim3(4), dim3(256), 0, e->stream, dst + (size_t)b * e->Np * VMAX, e->N, e->Np, ld,
+                               nb > 1 ? VMAX : cols, fill_rows, fill_cols);
+            HIPCK(hipGetLastError());
+        }
     }
     HIPCK(hipStreamSynchronize(e->stream));  // the caller's array is free again (and so are the staging buffers)
     release_staging(e);
@@ -753,7 +796,7 @@ int salnmf_upload_X_typed(salnmf_engine* e, const void* X, int dtype, int clip) 
     if (!e) return fail("null engine");
     e->xrowsum_valid = e->lgam_valid = e->x32_valid = e->xlx_valid = false;
     // pad rows / columns are exactly 0 (never clipped): they must contribute X/P = 0
-    return upload_rows_staged(e, e->X, X, dtype, e->V, VMAX, 0.0, 0.0, clip ? kEps : 0.0);
+    return upload_rows_staged(e, e->X, X, dtype, e->V, VMAX, 0.0, 0.0, clip ? kEps : 0.0, e->NB);
 }
 int salnmf_upload_X(salnmf_engine* e, const double* X, int clip) { return salnmf_upload_X_typed(e, X, SALNMF_F64, clip); }
 int salnmf_upload_W(salnmf_engine* e, const double* W) {
@@ -834,6 +877,52 @@ static int check_abort(salnmf_engine* e) {
     return 0;
 }
 
+// ---- n_features > 96: the passes run once per 96-feature block of X and W (include/salnmf.h: limits)
+// H half (update_H, _utils_klnmf.py:220-278; the H half of update_WH, :343-361) from (W, H) into Hout: U = R W^T summed
+// over the blocks' launches through Uacc, the last block's launch updates H
+static int blocked_update_H(salnmf_engine* e, double* Hout) {
+    for (int b = 0; b < e->NB; ++b) {
+        FusedParams p = fused_params(e);
+        to_block(e, p, b);
+        p.Hout = Hout;
+        p.Uacc = e->Uacc;
+        p.ublock = b == 0 ? 1 : (b == e->NB - 1 ? 3 : 2);
+        const FusedSel sel{e->KS, e->KTM, e->KR, false, true, false, true, false, true};
+        if (launch_fused_inst(sel, p, e->grid, e->stream, nullptr, nullptr)) return fail("no kernel instantiation for KS=%d KTM=%d KR=%d", e->KS, e->KTM, e->KR);
+        HIPCK(hipGetLastError());
+    }
+    return 0;
+}
+// numerator (w_kl * X / (W H)) @ H^T of every block from (W, H) -> Gblk (compact [K][width] per block)
+static int blocked_numerators(salnmf_engine* e) {
+    for (int b = 0; b < e->NB; ++b) {
+        FusedParams p = fused_params(e);
+        to_block(e, p, b);
+        CK((launch_fused<true, false, false>(e, p)));
+        TailParams t = tail_params(e, e->grid, e->Gblk + (size_t)b * e->K * VMAX, 0, 0, 0, false);
+        t.V = block_width(e, b);
+        hipLaunchKernelGGL(tail_kernel, dim3(e->K), dim3(TAIL_BLOCK), 0, e->stream, t);
+        HIPCK(hipGetLastError());
+    }
+    return 0;
+}
+static int blocked_finish_W(salnmf_engine* e, int n_given, int clip_mode) {
+    hipLaunchKernelGGL(w_finish_blocked_kernel, dim3(e->K), dim3(256), 0, e->stream, e->Gblk, e->red, e->W, e->W, e->V, e->K, n_given, clip_mode);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+// one joint step (update_WH, _utils_klnmf.py:281-361): both halves from the OLD (W, H) -- the new H goes to the second
+// buffer while the numerator passes still read the old one, then the buffers change roles
+static int blocked_kl_step_once(salnmf_engine* e, int n_given) {
+    if (n_given >= e->K) return blocked_update_H(e, e->H);  // W untouched (:330-331): in place
+    if (!e->Halt) HIPCK(hipMalloc(&e->Halt, (size_t)e->Np * e->KP * sizeof(double)));
+    CK(blocked_update_H(e, e->Halt));
+    CK(blocked_numerators(e));
+    CK(blocked_finish_W(e, n_given, SALNMF_CLIP_ALL));
+    std::swap(e->H, e->Halt);
+    return 0;
+}
+
 int salnmf_set_lockstep(salnmf_engine* e, int on) {
     if (!e) return fail("null engine");
     e->lockstep = on != 0;
@@ -842,6 +931,7 @@ int salnmf_set_lockstep(salnmf_engine* e, int on) {
 
 int salnmf_set_persistent(salnmf_engine* e, int on) {
     if (!e) return fail("null engine");
+    if (on && e->NB > 1) return single_block(e, "the persistent kernel");
     if (on && !built_with_persistent()) return fail("this build carries no persistent kernel (compile with -DSALNMF_WITH_PERSISTENT)");
     e->persistent = on != 0;
     return 0;
@@ -889,6 +979,7 @@ static int kl_steps_f32(salnmf_engine* e, int n_steps, int n_given) {
 }
 
 int salnmf_set_precision(salnmf_engine* e, int precision) {
+    if (e && e->NB > 1) return single_block(e, "the fp32 fast mode");
     if (!e) return fail("null engine");
     if (precision != SALNMF_PRECISION_F64 && precision != SALNMF_PRECISION_F32_FAST) return fail("unknown precision %d", precision);
     e->fast32 = precision == SALNMF_PRECISION_F32_FAST;
@@ -899,6 +990,11 @@ int salnmf_kl_step(salnmf_engine* e, int n_steps, int n_given) {
     if (!e) return fail("null engine");
     if (n_given < 0 || n_given > e->K) return fail("n_given out of range");
     HIPCK(hipSetDevice(e->device));
+    if (e->NB > 1) {
+        e->keep_valid = false;  // (the joint step uses the second H buffer itself)
+        for (int i = 0; i < n_steps; ++i) CK(blocked_kl_step_once(e, n_given));
+        return 0;
+    }
     if (e->fast32 && n_steps > 0) {
         if (e->wkl || e->wlh) return fail("the fp32 fast mode has no weighted step: clear the weights or set SALNMF_PRECISION_F64");
         return kl_steps_f32(e, n_steps, n_given);
@@ -926,6 +1022,16 @@ int salnmf_kl_step_keep(salnmf_engine* e, int n_steps, int n_given) {
     if (!e->Wkeep) HIPCK(hipMalloc(&e->Wkeep, (size_t)e->K * e->V * sizeof(double)));
     e->keep_valid = false;
     CK(flush_H_scale(e));
+    if (e->NB > 1) {
+        // feature blocks: the joint step exchanges H with the second buffer itself; the kept state is a copy
+        if (!e->Hkeep) HIPCK(hipMalloc(&e->Hkeep, (size_t)e->Np * e->KP * sizeof(double)));
+        HIPCK(hipMemcpyAsync(e->Hkeep, e->H, (size_t)e->Np * e->KP * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+        HIPCK(hipMemcpyAsync(e->Wkeep, e->W, (size_t)e->K * e->V * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+        CK(salnmf_kl_step(e, n_steps, n_given));
+        e->keep_has_W = true;
+        e->keep_valid = true;
+        return 0;
+    }
     if (e->fast32 || e->persistent) {
         // the fp32 fast mode and the persistent kernel update the state in place: keep a copy instead
         HIPCK(hipMemcpyAsync(e->Halt, e->H, (size_t)e->Np * e->KP * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
@@ -944,6 +1050,12 @@ int salnmf_kl_rollback(salnmf_engine* e) {
     if (!e) return fail("null engine");
     if (!e->keep_valid) return fail("no kept state: salnmf_kl_rollback undoes the last salnmf_kl_step_keep, once");
     // (the discarded steps may still be running: they write the buffers that become scratch, in stream order)
+    if (e->NB > 1) {
+        std::swap(e->H, e->Hkeep);
+        std::swap(e->W, e->Wkeep);
+        e->keep_valid = false;
+        return 0;
+    }
     std::swap(e->H, e->Halt);
     if (e->keep_has_W) std::swap(e->W, e->Wkeep);
     e->h_pending = false;
@@ -954,6 +1066,7 @@ int salnmf_kl_rollback(salnmf_engine* e) {
 int salnmf_update_H(salnmf_engine* e) {
     if (!e) return fail("null engine");
     HIPCK(hipSetDevice(e->device));
+    if (e->NB > 1) return blocked_update_H(e, e->H);
     FusedParams p = fused_params(e);
     CK((launch_fused<false, true, false>(e, p)));
     e->h_pending = false;
@@ -961,6 +1074,7 @@ int salnmf_update_H(salnmf_engine* e) {
 }
 
 int salnmf_kl_step_partial(salnmf_engine* e) {
+    if (e && e->NB > 1) return single_block(e, "the split step");
     if (!e) return fail("null engine");
     HIPCK(hipSetDevice(e->device));
     FusedParams p = fused_params(e);
@@ -970,6 +1084,7 @@ int salnmf_kl_step_partial(salnmf_engine* e) {
 }
 
 int salnmf_kl_step_finish(salnmf_engine* e, int n_given, int clip_mode) {
+    if (e && e->NB > 1) return single_block(e, "the split step");
     if (!e) return fail("null engine");
     HIPCK(hipSetDevice(e->device));
     if (n_given >= e->K) return 0;
@@ -980,6 +1095,10 @@ int salnmf_update_W(salnmf_engine* e, int n_given, int clip_mode) {
     if (!e) return fail("null engine");
     HIPCK(hipSetDevice(e->device));
     if (n_given >= e->K) return 0;  // _utils_klnmf.py:204-205
+    if (e->NB > 1) {
+        CK(blocked_numerators(e));
+        return blocked_finish_W(e, n_given, clip_mode);
+    }
     FusedParams p = fused_params(e);
     CK((launch_fused<true, false, false>(e, p)));
     if (sharded(e)) return sharded_tail(e, n_given, clip_mode);
@@ -998,13 +1117,15 @@ static int fwd_params(salnmf_engine* e, FwdParams& p) {
     p.out = e->objpart;
     p.N = e->N;
     p.V = e->V;
+    p.ldw = e->V;
     p.K = e->K;
     p.ntiles = e->ntiles;
     return 0;
 }
 
 // objective of (W, H[, hscale]) -> device scalar e->scal[slot] (all-reduced), no host sync
-static int objective_to_ptr(salnmf_engine* e, const double* W, const double* hscale, bool weighted, double* out, int grid = 0) {
+// the forward passes of one objective evaluation -> e->objpart[0 .. *nparts): per-workgroup partials, to be summed in order
+static int objective_partials(salnmf_engine* e, const double* W, const double* hscale, bool weighted, int grid, int* nparts) {
     FwdParams p;
     CK(fwd_params(e, p));
     p.W = W;
@@ -1014,8 +1135,31 @@ static int objective_to_ptr(salnmf_engine* e, const double* W, const double* hsc
         p.wlh = nullptr;
     }
     const int fgrid = grid > 0 ? grid : e->fgrid;
-    CK(launch_forward<0>(e, p, fgrid));
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, e->objpart, fgrid, 1, 1, out);
+    if (e->NB > 1) {
+        // the KL divergence is a sum over the features: one forward pass per feature block, each with the x-only
+        // constants of its own features; the l-half penalty (klnmf.py:75-79) once
+        for (int b = 0; b < e->NB; ++b) {
+            FwdParams pb = p;
+            pb.X = e->X + (size_t)b * e->Np * VMAX;
+            pb.W = W + (size_t)VMAX * b;
+            pb.V = block_width(e, b);
+            pb.xlx = e->xlx + (size_t)b * e->Np;
+            if (b > 0) pb.wlh = nullptr;
+            pb.out = e->objpart + (size_t)b * fgrid;
+            CK(launch_forward<0>(e, pb, fgrid));
+        }
+    } else {
+        CK(launch_forward<0>(e, p, fgrid));
+    }
+    *nparts = e->NB * fgrid;
+    return 0;
+}
+
+// objective of (W, H[, hscale]) -> device scalar *out (all-reduced), no host sync
+static int objective_to_ptr(salnmf_engine* e, const double* W, const double* hscale, bool weighted, double* out, int grid = 0) {
+    int nparts = 0;
+    CK(objective_partials(e, W, hscale, weighted, grid, &nparts));
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, e->objpart, nparts, 1, 1, out);
     HIPCK(hipGetLastError());
     return allreduce(e, out, 1);
 }
@@ -1050,17 +1194,16 @@ int salnmf_objective_async(salnmf_engine* e, int slot) {
     // The value lands in pinned host memory straight from the reducing kernel, and the slot's event is that kernel's own
     // completion signal: the reader waits for THIS objective only, not for whatever was queued behind it (the next
     // block of steps), and no copy packet sits in the stream.  A sharded engine all-reduces the device copy first.
-    FwdParams p;
-    CK(fwd_params(e, p));
-    CK(launch_forward<0>(e, p, e->fgrid));
+    int nparts = 0;
+    CK(objective_partials(e, e->W, nullptr, true, 0, &nparts));
     if (!sharded(e)) {
-        hipExtLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, nullptr, e->objev[slot], 0, e->objpart, e->fgrid, 1, 1,
+        hipExtLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, nullptr, e->objev[slot], 0, e->objpart, nparts, 1, 1,
                               e->objpin + slot, (const double*)nullptr);
         HIPCK(hipGetLastError());
         return 0;
     }
     if (!e->objring) HIPCK(hipMalloc(&e->objring, SALNMF_OBJECTIVE_SLOTS * sizeof(double)));
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, e->objpart, e->fgrid, 1, 1, e->objring + slot, (const double*)nullptr);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, e->objpart, nparts, 1, 1, e->objring + slot, (const double*)nullptr);
     HIPCK(hipGetLastError());
     CK(allreduce(e, e->objring + slot, 1));
     hipExtLaunchKernelGGL(copy_scalar_kernel, dim3(1), dim3(1), 0, e->stream, nullptr, e->objev[slot], 0, e->objpin + slot, (const double*)(e->objring + slot));
@@ -1087,10 +1230,27 @@ int salnmf_samplewise_kl(salnmf_engine* e, double* out) {
     double* dev = nullptr;
     FwdParams p;
     CK(fwd_params(e, p));
-    HIPCK(hipMalloc(&dev, (size_t)e->Np * sizeof(double)));
-    p.out = dev;
-    int rc = launch_forward<1>(e, p);
+    HIPCK(hipMalloc(&dev, (size_t)e->NB * e->Np * sizeof(double)));
+    int rc = 0;
+    for (int b = 0; b < e->NB && !rc; ++b) {  // (per-sample divergences are sums over the features: one pass per feature block)
+        FwdParams pb = p;
+        if (e->NB > 1) {
+            pb.X = e->X + (size_t)b * e->Np * VMAX;
+            pb.W = e->W + (size_t)VMAX * b;
+            pb.V = block_width(e, b);
+        }
+        pb.out = dev + (size_t)b * e->Np;
+        rc = launch_forward<1>(e, pb);
+    }
     if (!rc) rc = download(e, out, dev, (size_t)e->N);
+    if (!rc && e->NB > 1) {
+        std::vector<double> part((size_t)e->N);
+        for (int b = 1; b < e->NB && !rc; ++b) {
+            rc = download(e, part.data(), dev + (size_t)b * e->Np, (size_t)e->N);
+            if (!rc)
+                for (int64_t n = 0; n < e->N; ++n) out[n] += part[(size_t)n];
+        }
+    }
     (void)hipFree(dev);
     return rc;
 }
@@ -1103,8 +1263,24 @@ int salnmf_reconstruct(salnmf_engine* e, double* out) {
     CK(fwd_params(e, p));
     HIPCK(hipMalloc(&dev, (size_t)e->Np * VMAX * sizeof(double)));
     p.out = dev;
-    int rc = launch_forward<2>(e, p);
-    if (!rc) rc = download_padded(e, out, dev, e->V, VMAX);
+    int rc = 0;
+    if (e->NB == 1) {
+        rc = launch_forward<2>(e, p);
+        if (!rc) rc = download_padded(e, out, dev, e->V, VMAX);
+    } else {
+        // one feature block at a time: H @ W[:, block] into the scratch image, its columns into the caller's rows
+        std::vector<double> part((size_t)e->N * VMAX);
+        for (int b = 0; b < e->NB && !rc; ++b) {
+            FwdParams pb = p;
+            pb.W = e->W + (size_t)VMAX * b;
+            pb.V = block_width(e, b);
+            rc = launch_forward<2>(e, pb);
+            if (!rc) rc = download_padded(e, part.data(), dev, pb.V, VMAX);
+            if (!rc)
+                for (int64_t n = 0; n < e->N; ++n)
+                    memcpy(out + (size_t)n * e->V + (size_t)VMAX * b, part.data() + (size_t)n * pb.V, (size_t)pb.V * sizeof(double));
+        }
+    }
     (void)hipFree(dev);
     return rc;
 }
@@ -1118,6 +1294,7 @@ static int mv_logdet_to_slot(salnmf_engine* e, const double* W, double delta, in
 }
 
 int salnmf_mv_objective(salnmf_engine* e, double lam, double delta, double* out) {
+    if (e && e->NB > 1) return single_block(e, "MvNMF");
     if (!e || !out) return fail("null argument");
     HIPCK(hipSetDevice(e->device));
     CK(objective_to_slot(e, e->W, nullptr, false, 0));
@@ -1322,6 +1499,7 @@ static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double de
 }
 
 int salnmf_mv_update_W(salnmf_engine* e, int n_given, double lam, double delta, double* gamma_inout) {
+    if (e && e->NB > 1) return single_block(e, "MvNMF");
     if (!e || !gamma_inout) return fail("null argument");
     e->keep_valid = false;  // (the MvNMF steps use the second H buffer themselves)
     HIPCK(hipSetDevice(e->device));
@@ -1329,6 +1507,7 @@ int salnmf_mv_update_W(salnmf_engine* e, int n_given, double lam, double delta, 
 }
 
 int salnmf_mv_step(salnmf_engine* e, int n_steps, int n_given, double lam, double delta, double* gamma_inout) {
+    if (e && e->NB > 1) return single_block(e, "MvNMF");
     if (!e || !gamma_inout) return fail("null argument");
     if (n_given < 0 || n_given > e->K) return fail("n_given out of range");
     HIPCK(hipSetDevice(e->device));
@@ -1360,6 +1539,7 @@ int salnmf_mv_step(salnmf_engine* e, int n_steps, int n_given, double lam, doubl
 // ------------------------------------------------------------------------------------ CorrNMF (row f1)
 
 int salnmf_corr_configure(salnmf_engine* e, int dim_embeddings) {
+    if (e && e->NB > 1) return single_block(e, "CorrNMF");
     if (!e) return fail("null engine");
     if (dim_embeddings < 1 || dim_embeddings > CORR_DMAX) return fail("dim_embeddings must be in [1, %d], got %d", CORR_DMAX, dim_embeddings);
     HIPCK(hipSetDevice(e->device));
@@ -1837,6 +2017,7 @@ int salnmf_corr_poisson_llh(salnmf_engine* e, double* out) {
 // ------------------------------------------------------------------------------------ initialisation (row f3)
 
 int salnmf_init_gram(salnmf_engine* e, double* gram_out, double* xsum_out) {
+    if (e && e->NB > 1) return single_block(e, "the device-side initialisation");
     if (!e || !gram_out) return fail("null argument");
     HIPCK(hipSetDevice(e->device));
     const int nparts = e->grid * WAVES;
@@ -1870,6 +2051,7 @@ int salnmf_init_gram(salnmf_engine* e, double* gram_out, double* xsum_out) {
 }
 
 int salnmf_init_project(salnmf_engine* e, const double* B, double* posneg_out) {
+    if (e && e->NB > 1) return single_block(e, "the device-side initialisation");
     if (!e || !B || !posneg_out) return fail("null argument");
     HIPCK(hipSetDevice(e->device));
     const int K = e->K, V = e->V, KP = e->KP;
@@ -1895,6 +2077,7 @@ int salnmf_init_project(salnmf_engine* e, const double* B, double* posneg_out) {
 }
 
 int salnmf_init_finish(salnmf_engine* e, const double* scale, const int* take_neg, const double* post, double zero_below, double fill) {
+    if (e && e->NB > 1) return single_block(e, "the device-side initialisation");
     if (!e || !scale || !take_neg || !post) return fail("null argument");
     HIPCK(hipSetDevice(e->device));
     const int K = e->K;
@@ -1924,6 +2107,7 @@ int salnmf_init_finish(salnmf_engine* e, const double* scale, const int* take_ne
 }
 
 int salnmf_init_flat(salnmf_engine* e, const double* post) {
+    if (e && e->NB > 1) return single_block(e, "the device-side initialisation");
     if (!e || !post) return fail("null argument");
     HIPCK(hipSetDevice(e->device));
     e->h_pending = false;
@@ -1936,6 +2120,7 @@ int salnmf_init_flat(salnmf_engine* e, const double* post) {
 }
 
 int salnmf_init_separable(salnmf_engine* e, int n_select, int64_t* chosen_out) {
+    if (e && e->NB > 1) return single_block(e, "the device-side initialisation");
     if (!e || !chosen_out) return fail("null argument");
     if (n_select < 1 || (int64_t)n_select > e->N) return fail("n_select must be in [1, n_samples]");
     if (sharded(e)) return fail("the separableNMF selection needs all samples on one engine: not available on a sharded engine");
@@ -1978,6 +2163,7 @@ int salnmf_comm_unique_id(char* out_id) {
 }
 
 int salnmf_comm_init(salnmf_engine* e, const char* id_bytes, int n_ranks, int rank) {
+    if (e && e->NB > 1) return single_block(e, "a sample-sharded engine");
     if (!e || !id_bytes) return fail("null argument");
     if (e->comm) return fail("communicator already attached");
     if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail("rank %d out of range for %d ranks", rank, n_ranks);
@@ -2014,6 +2200,7 @@ int salnmf_comm_info(salnmf_engine* e, int* n_ranks, int* rank, int64_t* n_sampl
 }
 
 int salnmf_p2p_export(salnmf_engine* e, int n_ranks, int64_t max_count, char* handle_out) {
+    if (e && e->NB > 1) return single_block(e, "a sample-sharded engine");
     if (!e || !handle_out) return fail("null argument");
     if (e->p2p.local) return fail("the peer-to-peer inbox is exported already");
     if (n_ranks < 1 || n_ranks > P2P_MAX_RANKS) return fail("peer-to-peer exchange supports 1..%d ranks, not %d", P2P_MAX_RANKS, n_ranks);
@@ -2131,6 +2318,7 @@ static int ensure_events(salnmf_engine* e, size_t n) {
 
 int salnmf_profile_kl_steps(salnmf_engine* e, int n_steps, int n_given, int sample_stride, double* total_ms,
                             double* fused_avg_ms, double* tail_avg_ms) {
+    if (e && e->NB > 1) return single_block(e, "the profiling entry points");
     if (!e) return fail("null engine");
     if (n_steps < 1 || n_steps > 1000000) return fail("n_steps out of range");
     if (sample_stride < 1) sample_stride = 1;
@@ -2166,6 +2354,7 @@ int salnmf_profile_kl_steps(salnmf_engine* e, int n_steps, int n_given, int samp
 // to a scratch reconstruction buffer)
 static int profile_forward(salnmf_engine* e, int mode, int n_calls, double* avg_ms) {
     if (!e) return fail("null engine");
+    if (e->NB > 1) return single_block(e, "the profiling entry points");
     if (n_calls < 1 || n_calls > 100000) return fail("n_calls out of range");
     HIPCK(hipSetDevice(e->device));
     CK(ensure_events(e, (size_t)2 * n_calls));

@@ -126,9 +126,15 @@ struct FusedParams {
     double* __restrict__ KLpart;     // [gridDim.x]              (DO_STATS) unweighted partial of sum (p - x log p): the KL divergence minus
                                      //                          the x-only constant (tile_kl) (DO_U: optional, null = skip)
     int64_t N;
-    int V;
+    int V;                  // features of this pass (<= 96: one feature block)
+    int ldw;                // row stride of W (= V unless W points at one block of a wider matrix)
     int K;
     int64_t ntiles;
+    // feature blocks (n_features > 96; fused_kernel<..., BLOCKED>, update_H pass only): U = R W^T is a sum over the
+    // 96-feature blocks.  ublock = 1: first block, store U into Uacc; 2: add Uacc, store; 3: last block, add Uacc and
+    // update H with the total.  Uacc is [Np][KP] like H.
+    int ublock;
+    double* Uacc;
     // MvNMF update_H pass only (fused_kernel<!DO_G, DO_U, DO_STATS>), both optional:
     //  * sideW != null: the LAST workgroup of the grid processes no tiles; it runs the W-only algebra of the W step
     //    (mv_prepare_W_body: A = W Y_minus, B = W |Y|, log det(W W^T + delta I), mvnmf.py:19-24,48-54) on sideW beside the
@@ -279,8 +285,9 @@ __device__ __forceinline__ void bump_counter(unsigned* sync, int which) {
 }
 
 // W -> LDS with the padding described at the top of the file.  All loads in flight together.
+//   ldw: row stride of W in memory (= V; larger when W points at one 96-feature block of a wider signature matrix)
 template <int WROWS, bool SC1 = false>
-__device__ __forceinline__ void stage_W(double* Wl, const double* W, int K, int V, int tid) {
+__device__ __forceinline__ void stage_W(double* Wl, const double* W, int K, int V, int ldw, int tid) {
     constexpr int WPT = (WROWS * VMAX + BLOCK - 1) / BLOCK;
     constexpr int TOTAL = WPT * BLOCK;
     double wreg[WPT];
@@ -294,7 +301,7 @@ __device__ __forceinline__ void stage_W(double* Wl, const double* W, int K, int 
         int idx = tid + BLOCK * j + rot;
         idx = idx >= TOTAL ? idx - TOTAL : idx;
         int k = idx / VMAX, v = idx - k * VMAX;
-        const double* src = W + (k < K ? k : K - 1) * V + (v < V ? v : V - 1);
+        const double* src = W + (k < K ? k : K - 1) * ldw + (v < V ? v : V - 1);
         wreg[j] = SC1 ? __hip_atomic_load((const __attribute__((address_space(1))) double*)src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
     }
 #pragma unroll
@@ -587,9 +594,13 @@ struct EpiGeo {
 // row; everybody waits for the K rows, re-stages W into LDS and goes on.  That replaces two kernel boundaries,
 // the tail launch and the launch ramp per step by two counter hand-offs, and the first tile of the next step is
 // already in flight while a workgroup waits.
-template <int KS, int KTM, int KR, bool DO_G, bool DO_U, bool DO_STATS, bool WTS = false, bool PERSIST = false>
+//
+// BLOCKED (n_features > 96, update_H pass only): this launch covers ONE 96-feature block of X and W; the product
+// U = R W^T is accumulated over the blocks' launches through p.Uacc (p.ublock), the last block updates H.
+template <int KS, int KTM, int KR, bool DO_G, bool DO_U, bool DO_STATS, bool WTS = false, bool PERSIST = false, bool BLOCKED = false>
 __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
     static_assert(!PERSIST || (DO_G && DO_U && !DO_STATS && !WTS), "the persistent mode is the plain joint step");
+    static_assert(!BLOCKED || (DO_U && !DO_G && !DO_STATS && WTS && !PERSIST), "feature blocks: the weighted-capable update_H pass only");
     using G_ = Geo<KS>;
     constexpr int KT = KTM;  // MFMA tiles on the output side
     constexpr int KP = G_::KP, LS = G_::LS, HV = G_::HV;
@@ -898,6 +909,29 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (KR > 0) { using std::integral_constant; rs_stage(integral_constant<int, 8>{}, integral_constant<int, NVP>{}); rs_stage(integral_constant<int, 4>{}, integral_constant<int, (NVP / 2 > 1 ? NVP / 2 : 1)>{}); rs_stage(integral_constant<int, 2>{}, integral_constant<int, (NVP / 4 > 1 ? NVP / 4 : 1)>{}); rs_stage(integral_constant<int, 1>{}, integral_constant<int, (NVP / 8 > 1 ? NVP / 8 : 1)>{}); }
+            if (BLOCKED) {
+                // this block's share of U joins the earlier blocks' (order: block 0 + 1 + ...); all but the last block
+                // leave the running sum in Uacc and do not touch H
+                double* ua = p.Uacc + (n0 + q) * KP + c16;
+                if (p.ublock != 1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int kt = 0; kt < KT; ++kt) u[kt][r] += ua[4 * r * KP + 16 * kt];
+                }
+                const int jr = rs_idx >> 2, rr = rs_idx & 3;
+                const bool rem_owner = KR > 0 && jr < KR && (c16 & (NVP == 16 ? 0 : (NVP == 8 ? 1 : 3))) == 0;
+                double* uar = p.Uacc + (n0 + q + 4 * rr) * KP + KB + jr;
+                if (KR > 0 && rem_owner && p.ublock != 1) urem[0] += *uar;
+                if (p.ublock != 3) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int kt = 0; kt < KT; ++kt) ua[4 * r * KP + 16 * kt] = u[kt][r];
+                    if (KR > 0 && rem_owner) *uar = urem[0];
+                    return;  // (of the tile lambda)
+                }
+            }
             // ---- H update (_utils_klnmf.py:343-361), rows n = q+4r, columns k = 16kt+c16.
             // Unmasked: pad rows / columns just receive finite filler.  Non-temporal stores: 51 MB of H
             // per launch would otherwise sit dirty in L2 and be flushed at the kernel boundary
@@ -1101,10 +1135,10 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         // the first tile (its H rows were written by this very wave in the previous step) flies during the wait
         if (tile < nfull) load_tile(tile);
         if (step > 0 && !persist_wait_W(p.sync, p.abort_host, (unsigned)step * (unsigned)K, lds, tid)) return;
-        stage_W<G_::WROWS, true>(Wl, p.Wmut, K, V, tid);  // sc1 loads: rows published by other workgroups
+        stage_W<G_::WROWS, true>(Wl, p.Wmut, K, V, V, tid);  // sc1 loads: rows published by other workgroups
         __syncthreads();
     } else {
-        stage_W<G_::WROWS>(Wl, p.W, K, V, tid);
+        stage_W<G_::WROWS>(Wl, p.W, K, V, p.ldw, tid);
         __syncthreads();
         if (tile < nfull) load_tile(tile);
     }
@@ -1317,6 +1351,7 @@ struct FwdParams {
     double* __restrict__ out;           // mode 0: [gridDim.x]; mode 1: [Np]; mode 2: [Np][VMAX]
     int64_t N;
     int V;
+    int ldw;                            // row stride of W (= V unless W points at one feature block of a wider matrix)
     int K;
     int64_t ntiles;
 };
@@ -1350,7 +1385,7 @@ __global__ void __launch_bounds__(BLOCK, (fwd_lds_doubles<KS>() * 8 <= 80 * 1024
     double* ltab = hsl + KP;    // table of log_pos
     if (MODE == 0 || MODE == 3) stage_logtab(ltab, tid);
 
-    stage_W<FROWS>(Wl, p.W, K, V, tid);
+    stage_W<FROWS>(Wl, p.W, K, V, p.ldw, tid);
     __syncthreads();
 
     int hrow[HV], hcol[HV];
@@ -1639,6 +1674,63 @@ __global__ void pad_rows_kernel(double* __restrict__ dst, const T* __restrict__ 
         dst[i] = v;
     }
 }
+// The same for a matrix wider than one feature block (n_features > 96): the chunk's rows are scattered into nb blocks of
+// 96 columns each, dst[b][r][c] = src[r][96 b + c] (0 beyond cols); block_stride = doubles between consecutive blocks.
+template <typename T>
+__global__ void pad_rows_blocked_kernel(double* __restrict__ dst, const T* __restrict__ src, int64_t rows, int cols, int nb,
+                                        int64_t block_stride, double clip_lo) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t per_row = (int64_t)nb * VMAX;
+    for (; i < rows * per_row; i += stride) {
+        const int64_t r = i / per_row;
+        const int rc = (int)(i - r * per_row), b = rc / VMAX, c = rc - b * VMAX;
+        const int col = VMAX * b + c;
+        double v = 0.0;
+        if (col < cols) {
+            v = (double)src[r * cols + col];
+            if (clip_lo > 0.0) v = v < clip_lo ? clip_lo : v;
+        }
+        dst[(int64_t)b * block_stride + r * VMAX + c] = v;
+    }
+}
+
+// W tail of a problem with more than 96 features (_utils_klnmf.py:338-341 / :208-215): one workgroup per signature row.
+// Gblk holds the reduced numerator of every feature block, compact [K][vb] per block at stride K * 96; the row's
+// products W * G are summed in a fixed order (thread t: features t, t + 256, ...; then a binary tree), then normalise,
+// keep given rows, clip.  G (full [K][V]) is left behind as the engine's reduced numerator.
+__global__ void __launch_bounds__(256) w_finish_blocked_kernel(const double* __restrict__ Gblk, double* __restrict__ G, const double* __restrict__ W,
+                                                               double* __restrict__ Wout, int V, int K, int n_given, int clip_mode) {
+    __shared__ double red[256];
+    const int k = blockIdx.x, tid = threadIdx.x;
+    double part = 0.0;
+    for (int v = tid; v < V; v += 256) {
+        const int b = v / VMAX, vv = v - b * VMAX;
+        const int vb = V - VMAX * b < VMAX ? V - VMAX * b : VMAX;
+        const double g = Gblk[(int64_t)b * K * VMAX + k * vb + vv];
+        G[(int64_t)k * V + v] = g;
+        part += W[(int64_t)k * V + v] * g;
+    }
+    red[tid] = part;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if (tid < h) red[tid] += red[tid + h];
+        __syncthreads();
+    }
+    const double rowsum = red[0];
+    for (int v = tid; v < V; v += 256) {
+        const double wold = W[(int64_t)k * V + v];
+        double w = (wold * G[(int64_t)k * V + v]) / rowsum;
+        if (k < n_given) {
+            w = wold;
+            if (clip_mode == 0) w = clip_lo(w, kEps);
+        } else {
+            w = clip_lo(w, kEps);
+        }
+        Wout[(int64_t)k * V + v] = w;
+    }
+}
+
 // rows [r0, r1) of a padded matrix <- fill
 __global__ void fill_rows_kernel(double* __restrict__ dst, int64_t r0, int64_t r1, int ld, int cols, double fill_rows, double fill_cols) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + r0 * ld;

@@ -16,6 +16,7 @@ struct FusedSel {
     int KS, KTM, KR;               // geometry (salnmf.hip: pick_ks / salnmf_create)
     bool G, U, STATS, WTS;         // template switches of fused_kernel
     bool PERSIST;                  // the persistent multi-step variant (only in builds with SALNMF_WITH_PERSISTENT)
+    bool BLOCKED;                  // one 96-feature block of a wider problem: the update_H pass that accumulates U over blocks
 };
 
 // Return 0 when the kernel was launched (HIP launch errors are left for hipGetLastError), 1 when this build has no

@@ -26,12 +26,14 @@ class StandardNMF(SignatureNMF):
         instead of sklearn's randomized one) unless ``device_init=False`` or a ``seed`` is passed, which asks for
         the reference's seeded host computation (``initialize.py:221-255``)."""
         init_kwargs = {} if init_kwargs is None else init_kwargs.copy()
-        if self.device_init and self.init_method in DEVICE_METHODS and "seed" not in init_kwargs:
+        # (the device-side initialisation works on one 96-feature block: wider catalogues initialise on the host)
+        on_device = self.device_init and np.shape(self.adata.X)[1] <= 96
+        if on_device and self.init_method in DEVICE_METHODS and "seed" not in init_kwargs:
             if init_kwargs:
                 raise TypeError(f"init method '{self.init_method}' takes no keyword arguments besides 'seed': {sorted(init_kwargs)}")
             self._initialize_on_device(given_parameters)
             return
-        if self.device_init and self.init_method == "separableNMF" and not self.distributed and "chosen" not in init_kwargs:
+        if on_device and self.init_method == "separableNMF" and not self.distributed and "chosen" not in init_kwargs:
             # the K deflation rounds of the signature selection on the device (deterministic: the same indices with or
             # without a seed); the exposures are the host's legacy-RNG draw, as in the reference (methods.py:133)
             n_obs, n_vars = np.shape(self.adata.X)

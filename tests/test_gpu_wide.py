@@ -1,0 +1,112 @@
+"""GPU parity for catalogues wider than one 96-feature block: n_features in {97 .. 1536}.
+
+The reference has no limit on the number of mutation types (``_utils_klnmf.py:281-361``); the engine runs such problems
+one 96-feature block of X and W per launch.  Every KLNMF entry point against the oracle on ragged N, with weights,
+l-half penalties, given signatures and zeros in X."""
+
+import numpy as np
+import pytest
+
+import salamander_amd as sal
+from conftest import rel_l2
+from oracle import klnmf_oracle as orc
+from salamander_amd import Engine, _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def problem(V, N, K, seed):
+    X, W0, H0 = orc.synthetic_problem(V, N, K, seed=seed)
+    return X, W0, H0
+
+
+@pytest.mark.parametrize("V,N,K", [(97, 1000, 5), (192, 2049, 50), (288, 5003, 30), (1536, 777, 18), (100, 33, 64), (200, 4000, 17)])
+def test_wide_functions_against_the_oracle(V, N, K):
+    X, W0, H0 = problem(V, N, K, seed=V + N)
+    e = Engine(N, V, K)
+    e.upload_X(X), e.upload_W(W0), e.upload_H(H0)
+    assert np.array_equal(e.download_W(), W0) and np.array_equal(e.download_H(), H0)
+    assert np.isclose(e.objective(), orc.kl_divergence(X.T, W0.T, H0.T), rtol=1e-12)
+    assert np.allclose(e.samplewise_kl(), orc.samplewise_kl_divergence(X.T, W0.T, H0.T), rtol=1e-11)
+    assert rel_l2(e.reconstruct(), H0 @ W0) < 1e-14
+    # update_H, update_W (clip non-given only), then joint steps
+    e.update_H()
+    H1 = orc.update_H(X.T, W0.T, H0.T).T
+    assert rel_l2(e.download_H(), H1) < 1e-13
+    e.upload_H(H0)
+    e.update_W(2, _lib.CLIP_NON_GIVEN)
+    W1 = orc.update_W(X.T, W0.T, H0.T, n_given_signatures=2).T
+    assert rel_l2(e.download_W(), W1) < 1e-13 and np.array_equal(e.download_W()[:2], W0[:2])
+    e.upload_W(W0)
+    W, H = W0.T, H0.T
+    for _ in range(5):
+        W, H = orc.update_WH(X.T, W, H)
+    e.kl_step(5)
+    assert rel_l2(e.download_W(), W.T) < 1e-12 and rel_l2(e.download_H(), H.T) < 1e-12
+    assert np.isclose(e.objective(), orc.kl_divergence(X.T, W, H), rtol=1e-12)
+    e.close()
+
+
+@pytest.mark.parametrize("V,N,K,n_given", [(288, 1500, 12, 3), (130, 700, 50, 50), (1536, 300, 7, 0)])
+def test_wide_weighted_lhalf_given_and_zeros(V, N, K, n_given):
+    X, W0, H0 = problem(V, N, K, seed=5 * V)
+    rng = np.random.default_rng(V)
+    wk, wl = rng.uniform(0.5, 2.0, N), rng.uniform(0.0, 0.4, N)
+    Xz = X.copy()
+    Xz[rng.random(X.shape) < 0.05] = 0.0  # zeros through the function-level API (no clip)
+    e = Engine(N, V, K)
+    e.upload_X(Xz), e.upload_W(W0), e.upload_H(H0)
+    e.set_weights(wk, wl)
+    assert np.isclose(e.objective(), orc.klnmf_objective(Xz.T, W0.T, H0.T, wk, wl), rtol=1e-12)
+    W, H = W0.T, H0.T
+    for _ in range(4):
+        W, H = orc.update_WH(Xz.T, W, H, wk, wl, n_given)
+    e.kl_step(4, n_given)
+    assert rel_l2(e.download_W(), W.T) < 1e-12 and rel_l2(e.download_H(), H.T) < 1e-12
+    assert np.array_equal(e.download_W()[:n_given], np.clip(W0[:n_given], orc.EPSILON, None))
+    # the kept block / rollback and the queued objective work on wide engines too
+    Wk, Hk = e.download_W(), e.download_H()
+    e.objective_async(3)
+    e.kl_step_keep(3, n_given)
+    e.kl_rollback()
+    assert np.array_equal(e.download_W(), Wk) and np.array_equal(e.download_H(), Hk)
+    assert e.objective_read(3, 1)[0] == e.objective()
+    e.close()
+
+
+def test_wide_typed_ingest_and_the_refusals():
+    V, N, K = 288, 1201, 9
+    rng = np.random.default_rng(2)
+    counts = rng.poisson(3.0, size=(N, V))
+    e = Engine(N, V, K)
+    W0 = rng.dirichlet(np.ones(V), size=K)
+    H0 = rng.uniform(0.5, 2.0, size=(N, K))
+    outs = []
+    for dtype in ("float64", "int32", "uint16", "float32"):
+        e.upload_X(counts.astype(dtype), clip=True), e.upload_W(W0), e.upload_H(H0)
+        outs.append((e.objective(), e.reconstruct()))
+    Xc = counts.astype(float).clip(orc.EPSILON)
+    assert np.isclose(outs[0][0], orc.kl_divergence(Xc.T, W0.T, H0.T), rtol=1e-12)
+    assert all(o[0] == outs[0][0] and np.array_equal(o[1], outs[0][1]) for o in outs[1:])
+    for call in (lambda: e.mv_step(1, 0, 1.0, 1.0, 1.0), lambda: e.corr_configure(4), lambda: e.init_gram(), lambda: e.set_precision("f32")):
+        with pytest.raises(RuntimeError, match="n_features > 96"):
+            call()
+    e.close()
+    with pytest.raises(RuntimeError, match="n_features"):
+        Engine(10, 3073, 2)
+
+
+def test_wide_model_fit_matches_the_oracle_fit():
+    """``KLNMF.fit`` on an SBS-288-sized catalogue: host initialisation (the device one works on 96 features), queued
+    objectives, tolerance stop -- same iterations, history and factors as the restated reference loop."""
+    V, N, K = 288, 3000, 10
+    X, W0, H0 = problem(V, N, K, seed=11)
+    kw = dict(min_iterations=30, max_iterations=2000, conv_test_freq=10, tol=1e-5)
+    m = sal.models.KLNMF(K, "custom", **kw)
+    m.fit(sal.AnnData(X.copy()), init_kwargs={"signatures_mat": W0.copy(), "exposures_mat": H0.copy()})
+    W, H, it, hist = orc.fit_klnmf(X.T, W0.T, H0.T, **kw)
+    assert m.n_iterations_ == it and np.allclose(m.history["objective_function"], hist, rtol=1e-11)
+    assert rel_l2(m.asignatures.X, W.T) < 1e-8 and rel_l2(m.adata.obsm["exposures"], H.T) < 1e-8
+    d = sal.models.KLNMF(K, "nndsvd", min_iterations=5, max_iterations=5)
+    d.fit(sal.AnnData(X.copy()), init_kwargs={"seed": 0})
+    assert np.all(np.isfinite(d.asignatures.X)) and len(d.history["objective_function"]) == 0
