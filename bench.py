@@ -239,6 +239,31 @@ def extra_fast_mode(sal, device):
     }
 
 
+def extra_weighted_step(sal, device):
+    """The weighted instantiation of the joint step at c2 (KLNMF(fitting_kwargs={"weights_kl": ..., "weights_lhalf": ...})):
+    per-sample weights select fused_kernel<..., WTS = true> (no cooperative leftover tile, conditional loads in the tile loop)."""
+    from salamander_amd.synthetic import synthetic_problem
+
+    X, W0, H0 = synthetic_problem(V, N_C2, K, seed=0)
+    rng = np.random.default_rng(1)
+    res = {}
+    for name, (wk, wl) in (("weights_kl", (rng.uniform(0.5, 2.0, N_C2), None)), ("weights_kl_and_lhalf", (rng.uniform(0.5, 2.0, N_C2), rng.uniform(0.0, 0.2, N_C2)))):
+        e = sal.Engine(N_C2, V, K, device=device)
+        e.upload_X(X), e.upload_W(W0), e.upload_H(H0)
+        e.set_weights(wk, wl)
+        e.kl_step(50)
+        e.sync()
+        blocks = []
+        for _ in range(7):
+            t0 = time.perf_counter()
+            e.kl_step(200)
+            e.sync()
+            blocks.append((time.perf_counter() - t0) / 200)
+        e.close()
+        res[name] = statistics.median(blocks) * 1e6
+    return {"workload": f"c2 with per-sample weights: {V}x{N_C2}, k={K}, 7 blocks of 200 steps (median)", "us_per_step": res}
+
+
 def problem_rows(start, stop):
     """Rows [start, stop) of the 10^6-sample problem: 125 000-row blocks, block b drawn with seed b
     (per-shard seeds, no 8 GB host temporary).  W0 is block 0's."""
@@ -586,7 +611,7 @@ def main():
                 line["time_to_kl"] = time_to_kl(sal, X, W0, H0, n_cpu, target, cpu_s, local_rank)
             if not args.no_extra:
                 extra = {}
-                for name, fn in (("c4_mvnmf", extra_c4), ("c2_default_init_fit", extra_default_init_fit), ("c2_fp32_fast_mode", extra_fast_mode)):
+                for name, fn in (("c4_mvnmf", extra_c4), ("c2_default_init_fit", extra_default_init_fit), ("c2_fp32_fast_mode", extra_fast_mode), ("c2_weighted_step", extra_weighted_step)):
                     try:
                         extra[name] = fn(sal, local_rank)
                     except Exception as exc:  # an extra must never cost the headline line
