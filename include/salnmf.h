@@ -92,6 +92,11 @@ int salnmf_upload_H(salnmf_engine* e, const double* H);
 /* Per-sample weights (each n_samples long) or NULL to disable
  * (KLNMF._setup_fitting_parameters, klnmf.py:128-153). */
 int salnmf_set_weights(salnmf_engine* e, const double* weights_kl, const double* weights_lhalf);
+/* normalize_WH's exposure side (utils.py:155-158) + clip, applied lazily: from now on H is read as
+ * clip(H * scale[k], EPSILON) by every pass (scale: n_signatures values, the column sums of the raw signatures), and the
+ * first pass that rewrites H stores it that way -- the initialisation's 40 MB pass over the exposures disappears into
+ * the first update (initialize.py:116-118 with init_method="custom" inside fit). */
+int salnmf_set_H_scale(salnmf_engine* e, const double* scale);
 int salnmf_download_W(salnmf_engine* e, double* W);
 int salnmf_download_H(salnmf_engine* e, double* H);
 

@@ -38,6 +38,7 @@ SIGNATURES = {
     "salnmf_upload_W": (c_int, [_P, _D]),
     "salnmf_upload_H": (c_int, [_P, _D]),
     "salnmf_set_weights": (c_int, [_P, _D, _D]),
+    "salnmf_set_H_scale": (c_int, [_P, _D]),
     "salnmf_download_W": (c_int, [_P, _D]),
     "salnmf_download_H": (c_int, [_P, _D]),
     "salnmf_kl_step": (c_int, [_P, c_int, c_int]),

@@ -810,6 +810,18 @@ int salnmf_upload_H(salnmf_engine* e, const double* H) {
     return upload_padded(e, e ? e->H : nullptr, H, e ? e->K : 0, e ? e->KP : 0, 0.0, 1.0, 0.0);
 }
 
+int salnmf_set_H_scale(salnmf_engine* e, const double* scale) {
+    if (!e || !scale) return fail("null argument");
+    HIPCK(hipSetDevice(e->device));
+    CK(flush_H_scale(e));  // (an earlier pending rescale is applied first)
+    std::vector<double> cs((size_t)e->KP, 1.0);
+    for (int k = 0; k < e->K; ++k) cs[(size_t)k] = scale[k];
+    HIPCK(hipMemcpyAsync(e->cs, cs.data(), cs.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    HIPCK(hipStreamSynchronize(e->stream));  // (cs is a local)
+    e->h_pending = true;  // every reader of H applies clip(H * scale) on the fly until a pass rewrites H in full
+    return 0;
+}
+
 int salnmf_set_weights(salnmf_engine* e, const double* weights_kl, const double* weights_lhalf) {
     if (!e) return fail("null engine");
     HIPCK(hipSetDevice(e->device));
@@ -914,12 +926,17 @@ static int blocked_finish_W(salnmf_engine* e, int n_given, int clip_mode) {
 // one joint step (update_WH, _utils_klnmf.py:281-361): both halves from the OLD (W, H) -- the new H goes to the second
 // buffer while the numerator passes still read the old one, then the buffers change roles
 static int blocked_kl_step_once(salnmf_engine* e, int n_given) {
-    if (n_given >= e->K) return blocked_update_H(e, e->H);  // W untouched (:330-331): in place
+    if (n_given >= e->K) {  // W untouched (:330-331): in place
+        CK(blocked_update_H(e, e->H));
+        e->h_pending = false;
+        return 0;
+    }
     if (!e->Halt) HIPCK(hipMalloc(&e->Halt, (size_t)e->Np * e->KP * sizeof(double)));
     CK(blocked_update_H(e, e->Halt));
-    CK(blocked_numerators(e));
+    CK(blocked_numerators(e));  // (both halves read the old H, a pending rescale included)
     CK(blocked_finish_W(e, n_given, SALNMF_CLIP_ALL));
     std::swap(e->H, e->Halt);
+    e->h_pending = false;  // the new H was written in full
     return 0;
 }
 
@@ -1066,7 +1083,11 @@ int salnmf_kl_rollback(salnmf_engine* e) {
 int salnmf_update_H(salnmf_engine* e) {
     if (!e) return fail("null engine");
     HIPCK(hipSetDevice(e->device));
-    if (e->NB > 1) return blocked_update_H(e, e->H);
+    if (e->NB > 1) {
+        CK(blocked_update_H(e, e->H));
+        e->h_pending = false;
+        return 0;
+    }
     FusedParams p = fused_params(e);
     CK((launch_fused<false, true, false>(e, p)));
     e->h_pending = false;

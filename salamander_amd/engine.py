@@ -84,6 +84,12 @@ class Engine:
         H = _as_c(H, (self.N, self.K), "H")
         _lib.check(self._lib.salnmf_upload_H(self._h, _ptr(H)))
 
+    def set_H_scale(self, scale):
+        """Read H as ``clip(H * scale[k], EPSILON)`` from now on (``normalize_WH`` + clip of an initialisation, applied by
+        the first pass that rewrites H)."""
+        scale = _as_c(scale, (self.K,), "scale")
+        _lib.check(self._lib.salnmf_set_H_scale(self._h, _ptr(scale)))
+
     def set_weights(self, weights_kl=None, weights_lhalf=None):
         wk = None if weights_kl is None else _as_c(weights_kl, (self.N,), "weights_kl")
         wl = None if weights_lhalf is None else _as_c(weights_lhalf, (self.N,), "weights_lhalf")

@@ -175,9 +175,8 @@ class SignatureNMF(ABC):
             raise box["error"]
         self.adata.X = box["X"]
         self._exposures_out = box.get("H")
-        # adata.X just let go of the caller's unclipped matrix; if that was its last reference, returning 77 MB (c2) to the
-        # system costs ~5 ms: a helper thread holds the array for a moment longer and lets go of it off this thread
-        threading.Thread(target=lambda a: None, args=(raw,), name="salnmf-release", daemon=True).start()
+        # (adata.X just let go of the caller's unclipped matrix; if that was its last reference, returning 77 MB (c2) to the
+        # system costs ~5 ms here -- which is why fit() calls this while it waits for the device)
         del raw
 
     @abstractmethod
@@ -260,6 +259,7 @@ class SignatureNMF(ABC):
         e.upload_W(W)
         if "H" not in self._resident:
             e.upload_H(H)
+            self._initial_exposures_uploaded = True  # (fit: their host copy is let go of during the first device wait)
         self._resident = set()
         e.set_weights(*self._device_weights())
 
@@ -309,6 +309,7 @@ class SignatureNMF(ABC):
         verbosity_freq: int = 1000,
     ) -> "SignatureNMF":
         self._setup_adata(adata, background=self._background_setup)
+        self._initial_exposures_uploaded = False
         try:
             # inside fit() a device-side initialisation leaves the exposures on the device only: they come back once,
             # with the fitted ones (a 40 MB host array and its page faults less at c2)
@@ -388,6 +389,16 @@ class SignatureNMF(ABC):
 
         def read_pending():
             nonlocal first_slot, pending
+            # The host is about to wait for the device: the moment to finish the background setup.  Letting go of the
+            # caller's unclipped matrix returns 77 MB (c2) to the system, 5 ms during which the interpreter lock is held
+            # by whoever frees it -- here it falls into a wait that does not need the interpreter.
+            if pending:
+                self._finish_setup()
+                # likewise the host copy of the INITIAL exposures (40 MB at c2): the device has them, and fit() replaces
+                # adata.obsm["exposures"] with the fitted ones at its end
+                if getattr(self, "_initial_exposures_uploaded", False):
+                    self._initial_exposures_uploaded = False
+                    self.adata.obsm.pop("exposures", None)
             while pending:
                 n = min(pending, ring - first_slot)
                 of_values.extend(float(v) for v in self._device_objectives_read(first_slot, n))

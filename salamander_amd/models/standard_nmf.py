@@ -41,11 +41,46 @@ class StandardNMF(SignatureNMF):
             self._upload_X(e)
             init_kwargs["chosen"] = e.init_separable(self.n_signatures)
             self._resident = {"X"}
+        if self.init_method == "custom" and getattr(self, "_defer_exposures", False) and not self.distributed:
+            self._initialize_custom_on_device(given_parameters, init_kwargs)
+            return
         if self.init_method != "custom":  # ("custom" looks at the shape of X only)
             self._finish_setup()  # the host methods read the clipped adata.X
         self.asignatures = initialize_standard_nmf(
             self.adata, self.n_signatures, self.init_method, given_parameters, **init_kwargs
         )
+
+    def _initialize_custom_on_device(self, given_parameters, init_kwargs) -> None:
+        """``init_method="custom"`` inside ``fit``: the checks and the signature side of ``initialize_mat`` on the host
+        (K x V), the exposure side -- ``H * colsum`` and the clip, a pass over N x K -- on the device, applied lazily by
+        the first update (``Engine.set_H_scale``).  Same values as ``initialize_mat`` (the same product and clip per
+        entry); the normalised initial exposures are never materialised on the host: ``fit`` replaces
+        ``adata.obsm["exposures"]`` with the fitted ones anyway."""
+        from ..initialization import init_custom
+        from ..utils import EPSILON, type_checker
+
+        given_parameters = {} if given_parameters is None else given_parameters.copy()
+        dict_checker("given_parameters", given_parameters, GIVEN_PARAMETERS_STANDARD_NMF)
+        given = given_parameters.get("asignatures")
+        n_obs, n_vars = np.shape(self.adata.X)
+        from types import SimpleNamespace
+
+        S, E = init_custom(SimpleNamespace(shape=(n_obs, n_vars)), self.n_signatures, **init_kwargs)  # (only the shape of X is looked at)
+        S = np.array(S, dtype=np.float64)
+        if given is not None:
+            check_given_asignatures(given, self.adata, self.n_signatures)
+            given_mat = np.asarray(given.X)
+            type_checker("given_signatures_mat", given_mat, np.ndarray)
+            S[: given_mat.shape[0], :] = given_mat.copy()
+        colsum = S.T.sum(axis=0)
+        S_out = (S.T / colsum).clip(EPSILON).T
+        e = self._ensure_engine(n_obs, n_vars, self.n_signatures)
+        self._upload_X(e)
+        e.upload_H(np.ascontiguousarray(E, dtype=np.float64))
+        e.set_H_scale(colsum)
+        self.asignatures = package_signatures(self.adata, S_out, self.n_signatures, given)
+        self.adata.obsm.pop("exposures", None)  # fit() downloads the fitted exposures at its end
+        self._resident = {"X", "H"}
 
     def _initialize_on_device(self, given_parameters) -> None:
         given_parameters = {} if given_parameters is None else given_parameters.copy()

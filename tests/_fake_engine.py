@@ -32,6 +32,9 @@ class FakeEngine:
     def upload_H(self, H):
         self.H = np.array(H, dtype=float)
 
+    def set_H_scale(self, scale):
+        self.H = np.clip(self.H * np.asarray(scale)[None, :], orc.EPSILON, None)
+
     def set_weights(self, wkl=None, wlh=None):
         self.wkl, self.wlh = wkl, wlh
 

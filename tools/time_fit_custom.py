@@ -24,8 +24,9 @@ for background in (True, False, True, False, True):
     for name in ("_setup_adata", "_initialize", "_sync_to_device", "_fit_loop_queued", "_finish_setup", "_sync_from_device"):
         setattr(m, name, stamp(getattr(m, name), name, log))
     adata = sal.AnnData(X.copy())
+    kw = {"signatures_mat": W0.copy(), "exposures_mat": H0.copy()}
     t0 = time.perf_counter()
-    m.fit(adata, init_kwargs={"signatures_mat": W0.copy(), "exposures_mat": H0.copy()})
+    m.fit(adata, init_kwargs=kw)
     t = time.perf_counter() - t0
     if background:
         w = m._setup_box.get("seconds")
