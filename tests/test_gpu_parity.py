@@ -396,6 +396,28 @@ def test_kept_block_rollback_and_queued_objectives(N, K, n_given, weights, preci
     a.close(), b.close()
 
 
+@pytest.mark.parametrize("N,V,K", [(3000, 96, 50), (777, 83, 7), (1200, 288, 12)])
+def test_lazy_exposure_scale_of_the_initialisation(N, V, K):
+    """``Engine.set_H_scale`` (normalize_WH's exposure side + clip, initialize.py:116-118, applied by the first pass that
+    rewrites H): every reader sees clip(H * scale) bit for bit, and the steps continue from exactly that state."""
+    X, W0, H0 = orc.synthetic_problem(V, N, K, seed=N)
+    scale = np.random.default_rng(1).uniform(0.2, 3.0, K)
+    Hs = np.clip(H0 * scale[None, :], orc.EPSILON, None)
+    a, b = Engine(N, V, K), Engine(N, V, K)
+    for e, H in ((a, H0), (b, Hs)):
+        e.upload_X(X), e.upload_W(W0), e.upload_H(H)
+    a.set_H_scale(scale)
+    assert a.objective() == b.objective()
+    a.kl_step(3), b.kl_step(3)
+    # (to rounding: a pass that applies the scale on the fly does not use the cooperative leftover tile, which changes
+    # the order in which the numerator is summed)
+    assert rel_l2(a.download_W(), b.download_W()) < 1e-13 and rel_l2(a.download_H(), b.download_H()) < 1e-13
+    a.upload_H(H0)
+    a.set_H_scale(scale)
+    assert np.array_equal(a.download_H(), Hs)
+    a.close(), b.close()
+
+
 def test_model_fit_queued_loop_equals_blocking_loop_on_the_device():
     """``KLNMF.fit`` with the host out of the loop (queued objectives, speculative kept blocks) against the blocking loop
     (verbose): same stopping iteration, history and bits of W and H -- with a tolerance stop, i.e. through a rollback."""
