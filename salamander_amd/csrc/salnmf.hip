@@ -1745,10 +1745,11 @@ static int sample_embeddings_impl(salnmf_engine* const* engines, int n_engines, 
         p.status = dstatus;
     }
     const int grid = (int)std::min<int64_t>((e0->N + 3) / 4, 8192);
+    const size_t lds_bytes = (size_t)terms * (e0->dim | 1) * sizeof(double);  // the term matrix (corr_sample_embeddings_kernel)
     if (terms <= 64)
-        hipLaunchKernelGGL(corr_sample_embeddings_kernel<1>, dim3(grid), dim3(CORR_BLOCK), 0, e0->stream, p);
+        hipLaunchKernelGGL(corr_sample_embeddings_kernel<1>, dim3(grid), dim3(CORR_BLOCK), lds_bytes, e0->stream, p);
     else
-        hipLaunchKernelGGL(corr_sample_embeddings_kernel<2>, dim3(grid), dim3(CORR_BLOCK), 0, e0->stream, p);
+        hipLaunchKernelGGL(corr_sample_embeddings_kernel<2>, dim3(grid), dim3(CORR_BLOCK), lds_bytes, e0->stream, p);
     int rc = 0;
     if (hipGetLastError() != hipSuccess) rc = fail("corr_sample_embeddings_kernel launch failed");
     // the sample embeddings are shared: every modality's engine gets the result

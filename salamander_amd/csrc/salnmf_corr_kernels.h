@@ -200,7 +200,8 @@ constexpr int CORR_TERMS = 128;  // signatures of all modalities together
 
 template <int TPL>
 struct SampleEmbeddingEval {
-    const double* O;   // LDS [terms][CORR_LD]: the signature embeddings of all modalities
+    const double* O;   // LDS [terms][ld]: the signature embeddings of all modalities
+    int ld;            // its row stride: dim rounded up to an odd number (rows fall into different banks)
     const double* so;  // LDS [terms]: signature scalings
     double c[TPL];     // sample scaling of the modality of this lane's term(s)
     double a[TPL];     // aux of this lane's term(s) for this sample
@@ -224,7 +225,7 @@ struct SampleEmbeddingEval {
     __device__ __forceinline__ void products(double y, double (&s)[TPL]) {
         const double* row[TPL];
 #pragma unroll
-        for (int t = 0; t < TPL; ++t) row[t] = O + ((lane + 64 * t < T) ? lane + 64 * t : 0) * CORR_LD;
+        for (int t = 0; t < TPL; ++t) row[t] = O + ((lane + 64 * t < T) ? lane + 64 * t : 0) * ld;
         // four partial sums (m mod 4) per term: one chain of dim dependent FMAs would wait out every FMA's latency
         double a[TPL][4];
 #pragma unroll
@@ -254,15 +255,15 @@ struct SampleEmbeddingEval {
 #pragma unroll
         for (int t = 0; t < TPL; ++t) {
             const int n = T - 64 * t < 64 ? T - 64 * t : 64;  // terms held by this register of the lanes
-            const double* c = col + 64 * t * CORR_LD;
+            const double* c = col + 64 * t * ld;
             int i = 0;
             for (; i + 4 <= n; i += 4) {
-                r0 = __builtin_fma(lane_value(w[t], i), c[i * CORR_LD], r0);
-                r1 = __builtin_fma(lane_value(w[t], i + 1), c[(i + 1) * CORR_LD], r1);
-                r2 = __builtin_fma(lane_value(w[t], i + 2), c[(i + 2) * CORR_LD], r2);
-                r3 = __builtin_fma(lane_value(w[t], i + 3), c[(i + 3) * CORR_LD], r3);
+                r0 = __builtin_fma(lane_value(w[t], i), c[i * ld], r0);
+                r1 = __builtin_fma(lane_value(w[t], i + 1), c[(i + 1) * ld], r1);
+                r2 = __builtin_fma(lane_value(w[t], i + 2), c[(i + 2) * ld], r2);
+                r3 = __builtin_fma(lane_value(w[t], i + 3), c[(i + 3) * ld], r3);
             }
-            for (; i < n; ++i) r0 = __builtin_fma(lane_value(w[t], i), c[i * CORR_LD], r0);
+            for (; i < n; ++i) r0 = __builtin_fma(lane_value(w[t], i), c[i * ld], r0);
         }
         return lane < dim ? (r0 + r1) + (r2 + r3) : 0.0;
     }
@@ -346,7 +347,10 @@ struct SampleEmbeddingParams {
 
 template <int TPL>
 __global__ void __launch_bounds__(CORR_BLOCK) corr_sample_embeddings_kernel(SampleEmbeddingParams p) {
-    __shared__ double Ll[64 * TPL * CORR_LD];
+    // the term matrix in LDS, sized by the problem (T rows of `ld` doubles): at c5 (80 terms, dim 40) 26 KB instead of the
+    // 66.5 KB of the largest case, which is what lets three workgroups share a CU (the kernel is a chain of dependent
+    // evaluations per wave: more waves per SIMD hide more of its latency)
+    extern __shared__ __attribute__((aligned(16))) double Ll[];
     __shared__ double bl[64 * TPL];
     __shared__ int tmod[64 * TPL], tk[64 * TPL];  // term -> (modality, signature)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -361,15 +365,17 @@ __global__ void __launch_bounds__(CORR_BLOCK) corr_sample_embeddings_kernel(Samp
         bl[i] = mo < p.n_mod ? p.beta[mo][k] : 0.0;
     }
     __syncthreads();
-    for (int i = tid; i < 64 * TPL * CORR_LD; i += CORR_BLOCK) {
-        const int t = i / CORR_LD, m = i - t * CORR_LD;
-        Ll[i] = (t < T && m < dim) ? p.L[tmod[t]][tk[t] * dim + m] : 0.0;
+    const int ld = dim | 1;  // (odd; the column beyond dim, if any, is zero)
+    for (int i = tid; i < T * ld; i += CORR_BLOCK) {
+        const int t = i / ld, m = i - t * ld;
+        Ll[i] = m < dim ? p.L[tmod[t]][tk[t] * dim + m] : 0.0;
     }
     __syncthreads();
     // from here on the waves run independently (no workgroup barrier below)
     for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < p.N; n += (int64_t)gridDim.x * 4) {
         SampleEmbeddingEval<TPL> ev;
         ev.O = Ll;
+        ev.ld = ld;
         ev.so = bl;
         ev.variance = p.variance;
         ev.T = T;
