@@ -145,6 +145,7 @@ struct salnmf_engine {
     std::vector<hipEvent_t> objev;  // per slot: completion of the kernel that wrote it
     int mv_grid = 0, mv_fgrid = 0;  // grids that leave one CU free for stream2
     double *X = nullptr, *H = nullptr, *W = nullptr, *wkl = nullptr, *wlh = nullptr;
+    double *wones = nullptr, *wzeros = nullptr;  // [Np] fillers the weighted kernel loads from where a weight vector is absent
     double* Gpart = nullptr;     // [grid][K][VMAX]
     double* Hsumpart = nullptr;  // [grid][K]
     double* KLpart = nullptr;    // [grid]
@@ -231,6 +232,24 @@ static int pick_ks(int K) {
 
 // ------------------------------------------------------------------------------------ launches
 
+// the always-valid weight arrays of a weighted launch (salnmf_kernels.h: FusedParams::wkl_eff): the vectors themselves, or
+// fillers of ones / zeros where one of the two is absent
+static int weight_arrays(salnmf_engine* e, FusedParams& p) {
+    auto filler = [&](double*& buf, double value) -> int {
+        if (buf) return 0;
+        HIPCK(hipMalloc(&buf, (size_t)e->Np * sizeof(double)));
+        std::vector<double> host((size_t)e->Np, value);
+        HIPCK(hipMemcpyAsync(buf, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
+        HIPCK(hipStreamSynchronize(e->stream));
+        return 0;
+    };
+    if (!p.wkl) CK(filler(e->wones, 1.0));
+    if (!p.wlh) CK(filler(e->wzeros, 0.0));
+    p.wkl_eff = p.wkl ? p.wkl : e->wones;
+    p.wlh_eff = p.wlh ? p.wlh : e->wzeros;
+    return 0;
+}
+
 // ev_start / ev_stop (profiling only): bound to the dispatch itself, so that their elapsed time is the kernel's own
 // duration, as rocprofv3 reports it -- events recorded around the launch add their barrier packets to it.
 // The instantiations live in salnmf_fused_inst.hip / salnmf_forward_inst.hip (salnmf_launch.h).
@@ -241,7 +260,9 @@ static int launch_fused(salnmf_engine* e, const FusedParams& p, int grid = 0, hi
     const bool wts = p.wkl || p.wlh;
     if (wts && DO_STATS) return fail("internal: weighted pass with statistics is not instantiated");
     const FusedSel sel{e->KS, e->KTM, e->KR, DO_G, DO_U, DO_STATS, wts, false};
-    if (launch_fused_inst(sel, p, grid > 0 ? grid : e->grid, e->stream, ev_start, ev_stop))
+    FusedParams pw = p;
+    if (wts) CK(weight_arrays(e, pw));
+    if (launch_fused_inst(sel, pw, grid > 0 ? grid : e->grid, e->stream, ev_start, ev_stop))
         return fail("no kernel instantiation for KS=%d KTM=%d KR=%d", e->KS, e->KTM, e->KR);
     HIPCK(hipGetLastError());
     return 0;
@@ -471,7 +492,7 @@ void salnmf_destroy(salnmf_engine* e) {
     if (e->X32) (void)hipFree(e->X32);
     if (e->H32) (void)hipFree(e->H32);
     if (e->p2p.abort_dev) (void)hipFree(e->p2p.abort_dev);
-    double* bufs[] = {e->Gblk, e->Uacc, e->xlx, e->X, e->H, e->W, e->wkl, e->wlh, e->Gpart, e->Hsumpart, e->KLpart, e->red,
+    double* bufs[] = {e->wones, e->wzeros, e->Gblk, e->Uacc, e->xlx, e->X, e->H, e->W, e->wkl, e->wlh, e->Gpart, e->Hsumpart, e->KLpart, e->red,
                       e->objpart, e->scal, e->Wunc, e->Wtrial, e->mvA, e->mvB, e->cs, e->scratch, e->Halt, e->KLpart2, e->Wkeep, e->Hkeep, e->objring,
                       e->alpha, e->beta, e->Lemb, e->Uemb, e->aux, e->xrowsum, e->corrpart, e->gU, e->galpha, e->gaux};
     for (double* b : bufs)
@@ -899,6 +920,7 @@ static int blocked_update_H(salnmf_engine* e, double* Hout) {
         p.Hout = Hout;
         p.Uacc = e->Uacc;
         p.ublock = b == 0 ? 1 : (b == e->NB - 1 ? 3 : 2);
+        CK(weight_arrays(e, p));  // (the BLOCKED instantiation is the weighted-capable one)
         const FusedSel sel{e->KS, e->KTM, e->KR, false, true, false, true, false, true};
         if (launch_fused_inst(sel, p, e->grid, e->stream, nullptr, nullptr)) return fail("no kernel instantiation for KS=%d KTM=%d KR=%d", e->KS, e->KTM, e->KR);
         HIPCK(hipGetLastError());

@@ -120,6 +120,12 @@ struct FusedParams {
     const double* __restrict__ W;    // [K][V]
     const double* __restrict__ wkl;  // [Np] or null
     const double* __restrict__ wlh;  // [Np] or null
+    // WTS launches: always-valid arrays the tile loop loads its weights from -- wkl / wlh themselves, or the engine's
+    // filler arrays (ones / zeros) where one of them is null.  wkl / wlh keep deciding, as flags, which arithmetic runs;
+    // unconditional loads issued with the tile's other loads let hipcc count vmcnt instead of draining it at the loop's
+    // back edge (the weighted step was 29 % slower than the unweighted one, profiles/r03/bench_final1.json).
+    const double* __restrict__ wkl_eff;
+    const double* __restrict__ wlh_eff;
     const double* __restrict__ hscale;  // [KP] or null: H is read as clip(H*hscale) (MvNMF trial)
     double* __restrict__ Gpart;      // [gridDim.x][K][VMAX]     (DO_G) per-workgroup partial numerators
     double* __restrict__ Hsumpart;   // [gridDim.x][K]           (DO_STATS) row sums of H
@@ -566,6 +572,19 @@ struct EpiGeo {
     static constexpr int pos(int kt, int vt) { return (vt / VTR) * NT + kt * VTR + (vt % VTR); }
 };
 
+// H update with an l-half penalty (_utils_klnmf.py:349-361): I = 4 H (W^T aux) [w_kl^2]; D = w_lh^2 / 4 + I;
+// H' = (w_lh / 2 - sqrt(D))^2 / 4 [/ w_kl^2]  (the cooperative tile's form of the statements in process_tile)
+__device__ __forceinline__ double lhalf_update(double h, double u, double wl, double wk, bool has_wkl) {
+    const double wk2 = wk * wk;
+    double inter = 4.0 * h * u;
+    if (has_wkl) inter *= wk2;
+    const double disc = 0.25 * wl * wl + inter;
+    const double t = wl / 2 - sqrt(disc);
+    double hn = 0.25 * (t * t);
+    if (has_wkl) hn /= wk2;
+    return hn;
+}
+
 // ----------------------------------------------------------------------------------------------
 // Fused update pass.
 //   DO_G     accumulate G = (w_kl * R)^T-contracted numerator for the W update
@@ -607,7 +626,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
     constexpr int KB = 16 * KTM;                                   // first remainder column
     constexpr int NVP = KR == 0 ? 0 : (KR == 1 ? 4 : (KR == 2 ? 8 : 16));  // 4*KR values, padded to a power of two
     static_assert(KR >= 0 && KR <= 4 && KB + KR <= KP, "remainder columns must fit the padded layout");
-    __shared__ __attribute__((aligned(16))) double lds[G_::LDS_DOUBLES + KP + (DO_STATS ? LOGTAB_DOUBLES : 0)];
+    __shared__ __attribute__((aligned(16))) double lds[G_::LDS_DOUBLES + KP + (DO_STATS ? LOGTAB_DOUBLES : 0) + (WTS ? WAVES * 32 : 0)];
 
     // MvNMF update_H pass: the grid's last workgroup may be the one that does the W-only algebra instead of tiles
     constexpr bool MVU = DO_U && DO_STATS && !DO_G;
@@ -644,6 +663,8 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
     if (p.hscale && tid < KP) hsl[tid] = p.hscale[tid];
     double* ltab = hsl + KP;              // (DO_STATS) table of log_pos
     if (DO_STATS) stage_logtab(ltab, tid);
+    // (WTS) this wave's weights of the current tile: [16 rows][w_kl, w_lhalf], staged from the prefetch registers
+    double* wgt = ltab + (DO_STATS ? LOGTAB_DOUBLES : 0) + wave * 32;
 
     d4 g[KT][VT];
     double grem[KR > 0 ? KR : 1][VT];  // remainder rows of G: per-lane partials over this lane's sample rows
@@ -660,7 +681,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
     // Leftover round.  ntiles = R * (waves of the grid) + L: with 0 < L <= workgroups the L leftover tiles would keep
     // L waves busy for a whole tile time while the rest of the chip idles (c2: 106 of 1024 waves, 9.6 of 78 us).  In
     // the plain joint step they are instead worked on by all four waves of workgroup 0 .. L-1 (process_tile_coop below).
-    constexpr bool COOP = DO_G && DO_U && !DO_STATS && !WTS;
+    constexpr bool COOP = DO_G && DO_U && !DO_STATS;  // (with per-sample weights too: process_tile_coop honours them)
     using CO_ = EpiGeo<KT, KR, G_::LDS_DOUBLES>;
     static_assert(CO_::COOP_DOUBLES <= (WAVES - 1) * (G_::HL + G_::RL), "the cooperative tile's numerator park must fit the idle waves' LDS");
     const int64_t nleft = p.ntiles % tstride;
@@ -679,6 +700,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
     // prefetch registers: H tile (16-byte pieces of the contiguous block) and X tile (accumulator layout)
     d2 hpre[HV];
     double x[VT][4];
+    d2 wpre = (d2){1.0, 0.0};  // (WTS) {w_kl, w_lhalf} of row (lane & 15) of the prefetched tile
 
     auto load_tile = [&](int64_t t) __attribute__((always_inline)) {
         const int64_t n0 = t * 16;
@@ -690,10 +712,17 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         for (int vt = 0; vt < VT; ++vt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) x[vt][r] = xsrc[4 * r * VMAX + 16 * vt];
+        if (WTS) {
+            wpre[0] = p.wkl_eff[n0 + c16];
+            wpre[1] = p.wlh_eff[n0 + c16];
+        }
     };
 
     auto process_tile = [&](int64_t tile) __attribute__((always_inline)) {
         const int64_t n0 = tile * 16;
+        // (WTS) this tile's weights go to LDS with the H tile: the prefetch registers are reloaded in mid-tile, and
+        // holding 8 weights per lane across the tile pushed the weighted joint kernel past its 512 registers
+        if (WTS) *reinterpret_cast<d2*>(wgt + 2 * c16) = wpre;  // (the four q groups write the same values)
         // ---- stage the H tile (wave private; LDS ops of one wave are executed in order)
         if (p.hscale) {
             // MvNMF: H is read as clip(H * colsum(W_trial)) (a line-search trial, or the rescale of an accepted
@@ -806,7 +835,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
             if (wkl) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    double wk = wkl[n0 + 4 * r + q];
+                    double wk = wgt[2 * (q + 4 * r)];
 #pragma unroll
                     for (int kt = 0; kt < KT; ++kt) ga[r][kt] *= wk;
                 }
@@ -821,7 +850,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
                 // remainder rows: G[KB+j][v] += sum over this lane's rows n = q+4r of H[n][KB+j] * R[n][v]
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    double wk = wkl ? wkl[n0 + 4 * r + q] : 1.0;
+                    double wk = wkl ? wgt[2 * (q + 4 * r)] : 1.0;
 #pragma unroll
                     for (int j = 0; j < KR; ++j) {
                         double hv = Hl[(4 * r + q) * LS + KB + j];
@@ -950,9 +979,9 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int64_t n = n0 + q + 4 * r;
-                    const double wl = wlh[n];
+                    const double wl = wgt[2 * (q + 4 * r) + 1];
                     double wk2 = 1.0;
-                    if (wkl) { double w = wkl[n]; wk2 = w * w; }
+                    if (wkl) { double w = wgt[2 * (q + 4 * r)]; wk2 = w * w; }
 #pragma unroll
                     for (int kt = 0; kt < KT; ++kt) {
                         double inter = 4.0 * hcur[r][kt] * u[kt][r];
@@ -978,9 +1007,9 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
                     if (wlh == nullptr) {
                         hn = h * urem[0];
                     } else {
-                        const double wl = wlh[n];
+                        const double wl = wgt[2 * (q + 4 * r) + 1];
                         double wk2 = 1.0;
-                        if (wkl) { double w = wkl[n]; wk2 = w * w; }
+                        if (wkl) { double w = wgt[2 * (q + 4 * r)]; wk2 = w * w; }
                         double inter = 4.0 * h * urem[0];
                         if (wkl) inter *= wk2;
                         double disc = 0.25 * wl * wl + inter;
@@ -1046,7 +1075,15 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) xx[i][r] = (i < nvt) ? xsrc[4 * r * VMAX + 16 * (vt0 + i)] : 0.0;
         }
+        // (WTS) the tile's 16 weight pairs, through wave 0's weight slots in LDS
+        double* wg0 = ltab + (DO_STATS ? LOGTAB_DOUBLES : 0);
+        d2 wco = (d2){1.0, 0.0};
+        if (WTS && tid < 16) {
+            wco[0] = p.wkl_eff[n0 + tid];
+            wco[1] = p.wlh_eff[n0 + tid];
+        }
         __syncthreads();  // every wave has left its own last tile: wave 0's LDS regions are free
+        if (WTS && tid < 16) *reinterpret_cast<d2*>(wg0 + 2 * tid) = wco;
 #pragma unroll
         for (int j = 0; j < HR; ++j) {
             const int e = 2 * tid + 2 * BLOCK * j;
@@ -1079,7 +1116,11 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int kt = 0; kt < KT; ++kt) gc[kt] = mfma(Hs[(4 * r + q) * LS + 16 * kt + c16], pp[r], gc[kt]);
+                for (int kt = 0; kt < KT; ++kt) {
+                    double ha = Hs[(4 * r + q) * LS + 16 * kt + c16];
+                    if (WTS && wkl) ha *= wg0[2 * (4 * r + q)];
+                    gc[kt] = mfma(ha, pp[r], gc[kt]);
+                }
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
@@ -1089,7 +1130,11 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
                 for (int j = 0; j < KR; ++j) {
                     double t = 0.0;  // this feature column's sum over the 16 samples: 4 rows per lane, then the 4 q groups
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) t = __builtin_fma(Hs[(4 * r + q) * LS + KB + j], pp[r], t);
+                    for (int r = 0; r < 4; ++r) {
+                        double hv = Hs[(4 * r + q) * LS + KB + j];
+                        if (WTS && wkl) hv *= wg0[2 * (4 * r + q)];
+                        t = __builtin_fma(hv, pp[r], t);
+                    }
                     t += __shfl_xor(t, 16, 64);
                     t += __shfl_xor(t, 32, 64);
                     if (q == 0) cslab[CO_::REM + j * VMAX + 16 * VTI + c16] = t;
@@ -1115,8 +1160,10 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
             double* hdst = p.Hout + (n0 + q) * KP + 16 * kt + c16;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const double hn = clip_lo(Hs[(q + 4 * r) * LS + 16 * kt + c16] * u[r], p.hfloor);
-                __builtin_nontemporal_store(hn, &hdst[4 * r * KP]);
+                const double h = Hs[(q + 4 * r) * LS + 16 * kt + c16];
+                double hn = h * u[r];
+                if (WTS && wlh) hn = lhalf_update(h, u[r], wg0[2 * (q + 4 * r) + 1], wkl ? wg0[2 * (q + 4 * r)] : 1.0, wkl != nullptr);
+                __builtin_nontemporal_store(clip_lo(hn, WTS && wlh ? kEps : p.hfloor), &hdst[4 * r * KP]);
             }
         } else if (KR > 0 && wv == KT) {
             const int n = lane & 15, j = lane >> 4;
@@ -1125,7 +1172,10 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
                 const double* wr = Wl + (KB + j) * WS;
                 double dot = 0.0;
                 for (int v = 0; v < VMAX; ++v) dot = __builtin_fma(rr[v], wr[v], dot);
-                p.Hout[(n0 + n) * KP + KB + j] = clip_lo(Hs[n * LS + KB + j] * dot, p.hfloor);
+                const double h = Hs[n * LS + KB + j];
+                double hn = h * dot;
+                if (WTS && wlh) hn = lhalf_update(h, dot, wg0[2 * n + 1], wkl ? wg0[2 * n] : 1.0, wkl != nullptr);
+                p.Hout[(n0 + n) * KP + KB + j] = clip_lo(hn, WTS && wlh ? kEps : p.hfloor);
             }
         }
     };

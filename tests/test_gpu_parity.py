@@ -396,6 +396,28 @@ def test_kept_block_rollback_and_queued_objectives(N, K, n_given, weights, preci
     a.close(), b.close()
 
 
+@pytest.mark.parametrize("K,n_given,lhalf", [(50, 0, False), (50, 5, True), (30, 0, True), (16, 0, False)])
+def test_weighted_steps_through_the_cooperative_leftover_tile(K, n_given, lhalf):
+    """Per-sample weights at a size whose leftover round is worked on by whole workgroups (1074 tiles on 256 x 4 waves: 50
+    cooperative tiles, incl. the ragged last one): the weighted instantiation honours ``weights_kl`` / ``weights_lhalf``
+    there as in the ordinary tiles -- against the oracle."""
+    N = 16 * 1074 - 5
+    X, W0, H0 = orc.synthetic_problem(96, N, K, seed=K)
+    rng = np.random.default_rng(K)
+    wk = rng.uniform(0.5, 2.0, N)
+    wl = rng.uniform(0.0, 0.3, N) if lhalf else None
+    e = Engine(N, 96, K)
+    e.upload_X(X), e.upload_W(W0), e.upload_H(H0)
+    e.set_weights(wk, wl)
+    W, H = W0.T, H0.T
+    for _ in range(3):
+        W, H = orc.update_WH(X.T, W, H, wk, wl, n_given)
+    e.kl_step(3, n_given)
+    assert rel_l2(e.download_W(), W.T) < 1e-12 and rel_l2(e.download_H(), H.T) < 1e-12
+    assert np.isclose(e.objective(), orc.klnmf_objective(X.T, W, H, wk, wl), rtol=1e-12)
+    e.close()
+
+
 @pytest.mark.parametrize("N,V,K", [(3000, 96, 50), (777, 83, 7), (1200, 288, 12)])
 def test_lazy_exposure_scale_of_the_initialisation(N, V, K):
     """``Engine.set_H_scale`` (normalize_WH's exposure side + clip, initialize.py:116-118, applied by the first pass that
