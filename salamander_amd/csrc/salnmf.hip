@@ -144,6 +144,7 @@ struct salnmf_engine {
     double* objpin = nullptr;    // [SALNMF_OBJECTIVE_SLOTS] pinned host ring the queued objectives land in (salnmf_objective_async)
     std::vector<hipEvent_t> objev;  // per slot: completion of the kernel that wrote it
     int mv_grid = 0, mv_fgrid = 0;  // grids that leave one CU free for stream2
+    int mv_slabs = 0, mv_hparts = 0;  // workgroups of the last MvNMF numerator pass / of the update_H pass before it (what the tail reduces)
     double *X = nullptr, *H = nullptr, *W = nullptr, *wkl = nullptr, *wlh = nullptr;
     double *wones = nullptr, *wzeros = nullptr;  // [Np] fillers the weighted kernel loads from where a weight vector is absent
     double* Gpart = nullptr;     // [grid][K][VMAX]
@@ -311,7 +312,7 @@ static int single_block(const salnmf_engine* e, const char* what) {
 }
 
 static TailParams tail_params(salnmf_engine* e, int nslabs, double* G, int n_given, int clip_mode, int do_tail, bool with_stats, int hsum_parts = 0) {
-    TailParams t;
+    TailParams t{};
     t.Gpart = e->Gpart;
     t.G = G;
     t.W = e->W;
@@ -1404,7 +1405,31 @@ static int mv_numerator_pass(salnmf_engine* e, const double* W, const double* H,
     p.Hout = const_cast<double*>(H);
     p.hscale = hscale;
     CK((launch_fused<true, false, true>(e, p, grid)));
-    CK(launch_tail(e, grid, e->red, 0, 0, 0, true, nullptr, nullptr, hsum_parts));
+    e->mv_slabs = grid;        // what the tail that follows (now or after the line-search decision) has to reduce
+    e->mv_hparts = hsum_parts;
+    return 0;
+}
+
+// The tail of a numerator pass: G slabs, row sums of H and KL partials reduced in one launch (-> e->red).  with_root: the
+// same launch also evaluates the closed-form root and the first trial of the line search (tail_kernel: rootA; needs the
+// row sums from the preceding update_H pass and an unsharded engine); ev: bound to the launch's completion.
+static int mv_tail(salnmf_engine* e, bool with_root, double lam, int n_given, hipEvent_t ev) {
+    TailParams t = tail_params(e, e->mv_slabs, e->red, n_given, 0, 0, true, e->mv_hparts);
+    if (with_root) {
+        t.rootA = e->mvA;
+        t.rootB = e->mvB;
+        t.rootLogdet = e->scal + 3;
+        t.rootF0 = e->scal + 1;
+        t.rootWunc = e->Wunc;
+        t.rootWtrial = e->Wtrial;
+        t.rootCs = e->cs;
+        t.rootLam = lam;
+    }
+    if (ev)
+        hipExtLaunchKernelGGL(tail_kernel, dim3(e->K), dim3(TAIL_BLOCK), 0, e->stream, nullptr, ev, 0, t);
+    else
+        hipLaunchKernelGGL(tail_kernel, dim3(e->K), dim3(TAIL_BLOCK), 0, e->stream, t);
+    HIPCK(hipGetLastError());
     return 0;
 }
 
@@ -1421,7 +1446,7 @@ static int mv_numerator_pass(salnmf_engine* e, const double* W, const double* H,
 //            everything speculative is dropped and the backtracking loop evaluates its trials with the forward kernel.
 //   w_ready:  A, B and the log det of the current W are produced on the MAIN stream already (the side workgroup of the
 //            preceding update_H pass); otherwise mv_prepare_W_kernel is started on stream2 here and waited for
-//   g_ready:  (in) the numerator pass, tail and all-reduce of THIS step were queued by the previous call's speculation
+//   g_ready:  (in) the numerator pass of THIS step was queued by the previous call's speculation (its tail was not)
 static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double delta, double* gamma, bool have_hsum, bool w_ready,
                             bool speculate = false, bool* speculated = nullptr, bool g_ready = false) {
     if (speculated) *speculated = false;
@@ -1440,23 +1465,35 @@ static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double de
             CK(mv_numerator_pass(e, e->W, e->H, nullptr, e->grid, mv_side_total(e) - 1));
         else
             CK(mv_numerator_pass(e, e->W, e->H, nullptr, e->mv_grid, e->mv_grid));
+    }
+    // The tail of the numerator pass -- which the previous call's speculation queued WITHOUT its tail (g_ready), so that
+    // the tail runs after the line-search decision and can carry the closed-form root and the first trial of THIS step
+    // in the same launch (inside mv_step on an unsharded engine: one kernel and one boundary less per step).  A, B and
+    // the log det it reads come from the side workgroup of the preceding update_H pass (same stream), or from stream2.
+    const bool root_in_tail = have_hsum && !sharded(e);
+    if (!w_ready) HIPCK(hipStreamWaitEvent(e->stream, e->evPrepW, 0));
+    // (a non-speculative first trial is followed by the log det of the trial on stream2: the tail's completion is its event)
+    CK(mv_tail(e, root_in_tail, lam, n_given, root_in_tail && !speculate ? e->evTrial : nullptr));
+    if (!root_in_tail) {
+        // the rowsums_H partials came from the preceding update_H pass (have_hsum) or, for a stand-alone _update_W,
+        // come from a column-sum kernel over the current H
         if (!have_hsum) {
             hipLaunchKernelGGL(colsum_kernel, dim3(K), dim3(256), 0, e->stream, e->H, e->N, e->KP, e->red + K * V);
             HIPCK(hipGetLastError());
         }
         CK(allreduce(e, e->red, (size_t)K * V + K + 1));
     }
-    // W_unconstrained from A, B and the reduced sums; f0 = KL + lam * logdet(W) -> scal[1].  A, B and the log det come
-    // from stream2 (mv_prepare_W_kernel) unless the previous call's speculation produced them on this stream
-    if (!g_ready && !w_ready) HIPCK(hipStreamWaitEvent(e->stream, e->evPrepW, 0));
-    // (evaluated inside the first trial kernel below)
+    // otherwise: W_unconstrained from A, B and the reduced sums, f0 = KL + lam * logdet(W) -> scal[1], inside the first
+    // trial kernel below
     const MvRootParams root{e->mvA, e->mvB, e->red, e->red + K * V, e->red + K * V + K, e->scal + 3, e->scal + 1, lam, n_given};
     double g = *gamma;
     bool blend = false;
     for (;;) {
         const bool spec = speculate && !blend;
         // trial W: normalise + clip and the column sums for H on the main stream
-        if (spec)
+        if (!blend && root_in_tail)
+            ;  // (done by the tail launch above)
+        else if (spec)
             hipLaunchKernelGGL(mv_trial_light_kernel<true>, dim3(1), dim3(MV_BLOCK), 0, e->stream, e->W, e->Wunc, 1.0, 0, K, V, e->Wtrial, e->cs, root);
         else if (!blend)
             LAUNCH_WITH_EVENT(mv_trial_light_kernel<true>, dim3(1), dim3(MV_BLOCK), e->stream, e->evTrial, e->W, e->Wunc, 1.0, 0, K,
@@ -1494,9 +1531,9 @@ static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double de
                 CK(allreduce(e, e->scal + 2, 1));
                 HIPCK(hipEventRecord(e->evObj, e->stream));
             }
-            // ... and its numerator pass (W_trial as W, the new H) on the whole chip: it runs while the scalars travel to the host
+            // ... and its numerator pass (W_trial as W, the new H) on the whole chip: it runs while the scalars travel to the
+            // host.  Its tail waits for the decision (see above).
             CK(mv_numerator_pass(e, e->Wtrial, e->Halt, nullptr, e->grid, nwg));
-            CK(allreduce(e, e->red, (size_t)K * V + K + 1));
             HIPCK(hipStreamWaitEvent(e->stream3, e->evObj, 0));
             HIPCK(hipMemcpyAsync(e->hpin, e->scal, 5 * sizeof(double), hipMemcpyDeviceToHost, e->stream3));
             HIPCK(hipStreamSynchronize(e->stream3));

@@ -1579,6 +1579,19 @@ __global__ void __launch_bounds__(BLOCK, (fwd_lds_doubles<KS>() * 8 <= 80 * 1024
 // W tail (_utils_klnmf.py:338-341 / :208-215): one workgroup per signature k.
 //   stage 1 (nslabs > 0): G[k][:] = sum over the per-workgroup slabs, fixed order
 //   stage 2 (do_tail)   : W' = W*G ; W' /= sum_v W' ; keep given rows ; clip
+// One entry of update_W_unconstrained (mvnmf.py:55-65): the closed-form root from A = W Y_minus, B = W |Y|, the numerator
+// G and rowsums_H, with given rows kept and the others clipped.  One definition for the two kernels that evaluate it
+// (tail_kernel's root, mv_trial_light_kernel<true>), so that both produce the same bits.
+// No fused multiply-adds here: which products hipcc contracts depends on the code around the inlined body, and the
+// reference (NumPy) rounds every product and sum.
+__device__ __forceinline__ double mv_root_entry(double w, double wa, double wb, double wg, double hsum, double lam, bool given) {
+#pragma clang fp contract(off)
+    const double bb = hsum - 4.0 * lam * wa;
+    const double root = sqrt(bb * bb + 8.0 * lam * wb * wg);
+    const double wu = w * (root - bb) / (4.0 * lam * wb);
+    return given ? w : clip_lo(wu, kEps);
+}
+
 struct TailParams {
     const double* __restrict__ Gpart;  // [nslabs][K][VMAX]
     double* __restrict__ G;            // [K][V]
@@ -1599,11 +1612,24 @@ struct TailParams {
     double* __restrict__ kl_out;           // [1]
     int nparts;    // KL partials (workgroups of the numerator pass)
     int nparts_h;  // row-sum partials (workgroups of the preceding update_H pass)
+    // optional (MvNMF inside mv_step, unsharded; with hsum_part / kl_part): the first line-search trial in the same launch.
+    // Workgroup k holds everything row k of update_W_unconstrained needs once its sums are reduced (mvnmf.py:55-65:
+    // closed-form root from A, B, G[k], rowsums_H[k]; :80-81: normalise, clip; column sum for H), so the separate
+    // one-workgroup kernel (mv_trial_light_kernel<true>, 7.4 us + a boundary per step) is not launched.
+    const double* rootA;      // [K][V] W Y_minus; null = no root here
+    const double* rootB;      // [K][V] W |Y|
+    const double* rootLogdet; // [1] log det(W W^T + delta I) of the current W
+    double* rootF0;           // [1] f0 = KL + lam * log det  (mvnmf.py:79)
+    double* rootWunc;         // [K][V] W_unconstrained
+    double* rootWtrial;       // [K][V] normalised, clipped trial
+    double* rootCs;           // [KP] column sums of W_unconstrained (the factor H is rescaled by)
+    double rootLam;
 };
 
 #ifndef SALNMF_TEMPLATES_ONLY  // the plain kernels below are compiled by salnmf.hip only (salnmf_launch.h)
 __global__ void __launch_bounds__(TAIL_BLOCK) tail_kernel(TailParams p) {
     __shared__ TailScratch S;
+    __shared__ double mvsh[2];  // (MvNMF) this row's reduced rowsums_H entry, and the KL divergence (workgroup 0)
     const int k = blockIdx.x;
     const int K = p.K;
     if (p.hsum_part) {  // uniform over the grid
@@ -1621,11 +1647,47 @@ __global__ void __launch_bounds__(TAIL_BLOCK) tail_kernel(TailParams p) {
                 if ((int)threadIdx.x < h) hred[threadIdx.x] += hred[threadIdx.x + h];
                 __syncthreads();
             }
-            if (threadIdx.x == 0) (which == 0 ? p.hsum_out[k] : p.kl_out[0]) = which == 0 ? hred[0] : hred[0] + p.kl_const[0];
+            if (threadIdx.x == 0) {
+                const double value = which == 0 ? hred[0] : hred[0] + p.kl_const[0];
+                (which == 0 ? p.hsum_out[k] : p.kl_out[0]) = value;
+                mvsh[which] = value;  // (for the root below: through LDS, not back through global memory)
+            }
             __syncthreads();
         }
     }
     tail_row<TAIL_BLOCK, false>(S, threadIdx.x, k, p.Gpart, p.nslabs, p.G, p.W, p.Wout, p.V, K, p.n_given, p.clip_mode, p.do_tail != 0);
+    if (p.rootA) {  // (uniform over the grid; requires hsum_part, kl_part and nslabs > 0)
+        // tail_row left G[k][:] in S.red[0] behind a barrier; hsum_out[k] (and kl_out by workgroup 0) were stored by
+        // thread 0 of this workgroup above
+        const int tid = threadIdx.x, V = p.V;
+        __syncthreads();
+        const double hs = mvsh[0];
+        if (k == 0 && tid == 0) p.rootF0[0] = mvsh[1] + p.rootLam * p.rootLogdet[0];
+        double a = 0.0;
+        if (tid < V) {
+            a = mv_root_entry(p.W[k * V + tid], p.rootA[k * V + tid], p.rootB[k * V + tid], S.red[0][tid], hs, p.rootLam, k < p.n_given);
+            p.rootWunc[k * V + tid] = a;
+        }
+        if (tid < VMAX) S.wn[tid] = a;  // (0 beyond V)
+        __syncthreads();
+        // row sum in tail_row's fixed two-level order
+        if (tid < VMAX / 8) {
+            double t = 0.0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t += S.wn[8 * tid + i];
+            S.red[1][tid] = t;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+#pragma unroll
+            for (int i = 0; i < VMAX / 8; ++i) t += S.red[1][i];
+            S.rowsum = t;
+            p.rootCs[k] = t;
+        }
+        __syncthreads();
+        if (tid < V) p.rootWtrial[k * V + tid] = clip_lo(a / S.rowsum, kEps);
+    }
 }
 
 // out[j] = sum_i part[i*stride + j], j < width: one workgroup per output, fixed summation order

@@ -72,10 +72,7 @@ __global__ void __launch_bounds__(MV_BLOCK)
             int idx = threadIdx.x + MV_BLOCK * j;
             if (idx < total) {
                 const int k = idx / V;
-                const double bb = r.hsum[k] - 4.0 * r.lam * wa[j];
-                const double root = sqrt(bb * bb + 8.0 * r.lam * wb[j] * wg[j]);
-                const double wu = b[j] * (root - bb) / (4.0 * r.lam * wb[j]);
-                a[j] = (k < r.n_given) ? b[j] : clip_lo(wu, kEps);
+                a[j] = mv_root_entry(b[j], wa[j], wb[j], wg[j], r.hsum[k], r.lam, k < r.n_given);
                 Wunc[idx] = a[j];
             }
         }
@@ -99,9 +96,15 @@ __global__ void __launch_bounds__(MV_BLOCK)
     }
     __syncthreads();
     for (int k = threadIdx.x; k < K; k += MV_BLOCK) {
+        // the row sum in the W tail's fixed two-level order (12 groups of 8 consecutive features, then the groups): the
+        // root evaluated inside tail_kernel and this kernel give the same bits
         double s = 0.0;
-#pragma unroll 8
-        for (int v = 0; v < V; ++v) s += Wl[k * MV_WS + v];
+        for (int g0 = 0; g0 < MV_VMAX; g0 += 8) {
+            double t = 0.0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t += (g0 + i < V) ? Wl[k * MV_WS + g0 + i] : 0.0;
+            s += t;
+        }
         rs[k] = s;
         cs[k] = s;
     }
