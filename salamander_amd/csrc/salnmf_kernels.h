@@ -681,6 +681,10 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
     // Leftover round.  ntiles = R * (waves of the grid) + L: with 0 < L <= workgroups the L leftover tiles would keep
     // L waves busy for a whole tile time while the rest of the chip idles (c2: 106 of 1024 waves, 9.6 of 78 us).  In
     // the plain joint step they are instead worked on by all four waves of workgroup 0 .. L-1 (process_tile_coop below).
+    // (Tried for the two MvNMF passes as well, KR == 0: both got slower at c4 -- 38.8 -> 41.7 and 45.2 -> 47.1 us; their
+    // tile is half as long as the joint step's while the cooperative tile's fixed cost, three workgroup barriers and
+    // loads that nothing hides, stays, and the statistics code in the shared tile costs the main loop registers:
+    // profiles/r03/ab_step_variants.txt.)
     constexpr bool COOP = DO_G && DO_U && !DO_STATS;  // (with per-sample weights too: process_tile_coop honours them)
     using CO_ = EpiGeo<KT, KR, G_::LDS_DOUBLES>;
     static_assert(CO_::COOP_DOUBLES <= (WAVES - 1) * (G_::HL + G_::RL), "the cooperative tile's numerator park must fit the idle waves' LDS");
