@@ -93,27 +93,25 @@ def cpu_baseline(X, W0, H0, max_steps=500, budget_s=150.0):
 
 def device_loop_to_target(e, target, limit):
     """Steps on a resident engine until the objective (every 10 steps, as fit evaluates it) is at or below ``target``.
-    The host stays out of the way as ``KLNMF.fit`` does past ``min_iterations``: the next block of 10 steps is queued (as
-    a kept block) BEFORE the deciding objective is read, and rolled back once the target is met -- the clock stops when
+    The host stays out of the way as ``KLNMF.fit`` does past ``min_iterations``: the objective is queued TOGETHER with the
+    next block of 10 steps (``kl_step_objective``: evaluated inside that block's first update where the engine can; a
+    kept block), read while the block runs, and the block is rolled back once the target is met -- the clock stops when
     the host knows.  Returns (steps, objective there, seconds)."""
     e.objective_async(0)
     e.objective_read(0, 1)
     e.sync()
     t0 = time.perf_counter()
     e.kl_step(10)
-    e.objective_async(1)
     steps, slot = 10, 1
     while True:
-        e.kl_step_keep(10)
-        nxt = 1 + slot % 250
-        e.objective_async(nxt)
+        e.kl_step_objective(slot, 10, 0, keep=True)
         obj = float(e.objective_read(slot, 1)[0])
         if obj <= target * (1 + 1e-12) or steps >= limit:
             seconds = time.perf_counter() - t0
             e.kl_rollback()
             return steps, obj, seconds
         steps += 10
-        slot = nxt
+        slot = 1 + slot % 250
 
 
 def time_to_kl(sal, X, W0, H0, cpu_steps, target, cpu_seconds, device):
@@ -139,7 +137,7 @@ def time_to_kl(sal, X, W0, H0, cpu_steps, target, cpu_seconds, device):
         "gpu_objective_there": obj,
         "reached": bool(obj <= target * (1 + 1e-12)),
         "gpu_loop_seconds": loop_s,
-        "gpu_loop_protocol": "objective every 10 steps; the next block is queued before the deciding objective is read (kept block, rolled back at the target)",
+        "gpu_loop_protocol": "objective every 10 steps, evaluated inside the first update of the next block, which is queued before the deciding objective is read (kept block, rolled back at the target)",
         "gpu_fit_seconds_end_to_end": fit_s,
         "fit_objective_last": float(model.history["objective_function"][-1]) if model.history["objective_function"] else None,
     }

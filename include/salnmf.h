@@ -114,6 +114,14 @@ int salnmf_kl_step(salnmf_engine* e, int n_steps, int n_given);
  * objective that decides convergence (signature_nmf.py:373-380): the decision's host round trip hides behind the block. */
 int salnmf_kl_step_keep(salnmf_engine* e, int n_steps, int n_given);
 int salnmf_kl_rollback(salnmf_engine* e);
+/* The objective (klnmf.py:64-80) of the resident state into slot `slot` of the objective ring (as salnmf_objective_async),
+ * then n_steps >= 0 joint updates (keep != 0: as salnmf_kl_step_keep).  This is what SignatureNMF.fit does at every
+ * convergence test that does not end the fit (signature_nmf.py:358-385): the first update forms P = H W of exactly the
+ * state the objective is about, so -- unweighted, unsharded, n_features <= 96, n_given < n_signatures -- the divergence is
+ * evaluated inside that update's launch (one logarithm per entry on top of it) and reduced by a spare workgroup of its
+ * W tail; no forward pass of its own.  Otherwise, and for n_steps == 0, the calls named above in sequence.  The value
+ * equals salnmf_objective's to rounding (another summation order), not bit for bit. */
+int salnmf_kl_step_objective(salnmf_engine* e, int slot, int n_steps, int n_given, int keep);
 /* Switch the persistent multi-step launch of salnmf_kl_step on (1) or off (0, the default).  Measurement aid: the
  * default build does not carry that kernel (measured 10 % slower) and refuses on = 1 with an error; build with
  * SALNMF_WITH_PERSISTENT=1 (__graft_entry__.py) to get it. */

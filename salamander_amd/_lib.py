@@ -51,6 +51,7 @@ SIGNATURES = {
     "salnmf_objective_async": (c_int, [_P, c_int]),
     "salnmf_objective_read": (c_int, [_P, c_int, c_int, _D]),
     "salnmf_kl_step_keep": (c_int, [_P, c_int, c_int]),
+    "salnmf_kl_step_objective": (c_int, [_P, c_int, c_int, c_int, c_int]),
     "salnmf_kl_rollback": (c_int, [_P]),
     "salnmf_samplewise_kl": (c_int, [_P, _D]),
     "salnmf_reconstruct": (c_int, [_P, _D]),

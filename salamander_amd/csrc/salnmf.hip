@@ -428,9 +428,35 @@ static int flush_H_scale(salnmf_engine* e) {
 // (a weighted or sharded step, whose tail is more than one launch, falls back to records around the launches)
 //   keep: this step leaves the state it starts from untouched -- the new H goes to the second H buffer, the new W to
 //   Wkeep -- and the buffers change roles afterwards (salnmf_kl_step_keep)
-static int kl_step_once(salnmf_engine* e, int n_given, hipEvent_t* ev, bool keep = false) {
+//   obj_slot >= 0: the step also evaluates the objective of the state it starts from (the fused pass has P = H W of that
+//   state in registers anyway: one logarithm per entry on top, instead of a forward pass of its own) -- its KL partials are
+//   reduced by an extra workgroup of the tail launch straight into slot obj_slot of the pinned ring, and the slot's event
+//   is that launch's completion signal.  Unweighted, unsharded, n_given < K (salnmf_kl_step_objective checks).
+static int kl_step_once(salnmf_engine* e, int n_given, hipEvent_t* ev, bool keep = false, int obj_slot = -1) {
     FusedParams p = fused_params(e);
     const bool all_given = n_given >= e->K;  // _utils_klnmf.py:330-331: W untouched
+    if (obj_slot >= 0) {
+        if (keep) {
+            p.Hout = e->Halt;
+            e->Wdst = e->Wkeep;
+        }
+        CK((launch_fused<true, true, true>(e, p)));
+        e->h_pending = false;
+        TailParams t = tail_params(e, e->grid, e->red, n_given, SALNMF_CLIP_ALL, 1, false);
+        t.kl_part = e->KLpart;
+        t.kl_out = e->objpin + obj_slot;
+        t.nparts = e->grid;
+        t.kl_extra = 1;
+        hipExtLaunchKernelGGL(tail_kernel, dim3(e->K + 1), dim3(TAIL_BLOCK), 0, e->stream, nullptr, e->objev[obj_slot], 0, t);
+        HIPCK(hipGetLastError());
+        if (keep) {
+            std::swap(e->H, e->Halt);
+            std::swap(e->W, e->Wkeep);
+            e->Wdst = nullptr;
+            e->keep_has_W = true;
+        }
+        return 0;
+    }
     if (keep) {
         p.Hout = e->Halt;
         e->Wdst = all_given ? nullptr : e->Wkeep;
@@ -1226,15 +1252,21 @@ int salnmf_objective(salnmf_engine* e, double* out) {
     return read_scalars(e, 0, 1, out);
 }
 
-int salnmf_objective_async(salnmf_engine* e, int slot) {
-    if (!e) return fail("null engine");
+// the pinned ring of objective slots and slot's event
+static int ensure_objective_slot(salnmf_engine* e, int slot) {
     if (slot < 0 || slot >= SALNMF_OBJECTIVE_SLOTS) return fail("slot must be in [0, %d)", SALNMF_OBJECTIVE_SLOTS);
-    HIPCK(hipSetDevice(e->device));
     static_assert(SALNMF_OBJECTIVE_SLOTS * sizeof(double) <= SMALL_PINNED_BYTES, "the ring lives in one small pinned block");
     if (!e->objpin) HIPCK(acquire_pinned((void**)&e->objpin, 1));
     if (e->objev.empty()) e->objev.assign(SALNMF_OBJECTIVE_SLOTS, nullptr);
     // (with the system-scope fence: the host reads the slot once the event has completed)
     if (!e->objev[slot]) HIPCK(hipEventCreateWithFlags(&e->objev[slot], hipEventDisableTiming));
+    return 0;
+}
+
+int salnmf_objective_async(salnmf_engine* e, int slot) {
+    if (!e) return fail("null engine");
+    HIPCK(hipSetDevice(e->device));
+    CK(ensure_objective_slot(e, slot));
     // The value lands in pinned host memory straight from the reducing kernel, and the slot's event is that kernel's own
     // completion signal: the reader waits for THIS objective only, not for whatever was queued behind it (the next
     // block of steps), and no copy packet sits in the stream.  A sharded engine all-reduces the device copy first.
@@ -1252,6 +1284,32 @@ int salnmf_objective_async(salnmf_engine* e, int slot) {
     CK(allreduce(e, e->objring + slot, 1));
     hipExtLaunchKernelGGL(copy_scalar_kernel, dim3(1), dim3(1), 0, e->stream, nullptr, e->objev[slot], 0, e->objpin + slot, (const double*)(e->objring + slot));
     HIPCK(hipGetLastError());
+    return 0;
+}
+
+int salnmf_kl_step_objective(salnmf_engine* e, int slot, int n_steps, int n_given, int keep) {
+    if (!e) return fail("null engine");
+    if (n_given < 0 || n_given > e->K) return fail("n_given out of range");
+    if (n_steps < 0) return fail("n_steps must not be negative");
+    HIPCK(hipSetDevice(e->device));
+    const bool fold = n_steps > 0 && e->NB == 1 && !e->fast32 && !e->persistent && !sharded(e) && !e->wkl && !e->wlh && n_given < e->K;
+    if (!fold) {
+        // the objective as a forward pass of its own, then the steps
+        CK(salnmf_objective_async(e, slot));
+        if (n_steps == 0) return 0;
+        return keep ? salnmf_kl_step_keep(e, n_steps, n_given) : salnmf_kl_step(e, n_steps, n_given);
+    }
+    CK(ensure_objective_slot(e, slot));
+    CK(ensure_xlogx(e));
+    if (keep) {
+        if (!e->Halt) HIPCK(hipMalloc(&e->Halt, (size_t)e->Np * e->KP * sizeof(double)));
+        if (!e->Wkeep) HIPCK(hipMalloc(&e->Wkeep, (size_t)e->K * e->V * sizeof(double)));
+        CK(flush_H_scale(e));
+        e->keep_valid = false;
+    }
+    CK(kl_step_once(e, n_given, nullptr, keep != 0, slot));
+    for (int i = 1; i < n_steps; ++i) CK(kl_step_once(e, n_given, nullptr));
+    if (keep) e->keep_valid = true;
     return 0;
 }
 

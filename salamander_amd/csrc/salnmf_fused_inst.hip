@@ -61,7 +61,7 @@ static int launch_geometry(const FusedSel& s, const FusedParams& p, int grid, hi
         return 0;
     }
     // the variants the engine uses: joint step / update_H / update_W, each weighted or not; the two MvNMF passes
-    // with statistics (unweighted)
+    // with statistics (unweighted); the joint step that evaluates the objective of the state it starts from
 #define SALNMF_VARIANT(g_, u_, s_, w_)                                            \
     if (s.G == g_ && s.U == u_ && s.STATS == s_ && s.WTS == w_) {                 \
         launch_one<KS, KTM, KR, g_, u_, s_, w_>(p, grid, st, e0, e1);             \
@@ -75,6 +75,7 @@ static int launch_geometry(const FusedSel& s, const FusedParams& p, int grid, hi
     SALNMF_VARIANT(true, false, false, true)
     SALNMF_VARIANT(true, false, true, false)
     SALNMF_VARIANT(false, true, true, false)
+    SALNMF_VARIANT(true, true, true, false)
 #undef SALNMF_VARIANT
     return 1;
 }

@@ -330,7 +330,9 @@ __device__ __forceinline__ void stage_W(double* Wl, const double* W, int K, int 
 // single select: the range check is two min3/max3 chains over the high words.  Partial tiles and V < 96 take the masked
 // form; a P that is zero, denormal or not finite (an all-zero row of H or W through the function-level API) sends the
 // whole tile to the library path.
-template <bool ROWS>
+//   MB: logarithms evaluated side by side (their intermediates are 14 registers each: the joint step with the objective
+//   folded in has room for three at a time)
+template <bool ROWS, int MB = VT>
 __device__ __forceinline__ double tile_kl(const double (&x)[VT][4], const d4 (&pr)[VT], const double (&wv)[4], const double (&cv)[4],
                                           const double* __restrict__ tab, int64_t n0, int64_t N, int V, int q, int c16) {
     if (n0 + 16 <= N && V == VMAX) {  // (wave-uniform)
@@ -347,13 +349,18 @@ __device__ __forceinline__ double tile_kl(const double (&x)[VT][4], const d4 (&p
             double total = 0.0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                double ps[VT], lp[VT];
-#pragma unroll
-                for (int vt = 0; vt < VT; ++vt) ps[vt] = pr[vt][r];
-                log_pos_n<VT>(ps, tab, lp);
+                static_assert(VT % MB == 0, "batches of equal size");
                 double acc = (ROWS && c16 == 0) ? cv[r] : 0.0;
 #pragma unroll
-                for (int vt = 0; vt < VT; ++vt) acc += __builtin_fma(-x[vt][r], lp[vt], ps[vt]);
+                for (int b = 0; b < VT; b += MB) {
+                    double ps[MB], lp[MB];
+#pragma unroll
+                    for (int i = 0; i < MB; ++i) ps[i] = pr[b + i][r];
+                    log_pos_n<MB>(ps, tab, lp);
+#pragma unroll
+                    for (int i = 0; i < MB; ++i) acc += __builtin_fma(-x[b + i][r], lp[i], ps[i]);
+                    if (MB != VT) asm volatile("" : "+v"(acc));  // one batch after the other
+                }
                 if (ROWS) acc *= wv[r];
                 total += acc;
             }
@@ -630,6 +637,8 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
 
     // MvNMF update_H pass: the grid's last workgroup may be the one that does the W-only algebra instead of tiles
     constexpr bool MVU = DO_U && DO_STATS && !DO_G;
+    // (DO_G && DO_U && DO_STATS: the joint step that also evaluates the KL divergence of the state it starts from -- the
+    // objective of a convergence test, folded into the first step of the next block; no row sums of H there)
     const int nwg = (int)gridDim.x - ((MVU && p.sideW != nullptr) ? 1 : 0);  // workgroups that process tiles
     if (MVU && p.sideW != nullptr && (int)blockIdx.x == nwg) {
         static_assert(!MVU || KP * (MV_WS + 2 * MV_LD + 1) + 1 <= G_::LDS_DOUBLES, "the W-only algebra must fit this geometry's LDS");
@@ -671,7 +680,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
     double hsum[KT > 0 ? KT : 1];  // column sums of the updated H over this lane's rows (columns 16kt+c16)
     double hsum_rem = 0.0;         // same for the remainder column this lane owns
     double klacc = 0.0;
-    if (DO_STATS) {
+    if (MVU) {
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) hsum[kt] = 0.0;
     }
@@ -685,7 +694,8 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
     // tile is half as long as the joint step's while the cooperative tile's fixed cost, three workgroup barriers and
     // loads that nothing hides, stays, and the statistics code in the shared tile costs the main loop registers:
     // profiles/r03/ab_step_variants.txt.)
-    constexpr bool COOP = DO_G && DO_U && !DO_STATS;  // (with per-sample weights too: process_tile_coop honours them)
+    // The joint step with the objective folded in (DO_STATS) does the same: its numerator is summed in the plain step's order.
+    constexpr bool COOP = DO_G && DO_U;  // (with per-sample weights too: process_tile_coop honours them)
     using CO_ = EpiGeo<KT, KR, G_::LDS_DOUBLES>;
     static_assert(CO_::COOP_DOUBLES <= (WAVES - 1) * (G_::HL + G_::RL), "the cooperative tile's numerator park must fit the idle waves' LDS");
     const int64_t nleft = p.ntiles % tstride;
@@ -777,6 +787,12 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
             }
         }
 
+        // (joint step with the objective: the KL terms first, before the G operands below take their registers)
+        constexpr bool JKL = DO_G && DO_U && DO_STATS;
+        if (JKL) {
+            const double none[4] = {0.0, 0.0, 0.0, 0.0};
+            klacc += tile_kl<false, (KR >= 3 ? 2 : 3)>(x, pr, none, none, ltab, n0, N, V, q, c16);
+        }
         // G-phase A operands (H^T): issue the LDS reads now, they land under the divisions
         double ga[4][KT];
         if (DO_G) {
@@ -791,7 +807,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         // unweighted KL(X || P) of this tile from P before the division: always with the numerator pass (f0 of the MvNMF
         // line search), with the update_H pass only when asked (KLpart != null: a speculative pass evaluates the trial
         // it starts from, which saves the separate forward pass)
-        if (DO_STATS && (DO_G || p.KLpart != nullptr)) {
+        if (DO_STATS && !JKL && (DO_G || p.KLpart != nullptr)) {
             const double none[4] = {0.0, 0.0, 0.0, 0.0};
             klacc += tile_kl<false>(x, pr, none, none, ltab, n0, N, V, q, c16);
         }
@@ -977,7 +993,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
                     for (int kt = 0; kt < KT; ++kt) {
                         const double hn = clip_lo(hcur[r][kt] * u[kt][r], p.hfloor);
                         __builtin_nontemporal_store(hn, &hdst[4 * r * KP + 16 * kt]);
-                        if (DO_STATS) hsum[kt] += (n0 + q + 4 * r < N) ? hn : 0.0;
+                        if (MVU) hsum[kt] += (n0 + q + 4 * r < N) ? hn : 0.0;
                     }
             } else {
 #pragma unroll
@@ -996,7 +1012,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
                         if (wkl) hn /= wk2;
                         hn = clip_lo(hn, kEps);
                         __builtin_nontemporal_store(hn, &hdst[4 * r * KP + 16 * kt]);
-                        if (DO_STATS) hsum[kt] += (n < N) ? hn : 0.0;
+                        if (MVU) hsum[kt] += (n < N) ? hn : 0.0;
                     }
                 }
             }
@@ -1023,7 +1039,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
                     }
                     hn = clip_lo(hn, p.hfloor);
                     p.Hout[n * KP + KB + j] = hn;
-                    if (DO_STATS) hsum_rem += (n < N) ? hn : 0.0;
+                    if (MVU) hsum_rem += (n < N) ? hn : 0.0;
                 }
             }
         }
@@ -1105,6 +1121,27 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
             const double* wb = Wl + q * WS + 16 * VTI + c16;
 #pragma unroll
             for (int s2 = 0; s2 < KS; ++s2) pp = mfma(ha[4 * s2], wb[4 * s2 * WS], pp);
+            if (DO_STATS) {
+                // this feature tile's share of the unweighted KL partial (tile_kl's masked form, four entries per lane)
+                bool valid[4], ok = true;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    valid[r] = (n0 + q + 4 * r < N) && (16 * VTI + c16 < V);
+                    ok &= !valid[r] || log_pos_ok(pp[r]);
+                }
+                if (__all(ok)) {
+                    double ps[4], lp[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ps[r] = valid[r] ? pp[r] : 1.0;
+                    log_pos_n<4>(ps, ltab, lp);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) klacc += valid[r] ? __builtin_fma(-xv[r], lp[r], ps[r]) : 0.0;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (valid[r]) klacc += kl_term_p(xv[r], pp[r]);
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 pp[r] = div_path(xv[r], pp[r]);
@@ -1319,7 +1356,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
     if (PERSIST) {
         if (!persist_publish_and_tail(p.sync, p.abort_host, p.Gpart, p.G, p.Wmut, K, V, p.n_given, lds, step, tid)) return;
     }
-    if (DO_STATS && DO_U) {
+    if (MVU) {
         __syncthreads();
         // column k = 16kt + c16 (or KB + j) of the updated H: sum the 4 waves x 4 q-groups in fixed order
         double* S = lds;  // [16*KT + 16][16]: row = column index k, 16 slots = (wave, q)
@@ -1614,6 +1651,8 @@ struct TailParams {
     const double* __restrict__ kl_part;    // [nparts] or null: partials of sum (p - x log p) (tile_kl)
     const double* __restrict__ kl_const;   // [1] sum over the samples of c_d = sum_v (x log x - x), added to the reduced partials
     double* __restrict__ kl_out;           // [1]
+    int kl_extra;  // the grid has one workgroup more than rows: it only reduces kl_part (+ kl_const) into kl_out -- the
+                   // objective folded into a joint step (fused_kernel<.., true, true, true>); hsum_part is null then
     int nparts;    // KL partials (workgroups of the numerator pass)
     int nparts_h;  // row-sum partials (workgroups of the preceding update_H pass)
     // optional (MvNMF inside mv_step, unsharded; with hsum_part / kl_part): the first line-search trial in the same launch.
@@ -1636,6 +1675,21 @@ __global__ void __launch_bounds__(TAIL_BLOCK) tail_kernel(TailParams p) {
     __shared__ double mvsh[2];  // (MvNMF) this row's reduced rowsums_H entry, and the KL divergence (workgroup 0)
     const int k = blockIdx.x;
     const int K = p.K;
+    if (p.kl_extra && k == K) {  // (uniform over the workgroup) summation order of sum_partials_kernel
+        __shared__ double kred[256];
+        double s = 0.0;
+        if (threadIdx.x < 256) {
+            for (int i = threadIdx.x; i < p.nparts; i += 256) s += p.kl_part[i];
+            kred[threadIdx.x] = s;
+        }
+        __syncthreads();
+        for (int h = 128; h > 0; h >>= 1) {
+            if ((int)threadIdx.x < h) kred[threadIdx.x] += kred[threadIdx.x + h];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) p.kl_out[0] = kred[0] + p.kl_const[0];
+        return;
+    }
     if (p.hsum_part) {  // uniform over the grid
         __shared__ double hred[256];
         for (int which = 0; which < ((k == 0 && p.kl_part) ? 2 : 1); ++which) {

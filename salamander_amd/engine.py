@@ -157,6 +157,11 @@ class Engine:
         """``kl_step`` that keeps the state it starts from; :meth:`kl_rollback` returns to it."""
         _lib.check(self._lib.salnmf_kl_step_keep(self._h, int(n_steps), int(n_given)))
 
+    def kl_step_objective(self, slot: int, n_steps: int, n_given: int = 0, keep: bool = False):
+        """Objective of the resident state into ring slot ``slot``, then ``n_steps`` updates (``keep``: undoable); where
+        the engine can, the objective is evaluated inside the first update's launch (``salnmf_kl_step_objective``)."""
+        _lib.check(self._lib.salnmf_kl_step_objective(self._h, int(slot), int(n_steps), int(n_given), 1 if keep else 0))
+
     def kl_rollback(self):
         _lib.check(self._lib.salnmf_kl_rollback(self._h))
 

@@ -64,6 +64,9 @@ class KLNMF(StandardNMF):
     def _device_objective(self) -> float:
         return self._engine.objective()
 
+    def _device_can_queue(self) -> bool:
+        return True
+
     def _device_objective_async(self, slot: int) -> bool:
         self._engine.objective_async(slot)
         return True
@@ -73,6 +76,10 @@ class KLNMF(StandardNMF):
 
     def _device_steps_keep(self, n_steps: int, given_parameters) -> bool:
         self._engine.kl_step_keep(n_steps, self._n_given(given_parameters))
+        return True
+
+    def _device_objective_and_steps(self, slot: int, n_steps: int, given_parameters, keep: bool) -> bool:
+        self._engine.kl_step_objective(slot, n_steps, self._n_given(given_parameters), keep)
         return True
 
     def _device_rollback(self) -> None:

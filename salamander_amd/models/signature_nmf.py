@@ -272,6 +272,10 @@ class SignatureNMF(ABC):
         self.adata.obsm["exposures"] = self._engine.download_H(out)
 
     # asynchronous objectives (fit): models whose objective can be queued without a host round trip override these
+    def _device_can_queue(self) -> bool:
+        """Whether ``fit`` may use the queued loop (the hooks below)."""
+        return False
+
     def _device_objective_async(self, slot: int) -> bool:
         return False
 
@@ -281,6 +285,18 @@ class SignatureNMF(ABC):
     def _device_steps_keep(self, n_steps: int, given_parameters) -> bool:
         """Queue ``n_steps`` updates that can be undone by ``_device_rollback`` (False: not supported)."""
         return False
+
+    def _device_objective_and_steps(self, slot: int, n_steps: int, given_parameters, keep: bool) -> bool:
+        """Queue the objective of the current state into ``slot``, then ``n_steps`` (>= 0) updates -- undoable ones if
+        ``keep``.  Returns whether the updates were queued (False: ``keep`` asked for and not supported).  Models whose
+        engine can evaluate the objective inside the first update override this (``KLNMF``)."""
+        self._device_objective_async(slot)
+        if n_steps == 0:
+            return True
+        if keep:
+            return self._device_steps_keep(n_steps, given_parameters)
+        self._device_steps(n_steps, given_parameters)
+        return True
 
     def _device_rollback(self) -> None:
         raise NotImplementedError
@@ -320,7 +336,7 @@ class SignatureNMF(ABC):
                 self._defer_exposures = False
             self._setup_fitting_parameters(fitting_kwargs)
             self._sync_to_device()
-            if not verbose and self._device_objective_async(0):
+            if not verbose and self._device_can_queue():
                 of_values, n_iteration = self._fit_loop_queued(given_parameters)
             else:
                 of_values, n_iteration = self._fit_loop_blocking(given_parameters, verbose, verbosity_freq)
@@ -371,21 +387,23 @@ class SignatureNMF(ABC):
         return of_values, n_iteration
 
     def _fit_loop_queued(self, given_parameters):
-        """The same loop with the host out of the way (same objectives, same stopping iteration).
+        """The same loop with the host out of the way (same stopping iteration, objectives equal to rounding).
 
-        * Before ``min_iterations`` the convergence test cannot stop the fit (signature_nmf.py:373-380): objectives are
-          only QUEUED into the device's ring of slots and the steps keep being launched; the values are read in one go
-          when a decision first needs them.
-        * From ``min_iterations`` on every test needs its objective, so the next block of steps is queued BEFORE the
-          value is read -- as steps that keep the state they start from (``salnmf_kl_step_keep``: no copy) -- and the
-          read's round trip hides behind it; if the test says "converged" the block is rolled back.
-        The initial objective is in slot 0 already (queued by ``fit``)."""
+        * An objective is queued into the device's ring of slots TOGETHER with the updates that follow it
+          (``_device_objective_and_steps``): the first of those updates forms ``H W`` of exactly the state the objective is
+          about, so the engine evaluates the divergence inside that launch instead of in a forward pass of its own.
+        * Before ``min_iterations`` the convergence test cannot stop the fit (signature_nmf.py:373-380): nothing is read;
+          the values come back in one go when a decision first needs them.
+        * From ``min_iterations`` on every test needs its objective: the block behind it is queued as updates that keep
+          the state they start from (no copy), the read's round trip hides behind them, and if the test says
+          "converged" the block is rolled back.
+        The last objective of a fit (iteration cap reached) has no update behind it and is a forward pass."""
         from .. import _lib
 
         ring = _lib.OBJECTIVE_SLOTS
         freq = self.conv_test_freq
         of_values: list[float] = []
-        first_slot, pending = 0, 1  # slots [first_slot, first_slot + pending) hold queued, unread objectives
+        first_slot, pending = 0, 0  # slots [first_slot, first_slot + pending) hold queued, unread objectives
 
         def read_pending():
             nonlocal first_slot, pending
@@ -406,32 +424,33 @@ class SignatureNMF(ABC):
                 pending -= n
 
         n_iteration = 0  # the iteration the decisions below are about
-        n_queued = 0     # updates launched so far (ahead of n_iteration by one kept block at most)
+        n_queued = 0     # updates launched so far (ahead of n_iteration by one block at most)
         while True:
+            check = n_iteration % freq == 0  # (iteration 0: the initial objective)
+            last = n_iteration > 0 and n_iteration >= self.max_iterations
+            if check:
+                decide = not last and n_iteration > 0 and n_iteration >= self.min_iterations
+                nxt = n_iteration if last else self._next_stop(n_iteration)
+                if pending == ring:
+                    read_pending()
+                queued = self._device_objective_and_steps((first_slot + pending) % ring, nxt - n_iteration, given_parameters, decide)
+                pending += 1
+                if queued:
+                    n_queued = nxt
+                if decide:
+                    read_pending()
+                    prev, cur = of_values[-2], of_values[-1]
+                    if np.abs(prev - cur) / np.abs(prev) < self.tol:
+                        if queued:
+                            self._device_rollback()
+                        break
+            if last:
+                break
             stop = self._next_stop(n_iteration)
             if n_queued < stop:
                 self._device_steps(stop - n_queued, given_parameters)
                 n_queued = stop
             n_iteration = stop
-            check = n_iteration % freq == 0
-            if check:
-                if pending == ring:
-                    read_pending()
-                self._device_objective_async((first_slot + pending) % ring)
-                pending += 1
-            if n_iteration >= self.max_iterations:
-                break
-            if check and n_iteration >= self.min_iterations:
-                nxt = self._next_stop(n_iteration)
-                kept = self._device_steps_keep(nxt - n_iteration, given_parameters)
-                if kept:
-                    n_queued = nxt
-                read_pending()
-                prev, cur = of_values[-2], of_values[-1]
-                if np.abs(prev - cur) / np.abs(prev) < self.tol:
-                    if kept:
-                        self._device_rollback()
-                    break
         read_pending()
         return of_values, n_iteration
 

@@ -73,6 +73,16 @@ class FakeEngine:
         self.kl_step(n_steps, n_given)
         self.steps_log[-1] = ("keep", n_steps)
 
+    def kl_step_objective(self, slot, n_steps, n_given=0, keep=False):
+        self.objective_async(slot)
+        self.folded = getattr(self, "folded", 0) + (1 if n_steps > 0 else 0)
+        if n_steps == 0:
+            return
+        if keep:
+            self.kl_step_keep(n_steps, n_given)
+        else:
+            self.kl_step(n_steps, n_given)
+
     def kl_rollback(self):
         self.W, self.H = self._kept
         self._kept = None
