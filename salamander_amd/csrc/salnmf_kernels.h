@@ -1229,6 +1229,8 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         stage_W<G_::WROWS, true>(Wl, p.Wmut, K, V, V, tid);  // sc1 loads: rows published by other workgroups
         __syncthreads();
     } else {
+        // (the first tile's loads issued ahead of the staging instead: 69.7 -> 71.9 us per step at c2 -- the prologue's
+        // registers then overlap the tile's, 234 -> 256 VGPRs + 24 spill copies; profiles/r03/ab_step_variants.txt)
         stage_W<G_::WROWS>(Wl, p.W, K, V, p.ldw, tid);
         __syncthreads();
         if (tile < nfull) load_tile(tile);
