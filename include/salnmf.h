@@ -21,10 +21,10 @@
  *   - One engine = one GPU = one shard of the sample axis.
  *
  * Limits of this build (the reference has none; every BASELINE.json configuration fits):
- *   n_features <= 96, n_signatures <= 64, dim_embeddings <= 64, joint sample solves over at most 4 modalities /
- *   128 signatures.  Anything larger is refused with a message by salnmf_create / salnmf_corr_configure /
- *   salnmf_corr_update_sample_embeddings_multi -- never silently truncated.  They come from the register / LDS plan
- *   of the fused kernel.
+ *   n_features <= 3072, n_signatures <= 512 (salnmf_create: what is available beyond 96 features / 64 signatures),
+ *   dim_embeddings <= 64, joint sample solves over at most 4 modalities / 128 signatures.  Anything larger is refused
+ *   with a message by salnmf_create / salnmf_corr_configure / salnmf_corr_update_sample_embeddings_multi -- never
+ *   silently truncated.  They come from the register / LDS plan of the fused kernel.
  */
 #ifndef SALNMF_H
 #define SALNMF_H
@@ -64,12 +64,15 @@ int salnmf_build_flags(void);
 int salnmf_device_count(void);
 
 /* Create an engine for a shard of n_samples rows on HIP device `device`.
- * Limits of this build: n_signatures <= 64; n_features <= 3072.  Up to 96 features (every BASELINE configuration) the
- * whole API is available.  Wider catalogues (SBS-288, SBS-1536, ...) run the KLNMF entry points -- upload / download,
- * salnmf_kl_step (both halves from the old state, as update_WH), salnmf_update_H / _W, the objectives (blocking and
- * queued), salnmf_samplewise_kl, salnmf_reconstruct, per-sample weights -- one 96-feature block of X and W per launch
- * (U = R W^T accumulated over the blocks); MvNMF, CorrNMF, the device-side initialisation, the fp32 fast mode and
- * sample sharding answer with an error there. */
+ * Limits of this build: n_signatures <= 512; n_features <= 3072; not both n_signatures > 64 and n_features > 96.  Up to
+ * 96 features and 64 signatures (every BASELINE configuration) the whole API is available.  Wider catalogues (SBS-288,
+ * SBS-1536, ...) run the KLNMF entry points -- upload / download, salnmf_kl_step (both halves from the old state, as
+ * update_WH), salnmf_update_H / _W, the objectives (blocking and queued), salnmf_samplewise_kl, salnmf_reconstruct,
+ * per-sample weights -- one 96-feature block of X and W per launch (U = R W^T accumulated over the blocks).  More than 64
+ * signatures run the same entry points per chunk of <= 64 signatures: the product H W is accumulated over the chunks by a
+ * chain of forward launches, the last of which forms the ratio X / (H W) (or the objective), and the update passes run
+ * once per chunk on that ratio.  MvNMF, CorrNMF, the device-side initialisation, the fp32 fast mode and sample sharding
+ * answer with an error in both cases. */
 int salnmf_create(int device, int n_features, int64_t n_samples, int n_signatures,
                   salnmf_engine** out);
 void salnmf_destroy(salnmf_engine* e);

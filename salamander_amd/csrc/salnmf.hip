@@ -119,6 +119,12 @@ struct salnmf_engine {
     int device = 0;
     int V = 0, K = 0;
     int NB = 1;    // 96-feature blocks of X and W: 1 unless n_features > 96 (then only the KLNMF entry points are available)
+    // n_signatures > 64: chunks of <= 64 signatures (rows k0 .. k0 + K - 1 of W; H is stored chunk-major [NC][Np][64]),
+    // each with the kernel geometry of an engine of that many signatures; only the KLNMF entry points are available
+    struct Chunk { int k0, K, KS, KTM, KR; };
+    int NC = 1;
+    std::vector<Chunk> kc;
+    double* PR = nullptr;    // [Np][96] the product H W accumulated over the chunks, then the ratio X / (H W) (NC > 1)
     double* Gblk = nullptr;  // [NB][K][96] reduced numerators of the feature blocks (NB > 1)
     double* Uacc = nullptr;  // [Np][KP] running sum of U = R W^T over the feature blocks (NB > 1)
     int64_t N = 0, Np = 0, ntiles = 0;  // Np = 16 * ntiles: rows of the padded device layout
@@ -220,6 +226,8 @@ static void release_pinned(void* p, int small_block);
 static hipError_t acquire_pinned(void** out, int small_block);
 
 constexpr int NB_MAX = 32;  // feature blocks of 96: n_features <= 3072 (SBS-1536 needs 16)
+constexpr int KC = 64;      // signatures per chunk (the widest accumulator geometry of the fused pass)
+constexpr int NC_MAX = 8;   // signature chunks: n_signatures <= 512
 constexpr int SCAL_XLX = 8;  // slot of e->scal that holds the sum over the samples of xlx
 
 static const int kKS[] = {1, 2, 4, 8, 10, 13, 16};
@@ -308,8 +316,11 @@ static void to_block(const salnmf_engine* e, FusedParams& p, int b) {
 }
 static int single_block(const salnmf_engine* e, const char* what) {
     if (e->NB > 1) return fail("%s is not available for n_features > %d (this engine has %d): only the KLNMF entry points are", what, VMAX, e->V);
+    if (e->NC > 1) return fail("%s is not available for n_signatures > %d (this engine has %d): only the KLNMF entry points are", what, KC, e->K);
     return 0;
 }
+static inline bool split(const salnmf_engine* e) { return e->NB > 1 || e->NC > 1; }  // feature blocks or signature chunks
+static inline size_t h_doubles(const salnmf_engine* e) { return (size_t)e->NC * e->Np * e->KP; }
 
 static TailParams tail_params(salnmf_engine* e, int nslabs, double* G, int n_given, int clip_mode, int do_tail, bool with_stats, int hsum_parts = 0) {
     TailParams t{};
@@ -519,7 +530,7 @@ void salnmf_destroy(salnmf_engine* e) {
     if (e->X32) (void)hipFree(e->X32);
     if (e->H32) (void)hipFree(e->H32);
     if (e->p2p.abort_dev) (void)hipFree(e->p2p.abort_dev);
-    double* bufs[] = {e->wones, e->wzeros, e->Gblk, e->Uacc, e->xlx, e->X, e->H, e->W, e->wkl, e->wlh, e->Gpart, e->Hsumpart, e->KLpart, e->red,
+    double* bufs[] = {e->PR, e->wones, e->wzeros, e->Gblk, e->Uacc, e->xlx, e->X, e->H, e->W, e->wkl, e->wlh, e->Gpart, e->Hsumpart, e->KLpart, e->red,
                       e->objpart, e->scal, e->Wunc, e->Wtrial, e->mvA, e->mvB, e->cs, e->scratch, e->Halt, e->KLpart2, e->Wkeep, e->Hkeep, e->objring,
                       e->alpha, e->beta, e->Lemb, e->Uemb, e->aux, e->xrowsum, e->corrpart, e->gU, e->galpha, e->gaux};
     for (double* b : bufs)
@@ -553,7 +564,9 @@ int salnmf_create(int device, int n_features, int64_t n_samples, int n_signature
     if (!out) return fail("out is null");
     *out = nullptr;
     if (n_features < 1 || n_features > VMAX * NB_MAX) return fail("n_features must be in [1, %d], got %d", VMAX * NB_MAX, n_features);
-    if (n_signatures < 1 || n_signatures > 64) return fail("n_signatures must be in [1, 64], got %d", n_signatures);
+    if (n_signatures < 1 || n_signatures > KC * NC_MAX) return fail("n_signatures must be in [1, %d], got %d", KC * NC_MAX, n_signatures);
+    if (n_signatures > KC && n_features > VMAX)
+        return fail("n_signatures > %d together with n_features > %d is not available (got %d, %d)", KC, VMAX, n_signatures, n_features);
     if (n_samples < 1) return fail("n_samples must be positive");
     int ndev = 0;
     HIPCK(hipGetDeviceCount(&ndev));
@@ -572,15 +585,34 @@ int salnmf_create(int device, int n_features, int64_t n_samples, int n_signature
     e->ntiles = (n_samples + 15) / 16;
     e->Np = e->ntiles * 16;
     e->NB = (n_features + VMAX - 1) / VMAX;
-    e->KS = pick_ks(n_signatures);
-    e->KP = 16 * ((e->KS + 3) / 4);
     // output-side split: full MFMA tiles + up to 4 remainder columns on the VALU (K >= 17 only)
-    e->KTM = (n_signatures + 15) / 16;
-    e->KR = 0;
-    if (n_signatures > 16 && n_signatures % 16 >= 1 && n_signatures % 16 <= 4) {
-        e->KTM = n_signatures / 16;
-        e->KR = n_signatures % 16;
+    auto geometry = [](int k0, int k) {
+        salnmf_engine::Chunk c{k0, k, pick_ks(k), (k + 15) / 16, 0};
+        if (k > 16 && k % 16 >= 1 && k % 16 <= 4) {
+            c.KTM = k / 16;
+            c.KR = k % 16;
+        }
+        return c;
+    };
+    e->NC = (n_signatures + KC - 1) / KC;
+    const int ck = (n_signatures + e->NC - 1) / e->NC;  // chunks of equal size, the last one takes what is left
+    for (int c = 0, k0 = 0; c < e->NC; ++c) {
+        const int k = std::min(ck, n_signatures - k0);
+        salnmf_engine::Chunk ch = geometry(k0, k);
+        if (e->NC > 1) {
+            // all chunks share the 64-column layout of H: the two contraction depths whose padded width is 64, with the
+            // output side padded to whole tiles below 48 signatures (pad columns of H are 0, pad rows of W staged as 0)
+            if (k <= 48) ch = {k0, k, 13, 3, 0};
+            else if (k <= 52) ch = {k0, k, 13, 3, k - 48};
+            else ch = {k0, k, 16, 4, 0};
+        }
+        e->kc.push_back(ch);
+        k0 += k;
     }
+    e->KS = e->kc[0].KS;
+    e->KTM = e->kc[0].KTM;
+    e->KR = e->kc[0].KR;
+    e->KP = e->NC > 1 ? KC : 16 * ((e->KS + 3) / 4);
     int64_t wg_needed = (e->ntiles + WAVES - 1) / WAVES;
     e->grid = (int)std::min<int64_t>(prop.multiProcessorCount, wg_needed);
     e->fgrid = (int)std::min<int64_t>(2 * prop.multiProcessorCount, wg_needed);
@@ -605,13 +637,14 @@ int salnmf_create(int device, int n_features, int64_t n_samples, int n_signature
     for (hipEvent_t* ev : {&e->evW, &e->evPrepW, &e->evTrial, &e->evLogdet, &e->evObj})
         if (hipEventCreateWithFlags(ev, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) return cleanup(fail("event create failed"));
     ALLOC(e->X, (size_t)e->NB * Np * VMAX);
-    ALLOC(e->H, Np * KP);
+    ALLOC(e->H, (size_t)e->NC * Np * KP);
+    if (e->NC > 1) ALLOC(e->PR, Np * VMAX);
     ALLOC(e->W, K * V);
     ALLOC(e->Gpart, (size_t)e->grid * K * VMAX);
     ALLOC(e->Hsumpart, (size_t)e->grid * K);
     ALLOC(e->KLpart, (size_t)e->grid);
     ALLOC(e->red, K * V + K + 2);
-    ALLOC(e->objpart, (size_t)e->NB * e->fgrid);
+    ALLOC(e->objpart, (size_t)std::max(e->NB, e->NC) * e->fgrid);
     if (e->NB > 1) {
         ALLOC(e->Gblk, (size_t)e->NB * K * VMAX);
         ALLOC(e->Uacc, Np * KP);
@@ -754,7 +787,7 @@ static void parallel_copy(void* dst, const void* src, size_t bytes) {
 //   nb > 1 (X of an engine with more than 96 features): the rows are scattered into nb blocks of 96 columns, block b at
 //   dst + b * Np * 96 (pad_rows_blocked_kernel); ld, fill_cols and fill_rows are then 96, 0, 0
 static int upload_rows_staged(salnmf_engine* e, double* dst, const void* src, int dtype, int cols, int ld, double fill_cols, double fill_rows,
-                              double clip_lo, int nb = 1) {
+                              double clip_lo, int nb = 1, int bw = VMAX) {
     if (!e || !src) return fail("null argument");
     const size_t esz = dtype_size(dtype);
     if (!esz) return fail("unknown element type %d", dtype);
@@ -771,14 +804,14 @@ static int upload_rows_staged(salnmf_engine* e, double* dst, const void* src, in
         HIPCK(hipMemcpyAsync(e->stage_dev[slot], e->stage_host[slot], bytes, hipMemcpyHostToDevice, e->stream));
         double* out = dst + r0 * ld;
         if (nb > 1) {
-            const int g = (int)std::min<int64_t>(2048, (rows * nb * VMAX + 255) / 256);
-            const int64_t bs = (int64_t)e->Np * VMAX;
+            const int g = (int)std::min<int64_t>(2048, (rows * nb * ld + 255) / 256);
+            const int64_t bs = (int64_t)e->Np * ld;  // (blocks of bw source columns, stored at row stride ld)
             switch (dtype) {
-                case SALNMF_F64: hipLaunchKernelGGL(pad_rows_blocked_kernel<double>, dim3(g), dim3(256), 0, e->stream, out, static_cast<const double*>(e->stage_dev[slot]), rows, cols, nb, bs, clip_lo); break;
-                case SALNMF_F32: hipLaunchKernelGGL(pad_rows_blocked_kernel<float>, dim3(g), dim3(256), 0, e->stream, out, static_cast<const float*>(e->stage_dev[slot]), rows, cols, nb, bs, clip_lo); break;
-                case SALNMF_I32: hipLaunchKernelGGL(pad_rows_blocked_kernel<int32_t>, dim3(g), dim3(256), 0, e->stream, out, static_cast<const int32_t*>(e->stage_dev[slot]), rows, cols, nb, bs, clip_lo); break;
-                case SALNMF_I64: hipLaunchKernelGGL(pad_rows_blocked_kernel<int64_t>, dim3(g), dim3(256), 0, e->stream, out, static_cast<const int64_t*>(e->stage_dev[slot]), rows, cols, nb, bs, clip_lo); break;
-                default: hipLaunchKernelGGL(pad_rows_blocked_kernel<uint16_t>, dim3(g), dim3(256), 0, e->stream, out, static_cast<const uint16_t*>(e->stage_dev[slot]), rows, cols, nb, bs, clip_lo); break;
+                case SALNMF_F64: hipLaunchKernelGGL(pad_rows_blocked_kernel<double>, dim3(g), dim3(256), 0, e->stream, out, static_cast<const double*>(e->stage_dev[slot]), rows, cols, nb, bs, clip_lo, bw, ld); break;
+                case SALNMF_F32: hipLaunchKernelGGL(pad_rows_blocked_kernel<float>, dim3(g), dim3(256), 0, e->stream, out, static_cast<const float*>(e->stage_dev[slot]), rows, cols, nb, bs, clip_lo, bw, ld); break;
+                case SALNMF_I32: hipLaunchKernelGGL(pad_rows_blocked_kernel<int32_t>, dim3(g), dim3(256), 0, e->stream, out, static_cast<const int32_t*>(e->stage_dev[slot]), rows, cols, nb, bs, clip_lo, bw, ld); break;
+                case SALNMF_I64: hipLaunchKernelGGL(pad_rows_blocked_kernel<int64_t>, dim3(g), dim3(256), 0, e->stream, out, static_cast<const int64_t*>(e->stage_dev[slot]), rows, cols, nb, bs, clip_lo, bw, ld); break;
+                default: hipLaunchKernelGGL(pad_rows_blocked_kernel<uint16_t>, dim3(g), dim3(256), 0, e->stream, out, static_cast<const uint16_t*>(e->stage_dev[slot]), rows, cols, nb, bs, clip_lo, bw, ld); break;
             }
         } else
         switch (dtype) {
@@ -793,8 +826,9 @@ static int upload_rows_staged(salnmf_engine* e, double* dst, const void* src, in
     }
     if (e->Np > e->N) {
         for (int b = 0; b < nb; ++b) {
-            hipLaunchKernelGGL(fill_rows_kernel, dim3(4), dim3(256), 0, e->stream, dst + (size_t)b * e->Np * VMAX, e->N, e->Np, ld,
-                               nb > 1 ? VMAX : cols, fill_rows, fill_cols);
+            // (blocks: the pad rows carry fill_rows in the block's own columns, fill_cols beyond -- both 0 for X)
+            hipLaunchKernelGGL(fill_rows_kernel, dim3(4), dim3(256), 0, e->stream, dst + (size_t)b * e->Np * ld, e->N, e->Np, ld,
+                               nb > 1 ? std::min(bw, cols - b * bw) : cols, fill_rows, fill_cols);
             HIPCK(hipGetLastError());
         }
     }
@@ -811,7 +845,8 @@ static int upload_padded(salnmf_engine* e, double* dst, const double* src, int c
 // device padded [.][ld] -> host compact [N][cols]: the mirror image of the ingest -- per 32 MB chunk an unpad kernel
 // into a device staging buffer, an asynchronous DMA into a pinned buffer, and a multi-threaded host copy into the
 // caller's (pageable) array while the next chunk is on its way
-static int download_padded(salnmf_engine* e, double* dst, const double* src, int cols, int ld) {
+//   nb > 1: src is [nb][Np][ld], chunk b holding columns bw b .. bw b + bw - 1 (H with n_signatures > 64)
+static int download_padded(salnmf_engine* e, double* dst, const double* src, int cols, int ld, int nb = 1, int bw = 0) {
     if (!e || !dst) return fail("null argument");
     HIPCK(hipSetDevice(e->device));
     CK(ensure_staging(e));
@@ -822,8 +857,12 @@ static int download_padded(salnmf_engine* e, double* dst, const double* src, int
     auto issue = [&](int64_t c) -> int {
         const int slot = (int)(c & 1);
         const int64_t rows = rows_of(c);
-        hipLaunchKernelGGL(unpad_kernel, dim3(2048), dim3(256), 0, e->stream, static_cast<double*>(e->stage_dev[slot]),
-                           src + c * chunk_rows * ld, rows, cols, ld);
+        if (nb > 1)
+            hipLaunchKernelGGL(unpad_blocked_kernel, dim3(2048), dim3(256), 0, e->stream, static_cast<double*>(e->stage_dev[slot]),
+                               src + c * chunk_rows * ld, rows, cols, bw, ld, (int64_t)e->Np * ld);
+        else
+            hipLaunchKernelGGL(unpad_kernel, dim3(2048), dim3(256), 0, e->stream, static_cast<double*>(e->stage_dev[slot]),
+                               src + c * chunk_rows * ld, rows, cols, ld);
         HIPCK(hipGetLastError());
         HIPCK(hipMemcpyAsync(e->stage_host[slot], e->stage_dev[slot], (size_t)rows * row_bytes, hipMemcpyDeviceToHost, e->stream));
         HIPCK(hipEventRecord(e->stage_done[slot], e->stream));
@@ -855,11 +894,13 @@ int salnmf_upload_W(salnmf_engine* e, const double* W) {
 int salnmf_upload_H(salnmf_engine* e, const double* H) {
     if (e) e->h_pending = e->keep_valid = false;
     // pad columns 0, pad rows 1: finite, and positive in the rows so that P > 0 there
+    if (e && e->NC > 1) return upload_rows_staged(e, e->H, H, SALNMF_F64, e->K, e->KP, 0.0, 1.0, 0.0, e->NC, e->kc[0].K);
     return upload_padded(e, e ? e->H : nullptr, H, e ? e->K : 0, e ? e->KP : 0, 0.0, 1.0, 0.0);
 }
 
 int salnmf_set_H_scale(salnmf_engine* e, const double* scale) {
     if (!e || !scale) return fail("null argument");
+    if (e->NC > 1) return single_block(e, "a lazily applied exposure scale");
     HIPCK(hipSetDevice(e->device));
     CK(flush_H_scale(e));  // (an earlier pending rescale is applied first)
     std::vector<double> cs((size_t)e->KP, 1.0);
@@ -903,7 +944,7 @@ int salnmf_download_H(salnmf_engine* e, double* H) {
     if (!e) return fail("null engine");
     HIPCK(hipSetDevice(e->device));
     CK(flush_H_scale(e));
-    return download_padded(e, H, e->H, e->K, e->KP);
+    return download_padded(e, H, e->H, e->K, e->KP, e->NC, e->kc[0].K);
 }
 
 // n joint steps in one persistent launch (fused_kernel<..., PERSIST>): every workgroup must be resident, which the
@@ -989,6 +1030,86 @@ static int blocked_kl_step_once(salnmf_engine* e, int n_given) {
     return 0;
 }
 
+
+// ---- n_signatures > 64: the passes run per chunk of <= 64 signatures (include/salnmf.h: limits).  P = H W is a sum over
+// the chunks, so it is formed FIRST, by a chain of forward launches through e->PR (each adds its chunk's product; the
+// last one turns the sum into what is needed: the ratio X / P, the divergence, the per-sample divergences or P itself);
+// the update passes then run on the given ratio, once per chunk, each with the geometry of its chunk's size.
+static FwdParams chunk_fwd_params(salnmf_engine* e, const salnmf_engine::Chunk& c, int ci) {
+    FwdParams p{};
+    p.X = e->X;
+    p.H = e->H + (size_t)ci * e->Np * e->KP;
+    p.W = e->W + (size_t)c.k0 * e->V;
+    p.xlx = e->xlx;
+    p.N = e->N;
+    p.V = e->V;
+    p.ldw = e->V;
+    p.K = c.K;
+    p.ntiles = e->ntiles;
+    return p;
+}
+// the chain: chunks 0 .. NC-2 accumulate into e->PR (mode 2), the last chunk runs `last_mode` with `last` as its template
+// (out, weights) on top of the accumulated product
+static int chunk_chain(salnmf_engine* e, int last_mode, const FwdParams& last) {
+    for (int ci = 0; ci < e->NC; ++ci) {
+        const auto& c = e->kc[(size_t)ci];
+        FwdParams p = chunk_fwd_params(e, c, ci);
+        p.pin = ci == 0 ? nullptr : e->PR;
+        const bool is_last = ci == e->NC - 1;
+        if (is_last) {
+            p.wkl = last.wkl;
+            p.wlh = last.wlh;
+            p.out = last.out;
+        } else {
+            p.out = e->PR;
+        }
+        if (launch_forward_inst(c.KS, FWD_PIN + (is_last ? last_mode : 2), p, e->fgrid, e->stream, nullptr, nullptr))
+            return fail("no forward instantiation for KS=%d", c.KS);
+        HIPCK(hipGetLastError());
+    }
+    return 0;
+}
+static int chunk_ratio(salnmf_engine* e) {  // e->PR = X / (H W)
+    FwdParams last{};
+    last.out = e->PR;
+    return chunk_chain(e, 4, last);
+}
+// the update passes of every chunk on the ratio in e->PR: H half (do_u) into the chunk's columns of H, in place; W half
+// (do_g): numerator slabs, reduced and applied to the chunk's rows of W by the ordinary tail
+static int chunk_passes(salnmf_engine* e, bool do_g, bool do_u, int n_given, int clip_mode) {
+    for (int ci = 0; ci < e->NC; ++ci) {
+        const auto& c = e->kc[(size_t)ci];
+        const int given = std::max(0, std::min(c.K, n_given - c.k0));  // given rows inside this chunk
+        const bool g = do_g && given < c.K;
+        if (!g && !do_u) continue;
+        FusedParams p = fused_params(e);
+        p.X = e->PR;
+        p.H = p.Hout = e->H + (size_t)ci * e->Np * e->KP;
+        p.W = e->W + (size_t)c.k0 * e->V;
+        p.K = c.K;
+        p.hscale = nullptr;
+        CK(weight_arrays(e, p));
+        FusedSel sel{c.KS, c.KTM, c.KR, g, do_u, false, true, false, false};
+        sel.RGIVEN = true;
+        if (launch_fused_inst(sel, p, e->grid, e->stream, nullptr, nullptr)) return fail("no kernel instantiation for KS=%d KTM=%d KR=%d", c.KS, c.KTM, c.KR);
+        HIPCK(hipGetLastError());
+        if (g) {
+            TailParams t = tail_params(e, e->grid, e->red + (size_t)c.k0 * e->V, given, clip_mode, 1, false);
+            t.W = t.Wout = e->W + (size_t)c.k0 * e->V;
+            t.K = c.K;
+            hipLaunchKernelGGL(tail_kernel, dim3(c.K), dim3(TAIL_BLOCK), 0, e->stream, t);
+            HIPCK(hipGetLastError());
+        }
+    }
+    return 0;
+}
+// one joint step (update_WH, _utils_klnmf.py:281-361): both halves use the ratio of the OLD state, so each chunk's pass
+// updates its columns of H and its rows of W in place
+static int chunked_kl_step_once(salnmf_engine* e, int n_given) {
+    CK(chunk_ratio(e));
+    return chunk_passes(e, n_given < e->K, true, n_given, SALNMF_CLIP_ALL);
+}
+
 int salnmf_set_lockstep(salnmf_engine* e, int on) {
     if (!e) return fail("null engine");
     e->lockstep = on != 0;
@@ -997,7 +1118,7 @@ int salnmf_set_lockstep(salnmf_engine* e, int on) {
 
 int salnmf_set_persistent(salnmf_engine* e, int on) {
     if (!e) return fail("null engine");
-    if (on && e->NB > 1) return single_block(e, "the persistent kernel");
+    if (on && split(e)) return single_block(e, "the persistent kernel");
     if (on && !built_with_persistent()) return fail("this build carries no persistent kernel (compile with -DSALNMF_WITH_PERSISTENT)");
     e->persistent = on != 0;
     return 0;
@@ -1045,7 +1166,7 @@ static int kl_steps_f32(salnmf_engine* e, int n_steps, int n_given) {
 }
 
 int salnmf_set_precision(salnmf_engine* e, int precision) {
-    if (e && e->NB > 1) return single_block(e, "the fp32 fast mode");
+    if (e && split(e)) return single_block(e, "the fp32 fast mode");
     if (!e) return fail("null engine");
     if (precision != SALNMF_PRECISION_F64 && precision != SALNMF_PRECISION_F32_FAST) return fail("unknown precision %d", precision);
     e->fast32 = precision == SALNMF_PRECISION_F32_FAST;
@@ -1059,6 +1180,10 @@ int salnmf_kl_step(salnmf_engine* e, int n_steps, int n_given) {
     if (e->NB > 1) {
         e->keep_valid = false;  // (the joint step uses the second H buffer itself)
         for (int i = 0; i < n_steps; ++i) CK(blocked_kl_step_once(e, n_given));
+        return 0;
+    }
+    if (e->NC > 1) {
+        for (int i = 0; i < n_steps; ++i) CK(chunked_kl_step_once(e, n_given));
         return 0;
     }
     if (e->fast32 && n_steps > 0) {
@@ -1084,14 +1209,15 @@ int salnmf_kl_step_keep(salnmf_engine* e, int n_steps, int n_given) {
     if (n_given < 0 || n_given > e->K) return fail("n_given out of range");
     if (n_steps < 1) return fail("n_steps must be positive");
     HIPCK(hipSetDevice(e->device));
-    if (!e->Halt) HIPCK(hipMalloc(&e->Halt, (size_t)e->Np * e->KP * sizeof(double)));
+    if (!e->Halt && e->NC == 1) HIPCK(hipMalloc(&e->Halt, (size_t)e->Np * e->KP * sizeof(double)));
     if (!e->Wkeep) HIPCK(hipMalloc(&e->Wkeep, (size_t)e->K * e->V * sizeof(double)));
     e->keep_valid = false;
     CK(flush_H_scale(e));
-    if (e->NB > 1) {
-        // feature blocks: the joint step exchanges H with the second buffer itself; the kept state is a copy
-        if (!e->Hkeep) HIPCK(hipMalloc(&e->Hkeep, (size_t)e->Np * e->KP * sizeof(double)));
-        HIPCK(hipMemcpyAsync(e->Hkeep, e->H, (size_t)e->Np * e->KP * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+    if (split(e)) {
+        // feature blocks: the joint step exchanges H with the second buffer itself; signature chunks: the passes update H
+        // in place.  The kept state is a copy
+        if (!e->Hkeep) HIPCK(hipMalloc(&e->Hkeep, h_doubles(e) * sizeof(double)));
+        HIPCK(hipMemcpyAsync(e->Hkeep, e->H, h_doubles(e) * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
         HIPCK(hipMemcpyAsync(e->Wkeep, e->W, (size_t)e->K * e->V * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
         CK(salnmf_kl_step(e, n_steps, n_given));
         e->keep_has_W = true;
@@ -1116,7 +1242,7 @@ int salnmf_kl_rollback(salnmf_engine* e) {
     if (!e) return fail("null engine");
     if (!e->keep_valid) return fail("no kept state: salnmf_kl_rollback undoes the last salnmf_kl_step_keep, once");
     // (the discarded steps may still be running: they write the buffers that become scratch, in stream order)
-    if (e->NB > 1) {
+    if (split(e)) {
         std::swap(e->H, e->Hkeep);
         std::swap(e->W, e->Wkeep);
         e->keep_valid = false;
@@ -1137,6 +1263,10 @@ int salnmf_update_H(salnmf_engine* e) {
         e->h_pending = false;
         return 0;
     }
+    if (e->NC > 1) {
+        CK(chunk_ratio(e));
+        return chunk_passes(e, false, true, 0, 0);
+    }
     FusedParams p = fused_params(e);
     CK((launch_fused<false, true, false>(e, p)));
     e->h_pending = false;
@@ -1144,7 +1274,7 @@ int salnmf_update_H(salnmf_engine* e) {
 }
 
 int salnmf_kl_step_partial(salnmf_engine* e) {
-    if (e && e->NB > 1) return single_block(e, "the split step");
+    if (e && split(e)) return single_block(e, "the split step");
     if (!e) return fail("null engine");
     HIPCK(hipSetDevice(e->device));
     FusedParams p = fused_params(e);
@@ -1154,7 +1284,7 @@ int salnmf_kl_step_partial(salnmf_engine* e) {
 }
 
 int salnmf_kl_step_finish(salnmf_engine* e, int n_given, int clip_mode) {
-    if (e && e->NB > 1) return single_block(e, "the split step");
+    if (e && split(e)) return single_block(e, "the split step");
     if (!e) return fail("null engine");
     HIPCK(hipSetDevice(e->device));
     if (n_given >= e->K) return 0;
@@ -1168,6 +1298,10 @@ int salnmf_update_W(salnmf_engine* e, int n_given, int clip_mode) {
     if (e->NB > 1) {
         CK(blocked_numerators(e));
         return blocked_finish_W(e, n_given, clip_mode);
+    }
+    if (e->NC > 1) {
+        CK(chunk_ratio(e));
+        return chunk_passes(e, true, false, n_given, clip_mode);
     }
     FusedParams p = fused_params(e);
     CK((launch_fused<true, false, false>(e, p)));
@@ -1205,6 +1339,24 @@ static int objective_partials(salnmf_engine* e, const double* W, const double* h
         p.wlh = nullptr;
     }
     const int fgrid = grid > 0 ? grid : e->fgrid;
+    if (e->NC > 1) {
+        // the chain over the signature chunks; the last launch evaluates the divergence (and its own chunk's share of the
+        // l-half penalty, klnmf.py:75-79), the other chunks' shares come from a small kernel each
+        FwdParams last = p;
+        last.out = e->objpart;
+        CK(chunk_chain(e, 0, last));
+        int n = e->fgrid;
+        if (p.wlh) {
+            for (int ci = 0; ci + 1 < e->NC; ++ci) {
+                hipLaunchKernelGGL(lhalf_penalty_kernel, dim3(e->fgrid), dim3(256), 0, e->stream, e->H + (size_t)ci * e->Np * e->KP, p.wlh, e->N,
+                                   e->kc[(size_t)ci].K, e->KP, e->objpart + n);
+                HIPCK(hipGetLastError());
+                n += e->fgrid;
+            }
+        }
+        *nparts = n;
+        return 0;
+    }
     if (e->NB > 1) {
         // the KL divergence is a sum over the features: one forward pass per feature block, each with the x-only
         // constants of its own features; the l-half penalty (klnmf.py:75-79) once
@@ -1292,7 +1444,7 @@ int salnmf_kl_step_objective(salnmf_engine* e, int slot, int n_steps, int n_give
     if (n_given < 0 || n_given > e->K) return fail("n_given out of range");
     if (n_steps < 0) return fail("n_steps must not be negative");
     HIPCK(hipSetDevice(e->device));
-    const bool fold = n_steps > 0 && e->NB == 1 && !e->fast32 && !e->persistent && !sharded(e) && !e->wkl && !e->wlh && n_given < e->K;
+    const bool fold = n_steps > 0 && !split(e) && !e->fast32 && !e->persistent && !sharded(e) && !e->wkl && !e->wlh && n_given < e->K;
     if (!fold) {
         // the objective as a forward pass of its own, then the steps
         CK(salnmf_objective_async(e, slot));
@@ -1333,6 +1485,14 @@ int salnmf_samplewise_kl(salnmf_engine* e, double* out) {
     FwdParams p;
     CK(fwd_params(e, p));
     HIPCK(hipMalloc(&dev, (size_t)e->NB * e->Np * sizeof(double)));
+    if (e->NC > 1) {
+        FwdParams last{};
+        last.out = dev;
+        int rcc = chunk_chain(e, 1, last);
+        if (!rcc) rcc = download(e, out, dev, (size_t)e->N);
+        (void)hipFree(dev);
+        return rcc;
+    }
     int rc = 0;
     for (int b = 0; b < e->NB && !rc; ++b) {  // (per-sample divergences are sums over the features: one pass per feature block)
         FwdParams pb = p;
@@ -1366,7 +1526,12 @@ int salnmf_reconstruct(salnmf_engine* e, double* out) {
     HIPCK(hipMalloc(&dev, (size_t)e->Np * VMAX * sizeof(double)));
     p.out = dev;
     int rc = 0;
-    if (e->NB == 1) {
+    if (e->NC > 1) {
+        FwdParams last{};
+        last.out = dev;
+        rc = chunk_chain(e, 2, last);
+        if (!rc) rc = download_padded(e, out, dev, e->V, VMAX);
+    } else if (e->NB == 1) {
         rc = launch_forward<2>(e, p);
         if (!rc) rc = download_padded(e, out, dev, e->V, VMAX);
     } else {
@@ -1396,7 +1561,7 @@ static int mv_logdet_to_slot(salnmf_engine* e, const double* W, double delta, in
 }
 
 int salnmf_mv_objective(salnmf_engine* e, double lam, double delta, double* out) {
-    if (e && e->NB > 1) return single_block(e, "MvNMF");
+    if (e && split(e)) return single_block(e, "MvNMF");
     if (!e || !out) return fail("null argument");
     HIPCK(hipSetDevice(e->device));
     CK(objective_to_slot(e, e->W, nullptr, false, 0));
@@ -1637,7 +1802,7 @@ static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double de
 }
 
 int salnmf_mv_update_W(salnmf_engine* e, int n_given, double lam, double delta, double* gamma_inout) {
-    if (e && e->NB > 1) return single_block(e, "MvNMF");
+    if (e && split(e)) return single_block(e, "MvNMF");
     if (!e || !gamma_inout) return fail("null argument");
     e->keep_valid = false;  // (the MvNMF steps use the second H buffer themselves)
     HIPCK(hipSetDevice(e->device));
@@ -1645,7 +1810,7 @@ int salnmf_mv_update_W(salnmf_engine* e, int n_given, double lam, double delta, 
 }
 
 int salnmf_mv_step(salnmf_engine* e, int n_steps, int n_given, double lam, double delta, double* gamma_inout) {
-    if (e && e->NB > 1) return single_block(e, "MvNMF");
+    if (e && split(e)) return single_block(e, "MvNMF");
     if (!e || !gamma_inout) return fail("null argument");
     if (n_given < 0 || n_given > e->K) return fail("n_given out of range");
     HIPCK(hipSetDevice(e->device));
@@ -1677,7 +1842,7 @@ int salnmf_mv_step(salnmf_engine* e, int n_steps, int n_given, double lam, doubl
 // ------------------------------------------------------------------------------------ CorrNMF (row f1)
 
 int salnmf_corr_configure(salnmf_engine* e, int dim_embeddings) {
-    if (e && e->NB > 1) return single_block(e, "CorrNMF");
+    if (e && split(e)) return single_block(e, "CorrNMF");
     if (!e) return fail("null engine");
     if (dim_embeddings < 1 || dim_embeddings > CORR_DMAX) return fail("dim_embeddings must be in [1, %d], got %d", CORR_DMAX, dim_embeddings);
     HIPCK(hipSetDevice(e->device));
@@ -2156,7 +2321,7 @@ int salnmf_corr_poisson_llh(salnmf_engine* e, double* out) {
 // ------------------------------------------------------------------------------------ initialisation (row f3)
 
 int salnmf_init_gram(salnmf_engine* e, double* gram_out, double* xsum_out) {
-    if (e && e->NB > 1) return single_block(e, "the device-side initialisation");
+    if (e && split(e)) return single_block(e, "the device-side initialisation");
     if (!e || !gram_out) return fail("null argument");
     HIPCK(hipSetDevice(e->device));
     const int nparts = e->grid * WAVES;
@@ -2190,7 +2355,7 @@ int salnmf_init_gram(salnmf_engine* e, double* gram_out, double* xsum_out) {
 }
 
 int salnmf_init_project(salnmf_engine* e, const double* B, double* posneg_out) {
-    if (e && e->NB > 1) return single_block(e, "the device-side initialisation");
+    if (e && split(e)) return single_block(e, "the device-side initialisation");
     if (!e || !B || !posneg_out) return fail("null argument");
     HIPCK(hipSetDevice(e->device));
     const int K = e->K, V = e->V, KP = e->KP;
@@ -2216,7 +2381,7 @@ int salnmf_init_project(salnmf_engine* e, const double* B, double* posneg_out) {
 }
 
 int salnmf_init_finish(salnmf_engine* e, const double* scale, const int* take_neg, const double* post, double zero_below, double fill) {
-    if (e && e->NB > 1) return single_block(e, "the device-side initialisation");
+    if (e && split(e)) return single_block(e, "the device-side initialisation");
     if (!e || !scale || !take_neg || !post) return fail("null argument");
     HIPCK(hipSetDevice(e->device));
     const int K = e->K;
@@ -2246,7 +2411,7 @@ int salnmf_init_finish(salnmf_engine* e, const double* scale, const int* take_ne
 }
 
 int salnmf_init_flat(salnmf_engine* e, const double* post) {
-    if (e && e->NB > 1) return single_block(e, "the device-side initialisation");
+    if (e && split(e)) return single_block(e, "the device-side initialisation");
     if (!e || !post) return fail("null argument");
     HIPCK(hipSetDevice(e->device));
     e->h_pending = false;
@@ -2259,7 +2424,7 @@ int salnmf_init_flat(salnmf_engine* e, const double* post) {
 }
 
 int salnmf_init_separable(salnmf_engine* e, int n_select, int64_t* chosen_out) {
-    if (e && e->NB > 1) return single_block(e, "the device-side initialisation");
+    if (e && split(e)) return single_block(e, "the device-side initialisation");
     if (!e || !chosen_out) return fail("null argument");
     if (n_select < 1 || (int64_t)n_select > e->N) return fail("n_select must be in [1, n_samples]");
     if (sharded(e)) return fail("the separableNMF selection needs all samples on one engine: not available on a sharded engine");
@@ -2302,7 +2467,7 @@ int salnmf_comm_unique_id(char* out_id) {
 }
 
 int salnmf_comm_init(salnmf_engine* e, const char* id_bytes, int n_ranks, int rank) {
-    if (e && e->NB > 1) return single_block(e, "a sample-sharded engine");
+    if (e && split(e)) return single_block(e, "a sample-sharded engine");
     if (!e || !id_bytes) return fail("null argument");
     if (e->comm) return fail("communicator already attached");
     if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail("rank %d out of range for %d ranks", rank, n_ranks);
@@ -2339,7 +2504,7 @@ int salnmf_comm_info(salnmf_engine* e, int* n_ranks, int* rank, int64_t* n_sampl
 }
 
 int salnmf_p2p_export(salnmf_engine* e, int n_ranks, int64_t max_count, char* handle_out) {
-    if (e && e->NB > 1) return single_block(e, "a sample-sharded engine");
+    if (e && split(e)) return single_block(e, "a sample-sharded engine");
     if (!e || !handle_out) return fail("null argument");
     if (e->p2p.local) return fail("the peer-to-peer inbox is exported already");
     if (n_ranks < 1 || n_ranks > P2P_MAX_RANKS) return fail("peer-to-peer exchange supports 1..%d ranks, not %d", P2P_MAX_RANKS, n_ranks);
@@ -2457,7 +2622,7 @@ static int ensure_events(salnmf_engine* e, size_t n) {
 
 int salnmf_profile_kl_steps(salnmf_engine* e, int n_steps, int n_given, int sample_stride, double* total_ms,
                             double* fused_avg_ms, double* tail_avg_ms) {
-    if (e && e->NB > 1) return single_block(e, "the profiling entry points");
+    if (e && split(e)) return single_block(e, "the profiling entry points");
     if (!e) return fail("null engine");
     if (n_steps < 1 || n_steps > 1000000) return fail("n_steps out of range");
     if (sample_stride < 1) sample_stride = 1;
@@ -2493,7 +2658,7 @@ int salnmf_profile_kl_steps(salnmf_engine* e, int n_steps, int n_given, int samp
 // to a scratch reconstruction buffer)
 static int profile_forward(salnmf_engine* e, int mode, int n_calls, double* avg_ms) {
     if (!e) return fail("null engine");
-    if (e->NB > 1) return single_block(e, "the profiling entry points");
+    if (split(e)) return single_block(e, "the profiling entry points");
     if (n_calls < 1 || n_calls > 100000) return fail("n_calls out of range");
     HIPCK(hipSetDevice(e->device));
     CK(ensure_events(e, (size_t)2 * n_calls));

@@ -24,13 +24,13 @@ int launch_fused_inst(const FusedSel& s, const FusedParams& p, int grid, hipStre
     return 1;
 }
 
-template <int KS, int MODE>
+template <int KS, int MODE, bool PIN = false>
 static void launch_fwd_one(const FwdParams& p, int grid, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     const dim3 g(grid), b(BLOCK);
     if (ev_stop)
-        hipExtLaunchKernelGGL((forward_kernel<KS, MODE>), g, b, 0, stream, ev_start, ev_stop, 0, p);
+        hipExtLaunchKernelGGL((forward_kernel<KS, MODE, PIN>), g, b, 0, stream, ev_start, ev_stop, 0, p);
     else
-        hipLaunchKernelGGL((forward_kernel<KS, MODE>), g, b, 0, stream, p);
+        hipLaunchKernelGGL((forward_kernel<KS, MODE, PIN>), g, b, 0, stream, p);
 }
 
 template <int KS>
@@ -40,8 +40,18 @@ static int launch_fwd_mode(int mode, const FwdParams& p, int grid, hipStream_t s
         case 1: launch_fwd_one<KS, 1>(p, grid, st, e0, e1); return 0;
         case 2: launch_fwd_one<KS, 2>(p, grid, st, e0, e1); return 0;
         case 3: launch_fwd_one<KS, 3>(p, grid, st, e0, e1); return 0;
-        default: return 1;
+        default: break;
     }
+    if constexpr (KS >= 13) {  // (signature chunks use the geometries whose H layout is 64 columns wide)
+        switch (mode) {
+            case FWD_PIN + 0: launch_fwd_one<KS, 0, true>(p, grid, st, e0, e1); return 0;
+            case FWD_PIN + 1: launch_fwd_one<KS, 1, true>(p, grid, st, e0, e1); return 0;
+            case FWD_PIN + 2: launch_fwd_one<KS, 2, true>(p, grid, st, e0, e1); return 0;
+            case FWD_PIN + 4: launch_fwd_one<KS, 4, true>(p, grid, st, e0, e1); return 0;
+            default: break;
+        }
+    }
+    return 1;
 }
 
 #define SALNMF_KS_LIST(X) X(1) X(2) X(4) X(8) X(10) X(13) X(16)

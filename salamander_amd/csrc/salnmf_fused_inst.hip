@@ -35,13 +35,13 @@
 
 namespace salnmf {
 
-template <int KS, int KTM, int KR, bool G, bool U, bool STATS, bool WTS, bool PERSIST = false, bool BLOCKED = false>
+template <int KS, int KTM, int KR, bool G, bool U, bool STATS, bool WTS, bool PERSIST = false, bool BLOCKED = false, bool RGIVEN = false>
 static void launch_one(const FusedParams& p, int grid, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     const dim3 g(grid), b(BLOCK);
     if (ev_stop)
-        hipExtLaunchKernelGGL((fused_kernel<KS, KTM, KR, G, U, STATS, WTS, PERSIST, BLOCKED>), g, b, 0, stream, ev_start, ev_stop, 0, p);
+        hipExtLaunchKernelGGL((fused_kernel<KS, KTM, KR, G, U, STATS, WTS, PERSIST, BLOCKED, RGIVEN>), g, b, 0, stream, ev_start, ev_stop, 0, p);
     else
-        hipLaunchKernelGGL((fused_kernel<KS, KTM, KR, G, U, STATS, WTS, PERSIST, BLOCKED>), g, b, 0, stream, p);
+        hipLaunchKernelGGL((fused_kernel<KS, KTM, KR, G, U, STATS, WTS, PERSIST, BLOCKED, RGIVEN>), g, b, 0, stream, p);
 }
 
 template <int KS, int KTM, int KR>
@@ -54,6 +54,19 @@ static int launch_geometry(const FusedSel& s, const FusedParams& p, int grid, hi
 #else
         return 1;
 #endif
+    }
+    if (s.RGIVEN) {  // n_signatures > 64: one chunk's passes on the given ratio (weights honoured at run time)
+        // (chunks use the geometries whose H layout is 64 columns wide: salnmf.hip, salnmf_create)
+        if constexpr (KS >= 13) {
+            if (s.STATS || s.BLOCKED) return 1;
+            if (s.G && s.U) launch_one<KS, KTM, KR, true, true, false, true, false, false, true>(p, grid, st, e0, e1);
+            else if (s.U) launch_one<KS, KTM, KR, false, true, false, true, false, false, true>(p, grid, st, e0, e1);
+            else if (s.G) launch_one<KS, KTM, KR, true, false, false, true, false, false, true>(p, grid, st, e0, e1);
+            else return 1;
+            return 0;
+        } else {
+            return 1;
+        }
     }
     if (s.BLOCKED) {  // n_features > 96: the update_H pass over one feature block (weights honoured at run time)
         if (!(s.U && !s.G && !s.STATS)) return 1;

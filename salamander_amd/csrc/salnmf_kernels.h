@@ -623,8 +623,13 @@ __device__ __forceinline__ double lhalf_update(double h, double u, double wl, do
 //
 // BLOCKED (n_features > 96, update_H pass only): this launch covers ONE 96-feature block of X and W; the product
 // U = R W^T is accumulated over the blocks' launches through p.Uacc (p.ublock), the last block updates H.
-template <int KS, int KTM, int KR, bool DO_G, bool DO_U, bool DO_STATS, bool WTS = false, bool PERSIST = false, bool BLOCKED = false>
+//
+// RGIVEN (n_signatures > 64, one launch per chunk of <= 64 signatures): p.X holds the ratio R = X / (H W) over ALL
+// signatures (forward_kernel mode 4 at the end of a chain over the chunks) instead of X; the P phase and the division
+// are skipped, everything downstream -- G and U of this chunk's rows / columns, the H update -- is unchanged.
+template <int KS, int KTM, int KR, bool DO_G, bool DO_U, bool DO_STATS, bool WTS = false, bool PERSIST = false, bool BLOCKED = false, bool RGIVEN = false>
 __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
+    static_assert(!RGIVEN || (WTS && !DO_STATS && !PERSIST && !BLOCKED), "given ratio: the weighted-capable plain passes only");
     static_assert(!PERSIST || (DO_G && DO_U && !DO_STATS && !WTS), "the persistent mode is the plain joint step");
     static_assert(!BLOCKED || (DO_U && !DO_G && !DO_STATS && WTS && !PERSIST), "feature blocks: the weighted-capable update_H pass only");
     using G_ = Geo<KS>;
@@ -695,7 +700,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
     // loads that nothing hides, stays, and the statistics code in the shared tile costs the main loop registers:
     // profiles/r03/ab_step_variants.txt.)
     // The joint step with the objective folded in (DO_STATS) does the same: its numerator is summed in the plain step's order.
-    constexpr bool COOP = DO_G && DO_U;  // (with per-sample weights too: process_tile_coop honours them)
+    constexpr bool COOP = DO_G && DO_U && !RGIVEN;  // (with per-sample weights too: process_tile_coop honours them)
     using CO_ = EpiGeo<KT, KR, G_::LDS_DOUBLES>;
     static_assert(CO_::COOP_DOUBLES <= (WAVES - 1) * (G_::HL + G_::RL), "the cooperative tile's numerator park must fit the idle waves' LDS");
     const int64_t nleft = p.ntiles % tstride;
@@ -758,7 +763,12 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         d4 pr[VT];
 #pragma unroll
         for (int vt = 0; vt < VT; ++vt) pr[vt] = (d4){0, 0, 0, 0};
-        {
+        if (RGIVEN) {  // the tile of "X" is the ratio already
+#pragma unroll
+            for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pr[vt][r] = x[vt][r];
+        } else {
             const double* ha = Hl + c16 * LS + q;
             const double* wb = Wl + q * WS + c16;
             double a[2], b[2][VT];
@@ -814,7 +824,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         // ---- R = X / P in place (rows n = q + 4r, columns v = 16vt + c16); pads give 0 / P = 0
         // (div_path's sequence, six quotients at a time and stage by stage: independent chains next to each other)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < (RGIVEN ? 0 : 4); ++r) {
             double rc[VT], t0[VT], t1[VT];
 #pragma unroll
             for (int vt = 0; vt < VT; ++vt) rc[vt] = __builtin_amdgcn_rcp(pr[vt][r]);
@@ -1433,6 +1443,9 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
 //   mode 1: per-sample KL, zeros replaced by EPS in X and WH            _utils_klnmf.py:58-97
 //   mode 2: the reconstruction H @ W                                    signature_nmf.py:221-224
 //   mode 3: Poisson log-likelihood partial (CorrNMF ELBO), no factorial _utils_klnmf.py:98-133
+//   mode 4: the ratio X / (H @ W) of the update rules (the fused passes' division)   _utils_klnmf.py:333
+// PIN (n_signatures > 64, one launch per chunk of <= 64 signatures): P = pin + H_c @ W_c, so that a chain of launches
+// accumulates the product over the chunks (mode 2) and the last one evaluates what it is needed for (modes 0, 1, 4).
 struct FwdParams {
     const double* __restrict__ X;       // [Np][VMAX]
     const double* __restrict__ H;       // [Np][KP]
@@ -1441,7 +1454,9 @@ struct FwdParams {
     const double* __restrict__ wlh;     // [Np] or null
     const double* __restrict__ hscale;  // [KP] or null: H read as clip(H*hscale)
     const double* __restrict__ xlx;     // [Np] mode 0: c_d = sum_v (x log x - x) of every sample (xlogx_rowsum_kernel)
-    double* __restrict__ out;           // mode 0: [gridDim.x]; mode 1: [Np]; mode 2: [Np][VMAX]
+    const double* pin;                  // (PIN instantiations) [Np][VMAX] or null: P starts from this instead of 0 -- the product of
+                                        // the signature chunks before this one (n_signatures > 64); may be `out` itself
+    double* __restrict__ out;           // mode 0: [gridDim.x]; mode 1: [Np]; modes 2, 4: [Np][VMAX]
     int64_t N;
     int V;
     int ldw;                            // row stride of W (= V unless W points at one feature block of a wider matrix)
@@ -1455,7 +1470,7 @@ struct FwdParams {
 template <int KS>
 constexpr int fwd_lds_doubles() { return 4 * KS * WS + WAVES * Geo<KS>::HL + BLOCK + Geo<KS>::KP + LOGTAB_DOUBLES; }
 
-template <int KS, int MODE>
+template <int KS, int MODE, bool PIN = false>
 __global__ void __launch_bounds__(BLOCK, (fwd_lds_doubles<KS>() * 8 <= 80 * 1024 ? 2 : 1)) forward_kernel(FwdParams p) {
     using G_ = Geo<KS>;
     constexpr int KP = G_::KP, LS = G_::LS, HV = G_::HV;
@@ -1536,6 +1551,13 @@ __global__ void __launch_bounds__(BLOCK, (fwd_lds_doubles<KS>() * 8 <= 80 * 1024
         d4 pr[VT];
 #pragma unroll
         for (int vt = 0; vt < VT; ++vt) pr[vt] = (d4){0, 0, 0, 0};
+        if (PIN && p.pin) {
+            const double* psrc = p.pin + (n0 + q) * VMAX + c16;
+#pragma unroll
+            for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pr[vt][r] = psrc[4 * r * VMAX + 16 * vt];
+        }
         const double* ha = Hl + c16 * LS + q;
         const double* wb = Wl + q * WS + c16;
 #pragma unroll
@@ -1602,7 +1624,7 @@ __global__ void __launch_bounds__(BLOCK, (fwd_lds_doubles<KS>() * 8 <= 80 * 1024
 #pragma unroll
             for (int vt = 0; vt < VT; ++vt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dst[4 * r * VMAX + 16 * vt] = pr[vt][r];
+                for (int r = 0; r < 4; ++r) dst[4 * r * VMAX + 16 * vt] = MODE == 4 ? div_path(x[vt][r], pr[vt][r]) : pr[vt][r];
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -1846,25 +1868,56 @@ __global__ void pad_rows_kernel(double* __restrict__ dst, const T* __restrict__ 
         dst[i] = v;
     }
 }
-// The same for a matrix wider than one feature block (n_features > 96): the chunk's rows are scattered into nb blocks of
-// 96 columns each, dst[b][r][c] = src[r][96 b + c] (0 beyond cols); block_stride = doubles between consecutive blocks.
+// The same for a matrix wider than one block -- X with n_features > 96 (blocks of bw = 96 features), H with n_signatures >
+// 64 (chunks of bw = 64 signatures): the rows are scattered into nb blocks of bw columns each, dst[b][r][c] =
+// src[r][bw b + c] for c < bw (0 beyond cols and in the pad columns bw <= c < ldb of a block); ldb = row stride inside a block,
+// block_stride = doubles between consecutive blocks.
 template <typename T>
 __global__ void pad_rows_blocked_kernel(double* __restrict__ dst, const T* __restrict__ src, int64_t rows, int cols, int nb,
-                                        int64_t block_stride, double clip_lo) {
+                                        int64_t block_stride, double clip_lo, int bw, int ldb) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t per_row = (int64_t)nb * VMAX;
+    const int64_t per_row = (int64_t)nb * ldb;
     for (; i < rows * per_row; i += stride) {
         const int64_t r = i / per_row;
-        const int rc = (int)(i - r * per_row), b = rc / VMAX, c = rc - b * VMAX;
-        const int col = VMAX * b + c;
+        const int rc = (int)(i - r * per_row), b = rc / ldb, c = rc - b * ldb;
+        const int col = bw * b + c;
         double v = 0.0;
-        if (col < cols) {
+        if (c < bw && col < cols) {
             v = (double)src[r * cols + col];
             if (clip_lo > 0.0) v = v < clip_lo ? clip_lo : v;
         }
-        dst[(int64_t)b * block_stride + r * VMAX + c] = v;
+        dst[(int64_t)b * block_stride + r * ldb + c] = v;
     }
+}
+// blocks of bw columns at row stride ldb, [nb][.][ldb] -> compact [rows][cols]
+__global__ void unpad_blocked_kernel(double* __restrict__ dst, const double* __restrict__ src, int64_t rows, int cols, int bw, int ldb,
+                                     int64_t block_stride) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < rows * cols; i += stride) {
+        const int64_t r = i / cols;
+        const int col = (int)(i - r * cols), b = col / bw;
+        dst[i] = src[(int64_t)b * block_stride + r * ldb + (col - b * bw)];
+    }
+}
+// l-half penalty of one signature chunk (klnmf.py:75-79): part[workgroup] = sum_n w_n sum_{k < K} sqrt(H[n][k]), fixed order
+__global__ void __launch_bounds__(256) lhalf_penalty_kernel(const double* __restrict__ H, const double* __restrict__ wlh, int64_t N, int K, int ld,
+                                                            double* __restrict__ part) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N * ld; i += (int64_t)gridDim.x * 256) {
+        const int64_t n = i / ld;
+        const int k = (int)(i - n * ld);
+        if (k < K) s += wlh[n] * sqrt(H[i]);
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
 }
 
 // W tail of a problem with more than 96 features (_utils_klnmf.py:338-341 / :208-215): one workgroup per signature row.

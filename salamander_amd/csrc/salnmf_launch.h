@@ -17,11 +17,14 @@ struct FusedSel {
     bool G, U, STATS, WTS;         // template switches of fused_kernel
     bool PERSIST;                  // the persistent multi-step variant (only in builds with SALNMF_WITH_PERSISTENT)
     bool BLOCKED;                  // one 96-feature block of a wider problem: the update_H pass that accumulates U over blocks
+    bool RGIVEN = false;           // one chunk of <= 64 signatures of a wider problem: p.X holds the ratio X / (H W) over all of them
 };
 
 // Return 0 when the kernel was launched (HIP launch errors are left for hipGetLastError), 1 when this build has no
 // such instantiation.  ev_start / ev_stop (may be null) are bound to the dispatch itself (hipExtLaunchKernelGGL).
 int launch_fused_inst(const FusedSel& s, const FusedParams& p, int grid, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop);
+// (mode + FWD_PIN: the instantiation whose P starts from p.pin -- modes 0, 1, 2, 4)
+constexpr int FWD_PIN = 16;
 int launch_forward_inst(int KS, int mode, const FwdParams& p, int grid, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop);
 int launch_fused_f32_inst(int KS, const Fused32Params& p, int grid, hipStream_t stream);
 bool built_with_persistent();

@@ -26,8 +26,9 @@ class StandardNMF(SignatureNMF):
         instead of sklearn's randomized one) unless ``device_init=False`` or a ``seed`` is passed, which asks for
         the reference's seeded host computation (``initialize.py:221-255``)."""
         init_kwargs = {} if init_kwargs is None else init_kwargs.copy()
-        # (the device-side initialisation works on one 96-feature block: wider catalogues initialise on the host)
-        on_device = self.device_init and np.shape(self.adata.X)[1] <= 96
+        # (the device-side initialisation works on one 96-feature block and one 64-signature chunk: wider problems
+        # initialise on the host)
+        on_device = self.device_init and np.shape(self.adata.X)[1] <= 96 and self.n_signatures <= 64
         if on_device and self.init_method in DEVICE_METHODS and "seed" not in init_kwargs:
             if init_kwargs:
                 raise TypeError(f"init method '{self.init_method}' takes no keyword arguments besides 'seed': {sorted(init_kwargs)}")
@@ -41,7 +42,7 @@ class StandardNMF(SignatureNMF):
             self._upload_X(e)
             init_kwargs["chosen"] = e.init_separable(self.n_signatures)
             self._resident = {"X"}
-        if self.init_method == "custom" and getattr(self, "_defer_exposures", False) and not self.distributed:
+        if self.init_method == "custom" and getattr(self, "_defer_exposures", False) and not self.distributed and self.n_signatures <= 64:
             self._initialize_custom_on_device(given_parameters, init_kwargs)
             return
         if self.init_method != "custom":  # ("custom" looks at the shape of X only)

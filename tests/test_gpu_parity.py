@@ -256,7 +256,7 @@ def test_errors_are_exceptions_not_aborts():
     with pytest.raises(RuntimeError):
         Engine(10, 3073, 2)
     with pytest.raises(RuntimeError):
-        Engine(10, 96, 65)
+        Engine(10, 96, 513)
     with pytest.raises(RuntimeError):
         Engine(0, 96, 2)
     e = Engine(10, 96, 2)
@@ -269,7 +269,7 @@ def test_errors_are_exceptions_not_aborts():
 
 def test_limits_are_refused_with_a_message_and_closed_engines_raise():
     """The documented limits of this build (include/salnmf.h) and the ADVICE r1 NULL-handle case."""
-    for args, text in (((10, 3073, 2), "n_features"), ((10, 96, 65), "n_signatures")):
+    for args, text in (((10, 3073, 2), "n_features"), ((10, 96, 513), "n_signatures")):
         with pytest.raises(RuntimeError, match=text):
             Engine(*args)
     e = Engine(10, 96, 2)
