@@ -157,6 +157,12 @@ int salnmf_reconstruct(salnmf_engine* e, double* out);
  * line_search (:69-92).  gamma_inout carries MvNMF._gamma across calls. */
 int salnmf_mv_step(salnmf_engine* e, int n_steps, int n_given, double lam, double delta,
                    double* gamma_inout);
+/* salnmf_mv_step that also returns MvNMF.objective_function (mvnmf.py:149-156) of the state it leaves behind: the line
+ * search of the last step has evaluated exactly that (its accepted f, mvnmf.py:82-89), so a fit loop that tests
+ * convergence after a block of steps (signature_nmf.py:373-380) needs no salnmf_mv_objective call -- one forward pass, one
+ * log det and one host round trip less per test.  Equal to salnmf_mv_objective's value to rounding. */
+int salnmf_mv_step_objective(salnmf_engine* e, int n_steps, int n_given, double lam, double delta,
+                             double* gamma_inout, double* objective_out);
 /* only MvNMF._update_W (:190-195) / only _update_H (= salnmf_update_H) for the
  * reference's single-step tests (tests/test_mvnmf.py:70-76). */
 int salnmf_mv_update_W(salnmf_engine* e, int n_given, double lam, double delta,

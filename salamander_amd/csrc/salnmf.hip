@@ -1671,7 +1671,9 @@ static int mv_tail(salnmf_engine* e, bool with_root, double lam, int n_given, hi
 //            preceding update_H pass); otherwise mv_prepare_W_kernel is started on stream2 here and waited for
 //   g_ready:  (in) the numerator pass of THIS step was queued by the previous call's speculation (its tail was not)
 static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double delta, double* gamma, bool have_hsum, bool w_ready,
-                            bool speculate = false, bool* speculated = nullptr, bool g_ready = false) {
+                            bool speculate = false, bool* speculated = nullptr, bool g_ready = false, double* f_accepted = nullptr) {
+    // f_accepted: the line search's value at the accepted point (mvnmf.py:82,89), which IS the model's objective of the
+    // state this call leaves behind (kl_divergence_penalized of the normalised W and the rescaled H, mvnmf.py:27-34,149-156)
     if (speculated) *speculated = false;
     if (n_given >= e->K) return 0;
     CK(ensure_side_streams(e));
@@ -1772,6 +1774,7 @@ static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double de
             CK(read_scalars(e, 0, 5, v));
         }
         const double f0 = v[1], f1 = v[2] + lam * v[4];
+        if (f_accepted) *f_accepted = f1;  // (of the last trial: the accepted one when the loop ends)
         if (f1 > f0 && g > 1e-16) {  // mvnmf.py:84
             // (a rejected speculation is simply dropped: it wrote scratch buffers only -- Halt, the numerator slabs, A, B
             // and scal[3], which the next non-speculative step recomputes for the W it starts from -- and everything that
@@ -1810,8 +1813,13 @@ int salnmf_mv_update_W(salnmf_engine* e, int n_given, double lam, double delta, 
 }
 
 int salnmf_mv_step(salnmf_engine* e, int n_steps, int n_given, double lam, double delta, double* gamma_inout) {
+    return salnmf_mv_step_objective(e, n_steps, n_given, lam, delta, gamma_inout, nullptr);
+}
+
+int salnmf_mv_step_objective(salnmf_engine* e, int n_steps, int n_given, double lam, double delta, double* gamma_inout, double* objective_out) {
     if (e && split(e)) return single_block(e, "MvNMF");
     if (!e || !gamma_inout) return fail("null argument");
+    if (n_steps < 1 && objective_out) return fail("n_steps must be positive");
     if (n_given < 0 || n_given > e->K) return fail("n_given out of range");
     HIPCK(hipSetDevice(e->device));
     e->keep_valid = false;  // (the MvNMF steps use the second H buffer themselves)
@@ -1834,8 +1842,10 @@ int salnmf_mv_step(salnmf_engine* e, int n_steps, int n_given, double lam, doubl
             e->h_pending = false;
         }
         const bool was_ahead = ahead;
-        CK(mv_update_W_impl(e, n_given, lam, delta, gamma_inout, true, true, i + 1 < n_steps, &ahead, was_ahead));
+        CK(mv_update_W_impl(e, n_given, lam, delta, gamma_inout, true, true, i + 1 < n_steps, &ahead, was_ahead, objective_out));
     }
+    // (all signatures given: no line search ran -- the objective as a pass of its own)
+    if (objective_out && n_given >= e->K) return salnmf_mv_objective(e, lam, delta, objective_out);
     return 0;
 }
 

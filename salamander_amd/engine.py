@@ -181,6 +181,13 @@ class Engine:
         _lib.check(self._lib.salnmf_mv_step(self._h, int(n_steps), int(n_given), float(lam), float(delta), ctypes.byref(g)))
         return g.value
 
+    def mv_step_objective(self, n_steps: int, n_given: int, lam: float, delta: float, gamma: float) -> tuple[float, float]:
+        """``mv_step`` that also returns the objective of the state it leaves behind (the last line search's accepted
+        value): ``(gamma, objective)``."""
+        g, f = c_double(gamma), c_double()
+        _lib.check(self._lib.salnmf_mv_step_objective(self._h, int(n_steps), int(n_given), float(lam), float(delta), ctypes.byref(g), ctypes.byref(f)))
+        return g.value, f.value
+
     def mv_update_W(self, n_given: int, lam: float, delta: float, gamma: float) -> float:
         g = c_double(gamma)
         _lib.check(self._lib.salnmf_mv_update_W(self._h, int(n_given), float(lam), float(delta), ctypes.byref(g)))

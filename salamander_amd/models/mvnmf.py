@@ -44,6 +44,7 @@ class MvNMF(StandardNMF):
 
     def objective_function(self) -> float:
         self._sync_to_device()
+        self._objective_after_steps = None  # (whatever a fit loop left behind: the state may have been edited since)
         return self._device_objective()
 
     # -- the reference's single-step hooks (tests/test_mvnmf.py:70-76)
@@ -66,12 +67,18 @@ class MvNMF(StandardNMF):
 
     # -- device-resident pieces used by fit()
     def _device_steps(self, n_steps: int, given_parameters) -> None:
-        self._gamma = self._engine.mv_step(
+        # the last step's line search has evaluated the objective of the state the steps leave behind (its accepted value,
+        # mvnmf.py:82-89): kept for the convergence test that follows in fit()
+        self._gamma, self._objective_after_steps = self._engine.mv_step_objective(
             n_steps, self._n_given(given_parameters), self.lam, self.delta, self._gamma
         )
 
     def _device_objective(self) -> float:
+        cached, self._objective_after_steps = getattr(self, "_objective_after_steps", None), None
+        if cached is not None:
+            return cached
         return self._engine.mv_objective(self.lam, self.delta)
 
     def _setup_fitting_parameters(self, fitting_kwargs: dict[str, Any] | None = None) -> None:
+        self._objective_after_steps = None
         self._gamma = 1.0

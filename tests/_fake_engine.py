@@ -104,6 +104,10 @@ class FakeEngine:
             self.W, self.H = W.T.copy(), H.T.copy()
         return gamma
 
+    def mv_step_objective(self, n_steps, n_given, lam, delta, gamma):
+        gamma = self.mv_step(n_steps, n_given, lam, delta, gamma)
+        return gamma, self.mv_objective(lam, delta)
+
     def mv_update_W(self, n_given, lam, delta, gamma):
         Wu = orc.update_W_unconstrained(self.X.T, self.W.T, self.H.T, lam, delta, n_given)
         W, H, gamma = orc.line_search(self.X.T, self.W.T, self.H.T, lam, delta, gamma, Wu)

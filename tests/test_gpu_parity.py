@@ -169,6 +169,29 @@ def test_golden_mvnmf_all_steps_in_one_call(golden, tag):
     e2.close()
 
 
+@pytest.mark.parametrize("tag", ["a", "g", "bt1", "bt2"])
+def test_mv_step_returns_the_objective_of_the_state_it_leaves(golden, tag):
+    """``mv_step_objective``: the last line search's accepted value IS ``MvNMF.objective_function`` of the new state
+    (mvnmf.py:82-89 vs :149-156) -- equal to ``mv_objective`` to rounding, through accepted first trials and backtracking
+    (bt1, bt2), in one call and step by step, same state bit for bit as ``mv_step``; all signatures given: the objective as
+    a pass of its own."""
+    g = golden.mv
+    lam, delta, steps, ng = g[f"{tag}_par"]
+    a, b = (make_engine(g[f"{tag}_X"], g[f"{tag}_W0"], g[f"{tag}_H0"]) for _ in range(2))
+    ga = a.mv_step(int(steps), int(ng), lam, delta, 1.0)
+    gb, fb = b.mv_step_objective(int(steps), int(ng), lam, delta, 1.0)
+    assert ga == gb and np.array_equal(a.download_W(), b.download_W()) and np.array_equal(a.download_H(), b.download_H())
+    assert np.isclose(fb, a.mv_objective(lam, delta), rtol=1e-12, atol=0) and np.isclose(fb, g[f"{tag}_obj"], rtol=1e-9)
+    gamma = gb
+    for _ in range(3):
+        gamma, f = b.mv_step_objective(1, int(ng), lam, delta, gamma)
+        assert np.isclose(f, b.mv_objective(lam, delta), rtol=1e-12, atol=0)
+    K = b.K
+    _, f = b.mv_step_objective(2, K, lam, delta, gamma)
+    assert f == b.mv_objective(lam, delta)
+    a.close(), b.close()
+
+
 # ------------------------------------------------------------------ shapes: ragged N, V < 96, every K bucket
 @pytest.mark.parametrize(
     "V,N,K",
