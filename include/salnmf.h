@@ -160,9 +160,14 @@ int salnmf_mv_step(salnmf_engine* e, int n_steps, int n_given, double lam, doubl
 /* salnmf_mv_step that also returns MvNMF.objective_function (mvnmf.py:149-156) of the state it leaves behind: the line
  * search of the last step has evaluated exactly that (its accepted f, mvnmf.py:82-89), so a fit loop that tests
  * convergence after a block of steps (signature_nmf.py:373-380) needs no salnmf_mv_objective call -- one forward pass, one
- * log det and one host round trip less per test.  Equal to salnmf_mv_objective's value to rounding. */
+ * log det and one host round trip less per test.  Equal to salnmf_mv_objective's value to rounding.
+ * more_follows != 0: the caller expects to go on with another salnmf_mv_step* call (same delta, n_given).  Inside a call
+ * every step but the last already runs the first half of its successor speculatively while the host waits for the
+ * line-search scalars; with more_follows the last step does so too and the engine keeps that half step across the calls
+ * (W is the accepted trial, H already the successor's update).  Any other entry point first steps back to the plain
+ * accepted state (no kernel: the pre-update exposures are still there), so results never depend on the flag. */
 int salnmf_mv_step_objective(salnmf_engine* e, int n_steps, int n_given, double lam, double delta,
-                             double* gamma_inout, double* objective_out);
+                             double* gamma_inout, double* objective_out, int more_follows);
 /* only MvNMF._update_W (:190-195) / only _update_H (= salnmf_update_H) for the
  * reference's single-step tests (tests/test_mvnmf.py:70-76). */
 int salnmf_mv_update_W(salnmf_engine* e, int n_given, double lam, double delta,

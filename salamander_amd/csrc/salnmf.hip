@@ -181,6 +181,13 @@ struct salnmf_engine {
     int cgrid = 0;
     bool xrowsum_valid = false, lgam_valid = false;
     bool h_pending = false;      // H is to be read as clip(H * cs): the rescale of an accepted MvNMF trial, applied by the next reader
+    // salnmf_mv_step_objective(more_follows): the engine was left AHEAD -- the accepted trial is W, but H already holds the
+    // next step's update (the pre-update H, unscaled, sits in Halt with its scale in cs) and that step's W-only algebra
+    // and numerator slabs are done.  The next mv_step with the same (delta, n_given) continues from there; every other
+    // entry point first steps back to the plain accepted state (mv_settle: a swap, no kernel)
+    bool mv_ahead = false;
+    double mv_ahead_delta = 0.0;
+    int mv_ahead_given = 0;
     double lgam_sum = 0.0;       // sum gammaln(1 + X) over the local shard
     // ingest: two pinned host buffers + two device buffers of STAGE_BYTES each, reused by every upload
     void* stage_host[2] = {nullptr, nullptr};
@@ -240,6 +247,22 @@ static int pick_ks(int K) {
 }
 
 // ------------------------------------------------------------------------------------ launches
+
+// an engine left ahead by salnmf_mv_step_objective(more_follows) steps back to the plain accepted state of its last step:
+// W = the accepted trial, H = the pre-update exposures read as clip(H * cs) -- exactly what a non-speculative accept leaves
+static int mv_settle(salnmf_engine* e) {
+    if (!e->mv_ahead) return 0;
+    std::swap(e->H, e->Halt);
+    e->h_pending = true;
+    e->mv_ahead = false;
+    HIPCK(hipEventRecord(e->evW, e->stream));  // W is final for a later stand-alone W-only kernel on stream2
+    return 0;
+}
+// every entry point that takes an engine: its device current, no half-finished MvNMF step
+static int enter(salnmf_engine* e) {
+    HIPCK(hipSetDevice(e->device));
+    return mv_settle(e);
+}
 
 // the always-valid weight arrays of a weighted launch (salnmf_kernels.h: FusedParams::wkl_eff): the vectors themselves, or
 // fillers of ones / zeros where one of the two is absent
@@ -672,7 +695,7 @@ int salnmf_create(int device, int n_features, int64_t n_samples, int n_signature
 
 static int upload(salnmf_engine* e, double* dst, const double* src, size_t n) {
     if (!e || !src) return fail("null argument");
-    HIPCK(hipSetDevice(e->device));
+    CK(enter(e));
     HIPCK(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyHostToDevice, e->stream));
     HIPCK(hipStreamSynchronize(e->stream));
     return 0;
@@ -791,7 +814,7 @@ static int upload_rows_staged(salnmf_engine* e, double* dst, const void* src, in
     if (!e || !src) return fail("null argument");
     const size_t esz = dtype_size(dtype);
     if (!esz) return fail("unknown element type %d", dtype);
-    HIPCK(hipSetDevice(e->device));
+    CK(enter(e));
     CK(ensure_staging(e));
     const size_t row_bytes = (size_t)cols * esz;
     const int64_t chunk_rows = std::max<int64_t>(1, (int64_t)(STAGE_BYTES / row_bytes));
@@ -848,7 +871,7 @@ static int upload_padded(salnmf_engine* e, double* dst, const double* src, int c
 //   nb > 1: src is [nb][Np][ld], chunk b holding columns bw b .. bw b + bw - 1 (H with n_signatures > 64)
 static int download_padded(salnmf_engine* e, double* dst, const double* src, int cols, int ld, int nb = 1, int bw = 0) {
     if (!e || !dst) return fail("null argument");
-    HIPCK(hipSetDevice(e->device));
+    CK(enter(e));
     CK(ensure_staging(e));
     const size_t row_bytes = (size_t)cols * sizeof(double);
     const int64_t chunk_rows = std::max<int64_t>(1, (int64_t)(STAGE_BYTES / row_bytes));
@@ -888,10 +911,12 @@ int salnmf_upload_X_typed(salnmf_engine* e, const void* X, int dtype, int clip) 
 int salnmf_upload_X(salnmf_engine* e, const double* X, int clip) { return salnmf_upload_X_typed(e, X, SALNMF_F64, clip); }
 int salnmf_upload_W(salnmf_engine* e, const double* W) {
     if (!e) return fail("null engine");
+    CK(enter(e));
     e->keep_valid = false;
     return upload(e, e->W, W, (size_t)e->K * e->V);
 }
 int salnmf_upload_H(salnmf_engine* e, const double* H) {
+    if (e) CK(enter(e));
     if (e) e->h_pending = e->keep_valid = false;
     // pad columns 0, pad rows 1: finite, and positive in the rows so that P > 0 there
     if (e && e->NC > 1) return upload_rows_staged(e, e->H, H, SALNMF_F64, e->K, e->KP, 0.0, 1.0, 0.0, e->NC, e->kc[0].K);
@@ -901,7 +926,7 @@ int salnmf_upload_H(salnmf_engine* e, const double* H) {
 int salnmf_set_H_scale(salnmf_engine* e, const double* scale) {
     if (!e || !scale) return fail("null argument");
     if (e->NC > 1) return single_block(e, "a lazily applied exposure scale");
-    HIPCK(hipSetDevice(e->device));
+    CK(enter(e));
     CK(flush_H_scale(e));  // (an earlier pending rescale is applied first)
     std::vector<double> cs((size_t)e->KP, 1.0);
     for (int k = 0; k < e->K; ++k) cs[(size_t)k] = scale[k];
@@ -913,7 +938,7 @@ int salnmf_set_H_scale(salnmf_engine* e, const double* scale) {
 
 int salnmf_set_weights(salnmf_engine* e, const double* weights_kl, const double* weights_lhalf) {
     if (!e) return fail("null engine");
-    HIPCK(hipSetDevice(e->device));
+    CK(enter(e));
     HIPCK(hipStreamSynchronize(e->stream));
     auto set = [&](double*& dev, const double* host, double filler) -> int {
         if (!host) {
@@ -931,7 +956,7 @@ int salnmf_set_weights(salnmf_engine* e, const double* weights_kl, const double*
 
 static int download(salnmf_engine* e, double* dst, const double* src, size_t n) {
     if (!e || !dst) return fail("null argument");
-    HIPCK(hipSetDevice(e->device));
+    CK(enter(e));
     HIPCK(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     HIPCK(hipStreamSynchronize(e->stream));
     return check_abort(e);
@@ -942,7 +967,7 @@ int salnmf_download_W(salnmf_engine* e, double* W) {
 }
 int salnmf_download_H(salnmf_engine* e, double* H) {
     if (!e) return fail("null engine");
-    HIPCK(hipSetDevice(e->device));
+    CK(enter(e));
     CK(flush_H_scale(e));
     return download_padded(e, H, e->H, e->K, e->KP, e->NC, e->kc[0].K);
 }
@@ -1176,7 +1201,7 @@ int salnmf_set_precision(salnmf_engine* e, int precision) {
 int salnmf_kl_step(salnmf_engine* e, int n_steps, int n_given) {
     if (!e) return fail("null engine");
     if (n_given < 0 || n_given > e->K) return fail("n_given out of range");
-    HIPCK(hipSetDevice(e->device));
+    CK(enter(e));
     if (e->NB > 1) {
         e->keep_valid = false;  // (the joint step uses the second H buffer itself)
         for (int i = 0; i < n_steps; ++i) CK(blocked_kl_step_once(e, n_given));
@@ -1208,7 +1233,7 @@ int salnmf_kl_step_keep(salnmf_engine* e, int n_steps, int n_given) {
     if (!e) return fail("null engine");
     if (n_given < 0 || n_given > e->K) return fail("n_given out of range");
     if (n_steps < 1) return fail("n_steps must be positive");
-    HIPCK(hipSetDevice(e->device));
+    CK(enter(e));
     if (!e->Halt && e->NC == 1) HIPCK(hipMalloc(&e->Halt, (size_t)e->Np * e->KP * sizeof(double)));
     if (!e->Wkeep) HIPCK(hipMalloc(&e->Wkeep, (size_t)e->K * e->V * sizeof(double)));
     e->keep_valid = false;
@@ -1257,7 +1282,7 @@ int salnmf_kl_rollback(salnmf_engine* e) {
 
 int salnmf_update_H(salnmf_engine* e) {
     if (!e) return fail("null engine");
-    HIPCK(hipSetDevice(e->device));
+    CK(enter(e));
     if (e->NB > 1) {
         CK(blocked_update_H(e, e->H));
         e->h_pending = false;
@@ -1276,7 +1301,7 @@ int salnmf_update_H(salnmf_engine* e) {
 int salnmf_kl_step_partial(salnmf_engine* e) {
     if (e && split(e)) return single_block(e, "the split step");
     if (!e) return fail("null engine");
-    HIPCK(hipSetDevice(e->device));
+    CK(enter(e));
     FusedParams p = fused_params(e);
     CK((launch_fused<true, true, false>(e, p)));
     e->h_pending = false;
@@ -1286,14 +1311,14 @@ int salnmf_kl_step_partial(salnmf_engine* e) {
 int salnmf_kl_step_finish(salnmf_engine* e, int n_given, int clip_mode) {
     if (e && split(e)) return single_block(e, "the split step");
     if (!e) return fail("null engine");
-    HIPCK(hipSetDevice(e->device));
+    CK(enter(e));
     if (n_given >= e->K) return 0;
     return launch_tail(e, 0, e->red, n_given, clip_mode, 1);
 }
 
 int salnmf_update_W(salnmf_engine* e, int n_given, int clip_mode) {
     if (!e) return fail("null engine");
-    HIPCK(hipSetDevice(e->device));
+    CK(enter(e));
     if (n_given >= e->K) return 0;  // _utils_klnmf.py:204-205
     if (e->NB > 1) {
         CK(blocked_numerators(e));
@@ -1399,7 +1424,7 @@ static int read_scalars(salnmf_engine* e, int first, int count, double* out) {
 
 int salnmf_objective(salnmf_engine* e, double* out) {
     if (!e || !out) return fail("null argument");
-    HIPCK(hipSetDevice(e->device));
+    CK(enter(e));
     CK(objective_to_slot(e, e->W, nullptr, true, 0));
     return read_scalars(e, 0, 1, out);
 }
@@ -1417,7 +1442,7 @@ static int ensure_objective_slot(salnmf_engine* e, int slot) {
 
 int salnmf_objective_async(salnmf_engine* e, int slot) {
     if (!e) return fail("null engine");
-    HIPCK(hipSetDevice(e->device));
+    CK(enter(e));
     CK(ensure_objective_slot(e, slot));
     // The value lands in pinned host memory straight from the reducing kernel, and the slot's event is that kernel's own
     // completion signal: the reader waits for THIS objective only, not for whatever was queued behind it (the next
@@ -1443,7 +1468,7 @@ int salnmf_kl_step_objective(salnmf_engine* e, int slot, int n_steps, int n_give
     if (!e) return fail("null engine");
     if (n_given < 0 || n_given > e->K) return fail("n_given out of range");
     if (n_steps < 0) return fail("n_steps must not be negative");
-    HIPCK(hipSetDevice(e->device));
+    CK(enter(e));
     const bool fold = n_steps > 0 && !split(e) && !e->fast32 && !e->persistent && !sharded(e) && !e->wkl && !e->wlh && n_given < e->K;
     if (!fold) {
         // the objective as a forward pass of its own, then the steps
@@ -1469,7 +1494,7 @@ int salnmf_objective_read(salnmf_engine* e, int first, int count, double* out) {
     if (!e || !out) return fail("null argument");
     if (first < 0 || count < 0 || first + count > SALNMF_OBJECTIVE_SLOTS) return fail("slots out of range");
     if (count == 0) return 0;
-    HIPCK(hipSetDevice(e->device));
+    CK(enter(e));
     for (int i = first; i < first + count; ++i)
         if (e->objev.empty() || !e->objev[i]) return fail("slot %d has never been queued", i);
     // slots are filled in stream order: the caller reads ranges in the order it queued them, so the last one decides
@@ -1480,7 +1505,7 @@ int salnmf_objective_read(salnmf_engine* e, int first, int count, double* out) {
 
 int salnmf_samplewise_kl(salnmf_engine* e, double* out) {
     if (!e || !out) return fail("null argument");
-    HIPCK(hipSetDevice(e->device));
+    CK(enter(e));
     double* dev = nullptr;
     FwdParams p;
     CK(fwd_params(e, p));
@@ -1519,7 +1544,7 @@ int salnmf_samplewise_kl(salnmf_engine* e, double* out) {
 
 int salnmf_reconstruct(salnmf_engine* e, double* out) {
     if (!e || !out) return fail("null argument");
-    HIPCK(hipSetDevice(e->device));
+    CK(enter(e));
     double* dev = nullptr;
     FwdParams p;
     CK(fwd_params(e, p));
@@ -1563,7 +1588,7 @@ static int mv_logdet_to_slot(salnmf_engine* e, const double* W, double delta, in
 int salnmf_mv_objective(salnmf_engine* e, double lam, double delta, double* out) {
     if (e && split(e)) return single_block(e, "MvNMF");
     if (!e || !out) return fail("null argument");
-    HIPCK(hipSetDevice(e->device));
+    CK(enter(e));
     CK(objective_to_slot(e, e->W, nullptr, false, 0));
     CK(mv_logdet_to_slot(e, e->W, delta, 3));
     double v[4];
@@ -1808,22 +1833,27 @@ int salnmf_mv_update_W(salnmf_engine* e, int n_given, double lam, double delta, 
     if (e && split(e)) return single_block(e, "MvNMF");
     if (!e || !gamma_inout) return fail("null argument");
     e->keep_valid = false;  // (the MvNMF steps use the second H buffer themselves)
-    HIPCK(hipSetDevice(e->device));
+    CK(enter(e));
     return mv_update_W_impl(e, n_given, lam, delta, gamma_inout, false, false);
 }
 
 int salnmf_mv_step(salnmf_engine* e, int n_steps, int n_given, double lam, double delta, double* gamma_inout) {
-    return salnmf_mv_step_objective(e, n_steps, n_given, lam, delta, gamma_inout, nullptr);
+    return salnmf_mv_step_objective(e, n_steps, n_given, lam, delta, gamma_inout, nullptr, 0);
 }
 
-int salnmf_mv_step_objective(salnmf_engine* e, int n_steps, int n_given, double lam, double delta, double* gamma_inout, double* objective_out) {
+int salnmf_mv_step_objective(salnmf_engine* e, int n_steps, int n_given, double lam, double delta, double* gamma_inout, double* objective_out,
+                             int more_follows) {
     if (e && split(e)) return single_block(e, "MvNMF");
     if (!e || !gamma_inout) return fail("null argument");
     if (n_steps < 1 && objective_out) return fail("n_steps must be positive");
     if (n_given < 0 || n_given > e->K) return fail("n_given out of range");
     HIPCK(hipSetDevice(e->device));
+    // an engine left ahead by the previous call continues from there if this call is the continuation it speculated on
+    const bool resume = e->mv_ahead && n_steps > 0 && e->mv_ahead_delta == delta && e->mv_ahead_given == n_given;
+    if (!resume) CK(mv_settle(e));
+    e->mv_ahead = false;
     e->keep_valid = false;  // (the MvNMF steps use the second H buffer themselves)
-    bool ahead = false;  // this step's update_H pass, W-only algebra and numerator pass already ran during the previous step
+    bool ahead = resume;  // this step's update_H pass, W-only algebra and numerator pass already ran during the previous step
     for (int i = 0; i < n_steps; ++i) {
         const bool update_W = n_given < e->K;
         if (!ahead) {
@@ -1842,7 +1872,12 @@ int salnmf_mv_step_objective(salnmf_engine* e, int n_steps, int n_given, double 
             e->h_pending = false;
         }
         const bool was_ahead = ahead;
-        CK(mv_update_W_impl(e, n_given, lam, delta, gamma_inout, true, true, i + 1 < n_steps, &ahead, was_ahead, objective_out));
+        CK(mv_update_W_impl(e, n_given, lam, delta, gamma_inout, true, true, i + 1 < n_steps || more_follows != 0, &ahead, was_ahead, objective_out));
+    }
+    if (ahead) {  // (only with more_follows: the last step's speculation was accepted)
+        e->mv_ahead = true;
+        e->mv_ahead_delta = delta;
+        e->mv_ahead_given = n_given;
     }
     // (all signatures given: no line search ran -- the objective as a pass of its own)
     if (objective_out && n_given >= e->K) return salnmf_mv_objective(e, lam, delta, objective_out);
@@ -1855,7 +1890,7 @@ int salnmf_corr_configure(salnmf_engine* e, int dim_embeddings) {
     if (e && split(e)) return single_block(e, "CorrNMF");
     if (!e) return fail("null engine");
     if (dim_embeddings < 1 || dim_embeddings > CORR_DMAX) return fail("dim_embeddings must be in [1, %d], got %d", CORR_DMAX, dim_embeddings);
-    HIPCK(hipSetDevice(e->device));
+    CK(enter(e));
     HIPCK(hipStreamSynchronize(e->stream));
     double** bufs[] = {&e->alpha, &e->beta, &e->Lemb, &e->Uemb, &e->aux, &e->xrowsum, &e->corrpart};
     for (double** b : bufs) {
@@ -1885,7 +1920,7 @@ int salnmf_corr_configure(salnmf_engine* e, int dim_embeddings) {
 static int corr_ready(salnmf_engine* e) {
     if (!e) return fail("null engine");
     if (e->dim == 0) return fail("salnmf_corr_configure has not been called on this engine");
-    HIPCK(hipSetDevice(e->device));
+    CK(enter(e));
     return 0;
 }
 
@@ -2301,7 +2336,7 @@ int salnmf_corr_embedding_sumsq(salnmf_engine* e, double* out2) {
 
 int salnmf_corr_poisson_llh(salnmf_engine* e, double* out) {
     if (!e || !out) return fail("null argument");
-    HIPCK(hipSetDevice(e->device));
+    CK(enter(e));
     if (!e->lgam_valid) {
         const int g = 1024;
         CK(ensure_scratch(e, (size_t)g + 1));
@@ -2333,7 +2368,7 @@ int salnmf_corr_poisson_llh(salnmf_engine* e, double* out) {
 int salnmf_init_gram(salnmf_engine* e, double* gram_out, double* xsum_out) {
     if (e && split(e)) return single_block(e, "the device-side initialisation");
     if (!e || !gram_out) return fail("null argument");
-    HIPCK(hipSetDevice(e->device));
+    CK(enter(e));
     const int nparts = e->grid * WAVES;
     CK(ensure_scratch(e, (size_t)nparts * GRAM_PART + nparts + GRAM_PART + 2));
     double* part = e->scratch;
@@ -2367,7 +2402,7 @@ int salnmf_init_gram(salnmf_engine* e, double* gram_out, double* xsum_out) {
 int salnmf_init_project(salnmf_engine* e, const double* B, double* posneg_out) {
     if (e && split(e)) return single_block(e, "the device-side initialisation");
     if (!e || !B || !posneg_out) return fail("null argument");
-    HIPCK(hipSetDevice(e->device));
+    CK(enter(e));
     const int K = e->K, V = e->V, KP = e->KP;
     const int pgrid = (int)std::min<int64_t>(1024, e->ntiles);
     CK(ensure_scratch(e, (size_t)K * V + (size_t)pgrid * 2 * KP + 2 * KP));
@@ -2393,7 +2428,7 @@ int salnmf_init_project(salnmf_engine* e, const double* B, double* posneg_out) {
 int salnmf_init_finish(salnmf_engine* e, const double* scale, const int* take_neg, const double* post, double zero_below, double fill) {
     if (e && split(e)) return single_block(e, "the device-side initialisation");
     if (!e || !scale || !take_neg || !post) return fail("null argument");
-    HIPCK(hipSetDevice(e->device));
+    CK(enter(e));
     const int K = e->K;
     CK(ensure_scratch(e, (size_t)3 * K + 8));
     double* dscale = e->scratch;
@@ -2423,7 +2458,7 @@ int salnmf_init_finish(salnmf_engine* e, const double* scale, const int* take_ne
 int salnmf_init_flat(salnmf_engine* e, const double* post) {
     if (e && split(e)) return single_block(e, "the device-side initialisation");
     if (!e || !post) return fail("null argument");
-    HIPCK(hipSetDevice(e->device));
+    CK(enter(e));
     e->h_pending = false;
     CK(ensure_scratch(e, (size_t)e->K));
     CK(upload(e, e->scratch, post, (size_t)e->K));
@@ -2438,7 +2473,7 @@ int salnmf_init_separable(salnmf_engine* e, int n_select, int64_t* chosen_out) {
     if (!e || !chosen_out) return fail("null argument");
     if (n_select < 1 || (int64_t)n_select > e->N) return fail("n_select must be in [1, n_samples]");
     if (sharded(e)) return fail("the separableNMF selection needs all samples on one engine: not available on a sharded engine");
-    HIPCK(hipSetDevice(e->device));
+    CK(enter(e));
     const int grid = (int)std::min<int64_t>(1024, (e->N + 15) / 16);
     const size_t nR = (size_t)e->Np * VMAX;
     CK(ensure_scratch(e, nR + SEP_STATE + 2 * (size_t)grid + (size_t)n_select));
@@ -2481,7 +2516,7 @@ int salnmf_comm_init(salnmf_engine* e, const char* id_bytes, int n_ranks, int ra
     if (!e || !id_bytes) return fail("null argument");
     if (e->comm) return fail("communicator already attached");
     if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail("rank %d out of range for %d ranks", rank, n_ranks);
-    HIPCK(hipSetDevice(e->device));
+    CK(enter(e));
     CK(rccl_bind());
     ncclUniqueId id;
     memcpy(&id, id_bytes, sizeof id);
@@ -2520,7 +2555,7 @@ int salnmf_p2p_export(salnmf_engine* e, int n_ranks, int64_t max_count, char* ha
     if (n_ranks < 1 || n_ranks > P2P_MAX_RANKS) return fail("peer-to-peer exchange supports 1..%d ranks, not %d", P2P_MAX_RANKS, n_ranks);
     if (max_count < 1 || max_count > (int64_t)P2P_MAX_WG * P2P_BLOCK) return fail("max_count must be in 1..%d", P2P_MAX_WG * P2P_BLOCK);
     static_assert(sizeof(hipIpcMemHandle_t) == SALNMF_P2P_HANDLE_BYTES, "handle size");
-    HIPCK(hipSetDevice(e->device));
+    CK(enter(e));
     e->p2p.max_count = (size_t)max_count;
     e->p2p.slot = (size_t)max_count + P2P_MAX_WG;
     e->p2p.n_ranks = n_ranks;
@@ -2543,7 +2578,7 @@ int salnmf_p2p_connect(salnmf_engine* e, int rank, int n_ranks, const char* hand
     if (n_ranks != e->p2p.n_ranks || rank < 0 || rank >= n_ranks) return fail("rank %d of %d does not match the exported inbox (%d ranks)", rank, n_ranks, e->p2p.n_ranks);
     if (e->comm && (e->n_ranks != n_ranks || e->rank != rank)) return fail("rank %d of %d contradicts the RCCL communicator (%d of %d)", rank, n_ranks, e->rank, e->n_ranks);
     if (n_samples_total < e->N) return fail("n_samples_total %lld is smaller than this shard (%lld)", (long long)n_samples_total, (long long)e->N);
-    HIPCK(hipSetDevice(e->device));
+    CK(enter(e));
     for (int r = 0; r < n_ranks; ++r) {
         if (r == rank) {
             e->p2p.inbox[r] = e->p2p.local;
@@ -2597,11 +2632,12 @@ int salnmf_set_p2p(salnmf_engine* e, int on) {
 
 void* salnmf_device_ptr(salnmf_engine* e, int which) {
     if (!e) return nullptr;
+    if (enter(e)) return nullptr;
     switch (which) {
         case SALNMF_BUF_G: return e->red;
         case SALNMF_BUF_W: return e->W;
         case SALNMF_BUF_H:
-            if (hipSetDevice(e->device) != hipSuccess || flush_H_scale(e)) return nullptr;
+            if (flush_H_scale(e)) return nullptr;
             return e->H;
         case SALNMF_BUF_X: return e->X;
         case SALNMF_BUF_OBJ: return e->scal;
@@ -2614,7 +2650,7 @@ void* salnmf_stream(salnmf_engine* e) { return e ? (void*)e->stream : nullptr; }
 
 int salnmf_sync(salnmf_engine* e) {
     if (!e) return fail("null engine");
-    HIPCK(hipSetDevice(e->device));
+    CK(enter(e));
     HIPCK(hipStreamSynchronize(e->stream));
     return check_abort(e);
 }
@@ -2636,7 +2672,7 @@ int salnmf_profile_kl_steps(salnmf_engine* e, int n_steps, int n_given, int samp
     if (!e) return fail("null engine");
     if (n_steps < 1 || n_steps > 1000000) return fail("n_steps out of range");
     if (sample_stride < 1) sample_stride = 1;
-    HIPCK(hipSetDevice(e->device));
+    CK(enter(e));
     const int n_samples = (n_steps + sample_stride - 1) / sample_stride;
     CK(ensure_events(e, (size_t)4 * n_samples + 2));
     hipEvent_t first = e->events[4 * (size_t)n_samples], last = e->events[4 * (size_t)n_samples + 1];
@@ -2670,7 +2706,7 @@ static int profile_forward(salnmf_engine* e, int mode, int n_calls, double* avg_
     if (!e) return fail("null engine");
     if (split(e)) return single_block(e, "the profiling entry points");
     if (n_calls < 1 || n_calls > 100000) return fail("n_calls out of range");
-    HIPCK(hipSetDevice(e->device));
+    CK(enter(e));
     CK(ensure_events(e, (size_t)2 * n_calls));
     FwdParams p;
     CK(fwd_params(e, p));

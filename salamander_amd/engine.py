@@ -181,11 +181,13 @@ class Engine:
         _lib.check(self._lib.salnmf_mv_step(self._h, int(n_steps), int(n_given), float(lam), float(delta), ctypes.byref(g)))
         return g.value
 
-    def mv_step_objective(self, n_steps: int, n_given: int, lam: float, delta: float, gamma: float) -> tuple[float, float]:
+    def mv_step_objective(self, n_steps: int, n_given: int, lam: float, delta: float, gamma: float, more_follows: bool = False) -> tuple[float, float]:
         """``mv_step`` that also returns the objective of the state it leaves behind (the last line search's accepted
-        value): ``(gamma, objective)``."""
+        value): ``(gamma, objective)``.  ``more_follows``: the caller expects to continue with another ``mv_step``; the
+        engine then keeps the speculative first half of that step across the calls (any other call steps back first)."""
         g, f = c_double(gamma), c_double()
-        _lib.check(self._lib.salnmf_mv_step_objective(self._h, int(n_steps), int(n_given), float(lam), float(delta), ctypes.byref(g), ctypes.byref(f)))
+        _lib.check(self._lib.salnmf_mv_step_objective(self._h, int(n_steps), int(n_given), float(lam), float(delta), ctypes.byref(g), ctypes.byref(f),
+                                                      1 if more_follows else 0))
         return g.value, f.value
 
     def mv_update_W(self, n_given: int, lam: float, delta: float, gamma: float) -> float:

@@ -69,8 +69,9 @@ class MvNMF(StandardNMF):
     def _device_steps(self, n_steps: int, given_parameters) -> None:
         # the last step's line search has evaluated the objective of the state the steps leave behind (its accepted value,
         # mvnmf.py:82-89): kept for the convergence test that follows in fit()
+        # (inside fit the next block of steps normally follows: the engine keeps its speculative first half across the calls)
         self._gamma, self._objective_after_steps = self._engine.mv_step_objective(
-            n_steps, self._n_given(given_parameters), self.lam, self.delta, self._gamma
+            n_steps, self._n_given(given_parameters), self.lam, self.delta, self._gamma, more_follows=getattr(self, "_fit_running", False)
         )
 
     def _device_objective(self) -> float:

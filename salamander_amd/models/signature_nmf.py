@@ -336,10 +336,14 @@ class SignatureNMF(ABC):
                 self._defer_exposures = False
             self._setup_fitting_parameters(fitting_kwargs)
             self._sync_to_device()
-            if not verbose and self._device_can_queue():
-                of_values, n_iteration = self._fit_loop_queued(given_parameters)
-            else:
-                of_values, n_iteration = self._fit_loop_blocking(given_parameters, verbose, verbosity_freq)
+            self._fit_running = True  # (models may let the device run ahead between the blocks of one fit)
+            try:
+                if not verbose and self._device_can_queue():
+                    of_values, n_iteration = self._fit_loop_queued(given_parameters)
+                else:
+                    of_values, n_iteration = self._fit_loop_blocking(given_parameters, verbose, verbosity_freq)
+            finally:
+                self._fit_running = False
         finally:
             self._finish_setup()  # adata.X is the clipped matrix from here on (signature_nmf.py:281)
         self._sync_from_device()

@@ -104,7 +104,7 @@ class FakeEngine:
             self.W, self.H = W.T.copy(), H.T.copy()
         return gamma
 
-    def mv_step_objective(self, n_steps, n_given, lam, delta, gamma):
+    def mv_step_objective(self, n_steps, n_given, lam, delta, gamma, more_follows=False):
         gamma = self.mv_step(n_steps, n_given, lam, delta, gamma)
         return gamma, self.mv_objective(lam, delta)
 

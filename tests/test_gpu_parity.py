@@ -192,6 +192,46 @@ def test_mv_step_returns_the_objective_of_the_state_it_leaves(golden, tag):
     a.close(), b.close()
 
 
+@pytest.mark.parametrize("tag", ["a", "g", "bt1", "bt2"])
+def test_mv_steps_left_ahead_between_calls(golden, tag):
+    """``mv_step_objective(more_follows=True)`` keeps the speculative first half of the next step across calls: blocks of
+    steps chained that way, with and without other calls in between (which make the engine step back: objective, download,
+    a changed delta), end in the same state bit for bit as the plain calls, with the same gammas and objectives."""
+    g = golden.mv
+    lam, delta, steps, ng = g[f"{tag}_par"]
+    steps, ng = int(steps), int(ng)
+    a, b, c = (make_engine(g[f"{tag}_X"], g[f"{tag}_W0"], g[f"{tag}_H0"]) for _ in range(3))
+    ga, gb, gc = 1.0, 1.0, 1.0
+    fa, fb = [], []
+    done = 0
+    while done < steps:
+        n = min(2, steps - done)
+        ga, f = a.mv_step_objective(n, ng, lam, delta, ga)
+        fa.append(f)
+        gb, f = b.mv_step_objective(n, ng, lam, delta, gb, more_follows=True)
+        fb.append(f)
+        gc, f = c.mv_step_objective(n, ng, lam, delta, gc, more_follows=True)
+        # (c steps back for the call in between, then resumes afresh; the value of a speculative last step comes from the
+        # update_H pass's in-launch sum instead of a forward pass: equal to rounding)
+        assert np.isclose(f, fa[-1], rtol=1e-12, atol=0) and np.isclose(c.mv_objective(lam, delta), f, rtol=1e-12, atol=0)
+        done += n
+    assert ga == gb == gc and np.allclose(fa, fb, rtol=1e-12, atol=0)
+    Wa, Ha = a.download_W(), a.download_H()
+    assert np.array_equal(b.download_W(), Wa) and np.array_equal(b.download_H(), Ha)
+    assert np.array_equal(c.download_W(), Wa) and np.array_equal(c.download_H(), Ha)
+    # left ahead, then a different continuation: KL steps, and an MvNMF step with another delta
+    ga, _ = a.mv_step_objective(1, ng, lam, delta, ga)
+    gb, _ = b.mv_step_objective(1, ng, lam, delta, gb, more_follows=True)
+    a.kl_step(2, ng), b.kl_step(2, ng)
+    ga, _ = a.mv_step_objective(1, ng, lam, delta, ga)
+    gb, _ = b.mv_step_objective(1, ng, lam, delta, gb, more_follows=True)
+    ga, f1 = a.mv_step_objective(1, ng, lam, 2.0 * delta, ga)
+    gb, f2 = b.mv_step_objective(1, ng, lam, 2.0 * delta, gb, more_follows=True)
+    assert ga == gb and np.isclose(f1, f2, rtol=1e-12, atol=0)
+    assert np.array_equal(b.download_W(), a.download_W()) and np.array_equal(b.download_H(), a.download_H())
+    a.close(), b.close(), c.close()
+
+
 # ------------------------------------------------------------------ shapes: ragged N, V < 96, every K bucket
 @pytest.mark.parametrize(
     "V,N,K",
