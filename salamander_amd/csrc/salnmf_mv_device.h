@@ -15,43 +15,32 @@ constexpr int MV_LD = MV_KMAX + 1;  // padded leading dimension in LDS
 constexpr int MV_VMAX = 96;
 constexpr int MV_WS = 97;  // LDS row stride of W: odd, so different signature rows fall into different banks
 
-// sum_{m<n} a[m*sa] * b[m*sb] over LDS operands, reads issued in independent batches of 8 so that one
-// LDS latency is paid per batch instead of per element; fixed summation order
-__device__ __forceinline__ double mv_dot(const double* a, int sa, const double* b, int sb, int n) {
-    double s = 0.0;
-    int m = 0;
-    for (; m + 8 <= n; m += 8) {
-        double x[8], y[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { x[u] = a[(m + u) * sa]; y[u] = b[(m + u) * sb]; }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s += x[u] * y[u];
-    }
-    if (m < n) {  // last partial batch: clamped (in-bounds) reads, contributions masked by selects
-        double x[8], y[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int mm = (m + u < n) ? m + u : n - 1;
-            x[u] = a[mm * sa];
-            y[u] = b[mm * sb];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s += (m + u < n) ? x[u] * y[u] : 0.0;
-    }
-    return s;
-}
+typedef double mv_d4 __attribute__((ext_vector_type(4)));
 
 // S (LDS, [K][MV_LD]) <- Wl Wl^T + delta I, with Wl (LDS, [K][MV_WS]) rows = signatures.  NT = threads of the workgroup.
+// On the matrix cores: one 16 x 16 output tile per wave at a time (v_mfma_f64_16x16x4: A = W[16 ti + c16][4 s + q],
+// B = W[16 tj + c16][4 s + q], D register r = row q + 4 r, column c16), the feature axis in k-steps of 4 in order -- so an
+// entry's value does not depend on NT or on which wave computes it, and S[a][b] == S[b][a] bit for bit (the same products
+// in the same order).  Rows beyond K are clamped reads whose results are not stored.  (The VALU form -- one dot product per
+// thread, two LDS reads per FMA -- took 6.5 us of the side workgroup's 40 at K = 30.)
 template <int NT = MV_BLOCK>
 __device__ inline void mv_gram(const double* Wl, double* S, int K, int V, double delta) {
-    // symmetric: each pair a <= b is computed once and mirrored (the phase is LDS-bandwidth bound)
-    for (int idx = threadIdx.x; idx < K * K; idx += NT) {
-        int a = idx / K, b = idx - a * K;
-        if (a <= b) {
-            double s = mv_dot(Wl + a * MV_WS, 1, Wl + b * MV_WS, 1, V);
-            if (a == b) s += delta;
-            S[a * MV_LD + b] = s;
-            S[b * MV_LD + a] = s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c16 = lane & 15, q = lane >> 4;
+    const int KT = (K + 15) / 16, vsteps = (V + 3) / 4;
+    for (int t = wave; t < KT * KT; t += NT / 64) {  // (uniform per wave)
+        const int ti = t / KT, tj = t - ti * KT;
+        const double* ra = Wl + min(16 * ti + c16, K - 1) * MV_WS;
+        const double* rb = Wl + min(16 * tj + c16, K - 1) * MV_WS;
+        mv_d4 acc = (mv_d4){0, 0, 0, 0};
+        for (int s = 0; s < vsteps; ++s) {
+            const int v = 4 * s + q;
+            const double a = v < V ? ra[v] : 0.0, b = v < V ? rb[v] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 16 * ti + q + 4 * r, j = 16 * tj + c16;
+            if (i < K && j < K) S[i * MV_LD + j] = i == j ? acc[r] + delta : acc[r];
         }
     }
     __syncthreads();
@@ -67,37 +56,48 @@ __device__ inline void mv_gram(const double* Wl, double* S, int K, int V, double
 // factor).  Every element is a fixed expression of the previous step's matrix: the result does not depend on NT.
 // K steps of ~0.2 us replace the single-wave left-looking Cholesky (a chain of K dependent dot products, 20 us at
 // K = 30) and the column-by-column triangular inverse behind it (14 us).  Returns the buffer that holds the result.
-template <int NT, bool FULL>
-__device__ inline double* mv_eliminate(double* src, double* dst, double* piv, int K) {
-    constexpr int E = (MV_KMAX * MV_KMAX + NT - 1) / NT;  // elements per thread, at most
-    int off[E];      // i * MV_LD + j of this thread's elements, -1 = none
-    short ei[E], ej[E];
+// Work split: NT / K threads share a row, each with a run of SEG = ceil(K / (NT / K)) consecutive columns, so a step
+// costs a thread ONE read of its row's pivot-column entry, and per element the pivot row's entry (a broadcast among the
+// threads of the other rows) and the element itself.  All LDS reads of a step are issued together: a step pays one LDS
+// latency (the first form of this loop -- element by element with early exits -- paid one per element: 0.45 us per step at
+// K = 30 with 256 threads, 13 of the side workgroup's 40 us).  EA = a power of two >= SEG.
+template <int NT, bool FULL, int EA>
+__device__ __forceinline__ double* mv_eliminate_n(double* src, double* dst, double* piv, int K) {
+    const int tpr = NT / K > 0 ? NT / K : 1;  // threads per row (K <= NT)
+    const int seg = (K + tpr - 1) / tpr;
+    const int i = threadIdx.x / tpr, j0 = (threadIdx.x - i * tpr) * seg;
+    const bool row_live = i < K;
+    const int irow = row_live ? i : 0;
+    bool have[EA];
+    int col[EA];  // column of element e (clamped: reads stay in bounds)
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int idx = threadIdx.x + NT * e;
-        const int i = idx / K, j = idx - i * K;
-        ei[e] = (short)i;
-        ej[e] = (short)j;
-        off[e] = idx < K * K ? i * MV_LD + j : -1;
+    for (int e = 0; e < EA; ++e) {
+        have[e] = row_live && e < seg && j0 + e < K;
+        col[e] = have[e] ? j0 + e : 0;
     }
     for (int k = 0; k < K; ++k) {
         const double d = src[k * MV_LD + k];
+        const double f = src[irow * MV_LD + k];
+        double pr[EA], own[EA];
+#pragma unroll
+        for (int e = 0; e < EA; ++e) {
+            pr[e] = src[k * MV_LD + col[e]];
+            own[e] = src[irow * MV_LD + col[e]];
+        }
         const double rd = 1.0 / d;
         if (threadIdx.x == 0) piv[k] = d;
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            if (off[e] < 0) continue;
-            const int i = ei[e], j = ej[e];
-            if (!FULL && (i <= k || j <= k)) continue;
-            const double r = src[k * MV_LD + j] * rd;
+        for (int e = 0; e < EA; ++e) {
+            const int j = col[e];
+            if (!have[e] || (!FULL && (i <= k || j <= k))) continue;
+            const double r = pr[e] * rd;
             double v;
             if (i == k) {
                 v = (j == k) ? rd : r;
             } else {
-                const double f = src[i * MV_LD + k];
-                v = (j == k) ? -f * rd : __builtin_fma(-f, r, src[off[e]]);
+                v = (j == k) ? -f * rd : __builtin_fma(-f, r, own[e]);
             }
-            dst[off[e]] = v;
+            dst[i * MV_LD + j] = v;
         }
         __syncthreads();
         double* t = src;
@@ -105,6 +105,18 @@ __device__ inline double* mv_eliminate(double* src, double* dst, double* piv, in
         dst = t;
     }
     return src;
+}
+template <int NT, bool FULL>
+__device__ inline double* mv_eliminate(double* src, double* dst, double* piv, int K) {
+    constexpr int E = NT >= 1024 ? 4 : 16;  // SEG at K = MV_KMAX
+    static_assert(NT == 256 || NT == 1024, "the side workgroup of the fused pass or a stand-alone kernel");
+    const int tpr = NT / K > 0 ? NT / K : 1;
+    const int seg = (K + tpr - 1) / tpr;  // (uniform)
+    if (E >= 16 && seg > 8) return mv_eliminate_n<NT, FULL, (E >= 16 ? 16 : E)>(src, dst, piv, K);
+    if (E >= 8 && seg > 4) return mv_eliminate_n<NT, FULL, (E >= 8 ? 8 : E)>(src, dst, piv, K);
+    if (seg > 2) return mv_eliminate_n<NT, FULL, 4>(src, dst, piv, K);
+    if (seg > 1) return mv_eliminate_n<NT, FULL, 2>(src, dst, piv, K);
+    return mv_eliminate_n<NT, FULL, 1>(src, dst, piv, K);
 }
 
 // log det = sum_k log(pivot_k), fixed order; piv (LDS, [K]) is overwritten, `slot` = one LDS double of the caller's
@@ -159,30 +171,33 @@ __device__ __forceinline__ void mv_prepare_W_body(const double* __restrict__ W, 
     S = mv_eliminate<NT, true>(S, T, piv, K);  // Y = (W W^T + delta I)^-1
     const double ld = mv_logdet_from_pivots(piv, K, piv + K);
     if (threadIdx.x == 0) *logdet_out = ld;
-    for (int idx = threadIdx.x; idx < K * V; idx += NT) {
-        int k = idx / V, v = idx - k * V;
-        double A = 0.0, B = 0.0;
-        int m = 0;
-        for (; m + 8 <= K; m += 8) {
-            double y[8], wv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                y[u] = S[(m + u) * MV_LD + k];
-                wv[u] = Wl[(m + u) * MV_WS + v];
+    // A = Y_minus W and B = |Y| W on the matrix cores: one 16 x 16 output tile (signatures x features) per wave at a time,
+    // both products side by side, the contraction over the K signatures in k-steps of 4 in order (entries beyond K are
+    // zero operands); operand A is the entry Y[m][k] of the inverse, transformed on the fly (mvnmf.py:50-51)
+    {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c16 = lane & 15, q = lane >> 4;
+        const int KT = (K + 15) / 16, VT6 = (V + 15) / 16, ksteps = (K + 3) / 4;
+        for (int t = wave; t < KT * VT6; t += NT / 64) {  // (uniform per wave)
+            const int ti = t / VT6, tj = t - ti * VT6;
+            const int krow = min(16 * ti + c16, K - 1), vcol = min(16 * tj + c16, V - 1);
+            mv_d4 accA = (mv_d4){0, 0, 0, 0}, accB = (mv_d4){0, 0, 0, 0};
+            for (int s2 = 0; s2 < ksteps; ++s2) {
+                const int m = 4 * s2 + q;
+                const bool in = m < K;
+                const double y = in ? S[m * MV_LD + krow] : 0.0;
+                const double wv = in ? Wl[m * MV_WS + vcol] : 0.0;
+                accA = __builtin_amdgcn_mfma_f64_16x16x4f64(fmax(0.0, -y), wv, accA, 0, 0, 0);
+                accB = __builtin_amdgcn_mfma_f64_16x16x4f64(fabs(y), wv, accB, 0, 0, 0);
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                A += wv[u] * fmax(0.0, -y[u]);
-                B += wv[u] * fabs(y[u]);
+            for (int r = 0; r < 4; ++r) {
+                const int k = 16 * ti + q + 4 * r, v = 16 * tj + c16;
+                if (k < K && v < V) {
+                    Aout[k * V + v] = accA[r];
+                    Bout[k * V + v] = accB[r];
+                }
             }
         }
-        for (; m < K; ++m) {
-            const double y = S[m * MV_LD + k], wv = Wl[m * MV_WS + v];
-            A += wv * fmax(0.0, -y);
-            B += wv * fabs(y);
-        }
-        Aout[idx] = A;
-        Bout[idx] = B;
     }
 }
 
