@@ -748,6 +748,35 @@ def test_engine_first_then_torch_one_rccl_and_a_working_communicator():
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.returncode, r.stdout[-500:], r.stderr[-2000:])
 
 
+# (K = 1 is left out: with one signature every normalised trial IS the current W, so the line search compares two values
+# that differ by rounding only -- the reference's own gamma there is noise, 0.026 after three steps)
+@pytest.mark.parametrize("K", [2, 3, 5, 8, 16, 17, 22, 23, 31, 33, 42, 43, 45, 50, 57, 64])
+def test_mvnmf_w_only_algebra_every_size(K):
+    """The K x K algebra of the MvNMF W step (Gram matrix and the A / B products on the matrix cores, Gauss-Jordan
+    elimination in runs of columns per thread: ``csrc/salnmf_mv_device.h``) at every size class of its work split, in the
+    spare workgroup of the update_H pass (256 threads: steps inside one call) and in the stand-alone kernels (1024
+    threads: single steps, objective): three steps against the oracle, log det through the objective."""
+    V, N = 96, 900
+    X, W0, H0 = orc.synthetic_problem(V, N, K, seed=100 + K)
+    lam, delta = 0.7, 0.3
+    a, b = Engine(N, V, K), Engine(N, V, K)
+    for e in (a, b):
+        e.upload_X(X), e.upload_W(W0), e.upload_H(H0)
+    assert np.isclose(a.mv_objective(lam, delta), orc.kl_divergence_penalized(X.T, W0.T, H0.T, lam, delta), rtol=1e-11)
+    W, H, g = W0.T, H0.T, 1.0
+    for _ in range(3):
+        W, H, g = orc.mvnmf_step(X.T, W, H, lam, delta, g, 0)
+    ga = a.mv_step(3, 0, lam, delta, 1.0)
+    gb = 1.0
+    for _ in range(3):
+        gb = b.mv_step(1, 0, lam, delta, gb)
+    assert np.isclose(ga, g, rtol=1e-12) and ga == gb
+    assert rel_l2(a.download_W(), W.T) < 1e-9 and rel_l2(a.download_H(), H.T) < 1e-9
+    assert np.array_equal(a.download_W(), b.download_W()) and np.array_equal(a.download_H(), b.download_H())
+    assert np.isclose(a.mv_objective(lam, delta), orc.kl_divergence_penalized(X.T, W, H, lam, delta), rtol=1e-10)
+    a.close(), b.close()
+
+
 def test_mvnmf_mixed_call_sequences_match_oracle():
     """State machine check: MvNMF steps leave H lazily rescaled, W / H buffers swapped and (inside a call) the next
     update_H pass possibly pre-computed; every other entry point in between must see the same state as the oracle."""
