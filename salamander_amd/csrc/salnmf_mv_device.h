@@ -86,19 +86,19 @@ __device__ __forceinline__ double* mv_eliminate_n(double* src, double* dst, doub
         }
         const double rd = 1.0 / d;
         if (threadIdx.x == 0) piv[k] = d;
+        const double nfrd = -f * rd;
 #pragma unroll
-        for (int e = 0; e < EA; ++e) {
+        for (int e = 0; e < EA; ++e) {  // (selects, no branches: the EA chains advance side by side)
             const int j = col[e];
-            if (!have[e] || (!FULL && (i <= k || j <= k))) continue;
             const double r = pr[e] * rd;
-            double v;
-            if (i == k) {
-                v = (j == k) ? rd : r;
-            } else {
-                v = (j == k) ? -f * rd : __builtin_fma(-f, r, own[e]);
-            }
-            dst[i * MV_LD + j] = v;
+            const double in_row_k = (j == k) ? rd : r;
+            const double elsewhere = (j == k) ? nfrd : __builtin_fma(-f, r, own[e]);
+            const double v = (i == k) ? in_row_k : elsewhere;
+            if (have[e] && (FULL || (i > k && j > k))) dst[i * MV_LD + j] = v;
         }
+        // (Keeping every thread's elements in registers and publishing only row / column k + 1 through LDS was measured
+        // slower -- 61 -> 75 us for the side workgroup at K = 50: the step is bound by the issue of the per-element mask
+        // and select logic, not by LDS traffic.)
         __syncthreads();
         double* t = src;
         src = dst;
