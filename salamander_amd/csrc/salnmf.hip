@@ -1336,6 +1336,7 @@ int salnmf_update_W(salnmf_engine* e, int n_given, int clip_mode) {
 
 static int fwd_params(salnmf_engine* e, FwdParams& p) {
     CK(ensure_xlogx(e));  // (mode 0 reads them; computed once per upload of X)
+    p = FwdParams{};
     p.X = e->X;
     p.H = e->H;
     p.W = e->W;
@@ -1354,7 +1355,11 @@ static int fwd_params(salnmf_engine* e, FwdParams& p) {
 
 // objective of (W, H[, hscale]) -> device scalar e->scal[slot] (all-reduced), no host sync
 // the forward passes of one objective evaluation -> e->objpart[0 .. *nparts): per-workgroup partials, to be summed in order
-static int objective_partials(salnmf_engine* e, const double* W, const double* hscale, bool weighted, int grid, int* nparts) {
+//   direct != nullptr: where the engine runs ONE forward launch per objective (one feature block, one signature chunk), that
+//   launch also adds its partials up (forward_kernel: sum_out) and stores the objective to *direct; bound to ev if given.
+//   *nparts == 0 then says that no reduction is left to do
+static int objective_partials(salnmf_engine* e, const double* W, const double* hscale, bool weighted, int grid, int* nparts,
+                              double* direct = nullptr, hipEvent_t ev = nullptr) {
     FwdParams p;
     CK(fwd_params(e, p));
     p.W = W;
@@ -1396,6 +1401,13 @@ static int objective_partials(salnmf_engine* e, const double* W, const double* h
             CK(launch_forward<0>(e, pb, fgrid));
         }
     } else {
+        if (direct) {
+            p.sum_out = direct;
+            p.sum_counter = e->klcnt + 1;  // (its own word: the MvNMF update_H pass's counter is word 0)
+            CK(launch_forward<0>(e, p, fgrid, nullptr, ev));
+            *nparts = 0;
+            return 0;
+        }
         CK(launch_forward<0>(e, p, fgrid));
     }
     *nparts = e->NB * fgrid;
@@ -1405,9 +1417,11 @@ static int objective_partials(salnmf_engine* e, const double* W, const double* h
 // objective of (W, H[, hscale]) -> device scalar *out (all-reduced), no host sync
 static int objective_to_ptr(salnmf_engine* e, const double* W, const double* hscale, bool weighted, double* out, int grid = 0) {
     int nparts = 0;
-    CK(objective_partials(e, W, hscale, weighted, grid, &nparts));
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, e->objpart, nparts, 1, 1, out);
-    HIPCK(hipGetLastError());
+    CK(objective_partials(e, W, hscale, weighted, grid, &nparts, out));
+    if (nparts > 0) {
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, e->objpart, nparts, 1, 1, out);
+        HIPCK(hipGetLastError());
+    }
     return allreduce(e, out, 1);
 }
 static int objective_to_slot(salnmf_engine* e, const double* W, const double* hscale, bool weighted, int slot, int grid = 0) {
@@ -1448,13 +1462,17 @@ int salnmf_objective_async(salnmf_engine* e, int slot) {
     // completion signal: the reader waits for THIS objective only, not for whatever was queued behind it (the next
     // block of steps), and no copy packet sits in the stream.  A sharded engine all-reduces the device copy first.
     int nparts = 0;
-    CK(objective_partials(e, e->W, nullptr, true, 0, &nparts));
     if (!sharded(e)) {
-        hipExtLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, nullptr, e->objev[slot], 0, e->objpart, nparts, 1, 1,
-                              e->objpin + slot, (const double*)nullptr);
-        HIPCK(hipGetLastError());
+        // (one forward launch per objective: it adds its partials up itself and its completion is the slot's event)
+        CK(objective_partials(e, e->W, nullptr, true, 0, &nparts, e->objpin + slot, e->objev[slot]));
+        if (nparts > 0) {
+            hipExtLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, nullptr, e->objev[slot], 0, e->objpart, nparts, 1, 1,
+                                  e->objpin + slot, (const double*)nullptr);
+            HIPCK(hipGetLastError());
+        }
         return 0;
     }
+    CK(objective_partials(e, e->W, nullptr, true, 0, &nparts));
     if (!e->objring) HIPCK(hipMalloc(&e->objring, SALNMF_OBJECTIVE_SLOTS * sizeof(double)));
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, e->objpart, nparts, 1, 1, e->objring + slot, (const double*)nullptr);
     HIPCK(hipGetLastError());

@@ -1462,6 +1462,11 @@ struct FwdParams {
     int ldw;                            // row stride of W (= V unless W points at one feature block of a wider matrix)
     int K;
     int64_t ntiles;
+    // mode 0, optional: the final sum inside the launch (the workgroup that finishes last adds the partials in the order of
+    // sum_partials_kernel -- the same bits -- plus sum_addend[0], and stores the objective): no reduction kernel behind it
+    double* sum_out;            // [1] or null (device or pinned host memory)
+    const double* sum_addend;   // [1] or null
+    unsigned* sum_counter;      // arrival counter, zero between launches
 };
 
 // Two workgroups per CU (two waves per SIMD): the objective terms are VALU-heavy and the loads
@@ -1635,7 +1640,35 @@ __global__ void __launch_bounds__(BLOCK, (fwd_lds_doubles<KS>() * 8 <= 80 * 1024
         if (tid == 0) {
             double s = 0.0;
             for (int i = 0; i < BLOCK; ++i) s += red[i];
-            p.out[blockIdx.x] = s;
+            if (MODE == 0 && p.sum_out != nullptr) {
+                // (cdna_hip_programming.md, guideline 16, counter form: write-through partial, drained, then the ticket)
+                __hip_atomic_store((gdouble*)(p.out + blockIdx.x), s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned ticket = __hip_atomic_fetch_add((gsync_t*)p.sum_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                red[0] = (ticket == gridDim.x - 1u) ? 1.0 : 0.0;
+            } else {
+                p.out[blockIdx.x] = s;
+            }
+        }
+        if (MODE == 0 && p.sum_out != nullptr) {
+            __syncthreads();
+            const bool last = red[0] != 0.0;  // (uniform)
+            __syncthreads();
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // (no instruction: keeps the loads below the ticket)
+                double sum = 0.0;
+                for (int i = tid; i < (int)gridDim.x; i += BLOCK) sum += ld_shared<true>(p.out + i);
+                red[tid] = sum;
+                __syncthreads();
+                for (int h = BLOCK / 2; h > 0; h >>= 1) {
+                    if (tid < h) red[tid] += red[tid + h];
+                    __syncthreads();
+                }
+                if (tid == 0) {
+                    p.sum_out[0] = p.sum_addend ? red[0] + p.sum_addend[0] : red[0];
+                    __hip_atomic_store((gsync_t*)p.sum_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         }
     }
 }
