@@ -297,6 +297,31 @@ def test_fit_queues_objectives_until_min_iterations_then_speculates(fake_engine,
     assert np.array_equal(q.asignatures.X, b.asignatures.X) and np.array_equal(q.adata.obsm["exposures"], b.adata.obsm["exposures"])
 
 
+@pytest.mark.parametrize(
+    "min_it,max_it,freq,tol",
+    [(0, 5, 10, 1e-4), (1, 1, 1, 1e-4), (0, 0, 10, 1e-4), (5, 37, 10, 1e-9), (40, 400, 10, 1e-4), (40, 400, 7, 1e-3), (0, 400, 1, 1e-4),
+     (30, 30, 10, 1e-4), (25, 1000, 10, 1e-2), (10, 10000, 10, 1e-3), (3, 50, 3, 0.0)],
+)
+def test_queued_loop_equals_blocking_loop_over_the_parameter_space(fake_engine, counts, min_it, max_it, freq, tol):
+    """signature_nmf.py:358-385 has corner cases (cap below the test frequency, a cap that is no multiple of it, a zero
+    cap, tolerance hit at the first permitted test): the queued loop -- objectives folded into the following block,
+    speculative kept blocks, rollback -- stops at the same iteration with the same history and factors as the blocking one."""
+    X = counts.T.values.astype(float)
+    S0, E0 = init.initialize_mat(X.clip(utils.EPSILON), 2, "random", seed=5)
+    kw = dict(min_iterations=min_it, max_iterations=max_it, conv_test_freq=freq, tol=tol)
+    fits = []
+    for verbose in (0, 1):
+        m = sal.models.KLNMF(2, "custom", **kw)
+        m.fit(make_adata(counts), init_kwargs={"signatures_mat": S0.copy(), "exposures_mat": E0.copy()}, verbose=verbose, verbosity_freq=10**9)
+        fits.append(m)
+    q, b = fits
+    assert q.n_iterations_ == b.n_iterations_ and q.history["objective_function"] == b.history["objective_function"]
+    assert np.array_equal(q.asignatures.X, b.asignatures.X) and np.array_equal(q.adata.obsm["exposures"], b.adata.obsm["exposures"])
+    assert getattr(q._engine, "blocking_objectives", 0) == 0
+    W, H, it, hist = orc.fit_klnmf(X.T, S0.T, E0.T, **kw)
+    assert it == q.n_iterations_ and np.allclose(q.history["objective_function"], hist, rtol=1e-13)
+
+
 def test_fit_objective_ring_wraps(fake_engine, counts):
     """More queued objectives than the device ring has slots (256): the loop drains the ring when it is full."""
     m = sal.models.KLNMF(2, "flat", min_iterations=1100, max_iterations=1100, conv_test_freq=1)
