@@ -777,6 +777,26 @@ def test_mvnmf_w_only_algebra_every_size(K):
     a.close(), b.close()
 
 
+def test_mvnmf_model_fit_with_a_tolerance_stop_matches_the_oracle_fit():
+    """``MvNMF.fit`` over many blocks of ``conv_test_freq`` steps: the objectives are the line search's accepted values
+    (``mv_step_objective``) and the engine stays ahead between the blocks (``more_follows``) -- same stopping iteration,
+    history and factors as the restated reference loop (mvnmf.py:197-210 inside signature_nmf.py:358-385), then a second
+    fit on the same model object (no state of the first one may leak)."""
+    V, N, K = 96, 3000, 6
+    X, W0, H0 = orc.synthetic_problem(V, N, K, seed=21)
+    kw = dict(min_iterations=20, max_iterations=600, conv_test_freq=10, tol=1e-4)
+    lam, delta = 1.0, 1.0
+    W, H, _, it, hist = orc.fit_mvnmf(X.T, W0.T, H0.T, lam, delta, **kw)
+    assert 20 < it < 600
+    m = sal.models.MvNMF(K, "custom", lam, delta, **kw)
+    for _ in range(2):
+        m.fit(sal.AnnData(X.copy()), init_kwargs={"signatures_mat": W0.copy(), "exposures_mat": H0.copy()})
+        # (tolerances of the MvNMF goldens: the K x K inverse by elimination instead of LU moves the trajectory at 1e-9)
+        assert m.n_iterations_ == it and np.allclose(m.history["objective_function"], hist, rtol=1e-7)
+        assert rel_l2(m.asignatures.X, W.T) < 1e-6 and rel_l2(m.adata.obsm["exposures"], H.T) < 1e-6
+        assert np.isclose(m.objective_function(), m.history["objective_function"][-1], rtol=1e-12)  # (a pass of its own vs the step's value)
+
+
 def test_mvnmf_mixed_call_sequences_match_oracle():
     """State machine check: MvNMF steps leave H lazily rescaled, W / H buffers swapped and (inside a call) the next
     update_H pass possibly pre-computed; every other entry point in between must see the same state as the oracle."""
