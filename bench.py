@@ -290,22 +290,32 @@ def problem_rows(start, stop):
     return np.concatenate(Xs), np.concatenate(Hs)
 
 
-def validate_exchange(engine, dist, W0, H0, local_rank, steps=3):
-    """A few steps from the same start through RCCL and through the peer-to-peer exchange: W must agree to rounding
-    (the two add the ranks' numerators in different orders) and, with the exchange, be bit-identical on all ranks."""
+def validate_exchange(engine, dist, W0, H0, local_rank, steps=3, reference="rccl"):
+    """A few steps from the same start through the reference collective and through the peer-to-peer exchange: W must
+    agree to rounding (the two add the ranks' numerators in different orders) and, with the exchange, be bit-identical on
+    all ranks.  The reference is the engine's RCCL communicator, or -- where that could not be created -- the split step
+    with ``torch.distributed.all_reduce`` between its halves (``reference="host"``)."""
     import torch
 
-    out = {"p2p_valid": False, "validation_steps": steps}
+    out = {"p2p_valid": False, "validation_steps": steps, "validated_against": reference}
     rel, digest, good = float("inf"), 0.0, 0.0
+    W, failure = {}, None
+    # (the host-collective reference calls torch.distributed: it runs outside the try block, on every rank alike)
+    if reference == "host":
+        from salamander_amd.distributed import HostCollectiveAdapter, host_collective_steps
+
+        engine.upload_W(W0)  # (the split step exchanges nothing itself: the collective between its halves is torch's)
+        engine.upload_H(H0)
+        host_collective_steps(HostCollectiveAdapter(engine), steps)
+        W["ref"] = engine.download_W()
     try:  # (no torch.distributed call inside: a rank that fails must still meet the others in the all-reduce below)
-        W = {}
-        for mode in ("rccl", "p2p"):
+        for mode in (("rccl", "p2p") if reference == "rccl" else ("p2p",)):
             engine.set_p2p(mode == "p2p")
             engine.upload_W(W0)
             engine.upload_H(H0)
             engine.kl_step(steps)
-            W[mode] = engine.download_W()
-        rel = float(np.linalg.norm(W["p2p"] - W["rccl"]) / np.linalg.norm(W["rccl"]))
+            W["ref" if mode == "rccl" else mode] = engine.download_W()
+        rel = float(np.linalg.norm(W["p2p"] - W["ref"]) / np.linalg.norm(W["ref"]))
         digest = float(np.frombuffer(W["p2p"].tobytes(), dtype=np.uint32).astype(np.uint64).sum() % (1 << 52))
         good = 1.0 if rel < 1e-11 else 0.0
     except RuntimeError as exc:  # e.g. an exchange that gave up waiting for a peer
@@ -332,6 +342,7 @@ def main():
     ap.add_argument("--no-one-gpu-reference", action="store_true", help="N > 1: skip rank 0's run of the whole problem on one GPU")
     ap.add_argument("--busy-seconds", type=float, default=2.5, help="repeat the K-step block until the GPU was busy this long")
     ap.add_argument("--no-p2p", action="store_true", help="N > 1: RCCL all-reduce only, do not try the peer-to-peer exchange")
+    ap.add_argument("--simulate-no-rccl", action="store_true", help="rehearsal aid: behave as if the engine's RCCL communicator could not be created")
     ap.add_argument("--rehearse-sharded", action="store_true",
                     help="--gpus 1 only: run the N > 1 code path (process group, RCCL communicator in the engine, c3's row blocks, "
                     "one-GPU reference) at world size 1 -- a rehearsal of what the driver launches on a multi-GPU node")
@@ -382,10 +393,24 @@ def main():
         X, W0, H0 = synthetic_problem(V, n_local, K, seed=rank)
 
     engine = sal.Engine(n_local, V, K, device=local_rank)
+    rccl_ok = True
     if sharded:
         from salamander_amd.distributed import attach_communicator, broadcast_from_rank0
 
-        attach_communicator(engine)
+        # the engine's own RCCL communicator; if it cannot be created (on any rank) the run goes on with the peer-to-peer
+        # exchange alone, cross-checked against torch.distributed instead
+        err = None
+        try:
+            if args.simulate_no_rccl:
+                raise RuntimeError("simulated: no RCCL communicator (--simulate-no-rccl)")
+            attach_communicator(engine)
+        except RuntimeError as exc:
+            err = str(exc)
+        flags = [None] * world
+        dist.all_gather_object(flags, err)
+        rccl_ok = all(f is None for f in flags)
+        if not rccl_ok and rank == 0:
+            print(f"[bench] no RCCL communicator in the engine ({next(f for f in flags if f)}); peer-to-peer exchange only", file=sys.stderr)
         W0 = broadcast_from_rank0(W0)
     engine.upload_X(X)
     engine.upload_W(W0)
@@ -394,16 +419,20 @@ def main():
     # (salnmf_p2p_kernels.h).  Both are run; the exchange's result is checked against the RCCL result before it is timed,
     # and the line reports the faster VALID mode as `value` with both timings under config.exchange.
     exchange = None
-    if sharded and not args.no_p2p:
+    if sharded and not (args.no_p2p and rccl_ok):
         from salamander_amd.distributed import attach_peer_exchange
 
-        exchange = {"p2p_connected": bool(attach_peer_exchange(engine, n_total, required=False))}
+        exchange = {"p2p_connected": bool(attach_peer_exchange(engine, n_total, required=False)), "rccl_communicator": rccl_ok}
         if exchange["p2p_connected"]:
-            exchange.update(validate_exchange(engine, dist, W0, H0, local_rank))
-            if not exchange["p2p_valid"]:
+            exchange.update(validate_exchange(engine, dist, W0, H0, local_rank, reference="rccl" if rccl_ok else "host"))
+            if not exchange["p2p_valid"] and rccl_ok:
                 engine.set_p2p(False)
             engine.upload_W(W0)
             engine.upload_H(H0)
+        if not rccl_ok and not (exchange["p2p_connected"] and exchange.get("p2p_valid")):
+            raise SystemExit("bench: neither the engine's RCCL communicator nor a valid peer-to-peer exchange is available on this node")
+        if not rccl_ok:
+            engine.set_p2p(True)
 
     def barrier():
         engine.sync()
@@ -448,7 +477,10 @@ def main():
 
     first, n_blocks, blocks, median = timed_blocks()
     exchange_mode = "rccl" if sharded else None
-    if exchange is not None and exchange.get("p2p_valid"):
+    if exchange is not None and exchange.get("p2p_valid") and not rccl_ok:
+        exchange["p2p_ms_per_step"] = median / args.steps * 1e3
+        exchange_mode = "p2p"
+    elif exchange is not None and exchange.get("p2p_valid"):
         # the blocks above ran with the peer-to-peer exchange; the same protocol once more through RCCL
         exchange["p2p_ms_per_step"] = median / args.steps * 1e3
         engine.set_p2p(False)
