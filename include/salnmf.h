@@ -157,6 +157,15 @@ int salnmf_reconstruct(salnmf_engine* e, double* out);
  * line_search (:69-92).  gamma_inout carries MvNMF._gamma across calls. */
 int salnmf_mv_step(salnmf_engine* e, int n_steps, int n_given, double lam, double delta,
                    double* gamma_inout);
+/* The pieces of the W step as the reference exposes them (function-level API of mvnmf.py):
+ *   salnmf_mv_logdet                  volume_logdet (mvnmf.py:19-24) of the resident W
+ *   salnmf_mv_update_W_unconstrained  update_W_unconstrained (:37-66) from the resident (X, W, H) -> Wunc_out [K][V];
+ *                                     the resident state is not changed
+ *   salnmf_mv_line_search             line_search (:69-92) from the resident (X, W, H) with the caller's
+ *                                     W_unconstrained [K][V]: leaves the accepted W and the rescaled H resident, updates gamma */
+int salnmf_mv_logdet(salnmf_engine* e, double delta, double* out);
+int salnmf_mv_update_W_unconstrained(salnmf_engine* e, int n_given, double lam, double delta, double* Wunc_out);
+int salnmf_mv_line_search(salnmf_engine* e, double lam, double delta, double* gamma_inout, const double* Wunc);
 /* salnmf_mv_step that also returns MvNMF.objective_function (mvnmf.py:149-156) of the state it leaves behind: the line
  * search of the last step has evaluated exactly that (its accepted f, mvnmf.py:82-89), so a fit loop that tests
  * convergence after a block of steps (signature_nmf.py:373-380) needs no salnmf_mv_objective call -- one forward pass, one

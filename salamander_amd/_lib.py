@@ -56,6 +56,9 @@ SIGNATURES = {
     "salnmf_samplewise_kl": (c_int, [_P, _D]),
     "salnmf_reconstruct": (c_int, [_P, _D]),
     "salnmf_mv_step": (c_int, [_P, c_int, c_int, c_double, c_double, _D]),
+    "salnmf_mv_logdet": (c_int, [_P, c_double, _D]),
+    "salnmf_mv_update_W_unconstrained": (c_int, [_P, c_int, c_double, c_double, _D]),
+    "salnmf_mv_line_search": (c_int, [_P, c_double, c_double, _D, _D]),
     "salnmf_mv_step_objective": (c_int, [_P, c_int, c_int, c_double, c_double, _D, _D, c_int]),
     "salnmf_mv_update_W": (c_int, [_P, c_int, c_double, c_double, _D]),
     "salnmf_mv_objective": (c_int, [_P, c_double, c_double, _D]),

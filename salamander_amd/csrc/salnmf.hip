@@ -1714,14 +1714,28 @@ static int mv_tail(salnmf_engine* e, bool with_root, double lam, int n_given, hi
 //            preceding update_H pass); otherwise mv_prepare_W_kernel is started on stream2 here and waited for
 //   g_ready:  (in) the numerator pass of THIS step was queued by the previous call's speculation (its tail was not)
 static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double delta, double* gamma, bool have_hsum, bool w_ready,
-                            bool speculate = false, bool* speculated = nullptr, bool g_ready = false, double* f_accepted = nullptr) {
+                            bool speculate = false, bool* speculated = nullptr, bool g_ready = false, double* f_accepted = nullptr,
+                            double* wunc_out = nullptr, const double* wunc_given = nullptr) {
+    // wunc_out (salnmf_mv_update_W_unconstrained): stop behind the closed-form root and hand W_unconstrained back; the
+    // resident state is not changed.  wunc_given (salnmf_mv_line_search): the line search of mvnmf.py:69-92 from the
+    // resident (W, H) with the caller's W_unconstrained instead of the root.
     // f_accepted: the line search's value at the accepted point (mvnmf.py:82,89), which IS the model's objective of the
     // state this call leaves behind (kl_divergence_penalized of the normalised W and the rescaled H, mvnmf.py:27-34,149-156)
     if (speculated) *speculated = false;
     if (n_given >= e->K) return 0;
     CK(ensure_side_streams(e));
     const int K = e->K, V = e->V;
-    if (!g_ready) {
+    if (wunc_given) {
+        CK(flush_H_scale(e));
+        HIPCK(hipMemcpyAsync(e->Wunc, wunc_given, (size_t)K * V * sizeof(double), hipMemcpyHostToDevice, e->stream));
+        // f0 = KL(X || W H) + lam log det(W W^T + delta I) -> scal[1]  (mvnmf.py:79)
+        CK(objective_to_slot(e, e->W, nullptr, false, 0));
+        CK(mv_logdet_to_slot(e, e->W, delta, 3));
+        hipLaunchKernelGGL(combine_scalar_kernel, dim3(1), dim3(1), 0, e->stream, e->scal + 1, (const double*)e->scal, lam, (const double*)(e->scal + 3));
+        HIPCK(hipGetLastError());
+        HIPCK(hipStreamSynchronize(e->stream));  // (the caller's array is free again)
+    }
+    if (!g_ready && !wunc_given) {
         CK(flush_H_scale(e));  // a stand-alone call after an earlier step; inside mv_step the update_H pass consumed it
         if (!w_ready) CK(mv_start_prepare_W(e, delta, true));
         // the rowsums_H partials come from the preceding update_H pass (have_hsum) or, for a stand-alone _update_W,
@@ -1738,11 +1752,11 @@ static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double de
     // the tail runs after the line-search decision and can carry the closed-form root and the first trial of THIS step
     // in the same launch (inside mv_step on an unsharded engine: one kernel and one boundary less per step).  A, B and
     // the log det it reads come from the side workgroup of the preceding update_H pass (same stream), or from stream2.
-    const bool root_in_tail = have_hsum && !sharded(e);
-    if (!w_ready) HIPCK(hipStreamWaitEvent(e->stream, e->evPrepW, 0));
+    const bool root_in_tail = have_hsum && !sharded(e) && !wunc_given;
+    if (!w_ready && !wunc_given) HIPCK(hipStreamWaitEvent(e->stream, e->evPrepW, 0));
     // (a non-speculative first trial is followed by the log det of the trial on stream2: the tail's completion is its event)
-    CK(mv_tail(e, root_in_tail, lam, n_given, root_in_tail && !speculate ? e->evTrial : nullptr));
-    if (!root_in_tail) {
+    if (!wunc_given) CK(mv_tail(e, root_in_tail, lam, n_given, root_in_tail && !speculate ? e->evTrial : nullptr));
+    if (!root_in_tail && !wunc_given) {
         // the rowsums_H partials came from the preceding update_H pass (have_hsum) or, for a stand-alone _update_W,
         // come from a column-sum kernel over the current H
         if (!have_hsum) {
@@ -1763,6 +1777,9 @@ static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double de
             ;  // (done by the tail launch above)
         else if (spec)
             hipLaunchKernelGGL(mv_trial_light_kernel<true>, dim3(1), dim3(MV_BLOCK), 0, e->stream, e->W, e->Wunc, 1.0, 0, K, V, e->Wtrial, e->cs, root);
+        else if (!blend && wunc_given)  // the first trial is the caller's W_unconstrained, normalised and clipped (mvnmf.py:80-81)
+            LAUNCH_WITH_EVENT(mv_trial_light_kernel<false>, dim3(1), dim3(MV_BLOCK), e->stream, e->evTrial, e->W, e->Wunc, 1.0, 0, K,
+                              V, e->Wtrial, e->cs, root);
         else if (!blend)
             LAUNCH_WITH_EVENT(mv_trial_light_kernel<true>, dim3(1), dim3(MV_BLOCK), e->stream, e->evTrial, e->W, e->Wunc, 1.0, 0, K,
                               V, e->Wtrial, e->cs, root);
@@ -1770,6 +1787,7 @@ static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double de
             LAUNCH_WITH_EVENT(mv_trial_light_kernel<false>, dim3(1), dim3(MV_BLOCK), e->stream, e->evTrial, e->W, e->Wunc, g, 1, K, V,
                               e->Wtrial, e->cs, root);
         HIPCK(hipGetLastError());
+        if (wunc_out) return download(e, wunc_out, e->Wunc, (size_t)K * V);  // (W, H untouched; the trial buffers are scratch)
         double v[5];
         if (spec) {
             if (!e->Halt) HIPCK(hipMalloc(&e->Halt, (size_t)e->Np * e->KP * sizeof(double)));
@@ -1853,6 +1871,32 @@ int salnmf_mv_update_W(salnmf_engine* e, int n_given, double lam, double delta, 
     e->keep_valid = false;  // (the MvNMF steps use the second H buffer themselves)
     CK(enter(e));
     return mv_update_W_impl(e, n_given, lam, delta, gamma_inout, false, false);
+}
+
+int salnmf_mv_logdet(salnmf_engine* e, double delta, double* out) {
+    if (e && split(e)) return single_block(e, "MvNMF");
+    if (!e || !out) return fail("null argument");
+    CK(enter(e));
+    CK(mv_logdet_to_slot(e, e->W, delta, 3));
+    return read_scalars(e, 3, 1, out);
+}
+
+int salnmf_mv_update_W_unconstrained(salnmf_engine* e, int n_given, double lam, double delta, double* Wunc_out) {
+    if (e && split(e)) return single_block(e, "MvNMF");
+    if (!e || !Wunc_out) return fail("null argument");
+    if (n_given < 0 || n_given > e->K) return fail("n_given out of range");
+    CK(enter(e));
+    if (n_given >= e->K) return download(e, Wunc_out, e->W, (size_t)e->K * e->V);  // every column given: W itself (mvnmf.py:61)
+    double gamma = 1.0;
+    return mv_update_W_impl(e, n_given, lam, delta, &gamma, false, false, false, nullptr, false, nullptr, Wunc_out, nullptr);
+}
+
+int salnmf_mv_line_search(salnmf_engine* e, double lam, double delta, double* gamma_inout, const double* Wunc) {
+    if (e && split(e)) return single_block(e, "MvNMF");
+    if (!e || !gamma_inout || !Wunc) return fail("null argument");
+    e->keep_valid = false;
+    CK(enter(e));
+    return mv_update_W_impl(e, 0, lam, delta, gamma_inout, false, false, false, nullptr, false, nullptr, nullptr, Wunc);
 }
 
 int salnmf_mv_step(salnmf_engine* e, int n_steps, int n_given, double lam, double delta, double* gamma_inout) {

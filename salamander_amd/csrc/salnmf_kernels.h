@@ -1825,6 +1825,10 @@ __global__ void __launch_bounds__(256) sum_partials_kernel(const double* __restr
 
 // one double, device -> (pinned) host, as a kernel: its completion signal carries the event the reader waits for
 __global__ void copy_scalar_kernel(double* __restrict__ dst, const double* __restrict__ src) { *dst = *src; }
+// out = a + lam * b (the penalised objective from its two parts, mvnmf.py:27-34)
+__global__ void combine_scalar_kernel(double* __restrict__ out, const double* __restrict__ a, double lam, const double* __restrict__ b) {
+    *out = *a + lam * *b;
+}
 
 // c[n] = sum_v (x log x - x) over the features of sample n (0 where x == 0): the x-only part of the KL divergence
 // (tile_kl), once per upload of X.  Library log: any x the reference accepts.  X is [Np][ldx], pad rows are 0.

@@ -190,6 +190,26 @@ class Engine:
                                                       1 if more_follows else 0))
         return g.value, f.value
 
+    def mv_logdet(self, delta: float) -> float:
+        """``volume_logdet`` (mvnmf.py:19-24) of the resident signatures."""
+        out = c_double()
+        _lib.check(self._lib.salnmf_mv_logdet(self._h, float(delta), ctypes.byref(out)))
+        return out.value
+
+    def mv_update_W_unconstrained(self, n_given: int, lam: float, delta: float) -> np.ndarray:
+        """``update_W_unconstrained`` (mvnmf.py:37-66) from the resident state: ``(K, V)``; nothing resident changes."""
+        out = np.empty((self.K, self.V), dtype=np.float64)
+        _lib.check(self._lib.salnmf_mv_update_W_unconstrained(self._h, int(n_given), float(lam), float(delta), _ptr(out)))
+        return out
+
+    def mv_line_search(self, lam: float, delta: float, gamma: float, W_unconstrained) -> float:
+        """``line_search`` (mvnmf.py:69-92) from the resident state with the given ``W_unconstrained (K, V)``; the accepted
+        W and the rescaled H stay resident, the new gamma is returned."""
+        Wu = _as_c(W_unconstrained, (self.K, self.V), "W_unconstrained")
+        g = c_double(gamma)
+        _lib.check(self._lib.salnmf_mv_line_search(self._h, float(lam), float(delta), ctypes.byref(g), _ptr(Wu)))
+        return g.value
+
     def mv_update_W(self, n_given: int, lam: float, delta: float, gamma: float) -> float:
         g = c_double(gamma)
         _lib.check(self._lib.salnmf_mv_update_W(self._h, int(n_given), float(lam), float(delta), ctypes.byref(g)))

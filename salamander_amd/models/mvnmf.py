@@ -11,7 +11,52 @@ from __future__ import annotations
 
 from typing import Any, Literal
 
+import numpy as np
+
+from ._utils_klnmf import _engine_for
 from .standard_nmf import StandardNMF
+
+
+# -- the function-level entry points of the reference module, on the device: same names, argument order and shapes
+# (X (V, N), W (V, K), H (K, N)) as src/salamander/models/mvnmf.py:19-92.  Each call uploads its arguments to a fresh engine
+# and downloads the result; inputs are never modified.  The device-resident loop lives in MvNMF.fit.
+def volume_logdet(W: np.ndarray, delta: float) -> float:
+    """``log det(W^T W + delta I)`` (mvnmf.py:19-24)."""
+    W = np.asarray(W, dtype=np.float64)
+    V, K = W.shape
+    e = _engine_for(np.ones((V, 1)), W, np.ones((K, 1)))
+    try:
+        return e.mv_logdet(delta)
+    finally:
+        e.close()
+
+
+def kl_divergence_penalized(X: np.ndarray, W: np.ndarray, H: np.ndarray, lam: float, delta: float) -> float:
+    """``KL(X || W H) + lam * volume_logdet(W, delta)`` (mvnmf.py:27-34)."""
+    e = _engine_for(X, W, H)
+    try:
+        return e.mv_objective(lam, delta)
+    finally:
+        e.close()
+
+
+def update_W_unconstrained(X: np.ndarray, W: np.ndarray, H: np.ndarray, lam: float, delta: float, n_given_signatures: int = 0) -> np.ndarray:
+    """The closed-form root of the min-volume W step before the line search (mvnmf.py:37-66): ``(V, K)``."""
+    e = _engine_for(X, W, H)
+    try:
+        return e.mv_update_W_unconstrained(n_given_signatures, lam, delta).T
+    finally:
+        e.close()
+
+
+def line_search(X: np.ndarray, W: np.ndarray, H: np.ndarray, lam: float, delta: float, gamma: float, W_unconstrained: np.ndarray):
+    """Backtracking between ``W`` and ``W_unconstrained`` (mvnmf.py:69-92): ``(W_new, H_new, gamma)``."""
+    e = _engine_for(X, W, H)
+    try:
+        gamma = e.mv_line_search(lam, delta, gamma, np.asarray(W_unconstrained, dtype=np.float64).T)
+        return e.download_W().T, e.download_H().T, gamma
+    finally:
+        e.close()
 
 
 class MvNMF(StandardNMF):
@@ -52,6 +97,17 @@ class MvNMF(StandardNMF):
         self._sync_to_device()
         self._engine.update_H()
         self.adata.obsm["exposures"] = self._engine.download_H()
+
+    def _update_W_unconstrained(self, n_given_signatures: int = 0) -> np.ndarray:
+        """``(V, K)``, as the reference's hook returns it (mvnmf.py:167-175)."""
+        self._sync_to_device()
+        return self._engine.mv_update_W_unconstrained(n_given_signatures, self.lam, self.delta).T
+
+    def _line_search(self, W_unconstrained: np.ndarray) -> None:
+        """mvnmf.py:177-188: updates the signatures, the exposures and ``_gamma``."""
+        self._sync_to_device()
+        self._gamma = self._engine.mv_line_search(self.lam, self.delta, self._gamma, np.asarray(W_unconstrained, dtype=np.float64).T)
+        self._sync_from_device()
 
     def _update_W(self, n_given_signatures: int = 0) -> None:
         if n_given_signatures == self.n_signatures:

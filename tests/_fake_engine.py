@@ -108,6 +108,17 @@ class FakeEngine:
         gamma = self.mv_step(n_steps, n_given, lam, delta, gamma)
         return gamma, self.mv_objective(lam, delta)
 
+    def mv_logdet(self, delta):
+        return orc.volume_logdet(self.W.T, delta)
+
+    def mv_update_W_unconstrained(self, n_given, lam, delta):
+        return orc.update_W_unconstrained(self.X.T, self.W.T, self.H.T, lam, delta, n_given).T.copy()
+
+    def mv_line_search(self, lam, delta, gamma, W_unconstrained):
+        W, H, gamma = orc.line_search(self.X.T, self.W.T, self.H.T, lam, delta, gamma, np.asarray(W_unconstrained).T)
+        self.W, self.H = W.T.copy(), H.T.copy()
+        return gamma
+
     def mv_update_W(self, n_given, lam, delta, gamma):
         Wu = orc.update_W_unconstrained(self.X.T, self.W.T, self.H.T, lam, delta, n_given)
         W, H, gamma = orc.line_search(self.X.T, self.W.T, self.H.T, lam, delta, gamma, Wu)

@@ -777,6 +777,41 @@ def test_mvnmf_w_only_algebra_every_size(K):
     a.close(), b.close()
 
 
+@pytest.mark.parametrize("tag", ["a", "g", "bt1", "bt2"])
+def test_mvnmf_function_level_api(golden, tag):
+    """The module-level functions of the reference's ``mvnmf.py`` (``volume_logdet``, ``kl_divergence_penalized``,
+    ``update_W_unconstrained``, ``line_search``: :19-92) with the reference's argument order and shapes, and the model's
+    private hooks ``_update_W_unconstrained`` / ``_line_search`` (:167-188), against the oracle -- on the golden cases,
+    two of which backtrack."""
+    from salamander_amd.models import mvnmf
+
+    g = golden.mv
+    lam, delta, _, ng = g[f"{tag}_par"]
+    ng = int(ng)
+    X, W, H = g[f"{tag}_X"], g[f"{tag}_W0"], g[f"{tag}_H0"]
+    assert np.isclose(mvnmf.volume_logdet(W, delta), orc.volume_logdet(W, delta), rtol=1e-12)
+    assert np.isclose(mvnmf.kl_divergence_penalized(X, W, H, lam, delta), orc.kl_divergence_penalized(X, W, H, lam, delta), rtol=1e-11)
+    H1 = orc.update_H(X, W, H)
+    Wu = mvnmf.update_W_unconstrained(X, W, H1, lam, delta, ng)
+    Wu_ref = orc.update_W_unconstrained(X, W, H1, lam, delta, ng)
+    # (the K x K inverse by elimination instead of LU: 1e-11 .. 1e-10 on these cases)
+    assert Wu.shape == W.shape and rel_l2(Wu, Wu_ref) < 1e-9 and np.array_equal(Wu[:, :ng], W[:, :ng])
+    for gamma in (1.0, 0.37):
+        Wn, Hn, gn = mvnmf.line_search(X, W, H1, lam, delta, gamma, Wu_ref)
+        Wr, Hr, gr = orc.line_search(X, W, H1, lam, delta, gamma, Wu_ref)
+        assert np.isclose(gn, gr, rtol=1e-12) and rel_l2(Wn, Wr) < 1e-12 and rel_l2(Hn, Hr) < 1e-12
+    # the model's hooks: _update_W == _update_W_unconstrained + _line_search
+    a, b = (sal.models.MvNMF(W.shape[1], lam=lam, delta=delta) for _ in range(2))
+    for m in (a, b):
+        m.adata = sal.AnnData(X.T.copy())
+        m.asignatures = sal.AnnData(W.T.copy())
+        m.adata.obsm["exposures"] = H1.T.copy()
+    a._update_W(ng)
+    b._line_search(b._update_W_unconstrained(ng))
+    assert a._gamma == b._gamma and rel_l2(b.asignatures.X, a.asignatures.X) < 1e-13
+    assert rel_l2(b.adata.obsm["exposures"], a.adata.obsm["exposures"]) < 1e-13
+
+
 def test_mvnmf_model_fit_with_a_tolerance_stop_matches_the_oracle_fit():
     """``MvNMF.fit`` over many blocks of ``conv_test_freq`` steps: the objectives are the line search's accepted values
     (``mv_step_objective``) and the engine stays ahead between the blocks (``more_follows``) -- same stopping iteration,
