@@ -54,6 +54,15 @@ def samplewise_kl_divergence(X, W, H, weights=None) -> np.ndarray:
     return errors
 
 
+def poisson_llh(X, W, H) -> float:
+    """Poisson log-likelihood generalised to non-negative real counts, log-factorial terms included (:136-160)."""
+    e = _engine_for(X, W, H)
+    try:
+        return e.corr_poisson_llh()
+    finally:
+        e.close()
+
+
 def update_W(X, W, H, weights_kl=None, n_given_signatures: int = 0) -> np.ndarray:
     """W step, clipping only the non-given columns (:164-217)."""
     e = _engine_for(X, W, H, weights_kl, None)

@@ -67,6 +67,10 @@ def test_samplewise_kl_divergence(matrices_input, n_signatures, weights_kl):
     assert np.allclose(got[0], 3 * want[0]) and np.allclose(got[1:], 2 * want[1:])
 
 
+def test_poisson_llh(matrices_input, n_signatures):
+    assert np.allclose(_utils_klnmf.poisson_llh(*matrices_input), _load("poisson_llh", n_signatures))
+
+
 def test_update_W(matrices_input, n_signatures, weights_kl):
     want = _load("W_updated_standard", n_signatures)
     assert np.allclose(_utils_klnmf.update_W(*matrices_input), want)
