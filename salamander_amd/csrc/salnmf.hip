@@ -467,6 +467,10 @@ static int flush_H_scale(salnmf_engine* e) {
 //   reduced by an extra workgroup of the tail launch straight into slot obj_slot of the pinned ring, and the slot's event
 //   is that launch's completion signal.  Unweighted, unsharded, n_given < K (salnmf_kl_step_objective checks).
 static int kl_step_once(salnmf_engine* e, int n_given, hipEvent_t* ev, bool keep = false, int obj_slot = -1) {
+    struct ResetWdst {  // (a kept step redirects the W tail for the duration of this call only, also when a launch fails)
+        salnmf_engine* e;
+        ~ResetWdst() { e->Wdst = nullptr; }
+    } reset_wdst{e};
     FusedParams p = fused_params(e);
     const bool all_given = n_given >= e->K;  // _utils_klnmf.py:330-331: W untouched
     if (obj_slot >= 0) {
