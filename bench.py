@@ -251,6 +251,44 @@ def extra_fast_mode(sal, device):
     }
 
 
+def extra_c5(sal, device):
+    """Config c5 on ONE GPU: MultimodalCorrNMF, (96 + 83) x 200 000 counts, 40 + 40 signatures, dim_embeddings 40 --
+    whole device-resident updates (mmcorrnmf.py:430-470: scalings, exposures, aux, signature and sample embedding solves,
+    variance, signatures), the first two (allocations) left out."""
+    from salamander_amd.models import MultimodalCorrNMF
+    from salamander_amd.synthetic import synthetic_problem
+
+    N5 = 200000
+    Xa, _, _ = synthetic_problem(96, N5, 40, seed=1)
+    Xb, _, _ = synthetic_problem(83, N5, 40, seed=2)
+    mdata = sal.MuData({"sbs": sal.AnnData(Xa), "indel": sal.AnnData(Xb)})
+    np.random.seed(0)
+    model = MultimodalCorrNMF(ns_signatures=[40, 40], dim_embeddings=40, init_method="random", device=device)
+    model._setup_mdata(mdata)
+    model._initialize(None, {"seed": 0})
+    model._sync_to_device()
+    engines = list(model._engines.values())
+    steps = []
+    for _ in range(8):
+        for e in engines:
+            e.sync()
+        t0 = time.perf_counter()
+        model._device_steps(1, None)
+        for e in engines:
+            e.sync()
+        steps.append((time.perf_counter() - t0) * 1e3)
+    elbo = float(model._device_objective())
+    for e in engines:
+        e.close()
+    model._engines = {}
+    return {
+        "workload": "c5 on one GPU: MultimodalCorrNMF (96 + 83) x 200000, ns_signatures [40, 40], dim_embeddings 40, 8 device-resident updates",
+        "update_ms": steps,
+        "update_ms_median_after_warmup": statistics.median(steps[2:]),
+        "elbo_after": elbo,
+    }
+
+
 def extra_weighted_step(sal, device):
     """The weighted instantiation of the joint step at c2 (KLNMF(fitting_kwargs={"weights_kl": ..., "weights_lhalf": ...})):
     per-sample weights select fused_kernel<..., WTS = true> (no cooperative leftover tile, conditional loads in the tile loop)."""
@@ -655,7 +693,7 @@ def main():
                 line["time_to_kl"] = time_to_kl(sal, X, W0, H0, n_cpu, target, cpu_s, local_rank)
             if not args.no_extra:
                 extra = {}
-                for name, fn in (("c4_mvnmf", extra_c4), ("c2_default_init_fit", extra_default_init_fit), ("c2_fp32_fast_mode", extra_fast_mode), ("c2_weighted_step", extra_weighted_step)):
+                for name, fn in (("c4_mvnmf", extra_c4), ("c2_default_init_fit", extra_default_init_fit), ("c2_fp32_fast_mode", extra_fast_mode), ("c2_weighted_step", extra_weighted_step), ("c5_mmcorrnmf", extra_c5)):
                     try:
                         extra[name] = fn(sal, local_rank)
                     except Exception as exc:  # an extra must never cost the headline line

@@ -221,6 +221,7 @@ struct salnmf_engine {
     size_t ls_doubles = 0;
     int ls_S = 0, ls_dim = 0;
     bool lockstep = true;  // salnmf_set_lockstep(e, 0) forces the single-kernel form
+    hipEvent_t ls_ev[2] = {nullptr, nullptr};  // lockstep rounds: the count of live solves has reached the host
     double *gU = nullptr, *galpha = nullptr, *gaux = nullptr;
     size_t g_rows = 0;
     int g_dim = 0;
@@ -576,7 +577,7 @@ void salnmf_destroy(salnmf_engine* e) {
     if (e->psync) (void)hipFree(e->psync);
     if (e->klcnt) (void)hipFree(e->klcnt);
     for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
-    for (hipEvent_t ev : {e->evW, e->evPrepW, e->evTrial, e->evLogdet, e->evObj})
+    for (hipEvent_t ev : {e->evW, e->evPrepW, e->evTrial, e->evLogdet, e->evObj, e->ls_ev[0], e->ls_ev[1]})
         if (ev) (void)hipEventDestroy(ev);
     for (hipStream_t st : {e->stream2, e->stream3})
         if (st) {
@@ -2248,27 +2249,40 @@ static int lockstep_signature_solves(salnmf_engine* e, const double* U, const do
     // start: sg = sum_n aux[n][k] U[n][:] and the first requests (the start points)
     if (multi) hipLaunchKernelGGL(ls_begin_multi_kernel, grid, dim3(SIGT), 0, e->stream, q);
     else hipLaunchKernelGGL(ls_begin_kernel, grid, dim3(SIGT), 0, e->stream, q);
-    hipLaunchKernelGGL(ls_reduce_kernel, dim3(K), dim3(256), 0, e->stream, q.part, q.red, q.state, S, 2, 64, 1);
+    hipLaunchKernelGGL(ls_reduce_kernel, dim3(K, 1), dim3(256), 0, e->stream, q.part, q.red, q.state, S, 2, 64, 1);
     HIPCK(hipGetLastError());
     if (shard) CK(allreduce(e, q.red, (size_t)K * LS_REC));
     hipLaunchKernelGGL(ls_copy_sg_kernel, dim3((K * 64 + 255) / 256), dim3(256), 0, e->stream, q.red, q.sg, K);
     HIPCK(hipGetLastError());
     const int rec = 66 + dim * dim;
-    bool finished = false;
-    for (int round = 0; round < LS_EVAL_MAX + 2; ++round) {
+    for (hipEvent_t& ev : e->ls_ev)
+        if (!ev) HIPCK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    // one round: evaluation at every live signature's requested point, fixed-order sum of the partials, the solvers advance;
+    // the number of signatures that still want an evaluation travels to the host behind it (slot and event r & 1)
+    auto launch_round = [&](int r) -> int {
         // (dim % 16 != 0: the padded tile has room for the column of ones that makes the Hessian product yield the gradient too)
         if (multi && dim % 16 != 0) hipLaunchKernelGGL(ls_eval_multi_kernel<true>, grid, dim3(SIGT), 0, e->stream, q);
         else if (multi) hipLaunchKernelGGL(ls_eval_multi_kernel<false>, grid, dim3(SIGT), 0, e->stream, q);
         else hipLaunchKernelGGL(ls_eval_kernel, grid, dim3(SIGT), 0, e->stream, q);
-        hipLaunchKernelGGL(ls_reduce_kernel, dim3(K), dim3(256), 0, e->stream, q.part, q.red, q.state, S, 0, rec, 0);
+        hipLaunchKernelGGL(ls_reduce_kernel, dim3(K, (rec + 255) / 256), dim3(256), 0, e->stream, q.part, q.red, q.state, S, 0, rec, 0);
         HIPCK(hipGetLastError());
         if (shard) CK(allreduce(e, q.red, (size_t)K * LS_REC));
         HIPCK(hipMemsetAsync(q.active, 0, sizeof(int), e->stream));
         hipLaunchKernelGGL(ls_advance_kernel, dim3(K), dim3(64), 0, e->stream, q);
         HIPCK(hipGetLastError());
-        HIPCK(hipMemcpyAsync(hactive, q.active, sizeof(int), hipMemcpyDeviceToHost, e->stream));
-        HIPCK(hipStreamSynchronize(e->stream));
-        if (*hactive == 0) {
+        HIPCK(hipMemcpyAsync(hactive + (r & 1), q.active, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+        HIPCK(hipEventRecord(e->ls_ev[r & 1], e->stream));
+        return 0;
+    };
+    // The host only decides whether another round is needed.  Round r + 1 is queued BEFORE round r's count is read: if
+    // everything had finished it is a no-op on the device (the kernels return for signatures that want nothing), and
+    // otherwise the round trip of the count hides behind it (25 us per round before).
+    bool finished = false;
+    CK(launch_round(0));
+    for (int round = 0; round < LS_EVAL_MAX + 2; ++round) {
+        if (round + 1 < LS_EVAL_MAX + 2) CK(launch_round(round + 1));
+        HIPCK(hipEventSynchronize(e->ls_ev[round & 1]));
+        if (hactive[round & 1] == 0) {
             finished = true;
             break;
         }

@@ -352,9 +352,12 @@ __global__ void __launch_bounds__(SIGT) ls_eval_multi_kernel(LockstepParams q) {
 // red[k][e] = sum over the S chunk partials, fixed order; only the first `len` entries of a record are live
 __global__ void __launch_bounds__(256) ls_reduce_kernel(const double* __restrict__ part, double* __restrict__ red, const int* __restrict__ state,
                                                         int S, int first, int len, int all_signatures) {
+    // grid (K, ceil(len / 256)): one entry per thread (a record is 66 + dim^2 doubles: with one workgroup per signature the
+    // 17 MB of partials at c5 were read by 40 workgroups, 52 us per round)
     const int k = blockIdx.x;
     const bool live = all_signatures || state[k] == LS_NEED;
-    for (int e = first + threadIdx.x; e < first + len; e += 256) {
+    const int e = first + (int)blockIdx.y * 256 + (int)threadIdx.x;
+    if (e < first + len) {
         double t = 0.0;
         if (live)
             for (int s = 0; s < S; ++s) t += part[((int64_t)k * S + s) * LS_REC + e];
