@@ -79,6 +79,8 @@ class KLNMF(StandardNMF):
         return True
 
     def _device_objective_and_steps(self, slot: int, n_steps: int, given_parameters, keep: bool) -> bool:
+        if not self.objective_in_step:
+            return super()._device_objective_and_steps(slot, n_steps, given_parameters, keep)
         self._engine.kl_step_objective(slot, n_steps, self._n_given(given_parameters), keep)
         return True
 

@@ -47,6 +47,7 @@ class SignatureNMF(ABC):
         distributed: bool = False,
         device_init: bool = True,
         precision: str = "f64",
+        objective_in_step: bool = True,
     ):
         value_checker("init_method", init_method, INIT_METHODS)
         self.n_signatures = n_signatures
@@ -64,6 +65,10 @@ class SignatureNMF(ABC):
         # default is the reference's fp64 arithmetic
         value_checker("precision", precision, ("f64", "f32"))
         self.precision = precision
+        # ours: inside fit() the objective of a convergence test is evaluated in the launch of the update that follows it
+        # (models that can: KLNMF) -- the value of objective_function() to rounding.  False: always as a pass of its own,
+        # bit for bit objective_function() (and 3 % more wall clock at c2)
+        self.objective_in_step = objective_in_step
         self._resident: set[str] = set()  # what the device already holds from the initialisation: "X", "H"
 
         self.adata = AnnData()

@@ -560,6 +560,11 @@ def test_model_fit_queued_loop_equals_blocking_loop_on_the_device():
     assert np.array_equal(q.asignatures.X, b.asignatures.X) and np.array_equal(q.adata.obsm["exposures"], b.adata.obsm["exposures"])
     W, H, it, hist = orc.fit_klnmf(X.T, W0.T, H0.T, min_iterations=30, max_iterations=3000, conv_test_freq=10, tol=1e-5)
     assert it == q.n_iterations_ and np.allclose(q.history["objective_function"], hist, rtol=1e-11)
+    # objective_in_step=False: every objective as a pass of its own -- the blocking loop's history bit for bit
+    p = sal.models.KLNMF(8, "custom", min_iterations=30, max_iterations=3000, conv_test_freq=10, tol=1e-5, objective_in_step=False)
+    p.fit(sal.AnnData(X.copy()), init_kwargs={"signatures_mat": W0.copy(), "exposures_mat": H0.copy()})
+    assert p.n_iterations_ == b.n_iterations_ and p.history["objective_function"] == b.history["objective_function"]
+    assert np.array_equal(p.asignatures.X, b.asignatures.X) and np.array_equal(p.adata.obsm["exposures"], b.adata.obsm["exposures"])
     assert rel_l2(q.asignatures.X, W.T) < 1e-8 and rel_l2(q.adata.obsm["exposures"], H.T) < 1e-8
 
 
