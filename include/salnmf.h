@@ -246,6 +246,13 @@ int salnmf_corr_update_signature_embeddings(salnmf_engine* e, double variance, i
  * all-reduces the 1 + dim + dim^2 sums per signature of every round.  0 forces the single-kernel form; the two agree
  * to rounding of the sums. */
 int salnmf_set_lockstep(salnmf_engine* e, int on);
+/* The sample solves (both entry points above) run BATCHED where the shape allows (at most 80 signatures over all
+ * modalities, dim_embeddings <= 48; csrc/salnmf_corr_batched.hip): sixteen solves per wavefront advance in lockstep
+ * rounds, every round's evaluations as two fp64 MFMA products with the signature embeddings, the solver being the
+ * resumable form of the same Newton-CG (csrc/salnmf_ncg_machine.h).  0 forces one wavefront per sample
+ * (csrc/salnmf_corr_kernels.h), which larger shapes always use; the two agree to rounding of the sums (same solver,
+ * same problems, another summation order). */
+int salnmf_set_batched_sample_solves(salnmf_engine* e, int on);
 
 /* Opt-in fast mode of salnmf_kl_step: the joint update_WH step on the fp32 matrix cores (fp32 copies of X and H are made
  * on the device; W, the numerator's cross-workgroup sums and the W tail stay fp64; H is converted back at the end of every

@@ -221,6 +221,7 @@ struct salnmf_engine {
     size_t ls_doubles = 0;
     int ls_S = 0, ls_dim = 0;
     bool lockstep = true;  // salnmf_set_lockstep(e, 0) forces the single-kernel form
+    bool batched_samples = true;  // salnmf_set_batched_sample_solves(e, 0) forces one wavefront per sample
     hipEvent_t ls_ev[2] = {nullptr, nullptr};  // lockstep rounds: the count of live solves has reached the host
     double *gU = nullptr, *galpha = nullptr, *gaux = nullptr;
     size_t g_rows = 0;
@@ -1143,6 +1144,12 @@ static int chunked_kl_step_once(salnmf_engine* e, int n_given) {
 int salnmf_set_lockstep(salnmf_engine* e, int on) {
     if (!e) return fail("null engine");
     e->lockstep = on != 0;
+    return 0;
+}
+
+int salnmf_set_batched_sample_solves(salnmf_engine* e, int on) {
+    if (!e) return fail("null engine");
+    e->batched_samples = on != 0;
     return 0;
 }
 
@@ -2138,12 +2145,16 @@ static int sample_embeddings_impl(salnmf_engine* const* engines, int n_engines, 
         HIPCK(hipMalloc(&dstatus, (size_t)e0->N * sizeof(int)));
         p.status = dstatus;
     }
-    const int grid = (int)std::min<int64_t>((e0->N + 3) / 4, 8192);
-    const size_t lds_bytes = (size_t)terms * (e0->dim | 1) * sizeof(double);  // the term matrix (corr_sample_embeddings_kernel)
-    if (terms <= 64)
-        hipLaunchKernelGGL(corr_sample_embeddings_kernel<1>, dim3(grid), dim3(CORR_BLOCK), lds_bytes, e0->stream, p);
-    else
-        hipLaunchKernelGGL(corr_sample_embeddings_kernel<2>, dim3(grid), dim3(CORR_BLOCK), lds_bytes, e0->stream, p);
+    // sixteen solves per wavefront on the fp64 MFMA units where an instantiation covers the shape (csrc/salnmf_corr_batched.hip:
+    // <= 80 terms, dim <= 48), else one wavefront per sample
+    if (!(e0->batched_samples && launch_sample_embeddings_batched(p, terms, e0->stream))) {
+        const int grid = (int)std::min<int64_t>((e0->N + 3) / 4, 8192);
+        const size_t lds_bytes = (size_t)terms * (e0->dim | 1) * sizeof(double);  // the term matrix (corr_sample_embeddings_kernel)
+        if (terms <= 64)
+            hipLaunchKernelGGL(corr_sample_embeddings_kernel<1>, dim3(grid), dim3(CORR_BLOCK), lds_bytes, e0->stream, p);
+        else
+            hipLaunchKernelGGL(corr_sample_embeddings_kernel<2>, dim3(grid), dim3(CORR_BLOCK), lds_bytes, e0->stream, p);
+    }
     int rc = 0;
     if (hipGetLastError() != hipSuccess) rc = fail("corr_sample_embeddings_kernel launch failed");
     // the sample embeddings are shared: every modality's engine gets the result

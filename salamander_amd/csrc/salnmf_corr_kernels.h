@@ -11,6 +11,7 @@
 
 #include "salnmf_kernels.h"
 #include "salnmf_newtoncg.h"
+#include "salnmf_corr_params.h"
 
 namespace salnmf {
 
@@ -195,8 +196,6 @@ __global__ void corr_log_ratio_kernel(const double* __restrict__ first, const do
 // embedding; finally entries within EPSILON of zero are pushed to +-EPSILON (_utils_corrnmf.py:408-409).
 // One wavefront per sample: lane m <-> embedding component m, lane l <-> terms l (and l + 64 when
 // the modalities have more than 64 signatures in total, TPL = 2).
-constexpr int CORR_MODS = 4;     // modalities per joint solve
-constexpr int CORR_TERMS = 128;  // signatures of all modalities together
 
 template <int TPL>
 struct SampleEmbeddingEval {
@@ -331,19 +330,6 @@ struct SampleEmbeddingEval {
     __device__ inline bool exhausted() const { return false; }  // every loop of the solve is bounded and cheap here
 };
 
-struct SampleEmbeddingParams {
-    const double* aux[CORR_MODS];    // [Np][KP_mod]
-    const double* alpha[CORR_MODS];  // [Np]
-    const double* beta[CORR_MODS];   // [K_mod]
-    const double* L[CORR_MODS];      // [K_mod][dim]
-    int K[CORR_MODS], KP[CORR_MODS];
-    int n_mod;
-    double* U;                       // [N][dim]  in / out (shared by the modalities)
-    int* status;                     // [N] or null: ncg::Status of every solve
-    double variance;
-    int64_t N;
-    int dim, maxiter;
-};
 
 template <int TPL>
 __global__ void __launch_bounds__(CORR_BLOCK) corr_sample_embeddings_kernel(SampleEmbeddingParams p) {

@@ -127,6 +127,10 @@ class Engine:
         """Signature-embedding solves in lockstep rounds (default from 16 384 samples on) or one workgroup per signature."""
         _lib.check(self._lib.salnmf_set_lockstep(self._h, int(bool(on))))
 
+    def set_batched_sample_solves(self, on: bool = True):
+        """Sample-embedding solves sixteen per wavefront on the MFMA units (default where the shape allows) or one wavefront per sample."""
+        _lib.check(self._lib.salnmf_set_batched_sample_solves(self._h, int(bool(on))))
+
     def set_persistent(self, on: bool = True):
         """Run multi-step ``kl_step`` calls as one persistent launch (only in builds with ``SALNMF_WITH_PERSISTENT=1``:
         measured 10 % slower, so the default library does not carry that kernel) or as per-step launches (default)."""
