@@ -25,6 +25,18 @@
 
 using namespace salnmf;
 
+#ifdef SALNMF_DEV_POISON
+// development builds: every device allocation starts as NaNs (all bits set), so that a read of a buffer nobody has
+// written yet shows up in the results deterministically instead of depending on what the allocator hands back
+static hipError_t salnmf_poison_malloc(void** p, size_t n) {
+    hipError_t rc = (hipMalloc)(p, n);
+    if (rc == hipSuccess) rc = hipMemset(*p, 0xFF, n);
+    if (rc == hipSuccess) rc = hipDeviceSynchronize();  // (the fill runs on the null stream, the engine's streams do not wait for it)
+    return rc;
+}
+#define hipMalloc(p, n) salnmf_poison_malloc((void**)(p), (n))
+#endif
+
 static thread_local std::string g_err;
 
 static int fail(const char* fmt, ...) {
@@ -159,9 +171,9 @@ struct salnmf_engine {
     double* KLpart2 = nullptr;   // [grid] KL partials of a speculative update_H pass (the trial's objective)
     double* red = nullptr;       // [K*V | K | 1 | pad]  G, rowsums_H, KL of the local shard (then all-reduced)
     double* objpart = nullptr;   // [grid]
-    double* scal = nullptr;      // device scalars: [0]=objective, [1]=f0, [2]=f1, [3]=logdet0, [4]=logdet1, [5..7] CorrNMF sums, [SCAL_XLX]=sum of xlx
+    double* scal = nullptr;      // device scalars: [0]=objective, [1]=f0, [2]=f1, [3]=logdet0, [4]=logdet1, [5..7] CorrNMF sums
     unsigned* klcnt = nullptr;   // arrival counter of the in-launch KL sum of the MvNMF update_H pass (zero between launches)
-    double* xlx = nullptr;       // [Np] c_d = sum_v (x log x - x): the x-only part of the KL divergence (tile_kl), lazily computed
+    double* xlx = nullptr;       // [NB][Np][16] x-only constants of the KL terms per (sample, lane column) (tile_kl), lazily computed
     bool xlx_valid = false;
     double* Wunc = nullptr;      // MvNMF scratch [K][V]
     double* Wtrial = nullptr;    // [K][V]
@@ -237,7 +249,6 @@ static hipError_t acquire_pinned(void** out, int small_block);
 constexpr int NB_MAX = 32;  // feature blocks of 96: n_features <= 3072 (SBS-1536 needs 16)
 constexpr int KC = 64;      // signatures per chunk (the widest accumulator geometry of the fused pass)
 constexpr int NC_MAX = 8;   // signature chunks: n_signatures <= 512
-constexpr int SCAL_XLX = 8;  // slot of e->scal that holds the sum over the samples of xlx
 
 static const int kKS[] = {1, 2, 4, 8, 10, 13, 16};
 
@@ -293,6 +304,7 @@ static int launch_fused(salnmf_engine* e, const FusedParams& p, int grid = 0, hi
     // ones that collect statistics, are unweighted)
     const bool wts = p.wkl || p.wlh;
     if (wts && DO_STATS) return fail("internal: weighted pass with statistics is not instantiated");
+    if (DO_STATS && (DO_G || p.KLpart) && (!p.xlx || !e->xlx_valid)) return fail("internal: KL pass without the x-only constants (ensure_xlogx)");
     const FusedSel sel{e->KS, e->KTM, e->KR, DO_G, DO_U, DO_STATS, wts, false};
     FusedParams pw = p;
     if (wts) CK(weight_arrays(e, pw));
@@ -323,6 +335,7 @@ static FusedParams fused_params(salnmf_engine* e) {
     p.Gpart = e->Gpart;
     p.Hsumpart = e->Hsumpart;
     p.KLpart = e->KLpart;
+    p.xlx = e->xlx;  // (valid whenever a DO_STATS pass runs: ensure_xlogx)
     p.N = e->N;
     p.V = e->V;
     p.ldw = e->V;
@@ -362,7 +375,6 @@ static TailParams tail_params(salnmf_engine* e, int nslabs, double* G, int n_giv
     t.hsum_part = with_stats ? e->Hsumpart : nullptr;
     t.hsum_out = e->red + (size_t)e->K * e->V;
     t.kl_part = with_stats ? e->KLpart : nullptr;
-    t.kl_const = e->scal + SCAL_XLX;
     t.kl_out = e->red + (size_t)e->K * e->V + e->K;
     t.nparts = nslabs;
     t.nparts_h = hsum_parts > 0 ? hsum_parts : nslabs;
@@ -436,17 +448,28 @@ static int sharded_tail(salnmf_engine* e, int n_given, int clip_mode) {
     return launch_tail(e, 0, e->red, n_given, clip_mode, 1);
 }
 
-// the x-only part of the KL divergence (salnmf_kernels.h: tile_kl), once per upload of X: c_d per sample and their sum
+// The second H buffer (kept steps, MvNMF speculation): allocated at first use and ZEROED.  A pass that writes it covers
+// every row, but only the columns it computes (16 KTM + KR of the KP padded ones): the pad columns must hold finite
+// filler before the buffer is ever read as H -- they meet zero rows of W in the P product, and 0 * NaN is NaN.  (Found
+// with SALNMF_DEV_POISON: with K = 17, 33, 42-50 an MvNMF step that continued from an accepted speculation read
+// whatever hipMalloc had handed back.)
+static int ensure_halt(salnmf_engine* e) {
+    if (e->Halt) return 0;
+    const size_t bytes = (size_t)e->Np * e->KP * sizeof(double);
+    HIPCK(hipMalloc(&e->Halt, bytes));
+    HIPCK(hipMemsetAsync(e->Halt, 0, bytes, e->stream));
+    return 0;
+}
+
+// the x-only part of the KL divergence (salnmf_kernels.h: tile_kl), once per upload of X: the constants per (sample, lane column)
 static int ensure_xlogx(salnmf_engine* e) {
     if (e->xlx_valid) return 0;
-    if (!e->xlx) HIPCK(hipMalloc(&e->xlx, (size_t)e->NB * e->Np * sizeof(double)));
+    if (!e->xlx) HIPCK(hipMalloc(&e->xlx, (size_t)e->NB * e->Np * 16 * sizeof(double)));
     for (int b = 0; b < e->NB; ++b) {  // (feature blocks: the constants of every block's own features)
-        hipLaunchKernelGGL(xlogx_rowsum_kernel, dim3((unsigned)((e->Np + 15) / 16)), dim3(256), 0, e->stream, e->X + (size_t)b * e->Np * VMAX, e->Np,
-                           block_width(e, b), VMAX, e->xlx + (size_t)b * e->Np);
+        hipLaunchKernelGGL(xlogx_lane_kernel, dim3((unsigned)((e->Np + 15) / 16)), dim3(256), 0, e->stream, e->X + (size_t)b * e->Np * VMAX, e->Np,
+                           block_width(e, b), VMAX, e->xlx + (size_t)b * e->Np * 16);
         HIPCK(hipGetLastError());
     }
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, e->xlx, (int)e->Np, 1, 1, e->scal + SCAL_XLX, nullptr);
-    HIPCK(hipGetLastError());
     e->xlx_valid = true;
     return 0;
 }
@@ -1052,7 +1075,7 @@ static int blocked_kl_step_once(salnmf_engine* e, int n_given) {
         e->h_pending = false;
         return 0;
     }
-    if (!e->Halt) HIPCK(hipMalloc(&e->Halt, (size_t)e->Np * e->KP * sizeof(double)));
+    CK(ensure_halt(e));
     CK(blocked_update_H(e, e->Halt));
     CK(blocked_numerators(e));  // (both halves read the old H, a pending rescale included)
     CK(blocked_finish_W(e, n_given, SALNMF_CLIP_ALL));
@@ -1246,7 +1269,7 @@ int salnmf_kl_step_keep(salnmf_engine* e, int n_steps, int n_given) {
     if (n_given < 0 || n_given > e->K) return fail("n_given out of range");
     if (n_steps < 1) return fail("n_steps must be positive");
     CK(enter(e));
-    if (!e->Halt && e->NC == 1) HIPCK(hipMalloc(&e->Halt, (size_t)e->Np * e->KP * sizeof(double)));
+    if (e->NC == 1) CK(ensure_halt(e));
     if (!e->Wkeep) HIPCK(hipMalloc(&e->Wkeep, (size_t)e->K * e->V * sizeof(double)));
     e->keep_valid = false;
     CK(flush_H_scale(e));
@@ -1407,7 +1430,7 @@ static int objective_partials(salnmf_engine* e, const double* W, const double* h
             pb.X = e->X + (size_t)b * e->Np * VMAX;
             pb.W = W + (size_t)VMAX * b;
             pb.V = block_width(e, b);
-            pb.xlx = e->xlx + (size_t)b * e->Np;
+            pb.xlx = e->xlx + (size_t)b * e->Np * 16;
             if (b > 0) pb.wlh = nullptr;
             pb.out = e->objpart + (size_t)b * fgrid;
             CK(launch_forward<0>(e, pb, fgrid));
@@ -1447,6 +1470,17 @@ static int read_scalars(salnmf_engine* e, int first, int count, double* out) {
     for (int i = 0; i < count; ++i) out[i] = e->hpin[i];
     return 0;
 }
+
+#ifdef SALNMF_DEV_POISON
+// development builds only: raw device buffers for tools/poison_probe*.py (0 = xlx, 1 = objpart, 2 = KLpart)
+extern "C" int salnmf_debug_read(salnmf_engine* e, int which, double* out, int64_t count) {
+    const double* src = which == 0 ? e->xlx : which == 1 ? e->objpart : e->KLpart;
+    if (!src) return fail("buffer not allocated");
+    HIPCK(hipDeviceSynchronize());
+    HIPCK(hipMemcpy(out, src, (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+#endif
 
 int salnmf_objective(salnmf_engine* e, double* out) {
     if (!e || !out) return fail("null argument");
@@ -1509,7 +1543,7 @@ int salnmf_kl_step_objective(salnmf_engine* e, int slot, int n_steps, int n_give
     CK(ensure_objective_slot(e, slot));
     CK(ensure_xlogx(e));
     if (keep) {
-        if (!e->Halt) HIPCK(hipMalloc(&e->Halt, (size_t)e->Np * e->KP * sizeof(double)));
+        CK(ensure_halt(e));
         if (!e->Wkeep) HIPCK(hipMalloc(&e->Wkeep, (size_t)e->K * e->V * sizeof(double)));
         CK(flush_H_scale(e));
         e->keep_valid = false;
@@ -1802,7 +1836,7 @@ static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double de
         if (wunc_out) return download(e, wunc_out, e->Wunc, (size_t)K * V);  // (W, H untouched; the trial buffers are scratch)
         double v[5];
         if (spec) {
-            if (!e->Halt) HIPCK(hipMalloc(&e->Halt, (size_t)e->Np * e->KP * sizeof(double)));
+            CK(ensure_halt(e));
             if (!e->KLpart2) HIPCK(hipMalloc(&e->KLpart2, (size_t)e->grid * sizeof(double)));
             // The next step's update_H (+ row sums of the new H), which also evaluates this trial: KL(W_trial, H') -> scal[2],
             // summed inside the launch by the workgroup that finishes last.  The grid's last workgroup does no tiles: it
@@ -1819,12 +1853,11 @@ static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double de
             mv_side_params(e, sp, e->Wtrial, delta);
             if (!sharded(e)) {
                 sp.kl_out = e->scal + 2;
-                sp.kl_const = e->scal + SCAL_XLX;
                 sp.kl_counter = e->klcnt;
                 CK((launch_fused<false, true, true>(e, sp, total, nullptr, e->evObj)));  // evObj = the pass's own completion signal
             } else {
                 CK((launch_fused<false, true, true>(e, sp, total)));
-                hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, e->KLpart2, nwg, 1, 1, e->scal + 2, (const double*)(e->scal + SCAL_XLX));
+                hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, e->KLpart2, nwg, 1, 1, e->scal + 2, nullptr);
                 HIPCK(hipGetLastError());
                 CK(allreduce(e, e->scal + 2, 1));
                 HIPCK(hipEventRecord(e->evObj, e->stream));

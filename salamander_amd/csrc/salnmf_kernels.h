@@ -129,8 +129,8 @@ struct FusedParams {
     const double* __restrict__ hscale;  // [KP] or null: H is read as clip(H*hscale) (MvNMF trial)
     double* __restrict__ Gpart;      // [gridDim.x][K][VMAX]     (DO_G) per-workgroup partial numerators
     double* __restrict__ Hsumpart;   // [gridDim.x][K]           (DO_STATS) row sums of H
-    double* __restrict__ KLpart;     // [gridDim.x]              (DO_STATS) unweighted partial of sum (p - x log p): the KL divergence minus
-                                     //                          the x-only constant (tile_kl) (DO_U: optional, null = skip)
+    double* __restrict__ KLpart;     // [gridDim.x]              (DO_STATS) unweighted partial of the KL divergence (tile_kl) (DO_U: optional, null = skip)
+    const double* __restrict__ xlx;  // [Np][16]                 (DO_STATS) x-only constants of the KL terms per (sample, lane column): xlogx_lane_kernel
     int64_t N;
     int V;                  // features of this pass (<= 96: one feature block)
     int ldw;                // row stride of W (= V unless W points at one block of a wider matrix)
@@ -146,7 +146,7 @@ struct FusedParams {
     //    (mv_prepare_W_body: A = W Y_minus, B = W |Y|, log det(W W^T + delta I), mvnmf.py:19-24,48-54) on sideW beside the
     //    pass -- the latency chain that used to need a second stream and an event wait on this one;
     //  * kl_out != null (with KLpart): the workgroup that finishes last sums the KL partials in the order of
-    //    sum_partials_kernel and stores kl_out[0] = sum + kl_const[0] -- one kernel and one boundary less per MvNMF step.
+    //    sum_partials_kernel and stores kl_out[0] -- one kernel and one boundary less per MvNMF step.
     //    kl_counter: arrival counter, zero between launches (the last arriver resets it).
     const double* sideW;
     double sideDelta;
@@ -154,7 +154,6 @@ struct FusedParams {
     double* sideB;
     double* sideLogdet;
     double* kl_out;
-    const double* kl_const;
     unsigned* kl_counter;
     // persistent multi-step mode (PERSIST instantiation only): the joint update_WH step nsteps times in ONE launch
     int nsteps;
@@ -203,9 +202,15 @@ __device__ __forceinline__ double log_ratio(double x, double p) {
 // (the next term is < 1e-17).  3 integer + 12 fp64-rate instructions and one 16-byte LDS read per logarithm against 26 fp64
 // instructions (one of them a division chain) for log_ratio: the objective terms are fp64 VALU work on the pipe the
 // MFMAs use.  Error <= 2.5e-16 max(|log p|, 0.5) (tools/gen_logtab.py on the host, tools/log_probe.hip on the device).
-// The KL divergence is evaluated as  sum_d w_d [ c_d + sum_v (p - x log p) ],  c_d = sum_v (x log x - x)  (0 where
-// x = 0): the x-only part is computed once per upload of X (xlogx_rowsum_kernel, library log), so an objective costs ONE
-// logarithm per entry, of p alone.  _utils_klnmf.py:41-53: same value to rounding (entries with x = 0 contribute p).
+// The KL divergence is evaluated as  sum_d w_d sum_c [ c_dc + sum_{v = c mod 16} (p - x log p) ],  c_dc = sum_{v = c mod 16} (x log x - x)
+// (0 where x = 0): the x-only part is computed once per upload of X (xlogx_lane_kernel, library log), so an objective costs
+// ONE logarithm per entry, of p alone.  The constants are kept PER (sample, lane column) -- the six entries of a sample
+// that one lane of the accumulator layout holds -- and are added in that lane, before any sum over lanes, samples or
+// workgroups: x log x and x log p are each ~|x log x| and cancel to the entry's KL term, and a cancellation that happens
+// only in the final scalar (one constant per sample or per matrix) costs digits in proportion to sum |x log x| / KL,
+// 3-7 of them for counts of 1e5-1e6 or near-perfect fits.  Local, the error is eps |x log x| per lane and sample,
+// independent of the problem size and of the launch geometry.  _utils_klnmf.py:41-53: same value to rounding (entries
+// with x = 0 contribute p).
 constexpr int LOGTAB_DOUBLES = 2 * LOGTAB_N;
 __device__ __forceinline__ void stage_logtab(double* tab, int tid) {
     static_assert(LOGTAB_N == BLOCK, "one table entry per thread");
@@ -321,15 +326,15 @@ __device__ __forceinline__ void stage_W(double* Wl, const double* W, int K, int 
 }
 
 // Sum over one tile (accumulator layout: rows n = q+4r, columns v = 16vt+c16) of the per-sample weighted
-//   [c16 == 0 ? c_d : 0] + sum_v (p - x log p)
-// i.e. the tile's share of the KL divergence (see log_pos above).  ROWS: wv[r] / cv[r] are the weight and the x-only
-// constant c_d of sample n0 + q + 4r (loaded by the caller with the tile's other loads); without ROWS the sum is
-// unweighted and the constants are left to the caller (the fused passes add their sum once, in the reduction).
+//   c_dc + sum_{v of this lane} (p - x log p)
+// i.e. the tile's share of the KL divergence (see log_pos above).  cv[r] is the x-only constant of (sample n0 + q + 4r,
+// lane column c16), loaded by the caller with the tile's other loads; ROWS: wv[r] is the sample's weight, without ROWS the
+// sum is unweighted.
 // Entries outside [0,N) x [0,V) are skipped.  The objective terms are VALU-issue bound, so the common case -- a full
 // tile of a 96-feature problem whose P are all positive normal numbers, always the case inside fit() -- runs without a
 // single select: the range check is two min3/max3 chains over the high words.  Partial tiles and V < 96 take the masked
-// form; a P that is zero, denormal or not finite (an all-zero row of H or W through the function-level API) sends the
-// whole tile to the library path.
+// form (their pad entries have x = 0, hence constants 0); a P that is zero, denormal or not finite (an all-zero row of H
+// or W through the function-level API) sends the whole tile to the library path.
 //   MB: logarithms evaluated side by side (their intermediates are 14 registers each: the joint step with the objective
 //   folded in has room for three at a time)
 template <bool ROWS, int MB = VT>
@@ -350,7 +355,7 @@ __device__ __forceinline__ double tile_kl(const double (&x)[VT][4], const d4 (&p
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 static_assert(VT % MB == 0, "batches of equal size");
-                double acc = (ROWS && c16 == 0) ? cv[r] : 0.0;
+                double acc = cv[r];
 #pragma unroll
                 for (int b = 0; b < VT; b += MB) {
                     double ps[MB], lp[MB];
@@ -380,7 +385,7 @@ __device__ __forceinline__ double tile_kl(const double (&x)[VT][4], const d4 (&p
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const bool nvalid = n0 + q + 4 * r < N;
-            double acc = (ROWS && nvalid && c16 == 0) ? cv[r] : 0.0;
+            double acc = nvalid ? cv[r] : 0.0;
             double ps[VT], lp[VT];
 #pragma unroll
             for (int vt = 0; vt < VT; ++vt) {
@@ -401,7 +406,7 @@ __device__ __forceinline__ double tile_kl(const double (&x)[VT][4], const d4 (&p
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const bool nvalid = n0 + q + 4 * r < N;
-            double acc = (ROWS && nvalid && c16 == 0) ? cv[r] : 0.0;
+            double acc = nvalid ? cv[r] : 0.0;
 #pragma unroll
             for (int vt = 0; vt < VT; ++vt)
                 if (nvalid && 16 * vt + c16 < V) acc += kl_term_p(x[vt][r], pr[vt][r]);
@@ -759,6 +764,12 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         }
         __builtin_amdgcn_wave_barrier();
 
+        // (DO_STATS) the x-only constants of this lane's KL terms (tile_kl); they land under the P product
+        double cv[4] = {0.0, 0.0, 0.0, 0.0};
+        if (DO_STATS && (DO_G || p.KLpart != nullptr)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cv[r] = p.xlx[(n0 + q + 4 * r) * 16 + c16];
+        }
         // ---- P = Ht . W   (A = H[n=c16][k=4s+q], B = W[k=4s+q][v=16vt+c16])
         d4 pr[VT];
 #pragma unroll
@@ -801,7 +812,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         constexpr bool JKL = DO_G && DO_U && DO_STATS;
         if (JKL) {
             const double none[4] = {0.0, 0.0, 0.0, 0.0};
-            klacc += tile_kl<false, (KR >= 3 ? 2 : 3)>(x, pr, none, none, ltab, n0, N, V, q, c16);
+            klacc += tile_kl<false, (KR >= 3 ? 2 : 3)>(x, pr, none, cv, ltab, n0, N, V, q, c16);
         }
         // G-phase A operands (H^T): issue the LDS reads now, they land under the divisions
         double ga[4][KT];
@@ -819,7 +830,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         // it starts from, which saves the separate forward pass)
         if (DO_STATS && !JKL && (DO_G || p.KLpart != nullptr)) {
             const double none[4] = {0.0, 0.0, 0.0, 0.0};
-            klacc += tile_kl<false>(x, pr, none, none, ltab, n0, N, V, q, c16);
+            klacc += tile_kl<false>(x, pr, none, cv, ltab, n0, N, V, q, c16);
         }
         // ---- R = X / P in place (rows n = q + 4r, columns v = 16vt + c16); pads give 0 / P = 0
         // (div_path's sequence, six quotients at a time and stage by stage: independent chains next to each other)
@@ -1139,6 +1150,13 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
                     valid[r] = (n0 + q + 4 * r < N) && (16 * VTI + c16 < V);
                     ok &= !valid[r] || log_pos_ok(pp[r]);
                 }
+                // the lane column's x-only constants cover its six feature tiles, which the cooperative tile spreads over
+                // the waves: the wave of feature tile 0 adds them (the cancellation of these at most gridDim.x tiles then
+                // happens in the workgroup's sum instead of in the lane)
+                if (VTI == 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) klacc += p.xlx[(n0 + q + 4 * r) * 16 + c16];
+                }
                 if (__all(ok)) {
                     double ps[4], lp[4];
 #pragma unroll
@@ -1428,7 +1446,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
                     __syncthreads();
                 }
                 if (tid == 0) {
-                    p.kl_out[0] = Ks[0] + p.kl_const[0];
+                    p.kl_out[0] = Ks[0];
                     __hip_atomic_store((gsync_t*)p.kl_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
@@ -1453,7 +1471,7 @@ struct FwdParams {
     const double* __restrict__ wkl;     // [Np] or null
     const double* __restrict__ wlh;     // [Np] or null
     const double* __restrict__ hscale;  // [KP] or null: H read as clip(H*hscale)
-    const double* __restrict__ xlx;     // [Np] mode 0: c_d = sum_v (x log x - x) of every sample (xlogx_rowsum_kernel)
+    const double* __restrict__ xlx;     // [Np][16] mode 0: x-only constants of the KL terms per (sample, lane column) (xlogx_lane_kernel)
     const double* pin;                  // (PIN instantiations) [Np][VMAX] or null: P starts from this instead of 0 -- the product of
                                         // the signature chunks before this one (n_signatures > 64); may be `out` itself
     double* __restrict__ out;           // mode 0: [gridDim.x]; mode 1: [Np]; modes 2, 4: [Np][VMAX]
@@ -1526,11 +1544,11 @@ __global__ void __launch_bounds__(BLOCK, (fwd_lds_doubles<KS>() * 8 <= 80 * 1024
 #pragma unroll
                 for (int r = 0; r < 4; ++r) x[vt][r] = xsrc[4 * r * VMAX + 16 * vt];
         }
-        double wv[4] = {1.0, 1.0, 1.0, 1.0}, cv[4] = {0.0, 0.0, 0.0, 0.0};  // mode 0: weight and x-only constant of this lane's rows
+        double wv[4] = {1.0, 1.0, 1.0, 1.0}, cv[4] = {0.0, 0.0, 0.0, 0.0};  // mode 0: weight and x-only constants of this lane's rows
         if (MODE == 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                cv[r] = p.xlx[n0 + q + 4 * r];
+                cv[r] = p.xlx[(n0 + q + 4 * r) * 16 + c16];
                 if (p.wkl) wv[r] = p.wkl[n0 + q + 4 * r];
             }
         }
@@ -1705,10 +1723,9 @@ struct TailParams {
     // summation order of sum_partials_kernel
     const double* __restrict__ hsum_part;  // [nparts][K] or null
     double* __restrict__ hsum_out;         // [K]
-    const double* __restrict__ kl_part;    // [nparts] or null: partials of sum (p - x log p) (tile_kl)
-    const double* __restrict__ kl_const;   // [1] sum over the samples of c_d = sum_v (x log x - x), added to the reduced partials
+    const double* __restrict__ kl_part;    // [nparts] or null: partials of the KL divergence (tile_kl: x-only constants included)
     double* __restrict__ kl_out;           // [1]
-    int kl_extra;  // the grid has one workgroup more than rows: it only reduces kl_part (+ kl_const) into kl_out -- the
+    int kl_extra;  // the grid has one workgroup more than rows: it only reduces kl_part into kl_out -- the
                    // objective folded into a joint step (fused_kernel<.., true, true, true>); hsum_part is null then
     int nparts;    // KL partials (workgroups of the numerator pass)
     int nparts_h;  // row-sum partials (workgroups of the preceding update_H pass)
@@ -1744,7 +1761,7 @@ __global__ void __launch_bounds__(TAIL_BLOCK) tail_kernel(TailParams p) {
             if ((int)threadIdx.x < h) kred[threadIdx.x] += kred[threadIdx.x + h];
             __syncthreads();
         }
-        if (threadIdx.x == 0) p.kl_out[0] = kred[0] + p.kl_const[0];
+        if (threadIdx.x == 0) p.kl_out[0] = kred[0];
         return;
     }
     if (p.hsum_part) {  // uniform over the grid
@@ -1763,7 +1780,7 @@ __global__ void __launch_bounds__(TAIL_BLOCK) tail_kernel(TailParams p) {
                 __syncthreads();
             }
             if (threadIdx.x == 0) {
-                const double value = which == 0 ? hred[0] : hred[0] + p.kl_const[0];
+                const double value = hred[0];
                 (which == 0 ? p.hsum_out[k] : p.kl_out[0]) = value;
                 mvsh[which] = value;  // (for the root below: through LDS, not back through global memory)
             }
@@ -1830,17 +1847,16 @@ __global__ void combine_scalar_kernel(double* __restrict__ out, const double* __
     *out = *a + lam * *b;
 }
 
-// c[n] = sum_v (x log x - x) over the features of sample n (0 where x == 0): the x-only part of the KL divergence
-// (tile_kl), once per upload of X.  Library log: any x the reference accepts.  X is [Np][ldx], pad rows are 0.
-__global__ void __launch_bounds__(256) xlogx_rowsum_kernel(const double* __restrict__ X, int64_t Np, int V, int ldx, double* __restrict__ c) {
+// c[n][l] = sum over the features v = l mod 16 of sample n of (x log x - x) (0 where x == 0): the x-only part of the KL
+// terms that lane column l of the accumulator layout holds (tile_kl), once per upload of X.  Library log: any x the
+// reference accepts.  X is [Np][ldx], pad rows are 0.
+__global__ void __launch_bounds__(256) xlogx_lane_kernel(const double* __restrict__ X, int64_t Np, int V, int ldx, double* __restrict__ c) {
     const int64_t n = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
     const int l = threadIdx.x & 15;
     if (n >= Np) return;
     double s = 0.0;
     for (int v = l; v < V; v += 16) s += kl_term_x(X[n * ldx + v]);
-    // fixed order over the 16 lanes of a row
-    for (int m = 8; m > 0; m >>= 1) s += __shfl_xor(s, m, 64);
-    if (l == 0) c[n] = s;
+    c[n * 16 + l] = s;
 }
 
 // out[k] = sum over rows n < N of H[n][k] (padded layout, leading dimension ldh): one workgroup per

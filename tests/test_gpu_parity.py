@@ -886,3 +886,62 @@ def test_mvnmf_mixed_call_sequences_match_oracle():
     assert np.isclose(g_dev, g, rtol=1e-12)
     assert rel_l2(e.download_W(), W.T) < 1e-8 and rel_l2(e.download_H(), H.T) < 1e-8
     e.close()
+
+
+# ------------------------------------------------------------------ objective accuracy: high counts, perfect fits
+def _lane_constants(X):
+    """|x log x - x| summed over the six features one lane of the accumulator layout holds: the magnitudes whose
+    cancellation against x log p stays inside a lane (salnmf_kernels.h: tile_kl)."""
+    Xp = np.zeros((X.shape[0], 96))
+    Xp[:, : X.shape[1]] = X
+    t = np.where(Xp > 0, Xp * np.log(np.where(Xp > 0, Xp, 1.0)) - Xp, 0.0)
+    return np.abs(t.reshape(X.shape[0], 6, 16).sum(axis=1))
+
+
+@pytest.mark.parametrize("N,V,K,mean", [(16 * 1074 - 5, 96, 50, 5e7), (5003, 83, 12, 2e8), (20000, 96, 30, 3e6)])
+def test_objective_of_high_count_catalogues_matches_the_per_entry_form(N, V, K, mean):
+    """Counts of 1e5-1e6 per entry: x log x and x log p are ~1e7 each and cancel to a KL term of order 1.  The engine splits
+    the two (one logarithm per entry) but cancels them inside a lane, per (sample, lane column); the oracle evaluates the
+    reference's per-entry form x log(x / p) - x + p (``_utils_klnmf.py:41-53``).  rtol 1e-10 on every objective path: the
+    forward pass, the objective folded into a step, the weighted objective, MvNMF's penalised objective (sizes with a
+    cooperative leftover tile, ragged N, V < 96)."""
+    X, W0, H0 = orc.synthetic_problem(V, N, K, seed=3, mean_mutations=mean)
+    assert X.max() > 1e5
+    e = Engine(N, V, K)
+    e.upload_X(X), e.upload_W(W0), e.upload_H(H0)
+    e.kl_step(3, 0)
+    W, H = e.download_W(), e.download_H()
+    want = orc.kl_divergence(X.T, W.T, H.T)
+    assert np.isclose(e.objective(), want, rtol=1e-10, atol=0)
+    e.kl_step_objective(0, 1, 0, keep=True)  # the same state's objective inside a step
+    e.kl_rollback()
+    assert np.isclose(e.objective_read(0, 1)[0], want, rtol=1e-10, atol=0)
+    assert np.isclose(e.mv_objective(1.0, 1.0), orc.kl_divergence_penalized(X.T, W.T, H.T, 1.0, 1.0), rtol=1e-10, atol=0)
+    wk = np.random.default_rng(1).uniform(0.5, 2.0, N)
+    e.set_weights(wk, None)
+    assert np.isclose(e.objective(), orc.kl_divergence(X.T, W.T, H.T, wk), rtol=1e-10, atol=0)
+    got = e.samplewise_kl()
+    assert np.allclose(got, orc.samplewise_kl_divergence(X.T, W.T, H.T), rtol=1e-9, atol=0) and got.min() >= 0.0
+    e.close()
+
+
+@pytest.mark.parametrize("N,V,K,mean", [(4099, 96, 50, 2000.0), (3000, 96, 8, 1e7)])
+def test_objective_of_a_perfect_fit_is_zero_to_the_rounding_of_a_lane(N, V, K, mean):
+    """X = W H to rounding: the KL divergence is 0 (the reference's per-entry form gives ~1e-16 sum |x|).  The split form
+    leaves the rounding of x log x against x log p: at most a few eps times the magnitude held by one lane, summed in
+    quadrature over the lanes -- not eps times the sum over the whole matrix, which a constant per sample or per matrix
+    would leave (4-7 digits more at these sizes).  The per-sample divergences keep the per-entry form: >= -1e-12 sum_v x."""
+    _, W0, H0 = orc.synthetic_problem(V, N, K, seed=5, mean_mutations=mean)
+    X = H0 @ W0  # (N, V): not counts any more, but exactly representable products are not needed: P differs by rounding
+    e = Engine(N, V, K)
+    e.upload_X(X), e.upload_W(W0), e.upload_H(H0)
+    c = _lane_constants(X)
+    bound = 32 * np.finfo(float).eps * np.sqrt((c**2).sum())
+    for value in (e.objective(), e.mv_objective(0.0, 1.0)):
+        assert abs(value) <= bound, (value, bound, np.finfo(float).eps * c.sum())
+    e.kl_step_objective(0, 1, 0, keep=True)
+    e.kl_rollback()
+    assert abs(e.objective_read(0, 1)[0]) <= bound
+    errs = e.samplewise_kl()
+    assert errs.min() >= -1e-12 * X.sum(axis=1).max() and errs.max() <= 1e-9 * X.sum(axis=1).max()
+    e.close()
