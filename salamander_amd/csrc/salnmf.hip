@@ -1472,7 +1472,7 @@ static int read_scalars(salnmf_engine* e, int first, int count, double* out) {
 }
 
 #ifdef SALNMF_DEV_POISON
-// development builds only: raw device buffers for tools/poison_probe*.py (0 = xlx, 1 = objpart, 2 = KLpart)
+// development builds only: raw device buffers for ad-hoc probes (tests/dev/poison_probe.py) (0 = xlx, 1 = objpart, 2 = KLpart)
 extern "C" int salnmf_debug_read(salnmf_engine* e, int which, double* out, int64_t count) {
     const double* src = which == 0 ? e->xlx : which == 1 ? e->objpart : e->KLpart;
     if (!src) return fail("buffer not allocated");

@@ -1,7 +1,7 @@
 """Diagnostic: where do batched and one-wavefront-per-sample solves differ, and which one is closer to SciPy?"""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from scipy import optimize
 from oracle import corrnmf_oracle as co

@@ -2,7 +2,7 @@
 return NaN, at which sizes?  A NaN here is a read of memory nobody wrote."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import klnmf_oracle as orc
 from salamander_amd import Engine

@@ -662,7 +662,7 @@ def test_batched_sample_solves_agree_with_one_wavefront_per_sample(N, K, dim, ma
         assert (err < 1e-8).mean() >= 0.97
     # a flipped test changes a truncated solve (maxiter = 3) by a fraction of a Newton step: rare, and both results are
     # iterates of the same descent method -- the objective of every such solve must still have decreased
-    # (measured with tools/diag_batched.py, SciPy as the judge: 0.2 % of the solves at K = dim = 40 and 1 % of the runs to
+    # (measured with tests/dev/diag_batched.py, SciPy as the judge: 0.2 % of the solves at K = dim = 40 and 1 % of the runs to
     # convergence differ beyond these bounds, in half of them the batched result is the one SciPy agrees with)
     assert (err < (2e-4 if maxiter > 0 else 10 * dim * 1e-5)).mean() >= (0.995 if maxiter > 0 else 0.97)
     for n in np.flatnonzero(err >= 1e-6)[:20]:
