@@ -331,6 +331,7 @@ class SignatureNMF(ABC):
     ) -> "SignatureNMF":
         self._setup_adata(adata, background=self._background_setup)
         self._initial_exposures_uploaded = False
+        self._initial_exposures_backup = None
         try:
             # inside fit() a device-side initialisation leaves the exposures on the device only: they come back once,
             # with the fitted ones (a 40 MB host array and its page faults less at c2)
@@ -349,7 +350,15 @@ class SignatureNMF(ABC):
                     of_values, n_iteration = self._fit_loop_blocking(given_parameters, verbose, verbosity_freq)
             finally:
                 self._fit_running = False
+        except BaseException:
+            # the queued loop drops the host copy of the initial exposures while the device works (they come back fitted
+            # at the end): a fit that does not get there hands the caller's AnnData back as the reference would leave it
+            # after its initialisation (initialize.py:254), not without exposures
+            if self._initial_exposures_backup is not None and "exposures" not in self.adata.obsm:
+                self.adata.obsm["exposures"] = self._initial_exposures_backup
+            raise
         finally:
+            self._initial_exposures_backup = None
             self._finish_setup()  # adata.X is the clipped matrix from here on (signature_nmf.py:281)
         self._sync_from_device()
         self.n_iterations_ = n_iteration
@@ -425,7 +434,9 @@ class SignatureNMF(ABC):
                 # adata.obsm["exposures"] with the fitted ones at its end
                 if getattr(self, "_initial_exposures_uploaded", False):
                     self._initial_exposures_uploaded = False
-                    self.adata.obsm.pop("exposures", None)
+                    # (taken out of the caller's AnnData, kept by reference: fit() puts it back if the fit does not
+                    # complete -- an engine error or an interrupt must not leave the object without exposures)
+                    self._initial_exposures_backup = self.adata.obsm.pop("exposures", None)
             while pending:
                 n = min(pending, ring - first_slot)
                 of_values.extend(float(v) for v in self._device_objectives_read(first_slot, n))

@@ -297,6 +297,28 @@ def test_fit_queues_objectives_until_min_iterations_then_speculates(fake_engine,
     assert np.array_equal(q.asignatures.X, b.asignatures.X) and np.array_equal(q.adata.obsm["exposures"], b.adata.obsm["exposures"])
 
 
+def test_a_fit_that_fails_midway_leaves_the_callers_exposures_in_place(fake_engine, counts, monkeypatch):
+    """The queued loop takes the host copy of the initial exposures out of the caller's AnnData while the device works
+    (they come back fitted).  An engine error -- or an interrupt -- after that point must not leave the object without
+    them: the reference never removes ``obsm["exposures"]`` (``initialize.py:254``, ``klnmf.py:106``)."""
+    adata = make_adata(counts)
+    m = sal.models.KLNMF(2, "random", min_iterations=40, max_iterations=400, conv_test_freq=10, tol=1e-12)
+    calls = {"n": 0}
+    real = fake_engine.objective_read
+
+    def failing_read(self, first, count):
+        calls["n"] += 1
+        if calls["n"] >= 3:
+            raise RuntimeError("device lost")
+        return real(self, first, count)
+
+    monkeypatch.setattr(fake_engine, "objective_read", failing_read)
+    with pytest.raises(RuntimeError, match="device lost"):
+        m.fit(adata, init_kwargs={"seed": 1})
+    assert "exposures" in adata.obsm and adata.obsm["exposures"].shape == (10, 2) and np.isfinite(adata.obsm["exposures"]).all()
+    assert adata.X.min() >= utils.EPSILON  # the clipped matrix is in place as after any fit (signature_nmf.py:281)
+
+
 @pytest.mark.parametrize(
     "min_it,max_it,freq,tol",
     [(0, 5, 10, 1e-4), (1, 1, 1, 1e-4), (0, 0, 10, 1e-4), (5, 37, 10, 1e-9), (40, 400, 10, 1e-4), (40, 400, 7, 1e-3), (0, 400, 1, 1e-4),
