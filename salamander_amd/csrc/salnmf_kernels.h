@@ -1513,7 +1513,11 @@ __global__ void __launch_bounds__(BLOCK, (fwd_lds_doubles<KS>() * 8 <= 80 * 1024
     double* red = lds + FROWS * WS + WAVES * G_::HL;
     double* hsl = red + BLOCK;  // [KP] copy of hscale
     if (p.hscale && tid < KP) hsl[tid] = p.hscale[tid];
-    double* ltab = hsl + KP;    // table of log_pos
+    // table of log_pos, in LDS.  (Measured and dropped, profiles/r04/log_table.md: the same table through the vector L1
+    // -- global loads of the 4 KB __device__ array instead of ds_read_b128 -- 33.9 -> 41.3 us at c2: the lookup's latency
+    // then sits in front of every batch of logarithms; a conflict-free replicated table does not fit: two workgroups of
+    // this kernel leave 1.4 KB of a CU's 160 KB.)
+    double* ltab = hsl + KP;
     if (MODE == 0 || MODE == 3) stage_logtab(ltab, tid);
 
     stage_W<FROWS>(Wl, p.W, K, V, p.ldw, tid);
