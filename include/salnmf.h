@@ -116,6 +116,13 @@ int salnmf_kl_step(salnmf_engine* e, int n_steps, int n_given);
  * steps it discards may still be running.  For a caller that queues the next block of steps BEFORE it has read the
  * objective that decides convergence (signature_nmf.py:373-380): the decision's host round trip hides behind the block. */
 int salnmf_kl_step_keep(salnmf_engine* e, int n_steps, int n_given);
+/* Small cohorts: with at most `max_tiles` tiles of 16 samples (default 8 = 128 samples, at most 64), at most 16
+ * signatures, no weights, fp64, one device, salnmf_kl_step runs ALL n_steps of a call in ONE launch of ONE workgroup
+ * (csrc/salnmf_small.hip: W in LDS, workgroup barriers only) instead of two launches per step: 2.1x / 1.5x the per-step
+ * path's rate at 64 / 128 samples.  One workgroup has one CU's matrix pipes, so from 12 tiles on (the reference's own
+ * data/pcawg_breast_sbs.csv: 192 samples) the per-step path is as fast; hence the default.  Bit for bit the same W, H as
+ * the per-step path at every size (the summation orders are reproduced).  0 turns it off. */
+int salnmf_set_small_cohort_tiles(salnmf_engine* e, int max_tiles);
 int salnmf_kl_rollback(salnmf_engine* e);
 /* The objective (klnmf.py:64-80) of the resident state into slot `slot` of the objective ring (as salnmf_objective_async),
  * then n_steps >= 0 joint updates (keep != 0: as salnmf_kl_step_keep).  This is what SignatureNMF.fit does at every

@@ -45,6 +45,7 @@ SIGNATURES = {
     "salnmf_set_persistent": (c_int, [_P, c_int]),
     "salnmf_set_lockstep": (c_int, [_P, c_int]),
     "salnmf_set_batched_sample_solves": (c_int, [_P, c_int]),
+    "salnmf_set_small_cohort_tiles": (c_int, [_P, c_int]),
     "salnmf_set_precision": (c_int, [_P, c_int]),
     "salnmf_update_H": (c_int, [_P]),
     "salnmf_update_W": (c_int, [_P, c_int, c_int]),

@@ -127,6 +127,12 @@ static int rccl_bind() {
         if (rc_) return rc_;   \
     } while (0)
 
+// up to this many tiles (16 samples each) the one-workgroup multi-step kernel (salnmf_small.hip) beats two launches per
+// step: 5.2 against 10.9 us per step at 64 samples, 7.3 against 10.9 at 128; from 12 tiles on (c1: 11.1 against 10.9) one
+// CU's four matrix pipes are the bound -- 60 MFMAs per tile whatever K <= 16 is -- and the per-step path, which spreads
+// the tiles over one CU per four of them, is as fast or faster (profiles/r04/small_cohorts.md)
+constexpr int SMALL_TILES_DEFAULT = 8;
+
 struct salnmf_engine {
     int device = 0;
     int V = 0, K = 0;
@@ -234,6 +240,7 @@ struct salnmf_engine {
     int ls_S = 0, ls_dim = 0;
     bool lockstep = true;  // salnmf_set_lockstep(e, 0) forces the single-kernel form
     bool batched_samples = true;  // salnmf_set_batched_sample_solves(e, 0) forces one wavefront per sample
+    int small_max_tiles = SMALL_TILES_DEFAULT;  // salnmf_set_small_cohort_tiles: up to this many tiles salnmf_kl_step runs as one workgroup
     hipEvent_t ls_ev[2] = {nullptr, nullptr};  // lockstep rounds: the count of live solves has reached the host
     double *gU = nullptr, *galpha = nullptr, *gaux = nullptr;
     size_t g_rows = 0;
@@ -1170,6 +1177,13 @@ int salnmf_set_lockstep(salnmf_engine* e, int on) {
     return 0;
 }
 
+int salnmf_set_small_cohort_tiles(salnmf_engine* e, int max_tiles) {
+    if (!e) return fail("null engine");
+    if (max_tiles < 0) return fail("max_tiles must not be negative (0 turns the one-workgroup kernel off)");
+    e->small_max_tiles = max_tiles;
+    return 0;
+}
+
 int salnmf_set_batched_sample_solves(salnmf_engine* e, int on) {
     if (!e) return fail("null engine");
     e->batched_samples = on != 0;
@@ -1233,6 +1247,13 @@ int salnmf_set_precision(salnmf_engine* e, int precision) {
     return 0;
 }
 
+// small cohorts: one workgroup, all steps of a call in one launch (salnmf_small.hip); unweighted fp64 steps of an unsharded
+// engine with at most 16 signatures, at least one of them free
+static bool small_path(const salnmf_engine* e, int n_given) {
+    return e->NB == 1 && e->NC == 1 && !e->fast32 && !e->persistent && !sharded(e) && !e->wkl && !e->wlh && e->K <= 16 && n_given < e->K &&
+           e->ntiles <= std::min(e->small_max_tiles, SMALL_MAX_TILES);
+}
+
 int salnmf_kl_step(salnmf_engine* e, int n_steps, int n_given) {
     if (!e) return fail("null engine");
     if (n_given < 0 || n_given > e->K) return fail("n_given out of range");
@@ -1251,6 +1272,18 @@ int salnmf_kl_step(salnmf_engine* e, int n_steps, int n_given) {
         return kl_steps_f32(e, n_steps, n_given);
     }
     int i = 0;
+    if (small_path(e, n_given) && n_steps > 0) {
+        CK(flush_H_scale(e));  // (after an MvNMF step) the kernel reads H as it is
+        SmallParams sp{e->X, e->H, e->W, e->W, e->red, e->V, e->K, (int)e->ntiles, 0, n_given, SALNMF_CLIP_ALL};
+        constexpr int kMaxPerLaunch = 4096;  // bounds one launch to tens of milliseconds
+        while (i < n_steps) {
+            sp.nsteps = std::min(kMaxPerLaunch, n_steps - i);
+            if (launch_small_kl_steps(e->KS, sp, e->stream)) return fail("no small-cohort kernel for KS=%d", e->KS);
+            HIPCK(hipGetLastError());
+            i += sp.nsteps;
+        }
+        return 0;
+    }
     if (e->persistent && !sharded(e) && !e->wkl && !e->wlh && n_given < e->K && n_steps >= 2) {
         CK(flush_H_scale(e));  // (after an MvNMF step) the persistent kernel reads H as it is
         constexpr int kMaxPerLaunch = 64;  // bounds one launch to a few milliseconds
@@ -1284,8 +1317,8 @@ int salnmf_kl_step_keep(salnmf_engine* e, int n_steps, int n_given) {
         e->keep_valid = true;
         return 0;
     }
-    if (e->fast32 || e->persistent) {
-        // the fp32 fast mode and the persistent kernel update the state in place: keep a copy instead
+    if (e->fast32 || e->persistent || small_path(e, n_given)) {
+        // the fp32 fast mode, the persistent kernel and the small-cohort kernel update the state in place: keep a copy instead
         HIPCK(hipMemcpyAsync(e->Halt, e->H, (size_t)e->Np * e->KP * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
         HIPCK(hipMemcpyAsync(e->Wkeep, e->W, (size_t)e->K * e->V * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
         CK(salnmf_kl_step(e, n_steps, n_given));
@@ -1533,7 +1566,8 @@ int salnmf_kl_step_objective(salnmf_engine* e, int slot, int n_steps, int n_give
     if (n_given < 0 || n_given > e->K) return fail("n_given out of range");
     if (n_steps < 0) return fail("n_steps must not be negative");
     CK(enter(e));
-    const bool fold = n_steps > 0 && !split(e) && !e->fast32 && !e->persistent && !sharded(e) && !e->wkl && !e->wlh && n_given < e->K;
+    const bool fold = n_steps > 0 && !split(e) && !e->fast32 && !e->persistent && !sharded(e) && !e->wkl && !e->wlh && n_given < e->K &&
+                      !small_path(e, n_given);  // (small cohorts: a forward pass, then all steps in one launch)
     if (!fold) {
         // the objective as a forward pass of its own, then the steps
         CK(salnmf_objective_async(e, slot));

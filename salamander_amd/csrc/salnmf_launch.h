@@ -26,6 +26,19 @@ int launch_fused_inst(const FusedSel& s, const FusedParams& p, int grid, hipStre
 // (mode + FWD_PIN: the instantiation whose P starts from p.pin -- modes 0, 1, 2, 4)
 constexpr int FWD_PIN = 16;
 int launch_forward_inst(int KS, int mode, const FwdParams& p, int grid, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop);
+
+// Small cohorts (salnmf_small.hip): n_steps joint KL steps of an unweighted problem with at most SMALL_MAX_TILES tiles and
+// 16 signatures in ONE one-workgroup launch; same bits as the per-step path.  0 = launched, 1 = shape not covered.
+constexpr int SMALL_MAX_TILES = 64;
+struct SmallParams {
+    const double* __restrict__ X;  // [Np][VMAX]
+    double* __restrict__ H;        // [Np][16] in / out
+    const double* W;               // [K][V] in
+    double* Wout;                  // [K][V] out (normally == W)
+    double* G;                     // [K][V] the last step's reduced numerator (what the W tail leaves behind)
+    int V, K, ntiles, nsteps, n_given, clip_mode;
+};
+int launch_small_kl_steps(int KS, const SmallParams& p, hipStream_t stream);
 int launch_fused_f32_inst(int KS, const Fused32Params& p, int grid, hipStream_t stream);
 bool built_with_persistent();
 

@@ -127,6 +127,11 @@ class Engine:
         """Signature-embedding solves in lockstep rounds (default from 16 384 samples on) or one workgroup per signature."""
         _lib.check(self._lib.salnmf_set_lockstep(self._h, int(bool(on))))
 
+    def set_small_cohort_tiles(self, max_tiles: int = 8):
+        """Up to ``max_tiles`` tiles of 16 samples ``kl_step`` runs as one workgroup, all steps of a call in one launch
+        (``include/salnmf.h: salnmf_set_small_cohort_tiles``); 0 turns that off."""
+        _lib.check(self._lib.salnmf_set_small_cohort_tiles(self._h, int(max_tiles)))
+
     def set_batched_sample_solves(self, on: bool = True):
         """Sample-embedding solves sixteen per wavefront on the MFMA units (default where the shape allows) or one wavefront per sample."""
         _lib.check(self._lib.salnmf_set_batched_sample_solves(self._h, int(bool(on))))
