@@ -513,7 +513,10 @@ def main():
         blocks = [timed_block() for _ in range(n_blocks)]
         return first, n_blocks, blocks, statistics.median(blocks)
 
+    gpu_sections = {}  # wall-clock seconds of the sections in which the GPU is the one that works (launch gaps included)
+    t_sec = time.perf_counter()
     first, n_blocks, blocks, median = timed_blocks()
+    gpu_sections["timed_blocks"] = time.perf_counter() - t_sec
     exchange_mode = "rccl" if sharded else None
     if exchange is not None and exchange.get("p2p_valid") and not rccl_ok:
         exchange["p2p_ms_per_step"] = median / args.steps * 1e3
@@ -532,13 +535,42 @@ def main():
             exchange_mode = "p2p"
     if exchange is not None:
         exchange["used_for_value"] = exchange_mode
+        # where a sharded step's microseconds go, rank by rank (untimed; same launches, HIP events on the two dispatches
+        # and s_memrealtime stamps around the exchange inside the tail): printed with the line, so that the first run on a
+        # node says whether compute, the exchange's wire time or the ranks' skew (wait_for_peer_flags) is the long pole
+        if exchange.get("p2p_valid"):
+            was_p2p = exchange_mode == "p2p"
+            try:
+                if not was_p2p:
+                    engine.set_p2p(True)
+                barrier()
+                mine = engine.profile_sharded_steps(args.steps)
+                mine["rank"] = rank
+                if dist is not None and world > 1:
+                    rows = [None] * world
+                    dist.all_gather_object(rows, mine)
+                else:
+                    rows = [mine]
+                exchange["timeline_us_per_rank"] = rows
+                exchange["timeline_protocol"] = (
+                    f"{args.steps} steps per rank through the peer-to-peer tail; step / fused_pass / tail_exchange_launch from HIP events "
+                    "on the dispatches, the rest averaged over the tail's row workgroups from in-kernel 100 MHz stamps"
+                )
+            except Exception as exc:  # the timeline must never cost the headline line
+                exchange["timeline_error"] = f"{type(exc).__name__}: {exc}"
+            finally:
+                if not was_p2p:
+                    engine.set_p2p(False)
+                barrier()
 
     # untimed: kernel durations from HIP events bound to the dispatches of every 2nd step of 200 (100 samples each)
     barrier()
+    t_sec = time.perf_counter()
     _, fused_ms, tail_ms = engine.profile_kl_steps(200, 0, 2)
     objective = engine.objective()
     fwd_ms = engine.profile_objective(20)
     wh_ms = engine.profile_reconstruct(20)
+    gpu_sections["kernel_samples"] = time.perf_counter() - t_sec
     barrier()
 
     one_gpu = None
@@ -687,18 +719,31 @@ def main():
             line["cpu_baseline"] = sharded_cpu
             line["time_to_kl"] = sharded_ttk
         if not sharded:
-            if not args.no_cpu_baseline:
-                rec, (n_cpu, target, cpu_s) = cpu_baseline(X, W0, H0, args.cpu_steps, args.cpu_budget)
-                line["cpu_baseline"] = rec
-                line["time_to_kl"] = time_to_kl(sal, X, W0, H0, n_cpu, target, cpu_s, local_rank)
+            # the other single-GPU configurations FIRST, the CPU baseline (100 s of NumPy on the host cores, the GPU idle)
+            # last: a utilisation trace of this process shows the device at work for the first part of the run, then nothing
             if not args.no_extra:
                 extra = {}
                 for name, fn in (("c4_mvnmf", extra_c4), ("c2_default_init_fit", extra_default_init_fit), ("c2_fp32_fast_mode", extra_fast_mode), ("c2_weighted_step", extra_weighted_step), ("c5_mmcorrnmf", extra_c5)):
+                    t_sec = time.perf_counter()
                     try:
                         extra[name] = fn(sal, local_rank)
                     except Exception as exc:  # an extra must never cost the headline line
                         extra[name] = {"error": f"{type(exc).__name__}: {exc}"}
+                    gpu_sections["extra." + name] = time.perf_counter() - t_sec  # (includes the host's synthetic data and uploads)
                 line["extra"] = extra
+            if not args.no_cpu_baseline:
+                t_cpu = time.perf_counter()
+                rec, (n_cpu, target, cpu_s) = cpu_baseline(X, W0, H0, args.cpu_steps, args.cpu_budget)
+                line["cpu_baseline"] = rec
+                cpu_wall = time.perf_counter() - t_cpu
+                t_sec = time.perf_counter()
+                line["time_to_kl"] = time_to_kl(sal, X, W0, H0, n_cpu, target, cpu_s, local_rank)
+                gpu_sections["time_to_kl"] = time.perf_counter() - t_sec
+                line["cpu_baseline_wall_seconds"] = cpu_wall
+        # where this process's wall clock went: the GPU works in the sections listed (the timed blocks are pure device
+        # time; the extras include host-side data generation), it idles during the CPU baseline
+        line["gpu_seconds_total"] = sum(gpu_sections.values())
+        line["gpu_sections_seconds"] = gpu_sections
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     else:

@@ -97,6 +97,7 @@ SIGNATURES = {
     "salnmf_sync": (c_int, [_P]),
     "salnmf_profile_kl_steps": (c_int, [_P, c_int, c_int, c_int, _D, _D, _D]),
     "salnmf_profile_objective": (c_int, [_P, c_int, _D]),
+    "salnmf_profile_sharded_steps": (c_int, [_P, c_int, c_int, POINTER(c_double)]),
     "salnmf_profile_reconstruct": (c_int, [_P, c_int, _D]),
 }
 

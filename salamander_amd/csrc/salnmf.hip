@@ -228,6 +228,7 @@ struct salnmf_engine {
         int n_ranks = 0;                        // as exported
         unsigned long long seq = 0;
         unsigned* abort_dev = nullptr;          // device word: an exchange gave up (salnmf_p2p_kernels.h)
+        unsigned long long* stamps = nullptr;  // salnmf_profile_sharded_steps: where the next tail_p2p launch writes its stamps
         unsigned long long timeout_ticks = P2P_TIMEOUT_TICKS;
     } p2p;
     std::vector<int64_t> shard_N;  // n_samples of every rank's shard (filled by salnmf_comm_init)
@@ -417,6 +418,8 @@ static P2PParams next_exchange(salnmf_engine* e, double* buf, size_t count) {
     q.abort_host = e->pabort;
     q.abort_dev = e->p2p.abort_dev;
     q.timeout_ticks = e->p2p.timeout_ticks;
+    q.stamps = e->p2p.stamps;  // (null outside salnmf_profile_sharded_steps)
+    if (e->p2p.stamps) e->p2p.stamps += (size_t)6 * P2P_MAX_WG;
     return q;
 }
 
@@ -2855,6 +2858,62 @@ int salnmf_profile_kl_steps(salnmf_engine* e, int n_steps, int n_given, int samp
     if (total_ms) *total_ms = tot;
     if (fused_avg_ms) *fused_avg_ms = fused / n_samples;
     if (tail_avg_ms) *tail_avg_ms = tail / n_samples;
+    return 0;
+}
+
+// n_steps sharded joint steps with HIP events bound to every step's two dispatches and the in-kernel stamps of the
+// tail's exchange (salnmf_p2p_kernels.h: tail_p2p_kernel): where a sharded step's microseconds go, rank by rank.
+//   out[0] step (wall clock of the stream / n_steps)   out[1] fused pass   out[2] tail + exchange launch   (events)
+//   per row workgroup of the tail, averaged over rows and steps (s_memrealtime, 100 MHz):
+//   out[3] local slab reduction  out[4] stores to the peers + flags  out[5] wait for the peers' flags
+//   out[6] read + sum of the peers' rows  out[7] W row finish   out[8] the longest wait of any row and step
+// all in microseconds.  Needs the peer-to-peer exchange (a world of one rank included: the rehearsal).
+int salnmf_profile_sharded_steps(salnmf_engine* e, int n_steps, int n_given, double* out9) {
+    if (!e || !out9) return fail("null argument");
+    if (split(e)) return single_block(e, "the profiling entry points");
+    if (n_steps < 1 || n_steps > 4096) return fail("n_steps out of range");
+    CK(enter(e));
+    const size_t count = (size_t)e->K * e->V;
+    if (!(p2p_usable(e, count) && e->K <= P2P_MAX_WG)) return fail("the sharded timeline needs the peer-to-peer exchange (salnmf_p2p_connect, salnmf_set_p2p)");
+    if (e->wkl || e->wlh) return fail("the sharded timeline profiles the unweighted step");
+    CK(ensure_events(e, (size_t)4 * n_steps + 2));
+    unsigned long long* dstamps = nullptr;
+    const size_t n_stamps = (size_t)n_steps * 6 * P2P_MAX_WG;
+    HIPCK(hipMalloc(&dstamps, n_stamps * sizeof(unsigned long long)));
+    HIPCK(hipMemsetAsync(dstamps, 0, n_stamps * sizeof(unsigned long long), e->stream));
+    hipEvent_t first = e->events[4 * (size_t)n_steps], last = e->events[4 * (size_t)n_steps + 1];
+    int rc = 0;
+    HIPCK(hipEventRecord(first, e->stream));
+    e->p2p.stamps = dstamps;
+    for (int i = 0; i < n_steps && !rc; ++i) rc = kl_step_once(e, n_given, &e->events[4 * (size_t)i]);
+    e->p2p.stamps = nullptr;
+    if (!rc && hipEventRecord(last, e->stream) != hipSuccess) rc = fail("hipEventRecord failed");
+    if (!rc && hipStreamSynchronize(e->stream) != hipSuccess) rc = fail("hipStreamSynchronize failed");
+    std::vector<unsigned long long> st(n_stamps);
+    if (!rc && hipMemcpy(st.data(), dstamps, n_stamps * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) rc = fail("stamp download failed");
+    (void)hipFree(dstamps);
+    if (rc) return rc;
+    CK(check_abort(e));
+    double fused = 0, tail = 0, seg[5] = {0, 0, 0, 0, 0}, wait_max = 0;
+    for (int i = 0; i < n_steps; ++i) {
+        float a = 0, b = 0;
+        HIPCK(hipEventElapsedTime(&a, e->events[4 * (size_t)i], e->events[4 * (size_t)i + 1]));
+        HIPCK(hipEventElapsedTime(&b, e->events[4 * (size_t)i + 2], e->events[4 * (size_t)i + 3]));
+        fused += a;
+        tail += b;
+        for (int k = 0; k < e->K; ++k) {
+            const unsigned long long* s6 = st.data() + ((size_t)i * P2P_MAX_WG + k) * 6;
+            for (int j = 0; j < 5; ++j) seg[j] += (double)(s6[j + 1] - s6[j]) * 0.01;  // 100 MHz ticks -> us
+            wait_max = std::max(wait_max, (double)(s6[3] - s6[2]) * 0.01);
+        }
+    }
+    float tot = 0;
+    HIPCK(hipEventElapsedTime(&tot, first, last));
+    out9[0] = tot * 1e3 / n_steps;
+    out9[1] = fused * 1e3 / n_steps;
+    out9[2] = tail * 1e3 / n_steps;
+    for (int j = 0; j < 5; ++j) out9[3 + j] = seg[j] / ((double)n_steps * e->K);
+    out9[8] = wait_max;
     return 0;
 }
 

@@ -44,7 +44,15 @@ struct P2PParams {
     unsigned long long timeout_ticks;  // of the 100 MHz clock
     unsigned* abort_host;   // pinned host word: 2 = an exchange gave up
     unsigned* abort_dev;    // device word, set with it: later exchanges of this engine return at once instead of waiting again
+    // optional (salnmf_profile_sharded_steps): six s_memrealtime stamps (100 MHz) per workgroup of tail_p2p_kernel --
+    // [0] start [1] local slabs reduced [2] row stored to the peers, flags raised [3] every peer's flag seen
+    // [4] peers' rows read and summed [5] W row finished
+    unsigned long long* stamps;
 };
+
+__device__ __forceinline__ void p2p_stamp(const P2PParams& p, int wg, int i, int tid) {
+    if (p.stamps != nullptr && tid == 0) p.stamps[wg * 6 + i] = __builtin_amdgcn_s_memrealtime();
+}
 
 typedef __attribute__((address_space(1))) double gdouble_t;
 typedef __attribute__((address_space(1))) unsigned long long gflag_t;
@@ -79,6 +87,7 @@ __device__ __forceinline__ double p2p_exchange(const P2PParams& p, int idx, bool
         gflag_t* flag = (gflag_t*)(p.inbox[tid] + mine + p.max_count) + flag_idx;
         __hip_atomic_store(flag, p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    p2p_stamp(p, flag_idx, 2, tid);
     // wait for this workgroup's slice from every other source (lane r polls source r)
     if (tid < p.n_ranks && tid != p.rank) {
         const gflag_t* flag = (const gflag_t*)(p.inbox[p.rank] + ((size_t)p.parity * p.n_ranks + tid) * p.slot + p.max_count) + flag_idx;
@@ -95,6 +104,7 @@ __device__ __forceinline__ double p2p_exchange(const P2PParams& p, int idx, bool
         }
     }
     __syncthreads();
+    p2p_stamp(p, flag_idx, 3, tid);
     if (failed || !active) return 0.0;
     // all peers' values in flight together, then the sum in rank order (this rank's own term from the register)
     double t[P2P_MAX_RANKS];
@@ -133,11 +143,14 @@ __global__ void __launch_bounds__(TAIL_BLOCK) tail_p2p_kernel(TailP2PParams p) {
     __shared__ TailScratch S;
     const int k = blockIdx.x, tid = threadIdx.x;
     const TailParams& t = p.t;
+    p2p_stamp(p.x, k, 0, tid);
     const unsigned ab = p2p_abort_word(p.x, tid);  // (in flight beside the slab loads)
     const double wold = (tid < t.V) ? t.W[k * t.V + tid] : 0.0;  // old row of W, for the second half: likewise
     tail_row<TAIL_BLOCK, false>(S, tid, k, t.Gpart, t.nslabs, t.G, t.W, t.Wout, t.V, t.K, t.n_given, t.clip_mode, false);
+    p2p_stamp(p.x, k, 1, tid);
     const bool active = tid < t.V;  // (tail_row left the row's local sum in S.red[0][v], behind a barrier)
     const double total = p2p_exchange(p.x, k * t.V + tid, active, k, active ? S.red[0][tid] : 0.0, tid, ab);
+    p2p_stamp(p.x, k, 4, tid);
     // the reduced row goes to G (the engine's buffer) and, through LDS, straight into the W update: no store -> load
     // round trip through global memory in between
     if (active) {
@@ -146,6 +159,7 @@ __global__ void __launch_bounds__(TAIL_BLOCK) tail_p2p_kernel(TailP2PParams p) {
     }
     __syncthreads();
     tail_row<TAIL_BLOCK, false>(S, tid, k, nullptr, -1, t.G, t.W, t.Wout, t.V, t.K, t.n_given, t.clip_mode, true, wold);
+    p2p_stamp(p.x, k, 5, tid);
 }
 
 }  // namespace salnmf

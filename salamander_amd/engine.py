@@ -418,6 +418,15 @@ class Engine:
         )
         return t.value, f.value, w.value
 
+    def profile_sharded_steps(self, n_steps: int, n_given: int = 0) -> dict:
+        """Per-phase timeline of this rank's sharded joint step in microseconds (``include/salnmf.h:
+        salnmf_profile_sharded_steps``): HIP events around the two launches, in-kernel stamps around the exchange."""
+        out = (c_double * 9)()
+        _lib.check(self._lib.salnmf_profile_sharded_steps(self._h, int(n_steps), int(n_given), out))
+        keys = ("step", "fused_pass", "tail_exchange_launch", "local_slab_reduce", "peer_stores_and_flags", "wait_for_peer_flags",
+                "read_and_sum_peer_rows", "w_row_finish", "longest_flag_wait")
+        return {k: float(v) for k, v in zip(keys, out)}
+
     def profile_objective(self, n_calls: int) -> float:
         a = c_double()
         _lib.check(self._lib.salnmf_profile_objective(self._h, int(n_calls), ctypes.byref(a)))

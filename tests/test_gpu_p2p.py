@@ -46,7 +46,12 @@ def _worker(rank, world, port, out_dir, n_kl, n_mv):
         S_init = initialize_on_device(e, K, "nndsvd", None, N)
         H_init = e.download_H()
         e.upload_W(W0), e.upload_H(H0[a:b])
-        e.kl_step(n_kl, 0)
+        e.kl_step(n_kl - 4, 0)
+        # four of the steps through the profiling entry point: the same launches with events and in-kernel stamps -- the
+        # state must not notice, and every phase of the exchange must have taken a sane time on every rank
+        tl = e.profile_sharded_steps(4, 0)
+        assert all(np.isfinite(v) and v >= 0.0 for v in tl.values()) and tl["step"] > 0 and tl["longest_flag_wait"] < 5e6, tl
+        assert tl["fused_pass"] + tl["tail_exchange_launch"] <= 1.5 * tl["step"] + 50, tl
         Wk, Hk = e.download_W(), e.download_H()
         obj = e.objective()  # scalar all-reduce through the same exchange
         gamma = e.mv_step(n_mv, 0, LAM, DELTA, 1.0)
@@ -165,5 +170,14 @@ def test_peer_exchange_argument_checks():
     e.p2p_connect(0, [h], 64)
     e.kl_step(3, 0), ref.kl_step(3, 0)
     assert np.array_equal(e.download_W(), ref.download_W()) and np.array_equal(e.download_H(), ref.download_H())
+    # the per-phase timeline of the sharded step (world of one rank: no peer to wait for); same state afterwards
+    tl = e.profile_sharded_steps(5, 0)
+    ref.kl_step(5, 0)
+    assert np.array_equal(e.download_W(), ref.download_W()) and np.array_equal(e.download_H(), ref.download_H())
+    assert set(tl) == {"step", "fused_pass", "tail_exchange_launch", "local_slab_reduce", "peer_stores_and_flags", "wait_for_peer_flags",
+                       "read_and_sum_peer_rows", "w_row_finish", "longest_flag_wait"}
+    assert 0 < tl["step"] < 1e4 and 0 <= tl["wait_for_peer_flags"] <= tl["longest_flag_wait"] < 1e3 and tl["local_slab_reduce"] > 0
+    with pytest.raises(RuntimeError, match="peer-to-peer"):
+        ref.profile_sharded_steps(2, 0)
     with pytest.raises(RuntimeError, match="cannot be switched off"):
         e.set_p2p(False)
