@@ -4,6 +4,7 @@
 #include "../../include/salnmf.h"
 #include "salnmf_launch.h"
 #include "salnmf_mv_kernels.h"
+#include "salnmf_mv_wide_kernels.h"
 #include "salnmf_corr_kernels.h"
 #include "salnmf_corr_lockstep.h"
 #include "salnmf_init_kernels.h"
@@ -1686,12 +1687,85 @@ static int mv_logdet_to_slot(salnmf_engine* e, const double* W, double delta, in
     return 0;
 }
 
+// ---- MvNMF on more than 96 features (feature blocks, one signature chunk): the step of mvnmf.py:197-210 in its plain form
+// -- update_H over the blocks, the blocked numerator passes, the W-only algebra, root, and a host-driven line search
+// whose objectives are forward passes over the blocks.  No speculation: a 288- or 1 536-feature problem spends its time
+// in the passes over the samples, which are the KLNMF path's (csrc/salnmf_mv_wide_kernels.h has the kernels).
+static inline bool mv_wide(const salnmf_engine* e) { return e->NB > 1 && e->NC == 1; }
+static int mv_wide_check(const salnmf_engine* e) {
+    if (e->NC > 1) return single_block(e, "MvNMF");
+    if (sharded(e)) return fail("MvNMF on more than %d features is not available on a sample-sharded engine", VMAX);
+    return 0;
+}
+static int mv_wide_logdet(salnmf_engine* e, const double* W, double delta, int slot) {
+    hipLaunchKernelGGL(mv_logdet_wide_kernel, dim3(1), dim3(MV_BLOCK), 0, e->stream, W, e->K, e->V, delta, e->scal + slot);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+// numerator of (W, H) -> Gblk, rowsums_H -> red + K V, A = W Y_minus, B = W |Y| -> mvA, mvB, log det(W) -> scal[3]
+static int mv_wide_prepare(salnmf_engine* e, double delta) {
+    CK(flush_H_scale(e));  // (the column sums below read H as it is)
+    CK(blocked_numerators(e));
+    hipLaunchKernelGGL(colsum_kernel, dim3(e->K), dim3(256), 0, e->stream, e->H, e->N, e->KP, e->red + (size_t)e->K * e->V);
+    HIPCK(hipGetLastError());
+    hipLaunchKernelGGL(mv_prepare_W_wide_kernel, dim3(1), dim3(MV_BLOCK), 0, e->stream, e->W, e->K, e->V, delta, e->mvA, e->mvB, e->scal + 3);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+static int mv_wide_root(salnmf_engine* e, double lam, int n_given) {
+    hipLaunchKernelGGL(mv_trial_row_wide_kernel<true>, dim3(e->K), dim3(256), 0, e->stream, e->W, e->Wunc, 1.0, 0, e->K, e->V, e->Wtrial, e->cs, e->mvA,
+                       e->mvB, e->Gblk, e->red + (size_t)e->K * e->V, lam, n_given);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+// line_search (mvnmf.py:69-92) from the resident (W, H) with W_unconstrained in Wunc.  trial_ready: the first trial (the
+// normalised, clipped W_unconstrained) and its column sums are in Wtrial / cs already; have_logdet: scal[3] = log det(W).
+static int mv_wide_line_search(salnmf_engine* e, double lam, double delta, double* gamma, bool trial_ready, bool have_logdet, double* f_accepted) {
+    CK(flush_H_scale(e));
+    CK(objective_to_slot(e, e->W, nullptr, false, 0));  // KL(X || W H), unweighted (mvnmf.py:27-34)
+    if (!have_logdet) CK(mv_wide_logdet(e, e->W, delta, 3));
+    double g = *gamma;
+    bool blend = false;
+    for (;;) {
+        if (blend || !trial_ready) {
+            hipLaunchKernelGGL(mv_trial_row_wide_kernel<false>, dim3(e->K), dim3(256), 0, e->stream, e->W, e->Wunc, g, blend ? 1 : 0, e->K, e->V, e->Wtrial,
+                               e->cs, nullptr, nullptr, nullptr, nullptr, 0.0, 0);
+            HIPCK(hipGetLastError());
+        }
+        CK(mv_wide_logdet(e, e->Wtrial, delta, 4));
+        CK(objective_to_slot(e, e->Wtrial, e->cs, false, 2));  // KL(X || W_trial clip(H * colsum))
+        double v[5];
+        CK(read_scalars(e, 0, 5, v));
+        const double f0 = v[0] + lam * v[3], f1 = v[2] + lam * v[4];
+        if (f_accepted) *f_accepted = f1;
+        if (f1 > f0 && g > 1e-16) {  // mvnmf.py:84
+            g *= 0.8;
+            blend = true;
+            continue;
+        }
+        break;
+    }
+    *gamma = std::min(1.0, 1.2 * g);  // mvnmf.py:91
+    std::swap(e->W, e->Wtrial);
+    e->h_pending = true;  // H <- clip(H * colsum), applied by the readers until the next update_H pass writes H in full
+    return 0;
+}
+static int mv_wide_update_W(salnmf_engine* e, int n_given, double lam, double delta, double* gamma, double* f_accepted) {
+    if (n_given >= e->K) return 0;
+    CK(mv_wide_prepare(e, delta));
+    CK(mv_wide_root(e, lam, n_given));
+    return mv_wide_line_search(e, lam, delta, gamma, true, true, f_accepted);
+}
+
 int salnmf_mv_objective(salnmf_engine* e, double lam, double delta, double* out) {
-    if (e && split(e)) return single_block(e, "MvNMF");
+    if (e && split(e)) CK(mv_wide_check(e));
     if (!e || !out) return fail("null argument");
     CK(enter(e));
     CK(objective_to_slot(e, e->W, nullptr, false, 0));
-    CK(mv_logdet_to_slot(e, e->W, delta, 3));
+    if (mv_wide(e))
+        CK(mv_wide_logdet(e, e->W, delta, 3));
+    else
+        CK(mv_logdet_to_slot(e, e->W, delta, 3));
     double v[4];
     CK(read_scalars(e, 0, 4, v));
     *out = v[0] + lam * v[3];
@@ -1948,36 +2022,50 @@ static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double de
 }
 
 int salnmf_mv_update_W(salnmf_engine* e, int n_given, double lam, double delta, double* gamma_inout) {
-    if (e && split(e)) return single_block(e, "MvNMF");
+    if (e && split(e)) CK(mv_wide_check(e));
     if (!e || !gamma_inout) return fail("null argument");
     e->keep_valid = false;  // (the MvNMF steps use the second H buffer themselves)
     CK(enter(e));
+    if (mv_wide(e)) return mv_wide_update_W(e, n_given, lam, delta, gamma_inout, nullptr);
     return mv_update_W_impl(e, n_given, lam, delta, gamma_inout, false, false);
 }
 
 int salnmf_mv_logdet(salnmf_engine* e, double delta, double* out) {
-    if (e && split(e)) return single_block(e, "MvNMF");
+    if (e && split(e)) CK(mv_wide_check(e));
     if (!e || !out) return fail("null argument");
     CK(enter(e));
-    CK(mv_logdet_to_slot(e, e->W, delta, 3));
+    if (mv_wide(e))
+        CK(mv_wide_logdet(e, e->W, delta, 3));
+    else
+        CK(mv_logdet_to_slot(e, e->W, delta, 3));
     return read_scalars(e, 3, 1, out);
 }
 
 int salnmf_mv_update_W_unconstrained(salnmf_engine* e, int n_given, double lam, double delta, double* Wunc_out) {
-    if (e && split(e)) return single_block(e, "MvNMF");
+    if (e && split(e)) CK(mv_wide_check(e));
     if (!e || !Wunc_out) return fail("null argument");
     if (n_given < 0 || n_given > e->K) return fail("n_given out of range");
     CK(enter(e));
     if (n_given >= e->K) return download(e, Wunc_out, e->W, (size_t)e->K * e->V);  // every column given: W itself (mvnmf.py:61)
+    if (mv_wide(e)) {
+        CK(mv_wide_prepare(e, delta));
+        CK(mv_wide_root(e, lam, n_given));
+        return download(e, Wunc_out, e->Wunc, (size_t)e->K * e->V);  // (W, H untouched; the trial buffers are scratch)
+    }
     double gamma = 1.0;
     return mv_update_W_impl(e, n_given, lam, delta, &gamma, false, false, false, nullptr, false, nullptr, Wunc_out, nullptr);
 }
 
 int salnmf_mv_line_search(salnmf_engine* e, double lam, double delta, double* gamma_inout, const double* Wunc) {
-    if (e && split(e)) return single_block(e, "MvNMF");
+    if (e && split(e)) CK(mv_wide_check(e));
     if (!e || !gamma_inout || !Wunc) return fail("null argument");
     e->keep_valid = false;
     CK(enter(e));
+    if (mv_wide(e)) {
+        HIPCK(hipMemcpyAsync(e->Wunc, Wunc, (size_t)e->K * e->V * sizeof(double), hipMemcpyHostToDevice, e->stream));
+        HIPCK(hipStreamSynchronize(e->stream));  // (the caller's array is free again)
+        return mv_wide_line_search(e, lam, delta, gamma_inout, false, false, nullptr);
+    }
     return mv_update_W_impl(e, 0, lam, delta, gamma_inout, false, false, false, nullptr, false, nullptr, nullptr, Wunc);
 }
 
@@ -1987,11 +2075,26 @@ int salnmf_mv_step(salnmf_engine* e, int n_steps, int n_given, double lam, doubl
 
 int salnmf_mv_step_objective(salnmf_engine* e, int n_steps, int n_given, double lam, double delta, double* gamma_inout, double* objective_out,
                              int more_follows) {
-    if (e && split(e)) return single_block(e, "MvNMF");
+    if (e && split(e)) CK(mv_wide_check(e));
     if (!e || !gamma_inout) return fail("null argument");
     if (n_steps < 1 && objective_out) return fail("n_steps must be positive");
     if (n_given < 0 || n_given > e->K) return fail("n_given out of range");
     HIPCK(hipSetDevice(e->device));
+    if (mv_wide(e)) {
+        CK(enter(e));
+        e->keep_valid = false;
+        double f = 0.0;
+        for (int i = 0; i < n_steps; ++i) {
+            CK(blocked_update_H(e, e->H));  // MvNMF._update_H (mvnmf.py:162-165): in place, unweighted
+            e->h_pending = false;
+            CK(mv_wide_update_W(e, n_given, lam, delta, gamma_inout, &f));
+        }
+        if (objective_out) {
+            if (n_given >= e->K) return salnmf_mv_objective(e, lam, delta, objective_out);
+            *objective_out = f;  // the line search's value at the accepted point = the objective of the state left behind
+        }
+        return 0;
+    }
     // an engine left ahead by the previous call continues from there if this call is the continuation it speculated on
     const bool resume = e->mv_ahead && n_steps > 0 && e->mv_ahead_delta == delta && e->mv_ahead_given == n_given;
     if (!resume) CK(mv_settle(e));
