@@ -61,12 +61,54 @@ __global__ void __launch_bounds__(BLOCK) gram_kernel(const double* __restrict__ 
     if (lane == 0) xsum_part[(int64_t)blockIdx.x * WAVES + wave] = xs;
 }
 
+// More than 96 features: the off-diagonal blocks of X^T X.  Xa, Xb are two 96-feature blocks of X (padded layout each);
+// this launch forms the tiles (vt, wt), vt in [3 HALF, 3 HALF + 3), wt in [0, 6) of Xa^T Xb -- half of the block's 36
+// tiles, which is what the accumulators of one wave hold (the diagonal blocks go through gram_kernel).
+//   part[(blockIdx.x * WAVES + wave)][tile = 6 (vt - 3 HALF) + wt][r][lane] = G[16 vt + (lane >> 4) + 4 r][16 wt + (lane & 15)]
+constexpr int GRAMX_TILES = 3 * VT;
+constexpr int GRAMX_PART = GRAMX_TILES * 4 * 64;
+template <int HALF>
+__global__ void __launch_bounds__(BLOCK) gram_cross_kernel(const double* __restrict__ Xa, const double* __restrict__ Xb, int64_t ntiles,
+                                                            double* __restrict__ part) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c16 = lane & 15, q = lane >> 4;
+    d4 acc[GRAMX_TILES];
+#pragma unroll
+    for (int i = 0; i < GRAMX_TILES; ++i) acc[i] = (d4){0, 0, 0, 0};
+    const int64_t stride = (int64_t)gridDim.x * WAVES;
+    for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < ntiles; tile += stride) {
+        const double* sa = Xa + (tile * 16 + q) * VMAX + c16 + 48 * HALF;
+        const double* sb = Xb + (tile * 16 + q) * VMAX + c16;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            double xa[3], xb[VT];
+#pragma unroll
+            for (int vt = 0; vt < 3; ++vt) xa[vt] = sa[4 * s * VMAX + 16 * vt];
+#pragma unroll
+            for (int wt = 0; wt < VT; ++wt) xb[wt] = sb[4 * s * VMAX + 16 * wt];
+#pragma unroll
+            for (int vt = 0; vt < 3; ++vt)
+#pragma unroll
+                for (int wt = 0; wt < VT; ++wt) acc[VT * vt + wt] = mfma(xa[vt], xb[wt], acc[VT * vt + wt]);
+        }
+    }
+    double* out = part + ((int64_t)blockIdx.x * WAVES + wave) * GRAMX_PART + lane;
+#pragma unroll
+    for (int i = 0; i < GRAMX_TILES; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(i * 4 + r) * 64] = acc[i][r];
+}
+
 // H[n][j] = sum_v X[n][v] B[j][v] into the padded exposure layout [Np][KP] (pad rows 1, pad columns 0, as
 // salnmf_upload_H leaves them), and per workgroup the sums of squares of the positive and of the negative parts of
 // every column: posneg_part[blockIdx.x][j] and [KP + j].
 constexpr int PROJ_LD = VMAX + 1;  // odd row stride in LDS: conflict-free column access
+//   feature blocks (n_features > 96): one launch per block; X is that block, B points at the block's first column of the
+//   K x n_features operand (row stride ldb), V is the block's width.  `first`: the sum starts here; otherwise it continues
+//   from H.  `last`: the total is final -- filler, norms; otherwise the running sum goes back to H.
 __global__ void __launch_bounds__(256) init_project_kernel(const double* __restrict__ X, const double* __restrict__ B, double* __restrict__ H,
-                                                           int64_t N, int64_t ntiles, int V, int K, int KP, double* __restrict__ posneg_part) {
+                                                           int64_t N, int64_t ntiles, int V, int ldb, int K, int KP, double* __restrict__ posneg_part,
+                                                           int first, int last) {
     extern __shared__ __attribute__((aligned(16))) double plds[];
     double* Bl = plds;                 // [KP][PROJ_LD], rows >= K zero
     double* Xl = plds + KP * PROJ_LD;  // [16][PROJ_LD]
@@ -74,7 +116,7 @@ __global__ void __launch_bounds__(256) init_project_kernel(const double* __restr
     const int tid = threadIdx.x, r = tid >> 4, jg = tid & 15;
     for (int i = tid; i < KP * VMAX; i += 256) {
         const int j = i / VMAX, v = i - j * VMAX;
-        Bl[j * PROJ_LD + v] = (j < K && v < V) ? B[j * V + v] : 0.0;
+        Bl[j * PROJ_LD + v] = (j < K && v < V) ? B[(int64_t)j * ldb + v] : 0.0;
     }
     const int JJ = KP / 16;
     double pos2[4] = {0, 0, 0, 0}, neg2[4] = {0, 0, 0, 0};
@@ -91,11 +133,11 @@ __global__ void __launch_bounds__(256) init_project_kernel(const double* __restr
             const int j = jg + 16 * jj;
             const double* xr = Xl + r * PROJ_LD;
             const double* br = Bl + j * PROJ_LD;
-            double s = 0.0;
-            for (int v = 0; v < VMAX; ++v) s = __builtin_fma(xr[v], br[v], s);
             const bool valid = n < N && j < K;
+            double s = (first || !valid) ? 0.0 : H[n * KP + j];  // (blocks after the first continue the sum: block 0 + 1 + ...)
+            for (int v = 0; v < VMAX; ++v) s = __builtin_fma(xr[v], br[v], s);
             H[n * KP + j] = valid ? s : (j < K ? 1.0 : 0.0);
-            if (valid) {
+            if (valid && last) {
                 const double p = s > 0.0 ? s : 0.0, m = s < 0.0 ? s : 0.0;
                 pos2[jj] = __builtin_fma(p, p, pos2[jj]);
                 neg2[jj] = __builtin_fma(m, m, neg2[jj]);
@@ -146,14 +188,16 @@ __global__ void init_finish_kernel(InitFinishParams p) {
 }
 
 // init_flat (methods.py:58-66) + post-processing: exposure (n, j) = clip(rowsum(X_n) / K * post[j])
+//   nb feature blocks of X at stride Np * VMAX (pads are zero): the row sum runs over all of them, block after block
 __global__ void init_flat_kernel(const double* __restrict__ X, double* __restrict__ H, int64_t N, int64_t Np, int K, int KP,
-                                 const double* __restrict__ post) {
+                                 const double* __restrict__ post, int nb) {
     const int lane = threadIdx.x & 15;
     const int64_t row0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const int64_t rstride = ((int64_t)gridDim.x * blockDim.x) >> 4;
     for (int64_t n = row0; n < Np; n += rstride) {  // 16 lanes per row (Np is a multiple of 16: whole waves stay in step)
         double s = 0.0;
-        for (int v = lane; v < VMAX; v += 16) s += X[n * VMAX + v];
+        for (int b = 0; b < nb; ++b)
+            for (int v = lane; v < VMAX; v += 16) s += X[((int64_t)b * Np + n) * VMAX + v];
 #pragma unroll
         for (int m = 1; m < 16; m <<= 1) s += __shfl_xor(s, m, 64);
         const double e = s / K;

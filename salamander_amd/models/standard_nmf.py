@@ -26,9 +26,10 @@ class StandardNMF(SignatureNMF):
         instead of sklearn's randomized one) unless ``device_init=False`` or a ``seed`` is passed, which asks for
         the reference's seeded host computation (``initialize.py:221-255``)."""
         init_kwargs = {} if init_kwargs is None else init_kwargs.copy()
-        # (the device-side initialisation works on one 96-feature block and one 64-signature chunk: wider problems
-        # initialise on the host)
-        on_device = self.device_init and np.shape(self.adata.X)[1] <= 96 and self.n_signatures <= 64
+        # (more than 96 features: the Gram matrix is formed block pair by block pair; separableNMF's selection and more than
+        # 64 signatures stay on the host)
+        wide = np.shape(self.adata.X)[1] > 96
+        on_device = self.device_init and self.n_signatures <= 64 and not (wide and self.init_method == "separableNMF")
         if on_device and self.init_method in DEVICE_METHODS and "seed" not in init_kwargs:
             if init_kwargs:
                 raise TypeError(f"init method '{self.init_method}' takes no keyword arguments besides 'seed': {sorted(init_kwargs)}")

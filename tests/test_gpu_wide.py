@@ -88,7 +88,7 @@ def test_wide_typed_ingest_and_the_refusals():
     Xc = counts.astype(float).clip(orc.EPSILON)
     assert np.isclose(outs[0][0], orc.kl_divergence(Xc.T, W0.T, H0.T), rtol=1e-12)
     assert all(o[0] == outs[0][0] and np.array_equal(o[1], outs[0][1]) for o in outs[1:])
-    for call in (lambda: e.corr_configure(4), lambda: e.init_gram(), lambda: e.set_precision("f32")):
+    for call in (lambda: e.corr_configure(4), lambda: e.init_separable(3), lambda: e.set_precision("f32")):
         with pytest.raises(RuntimeError, match="n_features > 96"):
             call()
     e.close()
@@ -163,3 +163,34 @@ def test_wide_mvnmf_model_fit_matches_the_oracle_fit():
     # steps compound that)
     assert m.n_iterations_ == it and np.allclose(m.history["objective_function"], hist, rtol=1e-7)
     assert rel_l2(m.asignatures.X, W.T) < 1e-6 and rel_l2(m.adata.obsm["exposures"], H.T) < 1e-6
+
+
+@pytest.mark.parametrize("V,N,K,method", [(288, 2000, 10, "nndsvd"), (288, 777, 6, "nndsvda"), (200, 1500, 12, "nndsvd"), (1536, 600, 8, "nndsvd"), (288, 500, 5, "flat")])
+def test_wide_device_initialisation_matches_the_host_method(V, N, K, method):
+    """The deterministic initialisation methods on more than 96 features: the Gram matrix block pair by block pair, the
+    projection accumulated over the blocks.  Against the host method (``initialize_mat``: sklearn's NNDSVD with a seeded
+    randomized SVD) the leading, well separated singular vectors agree entry by entry; the exact SVD and the randomized
+    one differ in the trailing ones of a noisy matrix (device_init.py), so the comparison is through the reconstruction
+    and the subspace."""
+    from salamander_amd.device_init import initialize_on_device
+    from salamander_amd.initialization import initialize_mat
+
+    X, _, _ = problem(V, N, K, seed=V + N)
+    e = Engine(N, V, K)
+    e.upload_X(X)
+    S = initialize_on_device(e, K, method)
+    E = e.download_H()
+    e.close()
+    S_host, E_host = initialize_mat(X.clip(orc.EPSILON), K, method, seed=0)
+    assert S.shape == (K, V) and E.shape == (N, K) and S.min() >= orc.EPSILON and E.min() >= orc.EPSILON
+    rows = S.sum(axis=1)  # normalised, THEN clipped (initialize.py:116-118): a row sums to 1 plus at most V * EPSILON
+    assert np.all(rows >= 1.0 - 1e-12) and np.all(rows <= 1.0 + 1.01 * V * orc.EPSILON)
+    if method == "flat":
+        assert np.allclose(S, S_host, rtol=1e-12) and np.allclose(E, E_host, rtol=1e-12)
+        return
+    # the first signature (the dominant singular vector: no sign split, separated from the rest) entry by entry
+    assert np.allclose(S[0], S_host[0], rtol=1e-6, atol=1e-12) and np.allclose(E[:, 0], E_host[:, 0], rtol=1e-6)
+    # and the whole factorisation as an approximation of X: as good as the host's
+    err = np.linalg.norm(X - E @ S) / np.linalg.norm(X)
+    err_host = np.linalg.norm(X - E_host @ S_host) / np.linalg.norm(X)
+    assert err <= 1.02 * err_host + 1e-9, (err, err_host)
