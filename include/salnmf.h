@@ -308,8 +308,11 @@ int salnmf_init_flat(salnmf_engine* e, const double* post /* n_signatures */);
 /* separableNMF (methods.py:112-135), the signature side: n_select rounds of successive projection on the resident X
  * (every sample normalised to sum 1; argmax of the squared norms with np.argmax's tie rule; rank-1 deflation) ->
  * chosen_out[n_select] = the selected sample indices in selection order.  The exposures of that method come from the
- * host's legacy RNG (methods.py:133) and stay with the host layer.  Unsharded engines only. */
-int salnmf_init_separable(salnmf_engine* e, int n_select, int64_t* chosen_out);
+ * host's legacy RNG (methods.py:133) and stay with the host layer.  Unsharded engines only.  norms_out receives the winning squared norm of every round: after deflation by a
+ * rank-deficient or duplicated selection the remaining norms are at rounding level and the device's argmax (fused
+ * multiply-adds, another summation order) may then differ from np.argmax on the host -- the caller compares
+ * norms[k] with norms[0] and keeps the host's selection for such inputs (salamander_amd/models/standard_nmf.py). */
+int salnmf_init_separable(salnmf_engine* e, int n_select, int64_t* chosen_out, double* norms_out /* n_select or NULL */);
 
 /* Multi-GPU: one engine per process/GPU, sample axis sharded; the only exchange is an
  * RCCL all-reduce of the (K x V) numerator per W update (+ scalars for objectives; CorrNMF adds one gather

@@ -82,7 +82,7 @@ SIGNATURES = {
     "salnmf_init_project": (c_int, [_P, _D, _D]),
     "salnmf_init_finish": (c_int, [_P, _D, POINTER(c_int), _D, c_double, c_double]),
     "salnmf_init_flat": (c_int, [_P, _D]),
-    "salnmf_init_separable": (c_int, [_P, c_int, POINTER(c_int64)]),
+    "salnmf_init_separable": (c_int, [_P, c_int, POINTER(c_int64), _D]),
     "salnmf_comm_unique_id": (c_int, [ctypes.c_char_p]),
     "salnmf_comm_init": (c_int, [_P, ctypes.c_char_p, c_int, c_int]),
     "salnmf_comm_info": (c_int, [_P, POINTER(c_int), POINTER(c_int), POINTER(c_int64)]),

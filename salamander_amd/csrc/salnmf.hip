@@ -2778,7 +2778,7 @@ int salnmf_init_flat(salnmf_engine* e, const double* post) {
     return 0;
 }
 
-int salnmf_init_separable(salnmf_engine* e, int n_select, int64_t* chosen_out) {
+int salnmf_init_separable(salnmf_engine* e, int n_select, int64_t* chosen_out, double* norms_out) {
     if (e && split(e)) return single_block(e, "the device-side initialisation");
     if (!e || !chosen_out) return fail("null argument");
     if (n_select < 1 || (int64_t)n_select > e->N) return fail("n_select must be in [1, n_samples]");
@@ -2786,16 +2786,17 @@ int salnmf_init_separable(salnmf_engine* e, int n_select, int64_t* chosen_out) {
     CK(enter(e));
     const int grid = (int)std::min<int64_t>(1024, (e->N + 15) / 16);
     const size_t nR = (size_t)e->Np * VMAX;
-    CK(ensure_scratch(e, nR + SEP_STATE + 2 * (size_t)grid + (size_t)n_select));
+    CK(ensure_scratch(e, nR + SEP_STATE + 2 * (size_t)grid + 2 * (size_t)n_select));
     double* R = e->scratch;
     double* state = R + nR;
     double* pval = state + SEP_STATE;
     long long* pidx = reinterpret_cast<long long*>(pval + grid);
     long long* chosen = pidx + grid;
+    double* norms = reinterpret_cast<double*>(chosen + n_select);
     hipLaunchKernelGGL(sep_pass_kernel<true>, dim3(grid), dim3(SEP_BLOCK), 0, e->stream, e->X, R, e->N, e->V, state, pval, pidx);
     HIPCK(hipGetLastError());
     for (int k = 0; k < n_select; ++k) {
-        hipLaunchKernelGGL(sep_select_kernel, dim3(1), dim3(256), 0, e->stream, R, pval, pidx, grid, state, chosen, k);
+        hipLaunchKernelGGL(sep_select_kernel, dim3(1), dim3(256), 0, e->stream, R, pval, pidx, grid, state, chosen, norms, k);
         HIPCK(hipGetLastError());
         if (k + 1 < n_select) {
             hipLaunchKernelGGL(sep_pass_kernel<false>, dim3(grid), dim3(SEP_BLOCK), 0, e->stream, e->X, R, e->N, e->V, state, pval, pidx);
@@ -2804,6 +2805,7 @@ int salnmf_init_separable(salnmf_engine* e, int n_select, int64_t* chosen_out) {
     }
     static_assert(sizeof(long long) == sizeof(int64_t), "index type");
     HIPCK(hipMemcpyAsync(chosen_out, chosen, (size_t)n_select * sizeof(int64_t), hipMemcpyDeviceToHost, e->stream));
+    if (norms_out) HIPCK(hipMemcpyAsync(norms_out, norms, (size_t)n_select * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     HIPCK(hipStreamSynchronize(e->stream));
     return check_abort(e);
 }

@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(SEP_BLOCK) sep_pass_kernel(const double* __res
 // one workgroup: the global argmax of the per-workgroup candidates (lowest index on ties), u <- R_j, |u|^2, chosen[round] <- j
 __global__ void __launch_bounds__(256) sep_select_kernel(const double* __restrict__ R, const double* __restrict__ pval,
                                                          const long long* __restrict__ pidx, int nparts, double* __restrict__ state,
-                                                         long long* __restrict__ chosen, int round) {
+                                                         long long* __restrict__ chosen, double* __restrict__ norms, int round) {
     __shared__ double bval[256];
     __shared__ long long bidx[256];
     double b = -1.0;
@@ -315,6 +315,7 @@ __global__ void __launch_bounds__(256) sep_select_kernel(const double* __restric
     if (threadIdx.x == 0) {
         state[VMAX] = bval[0];
         chosen[round] = j;
+        norms[round] = bval[0];  // the winning squared norm: the caller checks that it is not at rounding level
     }
 }
 

@@ -26,6 +26,8 @@ exposures of ``separableNMF`` draw from NumPy's legacy global RNG and stay on th
 
 from __future__ import annotations
 
+import sys
+
 import numpy as np
 
 from .utils import EPSILON
@@ -87,9 +89,12 @@ def _single_blas_thread():
         import contextlib
 
         return contextlib.nullcontext()
-    if _blas_controller is None:
-        _blas_controller = ThreadpoolController()
-    return _blas_controller.limit(limits=1, user_api="blas")
+    # (rebuilt when the process has loaded more modules since: a BLAS that arrives later -- SciPy's OpenBLAS -- is not in a
+    # controller built before it, and limit() would silently not apply to it)
+    n_modules = len(sys.modules)
+    if _blas_controller is None or _blas_controller[1] != n_modules:
+        _blas_controller = (ThreadpoolController(), n_modules)
+    return _blas_controller[0].limit(limits=1, user_api="blas")
 
 
 def initialize_on_device(engine, n_signatures, method, given_signatures_mat=None, n_samples_total=None):

@@ -340,11 +340,13 @@ class Engine:
             raise ValueError(f"The shape of 'take_neg' has to be {(self.K,)}.")
         _lib.check(self._lib.salnmf_init_finish(self._h, _ptr(scale), neg.ctypes.data_as(POINTER(ctypes.c_int)), _ptr(post), float(zero_below), float(fill)))
 
-    def init_separable(self, n_select: int) -> np.ndarray:
-        """Sample indices chosen by the successive projection of ``separableNMF`` on the resident X, in selection order."""
+    def init_separable(self, n_select: int, return_norms: bool = False):
+        """Sample indices chosen by the successive projection of ``separableNMF`` on the resident X, in selection order;
+        ``return_norms``: also the winning squared norm of every round."""
         out = np.empty(int(n_select), dtype=np.int64)
-        _lib.check(self._lib.salnmf_init_separable(self._h, int(n_select), out.ctypes.data_as(POINTER(ctypes.c_int64))))
-        return out
+        norms = np.empty(int(n_select), dtype=np.float64)
+        _lib.check(self._lib.salnmf_init_separable(self._h, int(n_select), out.ctypes.data_as(POINTER(ctypes.c_int64)), _ptr(norms)))
+        return (out, norms) if return_norms else out
 
     def init_flat(self, post):
         post = _as_c(post, (self.K,), "post")

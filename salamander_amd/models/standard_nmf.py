@@ -41,7 +41,11 @@ class StandardNMF(SignatureNMF):
             n_obs, n_vars = np.shape(self.adata.X)
             e = self._ensure_engine(n_obs, n_vars, self.n_signatures)
             self._upload_X(e)
-            init_kwargs["chosen"] = e.init_separable(self.n_signatures)
+            chosen, norms = e.init_separable(self.n_signatures, return_norms=True)
+            # once the selected samples span the data (rank-deficient or duplicated rows) the remaining norms are rounding
+            # noise and the device's argmax need not be np.argmax's: such inputs keep the reference's host selection
+            if np.all(np.isfinite(norms)) and np.all(norms > 1e-12 * norms[0]):
+                init_kwargs["chosen"] = chosen
             self._resident = {"X"}
         if self.init_method == "custom" and getattr(self, "_defer_exposures", False) and not self.distributed and self.n_signatures <= 64:
             self._initialize_custom_on_device(given_parameters, init_kwargs)

@@ -146,16 +146,17 @@ class FakeEngine:
             E[E == 0] = fill
         self.H = np.clip(E * np.asarray(post)[None, :], orc.EPSILON, None)
 
-    def init_separable(self, n_select):
+    def init_separable(self, n_select, return_norms=False):
         R = self.X.T / self.X.T.sum(axis=0)
         chosen = np.empty(n_select, dtype=np.int64)
+        won = np.empty(n_select)
         for k in range(n_select):
             norms = (R**2).sum(axis=0)
             j = int(np.argmax(norms))
             u = R[:, j]
             R = R - np.outer(u, u @ R) / norms[j]
-            chosen[k] = j
-        return chosen
+            chosen[k], won[k] = j, norms[j]
+        return (chosen, won) if return_norms else chosen
 
     def init_flat(self, post):
         e = self.X.sum(axis=1) / self.K

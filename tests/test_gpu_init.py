@@ -210,3 +210,25 @@ def test_model_separable_init_uses_the_device_and_equals_the_host_path():
     m.fit(sal.AnnData(X.copy()), init_kwargs={"seed": 7})
     W, H, _, hist = orc.fit_klnmf(X.T, states[1][0].T, states[1][1].T, min_iterations=20, max_iterations=20)
     assert rel_l2(m.asignatures.X, W.T) < 1e-10 and np.allclose(m.history["objective_function"], hist, rtol=1e-11)
+
+
+def test_separable_selection_of_a_rank_deficient_catalogue_keeps_the_host_path():
+    """More signatures than the rank of X (duplicated samples): after the first ``rank`` rounds every remaining norm is
+    rounding noise, where the device's argmax (fused multiply-adds, another summation order) need not be ``np.argmax``'s.
+    The engine reports the winning norms; the model sees them collapse and keeps the reference's host selection, so the
+    initial state is the host path's bit for bit."""
+    rng = np.random.default_rng(0)
+    base = rng.poisson(50.0, size=(3, 96)).astype(float) + 1.0
+    X = base[rng.integers(0, 3, size=400)]  # 400 samples, three distinct rows: rank 3
+    e = Engine(400, 96, 6)
+    e.upload_X(X)
+    chosen, norms = e.init_separable(6, return_norms=True)
+    e.close()
+    assert norms[0] > 0 and np.all(norms[3:] <= 1e-12 * norms[0])  # the collapse is visible
+    states = []
+    for device_init in (True, False):
+        m = sal.models.KLNMF(6, "separableNMF", min_iterations=0, max_iterations=0, device_init=device_init)
+        m._setup_adata(sal.AnnData(X.copy()))
+        m._initialize(None, {"seed": 1})
+        states.append((np.array(m.asignatures.X), np.array(m.adata.obsm["exposures"])))
+    assert np.array_equal(states[0][0], states[1][0]) and np.array_equal(states[0][1], states[1][1])
