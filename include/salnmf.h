@@ -182,6 +182,12 @@ int salnmf_mv_line_search(salnmf_engine* e, double lam, double delta, double* ga
  * line-search scalars; with more_follows the last step does so too and the engine keeps that half step across the calls
  * (W is the accepted trial, H already the successor's update).  Any other entry point first steps back to the plain
  * accepted state (no kernel: the pre-update exposures are still there), so results never depend on the flag. */
+/* MvNMF steps of an unsharded engine are QUEUED AHEAD of the host (default): per step a tail launch and one pass over the
+ * samples (update_H with the trial + the numerator of the next W step: fused_kernel<.., MVJ>); the line-search decision
+ * of step i (mvnmf.py:84) is taken on the device, in the prologue of step i + 1's tail; the host reads a flag and the
+ * scalars once per call and resolves a rejected first trial on the classic path.  0 = the classic form: one host decision
+ * per step, two passes over the samples.  Same results bit for bit. */
+int salnmf_set_mv_queued(salnmf_engine* e, int on);
 int salnmf_mv_step_objective(salnmf_engine* e, int n_steps, int n_given, double lam, double delta,
                              double* gamma_inout, double* objective_out, int more_follows);
 /* only MvNMF._update_W (:190-195) / only _update_H (= salnmf_update_H) for the

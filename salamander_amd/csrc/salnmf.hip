@@ -242,6 +242,8 @@ struct salnmf_engine {
     int ls_S = 0, ls_dim = 0;
     bool lockstep = true;  // salnmf_set_lockstep(e, 0) forces the single-kernel form
     bool batched_samples = true;  // salnmf_set_batched_sample_solves(e, 0) forces one wavefront per sample
+    bool mv_queued = true;       // salnmf_set_mv_queued(e, 0): MvNMF steps with the host's line-search decision per step (the classic form)
+    unsigned* mvflag = nullptr;  // device word of the queued MvNMF steps: non-zero = a trial was rejected on the device
     int small_max_tiles = SMALL_TILES_DEFAULT;  // salnmf_set_small_cohort_tiles: up to this many tiles salnmf_kl_step runs as one workgroup
     hipEvent_t ls_ev[2] = {nullptr, nullptr};  // lockstep rounds: the count of live solves has reached the host
     double *gU = nullptr, *galpha = nullptr, *gaux = nullptr;
@@ -611,6 +613,7 @@ void salnmf_destroy(salnmf_engine* e) {
     if (e->ls_int) (void)hipFree(e->ls_int);
     if (e->psync) (void)hipFree(e->psync);
     if (e->klcnt) (void)hipFree(e->klcnt);
+    if (e->mvflag) (void)hipFree(e->mvflag);
     for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : {e->evW, e->evPrepW, e->evTrial, e->evLogdet, e->evObj, e->ls_ev[0], e->ls_ev[1]})
         if (ev) (void)hipEventDestroy(ev);
@@ -1178,6 +1181,13 @@ static int chunked_kl_step_once(salnmf_engine* e, int n_given) {
 int salnmf_set_lockstep(salnmf_engine* e, int on) {
     if (!e) return fail("null engine");
     e->lockstep = on != 0;
+    return 0;
+}
+
+int salnmf_set_mv_queued(salnmf_engine* e, int on) {
+    if (!e) return fail("null engine");
+    CK(enter(e));  // (an engine left ahead steps back first: the two forms speculate differently)
+    e->mv_queued = on != 0;
     return 0;
 }
 
@@ -1900,8 +1910,8 @@ static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double de
         // side workgroup, on this stream) the numerator pass has the whole chip, as the speculative one has: the same
         // slab order, hence the same bits of W, whether the steps come in one call or one by one; a stand-alone call
         // leaves one CU per XCD to the W-only kernel on stream2.
-        if (w_ready)
-            CK(mv_numerator_pass(e, e->W, e->H, nullptr, e->grid, mv_side_total(e) - 1));
+        if (w_ready)  // (on as many tile workgroups as a pass with the side workgroup: one slab order for every form of the step)
+            CK(mv_numerator_pass(e, e->W, e->H, nullptr, mv_side_total(e) - 1, mv_side_total(e) - 1));
         else
             CK(mv_numerator_pass(e, e->W, e->H, nullptr, e->mv_grid, e->mv_grid));
     }
@@ -1975,7 +1985,7 @@ static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double de
             }
             // ... and its numerator pass (W_trial as W, the new H) on the whole chip: it runs while the scalars travel to the
             // host.  Its tail waits for the decision (see above).
-            CK(mv_numerator_pass(e, e->Wtrial, e->Halt, nullptr, e->grid, nwg));
+            CK(mv_numerator_pass(e, e->Wtrial, e->Halt, nullptr, nwg, nwg));
             HIPCK(hipStreamWaitEvent(e->stream3, e->evObj, 0));
             HIPCK(hipMemcpyAsync(e->hpin, e->scal, 5 * sizeof(double), hipMemcpyDeviceToHost, e->stream3));
             HIPCK(hipStreamSynchronize(e->stream3));
@@ -2018,6 +2028,199 @@ static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double de
     std::swap(e->W, e->Wtrial);  // no copy: the trial buffer becomes W
     HIPCK(hipEventRecord(e->evW, e->stream));  // W is final for the next step's W-only kernels
     e->h_pending = true;
+    return 0;
+}
+
+// ---- MvNMF steps queued ahead of the host (unsharded engines, at least one free signature).
+// Per step TWO launches: the tail of the previous numerator half (reduce, closed-form root, first trial, f0) and the MVJ
+// pass (fused_kernel<.., MVJ>: update_H with the trial -- which evaluates the trial -- and the numerator half on the new H,
+// the next step's W-only algebra in its last workgroup).  The line-search decision of step i is taken ON THE DEVICE, in the
+// prologue of step i + 1's tail (TailParams::dec_*): accepted -> go on; rejected -> the flag is set and everything queued
+// behind returns at once.  The host queues a whole call's steps with the buffer roles alternating as if every first trial
+// were accepted (the common case), reads the flag and the scalars once at the end, and resolves a rejected step on the
+// classic path (blends evaluated by the forward kernel, mvnmf.py:84-90), then queues the rest.  The decision compares the
+// same doubles with the same operations as the host's, so the result is the classic form's bit for bit.
+static inline int mv_f0_slot(int step) { return (step & 1) ? 9 : 1; }  // f0 by step parity: a tail reads the previous step's while it writes its own
+
+// the backtracking part of line_search (mvnmf.py:84-90) from the resident (W, H), W_unconstrained in Wunc and f0 given;
+// g: the gamma the rejected first trial left (already multiplied by 0.8).  Accepts: W <- the blend's trial, H pending.
+static int mv_backtrack(salnmf_engine* e, double lam, double delta, double f0, double* g_io, double* f_accepted) {
+    const int K = e->K, V = e->V;
+    const MvRootParams root{e->mvA, e->mvB, e->red, e->red + K * V, e->red + K * V + K, e->scal + 3, e->scal + 1, lam, 0};
+    double g = *g_io;
+    for (;;) {
+        LAUNCH_WITH_EVENT(mv_trial_light_kernel<false>, dim3(1), dim3(MV_BLOCK), e->stream, e->evTrial, e->W, e->Wunc, g, 1, K, V, e->Wtrial, e->cs, root);
+        HIPCK(hipGetLastError());
+        HIPCK(hipStreamWaitEvent(e->stream2, e->evTrial, 0));
+        LAUNCH_WITH_EVENT(mv_logdet_kernel, dim3(1), dim3(MV_BLOCK), e->stream2, e->evLogdet, e->Wtrial, K, V, delta, e->scal + 4);
+        HIPCK(hipGetLastError());
+        CK(objective_to_slot(e, e->Wtrial, e->cs, false, 2, e->mv_fgrid));
+        HIPCK(hipStreamWaitEvent(e->stream, e->evLogdet, 0));
+        double v[5];
+        CK(read_scalars(e, 0, 5, v));
+        const double f1 = v[2] + lam * v[4];
+        if (f_accepted) *f_accepted = f1;
+        if (f1 > f0 && g > 1e-16) {
+            g *= 0.8;
+            continue;
+        }
+        break;
+    }
+    *g_io = g;
+    std::swap(e->W, e->Wtrial);
+    HIPCK(hipEventRecord(e->evW, e->stream));
+    e->h_pending = true;
+    return 0;
+}
+
+static int mv_steps_queued(salnmf_engine* e, int n_steps, int n_given, double lam, double delta, double* gamma, double* f_out, bool more_follows,
+                           bool resume) {
+    CK(ensure_side_streams(e));
+    CK(ensure_halt(e));
+    if (!e->KLpart2) HIPCK(hipMalloc(&e->KLpart2, (size_t)e->grid * sizeof(double)));
+    if (!e->mvflag) HIPCK(hipMalloc(&e->mvflag, 16));
+    const int total = mv_side_total(e), nwg = total - 1;
+    double g = *gamma, f_last = 0.0;
+    bool ahead = resume;
+    int done = 0;
+    while (done < n_steps) {
+        HIPCK(hipMemsetAsync(e->mvflag, 0, sizeof(unsigned), e->stream));
+        if (!ahead) {
+            // the first half of step `done`: update_H (+ the W-only algebra of W in the side workgroup), numerator pass
+            FusedParams p = fused_params(e);
+            p.wkl = nullptr;  // MvNMF._update_H passes no weights (mvnmf.py:162-165)
+            p.wlh = nullptr;
+            p.KLpart = nullptr;
+            mv_side_params(e, p, e->W, delta);
+            CK((launch_fused<false, true, true>(e, p, total)));
+            e->h_pending = false;
+            CK(mv_numerator_pass(e, e->W, e->H, nullptr, nwg, nwg));
+        }
+        // queue: tail_i (decides step i - 1, root + trial of step i), MVJ pass_i (evaluates trial i, first half of step i + 1)
+        const int first = done;
+        int queued = 0;       // steps whose MVJ pass is queued (their trial's decision is pending or on the device)
+        bool classic_last = false;
+        for (int i = first; i < n_steps; ++i) {
+            const bool spec = (i + 1 < n_steps) || more_follows;
+            TailParams t = tail_params(e, e->mv_slabs, e->red, n_given, 0, 0, true, e->mv_hparts);
+            t.rootA = e->mvA;
+            t.rootB = e->mvB;
+            t.rootLogdet = e->scal + 3;
+            t.rootF0 = e->scal + mv_f0_slot(i);
+            t.rootWunc = e->Wunc;
+            t.rootWtrial = e->Wtrial;
+            t.rootCs = e->cs;
+            t.rootLam = lam;
+            t.mv_flag = e->mvflag;
+            if (i > first) {  // (gamma of a step behind accepted first trials is >= the call's gamma: the `gamma > 1e-16` half of mvnmf.py:84 holds)
+                t.dec_f0 = e->scal + mv_f0_slot(i - 1);
+                t.dec_kl = e->scal + 2;
+                t.dec_logdet = e->scal + 3;
+                t.dec_lam = lam;
+                t.dec_code = (unsigned)(i - first);  // 1 + index within this batch of the step whose trial is rejected
+            }
+            if (!spec)
+                hipExtLaunchKernelGGL(tail_kernel, dim3(e->K), dim3(TAIL_BLOCK), 0, e->stream, nullptr, e->evTrial, 0, t);
+            else
+                hipLaunchKernelGGL(tail_kernel, dim3(e->K), dim3(TAIL_BLOCK), 0, e->stream, t);
+            HIPCK(hipGetLastError());
+            if (!spec) {
+                classic_last = true;
+                break;
+            }
+            FusedParams sp = fused_params(e);
+            sp.wkl = nullptr;
+            sp.wlh = nullptr;
+            sp.W = e->Wtrial;
+            sp.hscale = e->cs;
+            sp.Hout = e->Halt;
+            sp.KLpart = e->KLpart2;  // the update_H half's partials: the trial's KL, summed inside the launch -> scal[2]
+            sp.KLpartB = e->KLpart;  // the numerator half's: f0 of the next step, reduced by its tail
+            sp.kl_out = e->scal + 2;
+            sp.kl_counter = e->klcnt;
+            sp.skip_flag = e->mvflag;
+            mv_side_params(e, sp, e->Wtrial, delta);
+            const FusedSel sel{e->KS, e->KTM, e->KR, true, true, true, false, false, false, false, true};
+            if (launch_fused_inst(sel, sp, total, e->stream, nullptr, nullptr)) return fail("no kernel instantiation for KS=%d KTM=%d KR=%d", e->KS, e->KTM, e->KR);
+            HIPCK(hipGetLastError());
+            e->mv_slabs = nwg;
+            e->mv_hparts = nwg;
+            std::swap(e->W, e->Wtrial);  // as if accepted (undone below if it was not)
+            std::swap(e->H, e->Halt);
+            e->h_pending = false;
+            ++queued;
+        }
+        // one read for the whole batch: the flag and the scalars
+        unsigned code = 0;
+        double v[16];
+        HIPCK(hipMemcpyAsync(e->hpin, e->scal, 16 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        HIPCK(hipMemcpyAsync(reinterpret_cast<char*>(e->hpin) + 16 * sizeof(double), e->mvflag, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
+        HIPCK(hipStreamSynchronize(e->stream));
+        CK(check_abort(e));
+        for (int i = 0; i < 16; ++i) v[i] = e->hpin[i];
+        memcpy(&code, reinterpret_cast<char*>(e->hpin) + 16 * sizeof(double), sizeof code);
+        // which queued step (if any) is open: rejected on the device, or the last queued one (nobody has compared its f1
+        // with its f0 yet).  The steps before it were accepted on the device.
+        int open = -1;
+        if (code != 0) open = first + (int)code - 1;
+        else if (queued > 0 && !classic_last) open = first + queued - 1;  // (a classic last step's tail decided the last queued one)
+        for (int i = first; i < (open >= 0 ? open : first + queued); ++i) g = std::min(1.0, 1.2 * g);
+        if (open >= 0) {
+            // the open step's MVJ pass was the last one to write scal[2], scal[3] (everything behind a rejection returned at once)
+            const double f0 = v[mv_f0_slot(open)], f1 = v[2] + lam * v[3];
+            const bool rejected = (code != 0 || f1 > f0) && g > 1e-16;  // mvnmf.py:84
+            // the pointer swaps of the steps behind the open one (and, if rejected, its own) are undone
+            const int undo = first + queued - open - (rejected ? 0 : 1);
+            if (undo & 1) {
+                std::swap(e->W, e->Wtrial);
+                std::swap(e->H, e->Halt);
+            }
+            if (rejected) {
+                // (W, H) = the state the open step started its line search from: H unscaled with its scale in cs, W_unconstrained
+                // in Wunc; the numerator slabs, A, B, log det and the second H buffer hold the dropped speculation
+                g *= 0.8;
+                CK(mv_backtrack(e, lam, delta, f0, &g, &f_last));
+                ahead = false;
+            } else {
+                f_last = f1;
+                ahead = true;  // its MVJ pass is the first half of the next step
+            }
+            g = std::min(1.0, 1.2 * g);
+            done = open + 1;
+            if (done < n_steps || !classic_last) continue;
+        }
+        if (classic_last) {
+            // the call's last step without a continuation: its trial is evaluated by the forward kernel (no pass follows)
+            const int i = n_steps - 1;
+            HIPCK(hipStreamWaitEvent(e->stream2, e->evTrial, 0));
+            LAUNCH_WITH_EVENT(mv_logdet_kernel, dim3(1), dim3(MV_BLOCK), e->stream2, e->evLogdet, e->Wtrial, e->K, e->V, delta, e->scal + 4);
+            HIPCK(hipGetLastError());
+            CK(objective_to_slot(e, e->Wtrial, e->cs, false, 2, e->mv_fgrid));
+            HIPCK(hipStreamWaitEvent(e->stream, e->evLogdet, 0));
+            double w[16];
+            CK(read_scalars(e, 0, 16, w));
+            const double f0 = w[mv_f0_slot(i)], f1 = w[2] + lam * w[4];
+            f_last = f1;
+            if (f1 > f0 && g > 1e-16) {
+                g *= 0.8;
+                CK(mv_backtrack(e, lam, delta, f0, &g, &f_last));
+            } else {
+                std::swap(e->W, e->Wtrial);
+                HIPCK(hipEventRecord(e->evW, e->stream));
+                e->h_pending = true;
+            }
+            g = std::min(1.0, 1.2 * g);
+            done = n_steps;
+            ahead = false;
+        }
+    }
+    *gamma = g;
+    if (f_out) *f_out = f_last;
+    if (ahead) {  // (only with more_follows)
+        e->mv_ahead = true;
+        e->mv_ahead_delta = delta;
+        e->mv_ahead_given = n_given;
+    }
     return 0;
 }
 
@@ -2100,6 +2303,8 @@ int salnmf_mv_step_objective(salnmf_engine* e, int n_steps, int n_given, double 
     if (!resume) CK(mv_settle(e));
     e->mv_ahead = false;
     e->keep_valid = false;  // (the MvNMF steps use the second H buffer themselves)
+    if (e->mv_queued && !sharded(e) && n_given < e->K && n_steps > 0)
+        return mv_steps_queued(e, n_steps, n_given, lam, delta, gamma_inout, objective_out, more_follows != 0, resume);
     bool ahead = resume;  // this step's update_H pass, W-only algebra and numerator pass already ran during the previous step
     for (int i = 0; i < n_steps; ++i) {
         const bool update_W = n_given < e->K;

@@ -35,13 +35,13 @@
 
 namespace salnmf {
 
-template <int KS, int KTM, int KR, bool G, bool U, bool STATS, bool WTS, bool PERSIST = false, bool BLOCKED = false, bool RGIVEN = false>
+template <int KS, int KTM, int KR, bool G, bool U, bool STATS, bool WTS, bool PERSIST = false, bool BLOCKED = false, bool RGIVEN = false, bool MVJ = false>
 static void launch_one(const FusedParams& p, int grid, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     const dim3 g(grid), b(BLOCK);
     if (ev_stop)
-        hipExtLaunchKernelGGL((fused_kernel<KS, KTM, KR, G, U, STATS, WTS, PERSIST, BLOCKED, RGIVEN>), g, b, 0, stream, ev_start, ev_stop, 0, p);
+        hipExtLaunchKernelGGL((fused_kernel<KS, KTM, KR, G, U, STATS, WTS, PERSIST, BLOCKED, RGIVEN, MVJ>), g, b, 0, stream, ev_start, ev_stop, 0, p);
     else
-        hipLaunchKernelGGL((fused_kernel<KS, KTM, KR, G, U, STATS, WTS, PERSIST, BLOCKED, RGIVEN>), g, b, 0, stream, p);
+        hipLaunchKernelGGL((fused_kernel<KS, KTM, KR, G, U, STATS, WTS, PERSIST, BLOCKED, RGIVEN, MVJ>), g, b, 0, stream, p);
 }
 
 template <int KS, int KTM, int KR>
@@ -67,6 +67,11 @@ static int launch_geometry(const FusedSel& s, const FusedParams& p, int grid, hi
         } else {
             return 1;
         }
+    }
+    if (s.MVJ) {  // MvNMF: update_H + the numerator pass behind it in one pass
+        if (!(s.G && s.U && s.STATS && !s.WTS)) return 1;
+        launch_one<KS, KTM, KR, true, true, true, false, false, false, false, true>(p, grid, st, e0, e1);
+        return 0;
     }
     if (s.BLOCKED) {  // n_features > 96: the update_H pass over one feature block (weights honoured at run time)
         if (!(s.U && !s.G && !s.STATS)) return 1;

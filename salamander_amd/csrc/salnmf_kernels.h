@@ -131,6 +131,8 @@ struct FusedParams {
     double* __restrict__ Hsumpart;   // [gridDim.x][K]           (DO_STATS) row sums of H
     double* __restrict__ KLpart;     // [gridDim.x]              (DO_STATS) unweighted partial of the KL divergence (tile_kl) (DO_U: optional, null = skip)
     const double* __restrict__ xlx;  // [Np][16]                 (DO_STATS) x-only constants of the KL terms per (sample, lane column): xlogx_lane_kernel
+    double* __restrict__ KLpartB;    // [gridDim.x]              (MVJ) the numerator half's KL partial; KLpart then is the update_H half's (the trial's)
+    const unsigned* skip_flag;       // (DO_STATS, optional) device word: non-zero = return at once (a queued MvNMF trial was rejected)
     int64_t N;
     int V;                  // features of this pass (<= 96: one feature block)
     int ldw;                // row stride of W (= V unless W points at one block of a wider matrix)
@@ -632,8 +634,16 @@ __device__ __forceinline__ double lhalf_update(double h, double u, double wl, do
 // RGIVEN (n_signatures > 64, one launch per chunk of <= 64 signatures): p.X holds the ratio R = X / (H W) over ALL
 // signatures (forward_kernel mode 4 at the end of a chain over the chunks) instead of X; the P phase and the division
 // are skipped, everything downstream -- G and U of this chunk's rows / columns, the H update -- is unchanged.
-template <int KS, int KTM, int KR, bool DO_G, bool DO_U, bool DO_STATS, bool WTS = false, bool PERSIST = false, bool BLOCKED = false, bool RGIVEN = false>
+//   MVJ (MvNMF, with DO_G, DO_U, DO_STATS): update_H and the numerator pass behind it in ONE pass over the samples.  A
+//   sample's new exposures and its contribution to the next W step's numerator depend on that sample alone, so per tile
+//   the update_H half (P = H W, the trial's KL, R, U, H') and the numerator half on H' (P' = H' W, KL = f0, R', G += H'^T R')
+//   run back to back: X stays in registers, H' in the wave's LDS tile.  Per entry the arithmetic is the two passes'; the
+//   tile -> wave mapping and the slab order are those of an update_H pass with its side workgroup (salnmf.hip: the
+//   stand-alone numerator pass of an MvNMF step runs on the same number of tile workgroups), so the bits are the same.
+template <int KS, int KTM, int KR, bool DO_G, bool DO_U, bool DO_STATS, bool WTS = false, bool PERSIST = false, bool BLOCKED = false, bool RGIVEN = false,
+          bool MVJ = false>
 __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
+    static_assert(!MVJ || (DO_G && DO_U && DO_STATS && !WTS && !PERSIST && !BLOCKED && !RGIVEN), "MVJ: the unweighted MvNMF pass pair");
     static_assert(!RGIVEN || (WTS && !DO_STATS && !PERSIST && !BLOCKED), "given ratio: the weighted-capable plain passes only");
     static_assert(!PERSIST || (DO_G && DO_U && !DO_STATS && !WTS), "the persistent mode is the plain joint step");
     static_assert(!BLOCKED || (DO_U && !DO_G && !DO_STATS && WTS && !PERSIST), "feature blocks: the weighted-capable update_H pass only");
@@ -646,9 +656,11 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
     __shared__ __attribute__((aligned(16))) double lds[G_::LDS_DOUBLES + KP + (DO_STATS ? LOGTAB_DOUBLES : 0) + (WTS ? WAVES * 32 : 0)];
 
     // MvNMF update_H pass: the grid's last workgroup may be the one that does the W-only algebra instead of tiles
-    constexpr bool MVU = DO_U && DO_STATS && !DO_G;
+    constexpr bool MVU = DO_U && DO_STATS && (!DO_G || MVJ);
     // (DO_G && DO_U && DO_STATS: the joint step that also evaluates the KL divergence of the state it starts from -- the
     // objective of a convergence test, folded into the first step of the next block; no row sums of H there)
+    // (MvNMF, queued steps: a trial was rejected on the device -- everything queued behind it is a no-op)
+    if (DO_STATS && p.skip_flag != nullptr && __hip_atomic_load((gsync_t*)p.skip_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     const int nwg = (int)gridDim.x - ((MVU && p.sideW != nullptr) ? 1 : 0);  // workgroups that process tiles
     if (MVU && p.sideW != nullptr && (int)blockIdx.x == nwg) {
         static_assert(!MVU || KP * (MV_WS + 2 * MV_LD + 1) + 1 <= G_::LDS_DOUBLES, "the W-only algebra must fit this geometry's LDS");
@@ -690,6 +702,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
     double hsum[KT > 0 ? KT : 1];  // column sums of the updated H over this lane's rows (columns 16kt+c16)
     double hsum_rem = 0.0;         // same for the remainder column this lane owns
     double klacc = 0.0;
+    double klacc_b = 0.0;  // (MVJ) the numerator half's KL = f0 of the next step; klacc is the update_H half's (the trial's)
     if (MVU) {
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) hsum[kt] = 0.0;
@@ -705,7 +718,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
     // loads that nothing hides, stays, and the statistics code in the shared tile costs the main loop registers:
     // profiles/r03/ab_step_variants.txt.)
     // The joint step with the objective folded in (DO_STATS) does the same: its numerator is summed in the plain step's order.
-    constexpr bool COOP = DO_G && DO_U && !RGIVEN;  // (with per-sample weights too: process_tile_coop honours them)
+    constexpr bool COOP = DO_G && DO_U && !RGIVEN && !MVJ;  // (with per-sample weights too: process_tile_coop honours them)
     using CO_ = EpiGeo<KT, KR, G_::LDS_DOUBLES>;
     static_assert(CO_::COOP_DOUBLES <= (WAVES - 1) * (G_::HL + G_::RL), "the cooperative tile's numerator park must fit the idle waves' LDS");
     const int64_t nleft = p.ntiles % tstride;
@@ -742,13 +755,17 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         }
     };
 
-    auto process_tile = [&](int64_t tile) __attribute__((always_inline)) {
+    // HALF 0: the whole tile as the template switches say; (MVJ) HALF 1: the update_H half, HALF 2: the numerator half on
+    // the H' that half 1 left in the wave's LDS tile (no staging, no rescale, X still in registers)
+    auto process_half = [&](int64_t tile, auto halftag) __attribute__((always_inline)) {
+        constexpr int HALF = decltype(halftag)::value;
+        constexpr bool TG = DO_G && HALF != 1, TU = DO_U && HALF != 2;
         const int64_t n0 = tile * 16;
         // (WTS) this tile's weights go to LDS with the H tile: the prefetch registers are reloaded in mid-tile, and
         // holding 8 weights per lane across the tile pushed the weighted joint kernel past its 512 registers
         if (WTS) *reinterpret_cast<d2*>(wgt + 2 * c16) = wpre;  // (the four q groups write the same values)
         // ---- stage the H tile (wave private; LDS ops of one wave are executed in order)
-        if (p.hscale) {
+        if (HALF != 2 && p.hscale) {
             // MvNMF: H is read as clip(H * colsum(W_trial)) (a line-search trial, or the rescale of an accepted
             // one that no pass has materialised yet).  Applied here, where the prefetched tile is consumed
             // anyway, from the LDS copy of the scale
@@ -758,15 +775,17 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
                 hpre[j][1] = clip_lo(hpre[j][1] * hsl[hcol[j] + 1], kEps);
             }
         }
+        if (HALF != 2) {
 #pragma unroll
-        for (int j = 0; j < HV; ++j) {
-            *reinterpret_cast<d2*>(Hl + hrow[j] * LS + hcol[j]) = hpre[j];
+            for (int j = 0; j < HV; ++j) {
+                *reinterpret_cast<d2*>(Hl + hrow[j] * LS + hcol[j]) = hpre[j];
+            }
         }
         __builtin_amdgcn_wave_barrier();
 
         // (DO_STATS) the x-only constants of this lane's KL terms (tile_kl); they land under the P product
         double cv[4] = {0.0, 0.0, 0.0, 0.0};
-        if (DO_STATS && (DO_G || p.KLpart != nullptr)) {
+        if (DO_STATS && (TG || p.KLpart != nullptr)) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) cv[r] = p.xlx[(n0 + q + 4 * r) * 16 + c16];
         }
@@ -809,14 +828,14 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         }
 
         // (joint step with the objective: the KL terms first, before the G operands below take their registers)
-        constexpr bool JKL = DO_G && DO_U && DO_STATS;
+        constexpr bool JKL = TG && TU && DO_STATS;  // (never with MVJ: a half has one of the two)
         if (JKL) {
             const double none[4] = {0.0, 0.0, 0.0, 0.0};
             klacc += tile_kl<false, (KR >= 3 ? 2 : 3)>(x, pr, none, cv, ltab, n0, N, V, q, c16);
         }
         // G-phase A operands (H^T): issue the LDS reads now, they land under the divisions
         double ga[4][KT];
-        if (DO_G) {
+        if (TG) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const double* ha = Hl + (4 * r + q) * LS + c16;
@@ -828,9 +847,9 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         // unweighted KL(X || P) of this tile from P before the division: always with the numerator pass (f0 of the MvNMF
         // line search), with the update_H pass only when asked (KLpart != null: a speculative pass evaluates the trial
         // it starts from, which saves the separate forward pass)
-        if (DO_STATS && !JKL && (DO_G || p.KLpart != nullptr)) {
+        if (DO_STATS && !JKL && (TG || p.KLpart != nullptr)) {
             const double none[4] = {0.0, 0.0, 0.0, 0.0};
-            klacc += tile_kl<false>(x, pr, none, cv, ltab, n0, N, V, q, c16);
+            (HALF == 2 ? klacc_b : klacc) += tile_kl<false>(x, pr, none, cv, ltab, n0, N, V, q, c16);
         }
         // ---- R = X / P in place (rows n = q + 4r, columns v = 16vt + c16); pads give 0 / P = 0
         // (div_path's sequence, six quotients at a time and stage by stage: independent chains next to each other)
@@ -861,9 +880,9 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
 
         // prefetch the next tile: X and the staging registers are free from here on, and the loads
         // get the G and U phases to land
-        if (tile + tstride < nfull) load_tile(tile + tstride);
+        if (HALF != 1 && tile + tstride < nfull) load_tile(tile + tstride);  // (MVJ: X serves the second half too)
 
-        if (DO_U) {
+        if (TU) {
             // ---- transpose R through LDS: write accumulator layout, read A-operand layout
 #pragma unroll
             for (int vt = 0; vt < VT; ++vt)
@@ -872,7 +891,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         }
 
         // ---- G += (w_kl . Ht)^T . R   (A = H[n=4r+q][k=16kt+c16], B = register r of R)
-        if (DO_G) {
+        if (TG) {
             if (wkl) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -904,7 +923,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         }
         // remainder columns of U: per-lane partial dot products over this lane's 6 feature columns
         double urem[NVP > 0 ? NVP : 1];
-        if (DO_U && KR > 0) {
+        if (TU && KR > 0) {
 #pragma unroll
             for (int i = 0; i < NVP; ++i) urem[i] = 0.0;
             // (feature tile outermost: the 4 KR accumulation chains advance side by side; each still adds its six terms
@@ -924,7 +943,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         __builtin_amdgcn_wave_barrier();
 
 
-        if (DO_U) {
+        if (TU) {
             // ---- U = R . W^T   (A = R[n=c16][v=4s+q], B = W[k=16kt+c16][v=4s+q])
             d4 u[KT];
 #pragma unroll
@@ -1014,6 +1033,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
                     for (int kt = 0; kt < KT; ++kt) {
                         const double hn = clip_lo(hcur[r][kt] * u[kt][r], p.hfloor);
                         __builtin_nontemporal_store(hn, &hdst[4 * r * KP + 16 * kt]);
+                        if (HALF == 1) Hl[(q + 4 * r) * LS + 16 * kt + c16] = hn;  // (MVJ) the numerator half reads H' from here
                         if (MVU) hsum[kt] += (n0 + q + 4 * r < N) ? hn : 0.0;
                     }
             } else {
@@ -1060,6 +1080,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
                     }
                     hn = clip_lo(hn, p.hfloor);
                     p.Hout[n * KP + KB + j] = hn;
+                    if (HALF == 1) Hl[(q + 4 * r) * LS + KB + j] = hn;
                     if (MVU) hsum_rem += (n < N) ? hn : 0.0;
                 }
             }
@@ -1263,7 +1284,15 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         __syncthreads();
         if (tile < nfull) load_tile(tile);
     }
-    for (; tile < nfull; tile += tstride) process_tile(tile);
+    for (; tile < nfull; tile += tstride) {
+        using std::integral_constant;
+        if constexpr (MVJ) {
+            process_half(tile, integral_constant<int, 1>{});
+            process_half(tile, integral_constant<int, 2>{});
+        } else {
+            process_half(tile, integral_constant<int, 0>{});
+        }
+    }
     if (COOP && coop && (int64_t)blockIdx.x < nleft) process_tile_coop(nfull + blockIdx.x);
 
     // ---- workgroup reductions, fixed order (deterministic)
@@ -1411,7 +1440,18 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
             p.Hsumpart[(int64_t)blockIdx.x * K + tid] = t;
         }
     }
-    if (DO_STATS && (DO_G || p.KLpart != nullptr)) {
+    if (MVJ) {  // the numerator half's KL partial (f0 of the next step), reduced by the tail like a numerator pass's
+        __syncthreads();
+        double* Kb = lds;
+        Kb[tid] = klacc_b;
+        __syncthreads();
+        for (int h = BLOCK / 2; h > 0; h >>= 1) {
+            if (tid < h) Kb[tid] += Kb[tid + h];
+            __syncthreads();
+        }
+        if (tid == 0) p.KLpartB[blockIdx.x] = Kb[0];
+    }
+    if (DO_STATS && ((DO_G && !MVJ) || p.KLpart != nullptr)) {
         __syncthreads();
         double* Ks = lds;  // [BLOCK], fixed binary tree
         Ks[tid] = klacc;
@@ -1729,6 +1769,17 @@ struct TailParams {
     double* __restrict__ hsum_out;         // [K]
     const double* __restrict__ kl_part;    // [nparts] or null: partials of the KL divergence (tile_kl: x-only constants included)
     double* __restrict__ kl_out;           // [1]
+    // optional (MvNMF, steps queued ahead of the host: salnmf.hip, mv_steps_queued): the line-search decision of the
+    // PREVIOUS step on the device.  mv_flag: device word, non-zero = a trial was rejected, everything queued behind it
+    // returns at once.  dec_f0 != null: this launch first decides the previous step's first trial -- f1 = dec_kl +
+    // dec_lam * dec_logdet against dec_f0 (mvnmf.py:84), the host's expression operation for operation -- and on rejection
+    // stores dec_code to the flag and returns; the host resolves that step on the classic path.
+    unsigned* mv_flag;
+    const double* dec_f0;
+    const double* dec_kl;
+    const double* dec_logdet;
+    double dec_lam;
+    unsigned dec_code;
     int kl_extra;  // the grid has one workgroup more than rows: it only reduces kl_part into kl_out -- the
                    // objective folded into a joint step (fused_kernel<.., true, true, true>); hsum_part is null then
     int nparts;    // KL partials (workgroups of the numerator pass)
@@ -1753,6 +1804,23 @@ __global__ void __launch_bounds__(TAIL_BLOCK) tail_kernel(TailParams p) {
     __shared__ double mvsh[2];  // (MvNMF) this row's reduced rowsums_H entry, and the KL divergence (workgroup 0)
     const int k = blockIdx.x;
     const int K = p.K;
+    if (p.mv_flag != nullptr) {  // (uniform over the grid)
+        __shared__ int mv_exit;
+        if (threadIdx.x == 0) {
+            int ex = __hip_atomic_load((gsync_t*)p.mv_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+            if (!ex && p.dec_f0 != nullptr) {
+                // every workgroup evaluates the same three doubles: the same decision everywhere
+                const double f1 = __dadd_rn(p.dec_kl[0], __dmul_rn(p.dec_lam, p.dec_logdet[0]));
+                if (f1 > p.dec_f0[0]) {
+                    ex = 1;
+                    if (k == 0) __hip_atomic_store((gsync_t*)p.mv_flag, p.dec_code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            mv_exit = ex;
+        }
+        __syncthreads();
+        if (mv_exit) return;
+    }
     if (p.kl_extra && k == K) {  // (uniform over the workgroup) summation order of sum_partials_kernel
         __shared__ double kred[256];
         double s = 0.0;

@@ -18,6 +18,7 @@ struct FusedSel {
     bool PERSIST;                  // the persistent multi-step variant (only in builds with SALNMF_WITH_PERSISTENT)
     bool BLOCKED;                  // one 96-feature block of a wider problem: the update_H pass that accumulates U over blocks
     bool RGIVEN = false;           // one chunk of <= 64 signatures of a wider problem: p.X holds the ratio X / (H W) over all of them
+    bool MVJ = false;              // MvNMF: update_H and the numerator pass behind it in one pass (with G, U, STATS)
 };
 
 // Return 0 when the kernel was launched (HIP launch errors are left for hipGetLastError), 1 when this build has no

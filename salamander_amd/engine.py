@@ -127,6 +127,11 @@ class Engine:
         """Signature-embedding solves in lockstep rounds (default from 16 384 samples on) or one workgroup per signature."""
         _lib.check(self._lib.salnmf_set_lockstep(self._h, int(bool(on))))
 
+    def set_mv_queued(self, on: bool = True):
+        """MvNMF steps queued ahead of the host with the line-search decision on the device (default) or the classic form
+        (``include/salnmf.h: salnmf_set_mv_queued``)."""
+        _lib.check(self._lib.salnmf_set_mv_queued(self._h, int(bool(on))))
+
     def set_small_cohort_tiles(self, max_tiles: int = 8):
         """Up to ``max_tiles`` tiles of 16 samples ``kl_step`` runs as one workgroup, all steps of a call in one launch
         (``include/salnmf.h: salnmf_set_small_cohort_tiles``); 0 turns that off."""

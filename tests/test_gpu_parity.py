@@ -945,3 +945,65 @@ def test_objective_of_a_perfect_fit_is_zero_to_the_rounding_of_a_lane(N, V, K, m
     errs = e.samplewise_kl()
     assert errs.min() >= -1e-12 * X.sum(axis=1).max() and errs.max() <= 1e-9 * X.sum(axis=1).max()
     e.close()
+
+
+# ------------------------------------------------------------------ MvNMF: steps queued ahead of the host vs the classic form
+@pytest.mark.parametrize("tag", ["a", "g", "bt1", "bt2"])
+def test_mvnmf_queued_steps_equal_the_classic_form_bit_for_bit(golden, tag):
+    """Default: per step a tail and ONE pass over the samples (``fused_kernel<.., MVJ>``), the line-search decision on the
+    device, the host reading a flag once per call.  ``set_mv_queued(False)``: the classic form (two passes per step, the
+    host decides every step).  Same gammas, W, H and objectives bit for bit -- in one call, step by step, in blocks that
+    leave the engine ahead between calls; ``bt1`` / ``bt2`` reject first trials in the middle of a queued batch."""
+    g = golden.mv
+    lam, delta, steps, ng = g[f"{tag}_par"]
+    steps, ng = int(steps), int(ng)
+    outs = []
+    for queued in (True, False):
+        res = []
+        # (1) all steps in one call; (2) blocks of 2 with more_follows; (3) step by step
+        for mode in ("one", "blocks", "single"):
+            e = make_engine(g[f"{tag}_X"], g[f"{tag}_W0"], g[f"{tag}_H0"])
+            e.set_mv_queued(queued)
+            gamma, objs = 1.0, []
+            if mode == "one":
+                gamma = e.mv_step(steps, ng, lam, delta, gamma)
+            elif mode == "blocks":
+                left = steps
+                while left > 0:
+                    n = min(2, left)
+                    gamma, f = e.mv_step_objective(n, ng, lam, delta, gamma, more_follows=left > n)
+                    objs.append(f)
+                    left -= n
+            else:
+                for _ in range(steps):
+                    gamma = e.mv_step(1, ng, lam, delta, gamma)
+            res.append((gamma, e.download_W(), e.download_H(), objs, e.mv_objective(lam, delta)))
+            e.close()
+        outs.append(res)
+    for (gq, Wq, Hq, oq, fq), (gc, Wc, Hc, oc, fc) in zip(*outs):
+        assert gq == gc and np.array_equal(Wq, Wc) and np.array_equal(Hq, Hc) and oq == oc and fq == fc
+    # the three ways of splitting the steps agree among themselves, and with the golden trajectory
+    ref = outs[0][0]
+    for r in outs[0][1:]:
+        assert r[0] == ref[0] and np.array_equal(r[1], ref[1]) and np.array_equal(r[2], ref[2])
+    assert np.isclose(ref[0], g[f"{tag}_gammas"][-1], rtol=1e-12) and rel_l2(ref[1], g[f"{tag}_W"].T) < 1e-7
+
+
+@pytest.mark.parametrize("N,K", [(17003, 33), (900, 17), (40000, 50), (5000, 8)])
+def test_mvnmf_queued_steps_on_more_shapes(N, K):
+    X, W0, H0 = orc.synthetic_problem(96, N, K, seed=N % 97)
+    lam, delta = 1.0, 1.0
+    res = []
+    for queued in (True, False):
+        e = Engine(N, 96, K)
+        e.set_mv_queued(queued)
+        e.upload_X(X), e.upload_W(W0), e.upload_H(H0)
+        gamma, f = e.mv_step_objective(6, 0, lam, delta, 1.0, more_follows=True)
+        gamma, f2 = e.mv_step_objective(5, 0, lam, delta, gamma, more_follows=False)
+        res.append((gamma, f, f2, e.download_W(), e.download_H()))
+        e.close()
+    assert res[0][:3] == res[1][:3] and np.array_equal(res[0][3], res[1][3]) and np.array_equal(res[0][4], res[1][4])
+    W, H, g = W0.T, H0.T, 1.0
+    for _ in range(11):
+        W, H, g = orc.mvnmf_step(X.T, W, H, lam, delta, g, 0)
+    assert np.isclose(res[0][0], g, rtol=1e-12) and rel_l2(res[0][3], W.T) < 1e-7 and rel_l2(res[0][4], H.T) < 1e-7
