@@ -385,15 +385,18 @@ bool launch(const SampleEmbeddingParams& p, hipStream_t stream) {
 #else
     constexpr bool kProf = false;
 #endif
-    static bool attr_set = false;  // (one process, one device kind; the attribute is per function)
     auto kern = corr_sample_embeddings_batched_kernel<NE, NJ, kProf>;
-    if (!attr_set) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    // more than 64 KB of dynamic LDS needs the attribute, per function AND per device (a process may hold engines on several)
+    static bool attr_set[64] = {};
+    if (dev < 0 || dev >= 64) return false;
+    if (!attr_set[dev]) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lds::bytes) != hipSuccess) return false;
-        attr_set = true;
+        attr_set[dev] = true;
     }
     // one workgroup per CU; every wave gets a contiguous range of at least 16 samples (one per slot) where N allows
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int64_t max_waves = (int64_t)cus * BT_WAVES;
     const int64_t waves = std::max<int64_t>(1, std::min<int64_t>(max_waves, (p.N + 15) / 16));
     const int64_t per_wave = (p.N + waves - 1) / waves;
