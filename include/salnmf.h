@@ -71,8 +71,10 @@ int salnmf_device_count(void);
  * per-sample weights -- one 96-feature block of X and W per launch (U = R W^T accumulated over the blocks).  More than 64
  * signatures run the same entry points per chunk of <= 64 signatures: the product H W is accumulated over the chunks by a
  * chain of forward launches, the last of which forms the ratio X / (H W) (or the objective), and the update passes run
- * once per chunk on that ratio.  MvNMF, CorrNMF, the device-side initialisation, the fp32 fast mode and sample sharding
- * answer with an error in both cases. */
+ * once per chunk on that ratio.  On feature blocks also: MvNMF (the step in its plain form, salnmf_mv_wide_kernels.h),
+ * CorrNMF (its two passes over X block by block; everything else is K- and dim-sized) and the device-side
+ * initialisation except the separableNMF selection.  The fp32 fast mode and sample sharding answer with an error in both
+ * cases, MvNMF / CorrNMF / the initialisation on more than 64 signatures too. */
 int salnmf_create(int device, int n_features, int64_t n_samples, int n_signatures,
                   salnmf_engine** out);
 void salnmf_destroy(salnmf_engine* e);

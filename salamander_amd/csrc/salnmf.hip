@@ -1049,11 +1049,13 @@ static int check_abort(salnmf_engine* e) {
 // ---- n_features > 96: the passes run once per 96-feature block of X and W (include/salnmf.h: limits)
 // H half (update_H, _utils_klnmf.py:220-278; the H half of update_WH, :343-361) from (W, H) into Hout: U = R W^T summed
 // over the blocks' launches through Uacc, the last block's launch updates H
-static int blocked_update_H(salnmf_engine* e, double* Hout) {
+static int blocked_update_H(salnmf_engine* e, double* Hout, double hfloor = kEps, bool weighted = true) {
     for (int b = 0; b < e->NB; ++b) {
         FusedParams p = fused_params(e);
         to_block(e, p, b);
         p.Hout = Hout;
+        p.hfloor = hfloor;
+        if (!weighted) p.wkl = p.wlh = nullptr;
         p.Uacc = e->Uacc;
         p.ublock = b == 0 ? 1 : (b == e->NB - 1 ? 3 : 2);
         CK(weight_arrays(e, p));  // (the BLOCKED instantiation is the weighted-capable one)
@@ -1064,10 +1066,11 @@ static int blocked_update_H(salnmf_engine* e, double* Hout) {
     return 0;
 }
 // numerator (w_kl * X / (W H)) @ H^T of every block from (W, H) -> Gblk (compact [K][width] per block)
-static int blocked_numerators(salnmf_engine* e) {
+static int blocked_numerators(salnmf_engine* e, bool weighted = true) {
     for (int b = 0; b < e->NB; ++b) {
         FusedParams p = fused_params(e);
         to_block(e, p, b);
+        if (!weighted) p.wkl = p.wlh = nullptr;
         CK((launch_fused<true, false, false>(e, p)));
         TailParams t = tail_params(e, e->grid, e->Gblk + (size_t)b * e->K * VMAX, 0, 0, 0, false);
         t.V = block_width(e, b);
@@ -2339,7 +2342,9 @@ int salnmf_mv_step_objective(salnmf_engine* e, int n_steps, int n_given, double 
 // ------------------------------------------------------------------------------------ CorrNMF (row f1)
 
 int salnmf_corr_configure(salnmf_engine* e, int dim_embeddings) {
-    if (e && split(e)) return single_block(e, "CorrNMF");
+    // feature blocks (n_features > 96): the two passes over X run block by block (corr_compute_aux, corr_poisson_llh);
+    // everything else of CorrNMF is K- and dim-sized
+    if (e && e->NC > 1) return single_block(e, "CorrNMF");
     if (!e) return fail("null engine");
     if (dim_embeddings < 1 || dim_embeddings > CORR_DMAX) return fail("dim_embeddings must be in [1, %d], got %d", CORR_DMAX, dim_embeddings);
     CK(enter(e));
@@ -2421,7 +2426,8 @@ static CorrParams corr_params(salnmf_engine* e) {
 int salnmf_corr_update_sample_scalings(salnmf_engine* e) {
     CK(corr_ready(e));
     if (!e->xrowsum_valid) {
-        hipLaunchKernelGGL(rowsum_X_kernel, dim3(1024), dim3(256), 0, e->stream, e->X, e->Np, VMAX, e->xrowsum);
+        for (int b = 0; b < e->NB; ++b)  // (block b's sum joins the earlier blocks')
+            hipLaunchKernelGGL(rowsum_X_kernel, dim3(1024), dim3(256), 0, e->stream, e->X + (size_t)b * e->Np * VMAX, e->Np, VMAX, b > 0 ? 1 : 0, e->xrowsum);
         HIPCK(hipGetLastError());
         e->xrowsum_valid = true;
     }
@@ -2445,6 +2451,12 @@ int salnmf_corr_compute_exposures(salnmf_engine* e) {
 
 int salnmf_corr_compute_aux(salnmf_engine* e) {
     CK(corr_ready(e));
+    if (e->NB > 1) {
+        // U = R W^T summed over the feature blocks, aux = H * U unclipped by the last block's launch; the numerators of
+        // update_signatures block by block into Gblk (applied by salnmf_corr_update_signatures)
+        CK(blocked_update_H(e, e->aux, 0.0, false));
+        return blocked_numerators(e, false);
+    }
     FusedParams p = fused_params(e);
     p.wkl = nullptr;  // CorrNMF is unweighted (corrnmf_det.py:80-85)
     p.wlh = nullptr;
@@ -2460,6 +2472,7 @@ int salnmf_corr_update_signatures(salnmf_engine* e, int n_given) {
     CK(corr_ready(e));
     if (n_given < 0 || n_given > e->K) return fail("n_given out of range");
     if (n_given >= e->K) return 0;  // _utils_klnmf.py:204-205
+    if (e->NB > 1) return blocked_finish_W(e, n_given, SALNMF_CLIP_NON_GIVEN);
     return launch_tail(e, 0, e->red, n_given, SALNMF_CLIP_NON_GIVEN, 1);
 }
 
@@ -2809,8 +2822,11 @@ int salnmf_corr_poisson_llh(salnmf_engine* e, double* out) {
     if (!e->lgam_valid) {
         const int g = 1024;
         CK(ensure_scratch(e, (size_t)g + 1));
-        hipLaunchKernelGGL(lgamma_partial_kernel, dim3(g), dim3(256), 0, e->stream, e->X, e->N, e->V, VMAX, e->scratch);
-        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, e->scratch, g, 1, 1, e->scal + 5);
+        CK(ensure_scratch(e, (size_t)g * e->NB + 1));
+        for (int b = 0; b < e->NB; ++b)
+            hipLaunchKernelGGL(lgamma_partial_kernel, dim3(g), dim3(256), 0, e->stream, e->X + (size_t)b * e->Np * VMAX, e->N, block_width(e, b), VMAX,
+                               e->scratch + (size_t)b * g);
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, e->scratch, g * e->NB, 1, 1, e->scal + 5);
         HIPCK(hipGetLastError());
         CK(allreduce(e, e->scal + 5, 1));
         double v;
@@ -2822,8 +2838,15 @@ int salnmf_corr_poisson_llh(salnmf_engine* e, double* out) {
     CK(fwd_params(e, p));
     p.wkl = nullptr;
     p.wlh = nullptr;
-    CK(launch_forward<3>(e, p));
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, e->objpart, e->fgrid, 1, 1, e->scal + 6);
+    for (int b = 0; b < e->NB; ++b) {  // (a sum over the features: one pass per feature block)
+        FwdParams pb = p;
+        pb.X = e->X + (size_t)b * e->Np * VMAX;
+        pb.W = e->W + (size_t)VMAX * b;
+        pb.V = block_width(e, b);
+        pb.out = e->objpart + (size_t)b * e->fgrid;
+        CK(launch_forward<3>(e, pb));
+    }
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, e->objpart, e->fgrid * e->NB, 1, 1, e->scal + 6);
     HIPCK(hipGetLastError());
     CK(allreduce(e, e->scal + 6, 1));
     double v;
@@ -2984,27 +3007,38 @@ int salnmf_init_flat(salnmf_engine* e, const double* post) {
 }
 
 int salnmf_init_separable(salnmf_engine* e, int n_select, int64_t* chosen_out, double* norms_out) {
-    if (e && split(e)) return single_block(e, "the device-side initialisation");
+    if (e && e->NC > 1) return single_block(e, "the device-side initialisation");
     if (!e || !chosen_out) return fail("null argument");
     if (n_select < 1 || (int64_t)n_select > e->N) return fail("n_select must be in [1, n_samples]");
     if (sharded(e)) return fail("the separableNMF selection needs all samples on one engine: not available on a sharded engine");
     CK(enter(e));
     const int grid = (int)std::min<int64_t>(1024, (e->N + 15) / 16);
-    const size_t nR = (size_t)e->Np * VMAX;
-    CK(ensure_scratch(e, nR + SEP_STATE + 2 * (size_t)grid + 2 * (size_t)n_select));
+    const bool wide = e->NB > 1;  // rows of R over all feature blocks (sep_pass_wide_kernel)
+    const int ldr = e->NB * VMAX;
+    const size_t nR = (size_t)e->Np * ldr, nstate = wide ? (size_t)ldr + 2 : (size_t)SEP_STATE;
+    CK(ensure_scratch(e, nR + nstate + 2 * (size_t)grid + 2 * (size_t)n_select));
     double* R = e->scratch;
     double* state = R + nR;
-    double* pval = state + SEP_STATE;
+    double* pval = state + nstate;
     long long* pidx = reinterpret_cast<long long*>(pval + grid);
     long long* chosen = pidx + grid;
     double* norms = reinterpret_cast<double*>(chosen + n_select);
-    hipLaunchKernelGGL(sep_pass_kernel<true>, dim3(grid), dim3(SEP_BLOCK), 0, e->stream, e->X, R, e->N, e->V, state, pval, pidx);
+    auto pass = [&](bool init) {
+        if (wide) {
+            if (init) hipLaunchKernelGGL(sep_pass_wide_kernel<true>, dim3(grid), dim3(SEP_BLOCK), 0, e->stream, e->X, R, e->N, e->Np, e->V, ldr, state, pval, pidx);
+            else hipLaunchKernelGGL(sep_pass_wide_kernel<false>, dim3(grid), dim3(SEP_BLOCK), 0, e->stream, e->X, R, e->N, e->Np, e->V, ldr, state, pval, pidx);
+        } else {
+            if (init) hipLaunchKernelGGL(sep_pass_kernel<true>, dim3(grid), dim3(SEP_BLOCK), 0, e->stream, e->X, R, e->N, e->V, state, pval, pidx);
+            else hipLaunchKernelGGL(sep_pass_kernel<false>, dim3(grid), dim3(SEP_BLOCK), 0, e->stream, e->X, R, e->N, e->V, state, pval, pidx);
+        }
+    };
+    pass(true);
     HIPCK(hipGetLastError());
     for (int k = 0; k < n_select; ++k) {
-        hipLaunchKernelGGL(sep_select_kernel, dim3(1), dim3(256), 0, e->stream, R, pval, pidx, grid, state, chosen, norms, k);
+        hipLaunchKernelGGL(sep_select_kernel, dim3(1), dim3(256), 0, e->stream, R, pval, pidx, grid, state, chosen, norms, k, ldr);
         HIPCK(hipGetLastError());
         if (k + 1 < n_select) {
-            hipLaunchKernelGGL(sep_pass_kernel<false>, dim3(grid), dim3(SEP_BLOCK), 0, e->stream, e->X, R, e->N, e->V, state, pval, pidx);
+            pass(false);
             HIPCK(hipGetLastError());
         }
     }

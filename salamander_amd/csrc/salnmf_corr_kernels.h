@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(CORR_BLOCK) corr_logit_kernel(CorrParams p) {
 }
 
 // out[n] = sum_v X[n][v] on the padded layout [Np][96] (pads are 0): 16 lanes per row, 6 features each
-__global__ void __launch_bounds__(256) rowsum_X_kernel(const double* __restrict__ X, int64_t Np, int ldx, double* __restrict__ out) {
+__global__ void __launch_bounds__(256) rowsum_X_kernel(const double* __restrict__ X, int64_t Np, int ldx, int add, double* __restrict__ out) {
     const int c16 = threadIdx.x & 15;
     int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
     const int64_t stride = (int64_t)gridDim.x * 16;
@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(256) rowsum_X_kernel(const double* __restrict_
         for (int v = c16; v < ldx; v += 16) s += X[row * ldx + v];
 #pragma unroll
         for (int m = 1; m < 16; m <<= 1) s += __shfl_xor(s, m, 64);
-        if (c16 == 0) out[row] = s;
+        if (c16 == 0) out[row] = add ? out[row] + s : s;
     }
 }
 

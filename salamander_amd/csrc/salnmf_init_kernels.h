@@ -283,10 +283,64 @@ __global__ void __launch_bounds__(SEP_BLOCK) sep_pass_kernel(const double* __res
     }
 }
 
+// the same pass for more than 96 features: a sample's row of R is ldr = 96 * (number of feature blocks) doubles, X is read
+// block by block ([b][Np][96]); the row is walked twice (dot product or sum, then deflation + norm) instead of held in
+// registers.  state = u[ldr] | |u|^2
+template <bool INIT>
+__global__ void __launch_bounds__(SEP_BLOCK) sep_pass_wide_kernel(const double* __restrict__ X, double* __restrict__ R, int64_t N, int64_t Np, int V,
+                                                                   int ldr, const double* __restrict__ state, double* __restrict__ pval,
+                                                                   long long* __restrict__ pidx) {
+    __shared__ double bval[16];
+    __shared__ long long bidx[16];
+    const int slot = threadIdx.x >> 4, c = threadIdx.x & 15;
+    const double un = INIT ? 1.0 : state[ldr];
+    double best = -1.0;
+    long long besti = 0x7fffffffffffffffll;
+    for (int64_t n = (int64_t)blockIdx.x * 16 + slot; n < N; n += (int64_t)gridDim.x * 16) {
+        double* row = R + n * ldr;
+        double acc = 0.0;
+        for (int v = c; v < V; v += 16) {
+            if (INIT) acc += X[((int64_t)(v / VMAX) * Np + n) * VMAX + v % VMAX];
+            else acc = __builtin_fma(state[v], row[v], acc);
+        }
+#pragma unroll
+        for (int m = 8; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 16);
+        double nrm = 0.0;
+        for (int v = c; v < ldr; v += 16) {
+            double r = 0.0;
+            if (v < V) r = INIT ? X[((int64_t)(v / VMAX) * Np + n) * VMAX + v % VMAX] / acc : row[v] - (state[v] * acc) / un;
+            row[v] = r;
+            nrm = __builtin_fma(r, r, nrm);
+        }
+#pragma unroll
+        for (int m = 8; m > 0; m >>= 1) nrm += __shfl_xor(nrm, m, 16);
+        if (nrm > best) {
+            best = nrm;
+            besti = n;
+        }
+    }
+    if (c == 0) {
+        bval[slot] = best;
+        bidx[slot] = besti;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double b = bval[0];
+        long long bi = bidx[0];
+        for (int i = 1; i < 16; ++i)
+            if (bval[i] > b || (bval[i] == b && bidx[i] < bi)) {
+                b = bval[i];
+                bi = bidx[i];
+            }
+        pval[blockIdx.x] = b;
+        pidx[blockIdx.x] = bi;
+    }
+}
+
 // one workgroup: the global argmax of the per-workgroup candidates (lowest index on ties), u <- R_j, |u|^2, chosen[round] <- j
 __global__ void __launch_bounds__(256) sep_select_kernel(const double* __restrict__ R, const double* __restrict__ pval,
                                                          const long long* __restrict__ pidx, int nparts, double* __restrict__ state,
-                                                         long long* __restrict__ chosen, double* __restrict__ norms, int round) {
+                                                         long long* __restrict__ chosen, double* __restrict__ norms, int round, int ldr) {
     __shared__ double bval[256];
     __shared__ long long bidx[256];
     double b = -1.0;
@@ -311,9 +365,9 @@ __global__ void __launch_bounds__(256) sep_select_kernel(const double* __restric
         __syncthreads();
     }
     const long long j = bidx[0];
-    if (threadIdx.x < VMAX) state[threadIdx.x] = R[j * VMAX + threadIdx.x];
+    for (int t = threadIdx.x; t < ldr; t += 256) state[t] = R[j * ldr + t];
     if (threadIdx.x == 0) {
-        state[VMAX] = bval[0];
+        state[ldr] = bval[0];
         chosen[round] = j;
         norms[round] = bval[0];  // the winning squared norm: the caller checks that it is not at rounding level
     }

@@ -26,10 +26,9 @@ class StandardNMF(SignatureNMF):
         instead of sklearn's randomized one) unless ``device_init=False`` or a ``seed`` is passed, which asks for
         the reference's seeded host computation (``initialize.py:221-255``)."""
         init_kwargs = {} if init_kwargs is None else init_kwargs.copy()
-        # (more than 96 features: the Gram matrix is formed block pair by block pair; separableNMF's selection and more than
-        # 64 signatures stay on the host)
-        wide = np.shape(self.adata.X)[1] > 96
-        on_device = self.device_init and self.n_signatures <= 64 and not (wide and self.init_method == "separableNMF")
+        # (more than 96 features: the Gram matrix is formed block pair by block pair, separableNMF's deflation walks the rows
+        # over all feature blocks; more than 64 signatures stay on the host)
+        on_device = self.device_init and self.n_signatures <= 64
         if on_device and self.init_method in DEVICE_METHODS and "seed" not in init_kwargs:
             if init_kwargs:
                 raise TypeError(f"init method '{self.init_method}' takes no keyword arguments besides 'seed': {sorted(init_kwargs)}")

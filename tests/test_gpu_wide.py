@@ -88,9 +88,8 @@ def test_wide_typed_ingest_and_the_refusals():
     Xc = counts.astype(float).clip(orc.EPSILON)
     assert np.isclose(outs[0][0], orc.kl_divergence(Xc.T, W0.T, H0.T), rtol=1e-12)
     assert all(o[0] == outs[0][0] and np.array_equal(o[1], outs[0][1]) for o in outs[1:])
-    for call in (lambda: e.corr_configure(4), lambda: e.init_separable(3), lambda: e.set_precision("f32")):
-        with pytest.raises(RuntimeError, match="n_features > 96"):
-            call()
+    with pytest.raises(RuntimeError, match="n_features > 96"):
+        e.set_precision("f32")
     e.close()
     with pytest.raises(RuntimeError, match="n_features"):
         Engine(10, 3073, 2)
@@ -194,3 +193,147 @@ def test_wide_device_initialisation_matches_the_host_method(V, N, K, method):
     err = np.linalg.norm(X - E @ S) / np.linalg.norm(X)
     err_host = np.linalg.norm(X - E_host @ S_host) / np.linalg.norm(X)
     assert err <= 1.02 * err_host + 1e-9, (err, err_host)
+
+
+# ------------------------------------------------------------------ CorrNMF on more than 96 features
+
+
+@pytest.mark.parametrize("V,N,K,dim", [(97, 203, 3, 2), (200, 1000, 7, 3), (288, 2500, 18, 5), (1536, 333, 50, 50), (288, 4099, 64, 16)])
+def test_wide_corrnmf_dense_pieces_match_oracle(V, N, K, dim):
+    """The two CorrNMF passes over X (aux + the signature update's numerator; the Poisson log-likelihood) block by block, the
+    sample scalings from X's row sums over all blocks: each against the oracle, in the order of
+    ``CorrNMFDet._update_parameters`` (corrnmf_det.py:157-169)."""
+    from oracle import corrnmf_oracle as co
+    from salamander_amd import _lib
+
+    rng = np.random.default_rng(V + N + K)
+    X, W, _ = orc.synthetic_problem(V, N, K, seed=V + N)
+    beta = rng.normal(0.0, 0.3, size=K)
+    alpha = np.log(X.sum(axis=1) / K) + rng.normal(0.0, 0.1, size=N)
+    L, U = rng.normal(0.0, 0.5, size=(K, dim)), rng.normal(0.0, 0.5, size=(N, dim))
+    e = Engine(N, V, K)
+    e.upload_X(X), e.upload_W(W)
+    e.corr_configure(dim)
+    for which, a in ((_lib.CORR_SIGNATURE_SCALINGS, beta), (_lib.CORR_SAMPLE_SCALINGS, alpha), (_lib.CORR_SIGNATURE_EMBEDDINGS, L), (_lib.CORR_SAMPLE_EMBEDDINGS, U)):
+        e.corr_upload(which, a)
+    e.corr_update_sample_scalings()
+    alpha1 = co.update_sample_scalings(X, beta, L, U)
+    assert np.max(np.abs(e.corr_download(_lib.CORR_SAMPLE_SCALINGS) - alpha1)) < 1e-12
+    e.corr_compute_exposures()
+    H = co.compute_exposures(beta, alpha1, L, U)
+    assert rel_l2(e.download_H(), H) < 1e-12
+    e.corr_compute_aux()
+    aux = co.compute_aux(X, W, H)
+    assert rel_l2(e.corr_download(_lib.CORR_AUX).T, aux) < 1e-12
+    e.corr_update_signature_scalings()
+    assert np.max(np.abs(e.corr_download(_lib.CORR_SIGNATURE_SCALINGS) - co.update_signature_scalings(aux, alpha1, L, U))) < 1e-12
+    llh, want = e.corr_poisson_llh(), co.poisson_llh(X.T, W.T, H.T)
+    assert abs(llh - want) <= 1e-12 * abs(want)
+    n_given = K // 3
+    e.corr_update_signatures(n_given)
+    Wn = e.download_W()
+    assert rel_l2(Wn, orc.update_W(X.T, W.T, H.T, n_given_signatures=n_given).T) < 1e-12
+    assert np.array_equal(Wn[:n_given], W[:n_given])  # given signatures: untouched, not even clipped
+    assert rel_l2(e.download_H(), H) < 1e-12  # the aux pass leaves the exposures alone
+    e.close()
+
+
+def test_wide_corrnmf_model_updates_match_the_oracle_steps():
+    """Three full ``CorrNMFDet._update_parameters`` on an SBS-288-sized catalogue against the restated reference step, then
+    the ELBO of the resident state."""
+    from oracle import corrnmf_oracle as co
+    from salamander_amd.models import CorrNMFDet
+
+    V, N, K, dim = 288, 600, 6, 4
+    rng = np.random.default_rng(5)
+    X, W, _ = orc.synthetic_problem(V, N, K, seed=9)
+    adata = sal.AnnData(X.copy())
+    adata.obs["scalings"] = np.log(X.sum(axis=1) / K)
+    adata.obsm["embeddings"] = rng.normal(0, 0.3, (N, dim))
+    sigs = sal.AnnData(W.copy())
+    sigs.obs["scalings"] = rng.normal(0, 0.1, K)
+    sigs.obsm["embeddings"] = rng.normal(0, 0.3, (K, dim))
+    state = (W, sigs.obs["scalings"].values.copy(), adata.obs["scalings"].values.copy(), sigs.obsm["embeddings"].copy(),
+             adata.obsm["embeddings"].copy(), 1.0)
+    m = CorrNMFDet(n_signatures=K, dim_embeddings=dim)
+    m.adata, m.asignatures = adata, sigs
+    m.compute_exposures()
+    for _ in range(3):
+        want = co.corrnmf_det_step(X, *state)
+        state = want[:6]
+        m._update_parameters()
+    assert np.allclose(m.asignatures.X, want[0], rtol=1e-6, atol=1e-12)
+    assert np.allclose(adata.obsm["exposures"], want[6], rtol=1e-7)
+    assert np.allclose(sigs.obsm["embeddings"], want[3], rtol=1e-4, atol=1e-6)
+    assert np.allclose(adata.obsm["embeddings"], want[4], rtol=1e-4, atol=1e-6)
+    assert np.isclose(m.variance, want[5], rtol=1e-5)
+    elbo = co.elbo_corrnmf(adata.X, m.asignatures.X, adata.obsm["exposures"], sigs.obsm["embeddings"], adata.obsm["embeddings"], m.variance)
+    assert abs(m.objective_function() - elbo) <= 1e-10 * abs(elbo)
+
+
+def test_wide_multimodal_corrnmf_updates_match_the_oracle_steps():
+    """``MultimodalCorrNMF`` with an SBS-288-sized and an ID-83-sized modality (one engine on feature blocks, one on a single
+    block, the joint sample solves over both): three updates against the restated reference step, then the ELBO."""
+    from oracle import corrnmf_oracle as co
+    from salamander_amd.models.mmcorrnmf import MultimodalCorrNMF
+
+    N, dim, Ks, Vs = 400, 3, (5, 4), (288, 83)
+    rng = np.random.default_rng(17)
+    Xs, Ws, betas, alphas, Ls = [], [], [], [], []
+    for m, (K, V) in enumerate(zip(Ks, Vs)):
+        X, W, _ = orc.synthetic_problem(V, N, K, seed=40 + m)
+        Xs.append(X), Ws.append(W)
+        betas.append(rng.normal(0, 0.1, K)), alphas.append(np.log(X.sum(axis=1) / K)), Ls.append(rng.normal(0, 0.3, (K, dim)))
+    U, var = rng.normal(0, 0.3, (N, dim)), 1.0
+    mdata = sal.MuData({f"mod{m}": sal.AnnData(Xs[m].copy()) for m in range(2)})
+    mdata.obsm["embeddings"] = U.copy()
+    asignatures = {}
+    for m in range(2):
+        mdata[f"mod{m}"].obs["scalings"] = alphas[m]
+        a = sal.AnnData(Ws[m].copy())
+        a.obs["scalings"], a.obsm["embeddings"] = betas[m], Ls[m].copy()
+        asignatures[f"mod{m}"] = a
+    model = MultimodalCorrNMF(ns_signatures=list(Ks), dim_embeddings=dim)
+    model.mdata, model.asignatures = mdata, asignatures
+    model.compute_exposures()
+    model.variance = var
+    for _ in range(3):
+        model._update_parameters()
+        Ws, betas, alphas, Ls, U, var, Hs = co.mm_step(Xs, Ws, betas, alphas, Ls, U, var)
+    for m, name in enumerate(model.mod_names):
+        assert np.allclose(model.asignatures[name].X, Ws[m], rtol=1e-6, atol=1e-12)
+        assert np.allclose(model.mdata[name].obsm["exposures"], Hs[m], rtol=1e-6)
+        assert np.allclose(model.asignatures[name].obs["scalings"].values, betas[m], rtol=1e-6, atol=1e-9)
+        assert np.allclose(model.asignatures[name].obsm["embeddings"], Ls[m], rtol=1e-5, atol=1e-7)
+    assert np.allclose(model.mdata.obsm["embeddings"], U, rtol=1e-5, atol=1e-7)
+    assert np.isclose(model.variance, var, rtol=1e-6)
+    want = co.mm_elbo(Xs, Ws, [model.mdata[n].obsm["exposures"] for n in model.mod_names], Ls, U, var)
+    assert abs(model.objective_function() - want) <= 1e-6 * abs(want)
+
+
+@pytest.mark.parametrize("N,V,K", [(3000, 288, 20), (777, 97, 12), (5001, 200, 30), (400, 1536, 8)])
+def test_wide_separable_selection_equals_the_host_loop(N, V, K):
+    """separableNMF's K deflation rounds (methods.py:112-135) with a sample's row over all feature blocks: the same indices
+    as the host loop; and through the model: ``init_method="separableNMF"`` with and without the device."""
+    X, _, _ = orc.synthetic_problem(V, N, min(K, 8), seed=N)
+    e = Engine(N, V, K)
+    e.upload_X(X)
+    chosen, norms = e.init_separable(K, return_norms=True)
+    e.close()
+    R = X.T / X.T.sum(axis=0)
+    want = []
+    for _ in range(K):
+        nr = (R**2).sum(axis=0)
+        j = int(np.argmax(nr))
+        R = R - np.outer(R[:, j], R[:, j] @ R) / nr[j]
+        want.append(j)
+    assert chosen.tolist() == want and len(set(want)) == K and np.all(np.diff(norms) <= 0)
+    if V == 288:
+        got = []
+        for device_init in (True, False):
+            m = sal.models.KLNMF(K, "separableNMF", min_iterations=0, max_iterations=0, device_init=device_init)
+            m._setup_adata(sal.AnnData(X.copy()))
+            m._initialize(None, {"seed": 7})
+            got.append((np.array(m.asignatures.X), np.array(m.adata.obsm["exposures"]), set(m._resident)))
+        assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
+        assert got[0][2] == {"X"} and got[1][2] == set()
