@@ -2649,9 +2649,17 @@ static int lockstep_signature_solves(salnmf_engine* e, const double* U, const do
     int* hactive = reinterpret_cast<int*>(e->hpin);
     const dim3 grid(S, groups);
     // start: sg = sum_n aux[n][k] U[n][:] and the first requests (the start points)
-    if (multi) hipLaunchKernelGGL(ls_begin_multi_kernel, grid, dim3(SIGT), 0, e->stream, q);
-    else hipLaunchKernelGGL(ls_begin_kernel, grid, dim3(SIGT), 0, e->stream, q);
-    hipLaunchKernelGGL(ls_reduce_kernel, dim3(K, 1), dim3(256), 0, e->stream, q.part, q.red, q.state, S, 2, 64, 1);
+    if (multi) {
+        // sg = aux^T U as one MFMA product, four workgroups per CU; their partial sums [wg][K][64] borrow
+        // the front of q.part (K S LS_REC doubles)
+        const int nwg = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)4 * prop.multiProcessorCount, (n_rows + 255) / 256, (int64_t)S * LS_REC / 64}));
+        const int64_t rows_per_wg = ((n_rows + nwg - 1) / nwg + 255) / 256 * 256;
+        hipLaunchKernelGGL(ls_begin_mfma_kernel, dim3(nwg), dim3(256), 0, e->stream, q, q.part, rows_per_wg);
+        hipLaunchKernelGGL(ls_reduce_sg_kernel, dim3(K), dim3(1024), 0, e->stream, q.part, q.red, nwg, K, dim);
+    } else {
+        hipLaunchKernelGGL(ls_begin_kernel, grid, dim3(SIGT), 0, e->stream, q);
+        hipLaunchKernelGGL(ls_reduce_kernel, dim3(K, 1), dim3(256), 0, e->stream, q.part, q.red, q.state, S, 2, 64, 1);
+    }
     HIPCK(hipGetLastError());
     if (shard) CK(allreduce(e, q.red, (size_t)K * LS_REC));
     hipLaunchKernelGGL(ls_copy_sg_kernel, dim3((K * 64 + 255) / 256), dim3(256), 0, e->stream, q.red, q.sg, K);
@@ -2662,9 +2670,16 @@ static int lockstep_signature_solves(salnmf_engine* e, const double* U, const do
     // one round: evaluation at every live signature's requested point, fixed-order sum of the partials, the solvers advance;
     // the number of signatures that still want an evaluation travels to the host behind it (slot and event r & 1)
     auto launch_round = [&](int r) -> int {
-        // (dim % 16 != 0: the padded tile has room for the column of ones that makes the Hessian product yield the gradient too)
-        if (multi && dim % 16 != 0) hipLaunchKernelGGL(ls_eval_multi_kernel<true>, grid, dim3(SIGT), 0, e->stream, q);
-        else if (multi) hipLaunchKernelGGL(ls_eval_multi_kernel<false>, grid, dim3(SIGT), 0, e->stream, q);
+        if (multi && dim % 16 != 0) {
+            // the last block column's live columns of the group's signatures side by side (ls_eval_packed_kernel)
+            const int tail_cols = dim + 1 - 16 * ((dim + 15) / 16 - 1);
+            const int npk = (LS_GROUP * tail_cols + 15) / 16;
+            // <3, 40, ..>: three row tiles and three packed tiles as compile-time constants, the next tile of U prefetched
+            // into 40 registers per lane (c5's shape: dim 33 .. 40)
+            if (npk == 3 && dim > 32 && dim <= 40) hipLaunchKernelGGL((ls_eval_packed_kernel<3, 40, true, true>), grid, dim3(SIGT), 0, e->stream, q);
+            else if (npk <= 3) hipLaunchKernelGGL((ls_eval_packed_kernel<3, 0, false, false>), grid, dim3(SIGT), 0, e->stream, q);
+            else hipLaunchKernelGGL((ls_eval_packed_kernel<5, 0, false, false>), grid, dim3(SIGT), 0, e->stream, q);
+        } else if (multi) hipLaunchKernelGGL(ls_eval_multi_kernel, grid, dim3(SIGT), 0, e->stream, q);
         else hipLaunchKernelGGL(ls_eval_kernel, grid, dim3(SIGT), 0, e->stream, q);
         hipLaunchKernelGGL(ls_reduce_kernel, dim3(K, (rec + 255) / 256), dim3(256), 0, e->stream, q.part, q.red, q.state, S, 0, rec, 0);
         HIPCK(hipGetLastError());

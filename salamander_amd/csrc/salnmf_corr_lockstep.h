@@ -181,44 +181,102 @@ __device__ inline void ls_hess_tile3(const SignatureEmbeddingEval& ev, d4 (&acc)
     }
 }
 
-__global__ void __launch_bounds__(SIGT) ls_begin_multi_kernel(LockstepParams q) {
-    __shared__ double pool[SIG_POOL];
-    __shared__ double wt[SIGT], sred[SIGT], ybuf[64], red[4 * 64];
-    const int kbase = blockIdx.y * LS_GROUP, s = blockIdx.x;
-    SignatureEmbeddingEval ev;
-    ls_setup_eval(ev, q, pool, wt, sred, ybuf, red, kbase, s);
-    if (s == 0 && threadIdx.x < 64) {
-        for (int g = 0; g < LS_GROUP && kbase + g < q.sig.K; ++g) {
-            const int k = kbase + g;
-            const double x = ev.lane < q.sig.dim ? q.sig.L[k * q.sig.dim + ev.lane] : 0.0;
-            q.x0[k * 64 + ev.lane] = x;
-            q.req[k * 64 + ev.lane] = x;
-            if (threadIdx.x == 0) {
+// The start of the grouped solves as ONE matrix product on the fp64 MFMA units:  sg = aux^T U  (K x N times N x dim), every
+// signature at once (a pass per group of five signatures with each component summed through a chain of dependent FMAs
+// took 0.37 ms at c5, twice per update: 0.05 ms now); U and aux are read once, straight from global memory in operand
+// layout (A[k][n] = aux[n][k]: lane (k = lane & 15, n = lane >> 4); B[n][m] = U[n][m]), four workgroups per CU.  part2 [gridDim.x][K][64]: the workgroups' partial sums, added in order by ls_reduce_sg_kernel.
+__global__ void __launch_bounds__(256) ls_begin_mfma_kernel(LockstepParams q, double* __restrict__ part2, int64_t rows_per_wg) {
+    __shared__ double red[64 * 48];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c16 = lane & 15, qq = lane >> 4;
+    const int K = q.sig.K, dim = q.sig.dim, KP = q.sig.KP;
+    if (blockIdx.x == 0) {
+        for (int k = wave; k < K; k += 4) {
+            const double x = lane < dim ? q.sig.L[k * dim + lane] : 0.0;
+            q.x0[k * 64 + lane] = x;
+            q.req[k * 64 + lane] = x;
+            if (lane == 0) {
                 q.state[k] = LS_NEED;
                 q.n_evals[k] = 0;
             }
         }
     }
-    double r[LS_GROUP];
+    const int KT = (K + 15) / 16, DT = (dim + 15) / 16;  // <= 4, <= 3
+    d4 acc[4][3];
 #pragma unroll
-    for (int g = 0; g < LS_GROUP; ++g) r[g] = 0.0;
-    for (int64_t t0 = ev.n_begin; t0 < ev.n_end; t0 += SIGT) {
-        ev.stage(t0);
-        const int64_t n = t0 + ev.tid;
+    for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int g = 0; g < LS_GROUP; ++g) {
-            if (kbase + g >= q.sig.K) continue;  // uniform
-            wt[ev.tid] = n < ev.n_end ? q.sig.aux[n * q.sig.KP + kbase + g] : 0.0;
-            __syncthreads();
-            r[g] = ev.tile_weighted(r[g]);
-            __syncthreads();
+        for (int dt = 0; dt < 3; ++dt) acc[kt][dt] = (d4){0, 0, 0, 0};
+    const int64_t n0 = (int64_t)blockIdx.x * rows_per_wg;
+    const int64_t n1 = n0 + rows_per_wg < q.sig.N ? n0 + rows_per_wg : q.sig.N;
+    for (int64_t t = n0 + 64 * wave; t < n1; t += 256) {
+#pragma unroll 4
+        for (int sgrp = 0; sgrp < 16; ++sgrp) {
+            const int64_t n = t + 4 * sgrp + qq;
+            const bool valid = n < n1;
+            double a[4], b[3];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) a[kt] = (valid && 16 * kt + c16 < K) ? q.sig.aux[n * KP + 16 * kt + c16] : 0.0;
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt) b[dt] = (valid && 16 * dt + c16 < dim) ? q.sig.U[n * dim + 16 * dt + c16] : 0.0;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+                if (kt < KT) {
+#pragma unroll
+                    for (int dt = 0; dt < 3; ++dt)
+                        if (dt < DT) acc[kt][dt] = mfma(a[kt], b[dt], acc[kt][dt]);
+                }
         }
     }
+    // the four waves' sums in fixed order (((wave 0 + 1) + 2) + 3) through one staging buffer; D[row = q + 4 r][col = c16]
+    // of tile (kt, dt)
+    for (int src = 1; src < 4; ++src) {
+        if (wave == src) {
 #pragma unroll
-    for (int g = 0; g < LS_GROUP; ++g) {
-        if (kbase + g >= q.sig.K) continue;
-        const double t = ev.cross_wave(r[g]);
-        if (ev.wave == 0) q.part[((int64_t)(kbase + g) * q.S + s) * LS_REC + 2 + ev.lane] = t;
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[(16 * kt + qq + 4 * r) * 48 + 16 * dt + c16] = acc[kt][dt][r];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[kt][dt][r] += red[(16 * kt + qq + 4 * r) * 48 + 16 * dt + c16];
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        double* out = part2 + (int64_t)blockIdx.x * K * 64;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = 16 * kt + qq + 4 * r, m = 16 * dt + c16;
+                    if (k < K && m < dim) out[k * 64 + m] = acc[kt][dt][r];
+                }
+    }
+}
+
+// red[k][2 + m] = sum over the workgroups' partial sums of ls_begin_mfma_kernel: sixteen interleaved sub-sums (wave w:
+// partials w, w + 16, ... in order), then the sixteen in order
+__global__ void __launch_bounds__(1024) ls_reduce_sg_kernel(const double* __restrict__ part2, double* __restrict__ red, int nparts, int K, int dim) {
+    __shared__ double sub[16][64];
+    const int k = blockIdx.x, m = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double t = 0.0;
+    if (m < dim)
+        for (int s = w; s < nparts; s += 16) t += part2[((int64_t)s * K + k) * 64 + m];
+    sub[w][m] = t;
+    __syncthreads();
+    if (w == 0) {
+        double tot = sub[0][m];
+        for (int i = 1; i < 16; ++i) tot += sub[i][m];
+        red[(int64_t)k * LS_REC + 2 + m] = tot;
     }
 }
 
@@ -227,18 +285,10 @@ __device__ __forceinline__ double ls_lane_value(double v, int m) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), m), __builtin_amdgcn_readlane(__double2loint(v), m));
 }
 
-// AUG (dim not a multiple of 16, i.e. the 16-padded tile has a free component column): the staged tile carries a column of
-// ones at component `dim`, so the weighted Gram product that forms the Hessian,  sum_n w_n [U_n 1]^T [U_n 1],  also yields
-// the gradient part  sum_n w_n U_n  (column dim) and  sum_n w_n  (entry [dim][dim]) -- on the MFMAs that run anyway.
-// With that every wave works on ITS 64 samples of a tile from the logits to the Hessian with no workgroup barrier in
-// between, and the per-signature passes over the tile that were chains of dependent LDS reads are gone:
-//   * logits of the LS_GROUP signatures in ONE sweep over the sample's row (one LDS read per component, the requested
-//     points come from registers by v_readlane; per signature the FMA chain of row_dot, same bits) instead of LS_GROUP
-//     sweeps of two reads per FMA (5.2 k cycles each, measured: profiles/r03/c5_roofline.md);
-//   * no tile_weighted pass (2.6 k cycles per signature and tile) and no cross-wave sum of its result.
-// What differs from the single-kernel form: the gradient part and sum_n w_n are summed in the MFMA's order (rounding
-// level; same on every rank of a sharded solve).  !AUG keeps those two sums on the VALU (two barriers per signature).
-template <bool AUG>
+// dim a multiple of 16 (no free component column in the 16-padded tile: see ls_eval_packed_kernel for the other case): the
+// logits of the LS_GROUP signatures in ONE sweep over the sample's row (one LDS read per component, the requested points
+// come from registers by v_readlane; per signature the FMA chain of row_dot, same bits); gradient part and sum of the
+// weights on the VALU (two barriers per signature), the Hessian's Gram product on the MFMA units.
 __global__ void __launch_bounds__(SIGT) ls_eval_multi_kernel(LockstepParams q) {
     const int kbase = blockIdx.y * LS_GROUP, s = blockIdx.x;
     bool live[LS_GROUP], any = false;
@@ -274,7 +324,6 @@ __global__ void __launch_bounds__(SIGT) ls_eval_multi_kernel(LockstepParams q) {
         const bool in = n < ev.n_end;
         const double al = in ? q.sig.alpha[n] : 0.0;
         double* myrow = ev.Ut + ev.tid * ev.ldu;
-        if (AUG) myrow[dim] = 1.0;
         // <U_n, y_g> for the group's signatures in one sweep over the row (per signature: row_dot's FMA chain)
         double sd[LS_GROUP];
 #pragma unroll
@@ -304,46 +353,317 @@ __global__ void __launch_bounds__(SIGT) ls_eval_multi_kernel(LockstepParams q) {
             if (in) {
                 lin[g] = __builtin_fma(sd[g], auxv[g], lin[g]);
                 w = exp((cg[g] + al) + sd[g]);
-                if (!AUG) ex[g] += w;
+                ex[g] += w;
             }
             wt[ev.tid] = w;
-            if (AUG) {
-                __builtin_amdgcn_wave_barrier();  // (LDS operations of one wave execute in order: its own 64 weights)
-                ls_hess_tile3(ev, acc[g]);
-                __builtin_amdgcn_wave_barrier();
-            } else {
-                __syncthreads();
-                r[g] = ev.tile_weighted(r[g]);
-                ls_hess_tile3(ev, acc[g]);
-                __syncthreads();
-            }
+            __syncthreads();
+            r[g] = ev.tile_weighted(r[g]);
+            ls_hess_tile3(ev, acc[g]);
+            __syncthreads();
         }
-        if (AUG) __syncthreads();  // every wave is done with the tile before the next one is staged over it
     }
 #pragma unroll
     for (int g = 0; g < LS_GROUP; ++g) {
         if (!live[g]) continue;
         const int k = kbase + g;
-        double tot = 0.0, vex = 0.0;
-        if (!AUG) {
-            tot = ev.cross_wave(r[g]);
-            vex = ev.block_sum(ex[g]);
-        }
+        const double tot = ev.cross_wave(r[g]);
+        const double vex = ev.block_sum(ex[g]);
         const double vlin = ev.block_sum(lin[g]);
         d4 full[10];
 #pragma unroll
         for (int i = 0; i < 10; ++i) full[i] = (d4){0, 0, 0, 0};
         full[0] = acc[g][0], full[1] = acc[g][1], full[2] = acc[g][2], full[4] = acc[g][3], full[5] = acc[g][4], full[7] = acc[g][5];
-        ev.hess_finish(full, yg[g]);  // the (augmented) Hessian sum of this chunk in ev.Al [16 DT][CORR_LD]
+        ev.hess_finish(full, yg[g]);  // the Hessian sum of this chunk in ev.Al [16 DT][CORR_LD]
         double* out = q.part + ((int64_t)k * q.S + s) * LS_REC;
         if (ev.tid == 0) {
             out[0] = vlin;
-            out[1] = AUG ? ev.Al[dim * CORR_LD + dim] : vex;
+            out[1] = vex;
         }
-        if (ev.wave == 0) out[2 + ev.lane] = AUG ? (ev.lane < dim ? ev.Al[ev.lane * CORR_LD + dim] : 0.0) : tot;
+        if (ev.wave == 0) out[2 + ev.lane] = tot;
         for (int i = ev.tid; i < dim * dim; i += SIGT) {
             const int m = i / dim, j = i - m * dim;
             out[66 + i] = ev.Al[m * CORR_LD + j];
+        }
+        __syncthreads();  // Al / the staging copies are rewritten for the next signature
+    }
+}
+
+// ---- dim <= 48, NOT a multiple of 16: the 16-padded tile has a free component column.
+// (i) The staged tile carries a column of ones at component `dim`, so the weighted Gram product that forms the Hessian,
+// sum_n w_n [U_n 1]^T [U_n 1],  also yields the gradient part  sum_n w_n U_n  (column dim) and  sum_n w_n  (entry [dim][dim])
+// on the MFMAs that run anyway: every wave works on ITS 64 samples of a tile from the logits to the Hessian with no
+// workgroup barrier in between, no per-signature pass over the tile for the gradient, no cross-wave sum of it (the two sums
+// come out in the MFMA's order: rounding level, the same on every rank of a sharded solve).
+// (ii) The last block column is PACKED over the group's signatures.  Of the padded triangle's tiles, those of the last
+// block column carry only w = dim + 1 - 16 (DT - 1) live columns (c5: dim 40 -> 9 of 16): 1.87x the algorithmic MACs.  The
+// A operand of a tile (U^T, unweighted) is the same for every signature; only B = diag(weights_g) U differs.  So the
+// LS_GROUP x w live columns of that block column are laid side by side -- packed column P = g w + c of tile P / 16 is
+// weights_g[n] U[n][16 (DT - 1) + c]  -- and multiplied by the DT row tiles ONCE for the whole group: DT ceil(LS_GROUP w / 16)
+// MFMAs per four samples instead of LS_GROUP DT (c5: 9 instead of 15; 24 with the 15 dense ones instead of 30).  An entry
+// of a product does not depend on its column's neighbours: the bits are those of one product per signature.
+// (iii) PF: the next tile of U is on its way to registers while this tile's products run.  FIX: the common tile counts as
+// compile-time constants.  582 -> 458 us per round at c5 for (ii) + (iii) (profiles/r04/lockstep_packed.md).
+//   wt5 [SIGT][6]: the tile's weights, sample-major (slot 5 = 0: the operand of packed columns beyond LS_GROUP w)
+template <int PKMAX, int PF, bool AG, bool FIX>
+__global__ void __launch_bounds__(SIGT) ls_eval_packed_kernel(LockstepParams q) {
+    const int kbase = blockIdx.y * LS_GROUP, s = blockIdx.x;
+    bool live[LS_GROUP], any = false;
+#pragma unroll
+    for (int g = 0; g < LS_GROUP; ++g) {
+        live[g] = kbase + g < q.sig.K && q.state[kbase + g] == LS_NEED;  // uniform over the workgroup
+        any |= live[g];
+    }
+    if (!any) return;
+    __shared__ double pool[SIG_POOL];
+    __shared__ double wt5[SIGT * 6], sred[SIGT], ybuf0[64], red[4 * 64];
+    SignatureEmbeddingEval ev;
+    ls_setup_eval(ev, q, pool, wt5, sred, ybuf0, red, kbase, s);
+    const int dim = q.sig.dim, DT = ev.DT, ldu = ev.ldu;
+    const int c16 = ev.lane & 15, qq = ev.lane >> 4;
+    const int tail0 = 16 * (DT - 1), w = dim + 1 - tail0;  // the last block column: first component, live columns
+    const int NPK = (LS_GROUP * w + 15) / 16;               // packed tiles (<= PKMAX: the launcher's choice)
+    // this lane's column of packed tile p: signature slot pg (5 = none), component column pc
+    int pg[PKMAX], pc[PKMAX];
+#pragma unroll
+    for (int p = 0; p < PKMAX; ++p) {
+        const int P = 16 * p + c16;
+        pg[p] = P / w < LS_GROUP ? P / w : LS_GROUP;
+        pc[p] = tail0 + (P / w < LS_GROUP ? P % w : 0);
+    }
+    double cg[LS_GROUP], yg[LS_GROUP];
+#pragma unroll
+    for (int g = 0; g < LS_GROUP; ++g) {
+        const int k = live[g] ? kbase + g : kbase;
+        cg[g] = q.sig.beta[k];
+        yg[g] = (live[g] && ev.lane < dim) ? q.req[k * 64 + ev.lane] : 0.0;
+    }
+    for (int i = ev.tid; i < SIGT * 6; i += SIGT) wt5[i] = 0.0;  // (signatures that asked for nothing keep weight 0)
+    double lin[LS_GROUP];
+    d4 dense[LS_GROUP][3], packed[3][PKMAX];
+#pragma unroll
+    for (int g = 0; g < LS_GROUP; ++g) {
+        lin[g] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) dense[g][i] = (d4){0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int p = 0; p < PKMAX; ++p) packed[i][p] = (d4){0, 0, 0, 0};
+    // PF: the NEXT tile of U travels from global memory to registers (element tid + 256 u of the tile's SIGT x dim block)
+    // while this tile's products run, and to LDS behind them -- with one wave per SIMD nothing else hides that latency
+    double pf[PF > 0 ? PF : 1];
+    const int64_t u_end = q.sig.N * (int64_t)dim;
+    auto pf_load = [&](int64_t t0) {
+        const int64_t base = t0 * dim;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {  // (unconditional loads at clamped addresses: no branch around any of them)
+            const int64_t i = base + ev.tid + (int64_t)u * SIGT;
+            pf[u] = q.sig.U[i < u_end ? i : u_end - 1];  // (rows beyond N are zeroed when the value is used: pf_store)
+        }
+    };
+    auto pf_store = [&](int64_t t0) {
+        int j = ev.tid / dim, m = ev.tid - j * dim;
+        const int dj = SIGT / dim, dm = SIGT - dj * dim;
+#pragma unroll
+        for (int u = 0; u < PF; ++u)
+            if (u < dim) {
+                ev.Ut[j * ldu + m] = t0 * dim + ev.tid + (int64_t)u * SIGT < u_end ? pf[u] : 0.0;
+                j += dj, m += dm;
+                if (m >= dim) m -= dim, ++j;
+            }
+        // (elements PF .. dim - 1 of this lane, if any: loaded here, eight at a time)
+        const int64_t base = t0 * dim;
+        for (int u0 = PF; u0 < dim; u0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t i = base + ev.tid + (int64_t)(u0 + u) * SIGT;
+                v[u] = q.sig.U[i < u_end ? i : u_end - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (u0 + u < dim) {
+                    ev.Ut[j * ldu + m] = base + ev.tid + (int64_t)(u0 + u) * SIGT < u_end ? v[u] : 0.0;
+                    j += dj, m += dm;
+                    if (m >= dim) m -= dim, ++j;
+                }
+        }
+        const int dpad = 16 * DT - dim;  // (component columns up to the next multiple of 16 stay zero: ev.stage)
+        for (int i = ev.tid; i < SIGT * dpad; i += SIGT) {
+            const int jj = i / dpad;
+            ev.Ut[jj * ldu + dim + (i - jj * dpad)] = 0.0;
+        }
+        __syncthreads();
+    };
+    // the per-sample scalars of the next tile likewise (issued BEFORE the tile's elements: loads return in order, and these
+    // are needed first)
+    double al_n = 0.0, aux_n[LS_GROUP];
+    auto scalars_load = [&](int64_t t0) {
+        const int64_t n = t0 + ev.tid;
+        const bool in = n < ev.n_end;
+        const int64_t nc = in ? n : ev.n_end - 1;
+        al_n = q.sig.alpha[nc];  // (samples beyond the chunk: their values are not used -- `in` below)
+#pragma unroll
+        for (int g = 0; g < LS_GROUP; ++g) aux_n[g] = q.sig.aux[nc * q.sig.KP + (kbase + g < q.sig.K ? kbase + g : kbase)];
+    };
+    scalars_load(ev.n_begin);
+    if (PF > 0) pf_load(ev.n_begin);
+    for (int64_t t0 = ev.n_begin; t0 < ev.n_end; t0 += SIGT) {
+        if (PF > 0) pf_store(t0);
+        else ev.stage(t0);  // (ends with a workgroup barrier; rows 64 wave .. 64 wave + 63 are this wave's samples)
+        const int64_t n = t0 + ev.tid;
+        const bool in = n < ev.n_end;
+        const double al = al_n;
+        double auxv[LS_GROUP];
+#pragma unroll
+        for (int g = 0; g < LS_GROUP; ++g) auxv[g] = aux_n[g];
+        if (t0 + SIGT < ev.n_end) {
+            scalars_load(t0 + SIGT);
+            if (PF > 0) pf_load(t0 + SIGT);
+        }
+        double* myrow = ev.Ut + ev.tid * ldu;
+        myrow[dim] = 1.0;
+        // <U_n, y_g> for the group's signatures in one sweep over the row (per signature row_dot's FMA chain; the points'
+        // components by v_readlane -- as LDS broadcasts they were slower: 476 against 458 us per round at c5)
+        double sd[LS_GROUP];
+#pragma unroll
+        for (int g = 0; g < LS_GROUP; ++g) sd[g] = 0.0;
+        int m = 0;
+        for (; m + 4 <= dim; m += 4) {
+            double x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[u] = myrow[m + u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int g = 0; g < LS_GROUP; ++g) sd[g] = __builtin_fma(x[u], ls_lane_value(yg[g], m + u), sd[g]);
+        }
+        for (; m < dim; ++m) {
+            const double x = myrow[m];
+#pragma unroll
+            for (int g = 0; g < LS_GROUP; ++g) sd[g] = __builtin_fma(x, ls_lane_value(yg[g], m), sd[g]);
+        }
+#pragma unroll
+        for (int g = 0; g < LS_GROUP; ++g) {
+            if (!live[g]) continue;  // uniform
+            double wgt = 0.0;
+            if (in) {
+                lin[g] = __builtin_fma(sd[g], auxv[g], lin[g]);
+                wgt = exp((cg[g] + al) + sd[g]);
+            }
+            wt5[ev.tid * 6 + g] = wgt;
+        }
+        __builtin_amdgcn_wave_barrier();  // (LDS operations of one wave execute in order: its own 64 rows and weights)
+        // the wave's 64 samples, four per step: operands one step ahead of the MFMAs that use them
+        const double* ub = ev.Ut + (64 * ev.wave + qq) * ldu;
+        const double* wb = wt5 + (64 * ev.wave + qq) * 6;
+        // (FIX: the tile counts of the common shape -- three row tiles, three packed tiles -- as compile-time constants; as
+        // runtime values every MFMA sits behind a scalar branch of its own)
+        const int dt = FIX ? 3 : DT, npk = FIX ? 3 : NPK;
+        // the dense leading tiles, signature by signature (one branch per signature and tile, not per step)
+        if (dt > 1) {
+#pragma unroll
+            for (int g = 0; g < LS_GROUP; ++g) {
+                if (!live[g]) continue;
+                double a[2][2], wv[2];
+                auto fetch = [&](int buf, int sgrp) {
+                    const double* ur = ub + 4 * sgrp * ldu;
+                    a[buf][0] = ur[c16];
+                    a[buf][1] = dt > 2 ? ur[16 + c16] : 0.0;
+                    wv[buf] = wb[4 * sgrp * 6 + g];
+                };
+                fetch(0, 0);
+#pragma unroll
+                for (int sgrp = 0; sgrp < 16; ++sgrp) {
+                    const int cur = sgrp & 1;
+                    if (sgrp + 1 < 16) fetch(cur ^ 1, sgrp + 1);
+                    const double b0 = wv[cur] * a[cur][0];
+                    if (AG) mfma_agpr(dense[g][0], a[cur][0], b0); else dense[g][0] = mfma(a[cur][0], b0, dense[g][0]);
+                    if (dt > 2) {
+                        const double b1 = wv[cur] * a[cur][1];
+                        if (AG) mfma_agpr(dense[g][1], a[cur][0], b1); else dense[g][1] = mfma(a[cur][0], b1, dense[g][1]);
+                        if (AG) mfma_agpr(dense[g][2], a[cur][1], b1); else dense[g][2] = mfma(a[cur][1], b1, dense[g][2]);
+                    }
+                }
+            }
+        }
+        // the packed last block column, once for the group
+        {
+            double a[2][3], pu[2][PKMAX], pw[2][PKMAX];
+            auto fetch = [&](int buf, int sgrp) {
+                const double* ur = ub + 4 * sgrp * ldu;
+                const double* wr = wb + 4 * sgrp * 6;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) a[buf][t] = t < dt ? ur[16 * t + c16] : 0.0;
+#pragma unroll
+                for (int p = 0; p < PKMAX; ++p)
+                    if (p < npk) {
+                        pu[buf][p] = ur[pc[p]];
+                        pw[buf][p] = wr[pg[p]];
+                    }
+            };
+            fetch(0, 0);
+#pragma unroll
+            for (int sgrp = 0; sgrp < 16; ++sgrp) {
+                const int cur = sgrp & 1;
+                if (sgrp + 1 < 16) fetch(cur ^ 1, sgrp + 1);
+#pragma unroll
+                for (int p = 0; p < PKMAX; ++p)
+                    if (p < npk) {
+                        const double bp = pw[cur][p] * pu[cur][p];
+#pragma unroll
+                        for (int t = 0; t < 3; ++t)
+                            if (t < dt) { if (AG) mfma_agpr(packed[t][p], a[cur][t], bp); else packed[t][p] = mfma(a[cur][t], bp, packed[t][p]); }
+                    }
+            }
+        }
+        __syncthreads();  // every wave is done with the tile before the next one is staged over it
+    }
+#pragma unroll
+    for (int g = 0; g < LS_GROUP; ++g) {
+        if (!live[g]) continue;
+        const int k = kbase + g;
+        const double vlin = ev.block_sum(lin[g]);
+        // this signature's (augmented) Hessian sum: the waves' parts to their staging copies, then the fixed-order sum
+        double* mine = ev.Ut + ev.wave * (16 * DT) * CORR_LD;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = qq + 4 * r;
+            if (DT > 1) mine[row * CORR_LD + c16] = dense[g][0][r];
+            if (DT > 2) {
+                mine[row * CORR_LD + 16 + c16] = dense[g][1][r];
+                mine[(16 + c16) * CORR_LD + row] = dense[g][1][r];
+                mine[(16 + row) * CORR_LD + 16 + c16] = dense[g][2][r];
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < PKMAX; ++p)
+            if (p < NPK && pg[p] == g) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+                    if (t < DT) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = 16 * t + qq + 4 * r;
+                            mine[row * CORR_LD + pc[p]] = packed[t][p][r];
+                            if (t < DT - 1) mine[pc[p] * CORR_LD + row] = packed[t][p][r];  // lower triangle = mirror
+                        }
+                    }
+            }
+        __syncthreads();
+        const int nA = 16 * DT * CORR_LD;
+        for (int i = ev.tid; i < nA; i += SIGT) ev.Al[i] = ((ev.Ut[i] + ev.Ut[nA + i]) + ev.Ut[2 * nA + i]) + ev.Ut[3 * nA + i];
+        __syncthreads();
+        double* out = q.part + ((int64_t)k * q.S + s) * LS_REC;
+        if (ev.tid == 0) {
+            out[0] = vlin;
+            out[1] = ev.Al[dim * CORR_LD + dim];
+        }
+        if (ev.wave == 0) out[2 + ev.lane] = ev.lane < dim ? ev.Al[ev.lane * CORR_LD + dim] : 0.0;
+        for (int i = ev.tid; i < dim * dim; i += SIGT) {
+            const int mm = i / dim, j = i - mm * dim;
+            out[66 + i] = ev.Al[mm * CORR_LD + j];
         }
         __syncthreads();  // Al / the staging copies are rewritten for the next signature
     }

@@ -563,7 +563,14 @@ def test_embedding_solves_terminate_on_non_finite_input():
     assert np.isfinite(got[clean]).all()
 
 
-@pytest.mark.parametrize("N,K,dim", [(20000, 12, 8), (33000, 40, 40), (17000, 3, 2), (16500, 64, 64)])
+@pytest.mark.parametrize(
+    "N,K,dim",
+    [(20000, 12, 8), (33000, 40, 40), (17000, 3, 2), (16500, 64, 64),
+     # every shape class of the grouped evaluation kernels (salnmf_corr_lockstep.h): row tiles 1 / 2 / 3, packed tiles 1 .. 5,
+     # dim a multiple of 16 (the unpacked form), groups that are not full
+     (17000, 7, 20), (17000, 11, 30), (16500, 6, 45), (16500, 9, 36), (17000, 13, 33), (17000, 4, 15), (17000, 5, 16), (16500, 6, 32),
+     (16500, 7, 48), (17000, 8, 37)],
+)
 def test_lockstep_signature_solves_agree_with_the_single_kernel_form(N, K, dim):
     """From 16 384 samples on the signature solves advance in lockstep rounds (evaluation over chunks x signatures, the
     solvers replayed from their logs).  Same problems, same solver, the sums of an evaluation in a different order:
