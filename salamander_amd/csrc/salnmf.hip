@@ -2605,7 +2605,7 @@ static int lockstep_signature_solves(salnmf_engine* e, const double* U, const do
     const int64_t chunk = ((n_rows + S - 1) / S + SIGT - 1) / SIGT * SIGT;
     // one allocation: [x0 | req | sg] (K x 64 each), part (K S REC), red (K REC), log_y, log_g (K EVAL 64), log_f (K EVAL), log_H (K EVAL dim^2)
     const size_t nd = (size_t)3 * K * 64 + (size_t)K * S * LS_REC + (size_t)K * LS_REC + (size_t)2 * K * LS_EVAL_MAX * 64 +
-                      (size_t)K * LS_EVAL_MAX + (size_t)K * LS_EVAL_MAX * dim * dim;
+                      (size_t)K * LS_EVAL_MAX + (size_t)K * LS_EVAL_MAX * dim * dim + (size_t)K * LS_CP;
     if (e->ls_doubles < nd || e->ls_S != S || e->ls_dim != dim) {
         if (e->ls_buf) HIPCK(hipFree(e->ls_buf));
         e->ls_buf = nullptr;
@@ -2641,7 +2641,8 @@ static int lockstep_signature_solves(salnmf_engine* e, const double* U, const do
     q.log_y = b; b += (size_t)K * LS_EVAL_MAX * 64;
     q.log_g = b; b += (size_t)K * LS_EVAL_MAX * 64;
     q.log_f = b; b += (size_t)K * LS_EVAL_MAX;
-    q.log_H = b;
+    q.log_H = b; b += (size_t)K * LS_EVAL_MAX * dim * dim;
+    q.cp = b;
     q.state = e->ls_int;
     q.n_evals = e->ls_int + 64;
     q.sig.status = e->ls_int + 128;

@@ -17,7 +17,8 @@
 //                      asks for a point that is not in the log: that is the next request.  No solver state has to be
 //                      saved and ncg::minimize is used unchanged -- the same code that solves the sample embeddings.
 //                      A replay costs the CG iterations again (Hessian-vector products from the logged Hessians, no
-//                      pass over samples): tens of microseconds against a pass of hundreds.
+//                      pass over samples); it resumes at the top of the last Newton iteration the previous rounds
+//                      reached (ncg::Checkpoint), so only that iteration's CG solve and trial points are replayed.
 //
 // The host loops rounds until no signature asks for another evaluation (one 4-byte read-back per round).  Results:
 // objective, gradient and Hessian are the same sums in a different order (chunks), so iterates agree with the
@@ -30,6 +31,7 @@ namespace salnmf {
 constexpr int LS_EVAL_MAX = 192;                    // evaluations per solve kept in the log; beyond: single-kernel fallback
 constexpr int LS_REC = 2 + 64 + 64 * 64;            // doubles per evaluation record: [lin, ex | r (64) | Hessian (dim x dim, compact)]
 constexpr int LS_NEED = 0, LS_DONE = 1, LS_FALLBACK = SIG_ONLY_VALUE;
+constexpr int LS_CP = 2 * 64 + 8;                   // doubles per checkpoint: xk, g_next (64 each) | 3 scalars | k, flags, cursor, valid
 
 struct LockstepParams {
     SignatureEmbeddingParams sig;  // aux, alpha, beta, U, L (in / out), status, variance, N, K, KP, dim, maxiter
@@ -47,6 +49,7 @@ struct LockstepParams {
     double* log_f;                 // [K][LS_EVAL_MAX]
     double* log_g;                 // [K][LS_EVAL_MAX][64]
     double* log_H;                 // [K][LS_EVAL_MAX][dim * dim]
+    double* cp;                    // [K][LS_CP]: the solve's state at the top of the last Newton iteration it reached (ncg::Checkpoint)
 };
 
 __device__ inline void ls_setup_eval(SignatureEmbeddingEval& ev, const LockstepParams& q, double* pool, double* wt, double* sred, double* ybuf,
@@ -709,9 +712,11 @@ struct ReplayEval {
     __device__ inline int lookup(double y) {
         if (cursor < n && is(cursor, y)) return cursor++;
         if (cursor > 0 && is(cursor - 1, y)) return cursor - 1;  // the point just evaluated, asked for again (fun, then grad)
-        for (int i = n - 1; i >= 0; --i)
-            if (is(i, y)) return i;
-        return -1;
+        // anywhere else in the record (the last match): no early exit, so that the loads of the scan are independent of one
+        // another -- with one it is a chain of n memory round trips, paid in full whenever the point is new
+        int found = -1;
+        for (int i = 0; i < n; ++i) found = is(i, y) ? i : found;
+        return found;
     }
     __device__ inline int find_or_ask(double y) {
         if (pending) return -1;
@@ -749,10 +754,12 @@ struct ReplayEval {
         if (!have_H) return 0.0;
         double r = 0.0;
         const double* row = Hl + (lane < dim ? lane : 0) * CORR_LD;
-        for (int j = 0; j < dim; ++j) r = __builtin_fma(row[j], __shfl(v, j, 64), r);
+        for (int j = 0; j < dim; ++j) r = __builtin_fma(row[j], ls_lane_value(v, j), r);  // (v_readlane: j is wave-uniform)
         return lane < dim ? r + v / variance : 0.0;
     }
     __device__ inline bool exhausted() const { return pending; }
+    __device__ inline int tag() const { return cursor; }
+    __device__ inline void set_tag(int t) { cursor = t; }
 };
 
 // one wavefront per signature: log the evaluation that has just been reduced, replay the solve, ask or finish
@@ -799,8 +806,28 @@ __global__ void __launch_bounds__(64) ls_advance_kernel(LockstepParams q) {
     ev.Hl = Hl;
     ev.have_H = false;
     double x = q.x0[k * 64 + lane];
-    const int st = ncg::minimize(ev, x, dim, q.sig.maxiter);
+    // resume at the top of the last Newton iteration the previous rounds reached (its CG solve and the line search's
+    // earlier trial points are replayed from the record; the iterations before it are not: a round's advance used to cost
+    // all of them again, 60 us per round at c5)
+    double* cpm = q.cp + (int64_t)k * LS_CP;
+    ncg::Checkpoint cp;
+    cp.valid = i > 0 && cpm[128 + 7] != 0.0;
+    if (cp.valid) {
+        cp.xk = cpm[lane], cp.g_next = cpm[64 + lane];
+        cp.old_fval = cpm[128], cp.old_old_fval = cpm[129], cp.update_l1norm = cpm[130];
+        cp.k = (int)cpm[131], cp.have_old_old = (int)cpm[132], cp.have_g_next = (int)cpm[133], cp.tag = (int)cpm[134];
+    }
+    const int st = ncg::minimize(ev, x, dim, q.sig.maxiter, nullptr, &cp);
     if (ev.pending) {
+        if (cp.valid) {
+            cpm[lane] = cp.xk, cpm[64 + lane] = cp.g_next;
+            if (lane == 0) {
+                cpm[128] = cp.old_fval, cpm[129] = cp.old_old_fval, cpm[130] = cp.update_l1norm;
+                cpm[131] = cp.k, cpm[132] = cp.have_old_old, cpm[133] = cp.have_g_next, cpm[134] = cp.tag, cpm[135] = 1.0;
+            }
+        } else if (lane == 0) {
+            cpm[135] = 0.0;
+        }
         q.req[k * 64 + lane] = lane < dim ? ev.req : 0.0;
         if (lane == 0) {
             q.n_evals[k] = i + 1;

@@ -304,9 +304,24 @@ __device__ inline bool search_wolfe2(E& ev, double xk, double pk, double phi0, b
     return true;
 }
 
+// The state of a solve at the top of a Newton iteration: everything the loop carries.  A caller that runs minimize again
+// and again on a growing record of evaluations (the lockstep signature solves) passes one, and the solve resumes at the
+// last iteration it had reached instead of at the start point -- the same arithmetic from there on.
+struct NoCheckpoint {
+    static constexpr bool enabled = false;
+};
+struct Checkpoint {
+    static constexpr bool enabled = true;
+    double xk, g_next;  // per lane
+    double old_fval, old_old_fval, update_l1norm;
+    int k, have_old_old, have_g_next;
+    int tag;            // the evaluator's own position (E::tag / E::set_tag), e.g. a cursor into its record
+    bool valid;
+};
+
 // ---- truncated Newton iteration.  x: per-lane component of the start, overwritten by the result.
-template <class E>
-__device__ inline int minimize(E& ev, double& x, int dim, int maxiter, int* n_iter = nullptr) {
+template <class E, class CP = NoCheckpoint>
+__device__ inline int minimize(E& ev, double& x, int dim, int maxiter, int* n_iter = nullptr, CP* cp = nullptr) {
     const double xtol = dim * 1e-5;
     const int cg_maxiter = 20 * dim;
     constexpr double float64eps = DBL_EPSILON;
@@ -318,9 +333,22 @@ __device__ inline int minimize(E& ev, double& x, int dim, int maxiter, int* n_it
     int status = OK;
     double g_next;  // gradient at xk when an evaluation at that very point already produced it
     bool have_g_next = true;
-    ev.fun_grad(xk, old_fval, g_next);
+    bool resumed = false;
+    if constexpr (CP::enabled) {
+        if (cp->valid) {
+            xk = cp->xk, g_next = cp->g_next, old_fval = cp->old_fval, old_old_fval = cp->old_old_fval, update_l1norm = cp->update_l1norm;
+            k = cp->k, have_old_old = cp->have_old_old != 0, have_g_next = cp->have_g_next != 0;
+            ev.set_tag(cp->tag);
+            resumed = true;
+        }
+    }
+    if (!resumed) ev.fun_grad(xk, old_fval, g_next);
     while (update_l1norm > xtol) {
         if (k >= maxiter || ev.exhausted()) { status = MAXITER; break; }
+        if constexpr (CP::enabled) {  // (not exhausted: every value below is the solve's own)
+            cp->xk = xk, cp->g_next = g_next, cp->old_fval = old_fval, cp->old_old_fval = old_old_fval, cp->update_l1norm = update_l1norm;
+            cp->k = k, cp->have_old_old = have_old_old, cp->have_g_next = have_g_next, cp->tag = ev.tag(), cp->valid = true;
+        }
         // search direction: CG on  H p = -g  from p = 0, stopped by the forcing term or by curvature
         const double gfk = have_g_next ? g_next : ev.grad(xk);
         const double b = -gfk;
