@@ -50,6 +50,9 @@ struct LockstepParams {
     double* log_g;                 // [K][LS_EVAL_MAX][64]
     double* log_H;                 // [K][LS_EVAL_MAX][dim * dim]
     double* cp;                    // [K][LS_CP]: the solve's state at the top of the last Newton iteration it reached (ncg::Checkpoint)
+    int lin_from_sg;               // the evaluation kernel leaves the linear term sum_n aux[n][k] <U_n, y> to ls_advance_kernel, which forms
+                                   // it as <y, sg_k> (sg = aux^T U is the solve's constant anyway): no aux traffic in the rounds
+    long long* prof;               // development builds (SALNMF_DEV_PROFILE): [8] shader-clock ticks per section of ls_eval_packed_kernel, or null
 };
 
 __device__ inline void ls_setup_eval(SignatureEmbeddingEval& ev, const LockstepParams& q, double* pool, double* wt, double* sred, double* ybuf,
@@ -433,19 +436,35 @@ __global__ void __launch_bounds__(SIGT) ls_eval_packed_kernel(LockstepParams q) 
         pg[p] = P / w < LS_GROUP ? P / w : LS_GROUP;
         pc[p] = tail0 + (P / w < LS_GROUP ? P % w : 0);
     }
-    double cg[LS_GROUP], yg[LS_GROUP];
+    // The logits <U_n, y_g> of a tile as MFMA products too:  D[signature slot][sample] = Y . U^T  with A = Y (row i = slot
+    // i < LS_GROUP, else 0; k = component) held in registers for the whole launch and B = U^T read from the staged tile.
+    // Lane (q, c16) of the result holds, per 16-sample tile, slot q (register 0) and -- lanes q = 0 only -- slot 4
+    // (register 1) of sample c16.  (As chains of FMAs with the points' components by v_readlane this phase took 11.6 k of
+    // a tile's 48 k cycles: a readlane's scalar result stalls the FMA that consumes it.)
+    static_assert(LS_GROUP == 5, "slot layout of the logits product");
+    constexpr int KSMAX = FIX ? 10 : 12;  // dim <= 48 (FIX: <= 40)
+    const int KSn = (dim + 3) / 4;
+    int livemask = 0;
 #pragma unroll
-    for (int g = 0; g < LS_GROUP; ++g) {
-        const int k = live[g] ? kbase + g : kbase;
-        cg[g] = q.sig.beta[k];
-        yg[g] = (live[g] && ev.lane < dim) ? q.req[k * 64 + ev.lane] : 0.0;
+    for (int g = 0; g < LS_GROUP; ++g) livemask |= live[g] ? 1 << g : 0;
+    // (Y in LDS, [component][slot | 0]: as registers its ten k-steps were what pushed the kernel into scratch)
+    __shared__ double ysh[48 * 6];
+    for (int i = ev.tid; i < 48 * 6; i += SIGT) {
+        const int comp = i / 6, slot = i - comp * 6;
+        const bool mine = slot < LS_GROUP && ((livemask >> slot) & 1) && comp < dim;
+        const int krow = mine ? kbase + slot : kbase;
+        const double v = q.req[krow * 64 + comp];  // (unconditional load at a valid address, masked afterwards)
+        ysh[i] = mine ? v : 0.0;
     }
+    const double* yl = ysh + qq * 6 + (c16 < LS_GROUP ? c16 : LS_GROUP);  // this lane's A operand of k-step ks: yl[24 ks]
+    const bool live_lo = (livemask >> qq) & 1;  // this lane's slot q
+    const bool live_hi = live[4] && qq == 0;
+    const int slot_lo = kbase + qq < q.sig.K ? kbase + qq : kbase, slot_hi = kbase + 4 < q.sig.K ? kbase + 4 : kbase;
+    const double cg_lo = q.sig.beta[slot_lo], cg_hi = q.sig.beta[slot_hi];
     for (int i = ev.tid; i < SIGT * 6; i += SIGT) wt5[i] = 0.0;  // (signatures that asked for nothing keep weight 0)
-    double lin[LS_GROUP];
     d4 dense[LS_GROUP][3], packed[3][PKMAX];
 #pragma unroll
     for (int g = 0; g < LS_GROUP; ++g) {
-        lin[g] = 0.0;
 #pragma unroll
         for (int i = 0; i < 3; ++i) dense[g][i] = (d4){0, 0, 0, 0};
     }
@@ -453,30 +472,49 @@ __global__ void __launch_bounds__(SIGT) ls_eval_packed_kernel(LockstepParams q) 
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int p = 0; p < PKMAX; ++p) packed[i][p] = (d4){0, 0, 0, 0};
+#ifdef SALNMF_DEV_PROFILE
+    long long tks[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tk0 = __builtin_amdgcn_s_memtime(), tk1;
+#define LS_TICK(i) do { tk1 = __builtin_amdgcn_s_memtime(); tks[i] += tk1 - tk0; tk0 = tk1; } while (0)
+#else
+#define LS_TICK(i) do { } while (0)
+#endif
     // PF: the NEXT tile of U travels from global memory to registers (element tid + 256 u of the tile's SIGT x dim block)
     // while this tile's products run, and to LDS behind them -- with one wave per SIMD nothing else hides that latency
     double pf[PF > 0 ? PF : 1];
     const int64_t u_end = q.sig.N * (int64_t)dim;
+    // (a tile that lies inside the samples -- every one but possibly the last -- takes the plain forms: no clamp and no
+    // select per element; the LDS position of element u + 1 follows from that of element u by additions)
     auto pf_load = [&](int64_t t0) {
-        const int64_t base = t0 * dim;
+        const double* src = q.sig.U + t0 * dim + ev.tid;
+        if (t0 + SIGT <= q.sig.N) {  // uniform
 #pragma unroll
-        for (int u = 0; u < PF; ++u) {  // (unconditional loads at clamped addresses: no branch around any of them)
-            const int64_t i = base + ev.tid + (int64_t)u * SIGT;
-            pf[u] = q.sig.U[i < u_end ? i : u_end - 1];  // (rows beyond N are zeroed when the value is used: pf_store)
+            for (int u = 0; u < PF; ++u) pf[u] = src[u * SIGT];
+        } else {
+            const int64_t base = t0 * dim;
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {  // (unconditional loads at clamped addresses: no branch around any of them)
+                const int64_t i = base + ev.tid + (int64_t)u * SIGT;
+                pf[u] = q.sig.U[i < u_end ? i : u_end - 1];  // (rows beyond N are zeroed when the value is used: pf_store)
+            }
         }
     };
+    const int pf_j0 = ev.tid / dim, pf_m0 = ev.tid - pf_j0 * dim, pf_dj = SIGT / dim, pf_dm = SIGT - pf_dj * dim;
     auto pf_store = [&](int64_t t0) {
-        int j = ev.tid / dim, m = ev.tid - j * dim;
-        const int dj = SIGT / dim, dm = SIGT - dj * dim;
+        int m = pf_m0;
+        double* dst = ev.Ut + pf_j0 * ldu + pf_m0;
+        const int step = pf_dj * ldu + pf_dm, wrap = ldu - dim;  // to the next element; extra when it starts a new row
+        const bool inside = t0 + SIGT <= q.sig.N;               // uniform
+        const int64_t base = t0 * dim;
 #pragma unroll
         for (int u = 0; u < PF; ++u)
-            if (u < dim) {
-                ev.Ut[j * ldu + m] = t0 * dim + ev.tid + (int64_t)u * SIGT < u_end ? pf[u] : 0.0;
-                j += dj, m += dm;
-                if (m >= dim) m -= dim, ++j;
+            if ((FIX && u < 32) || u < dim) {  // (FIX: dim > 32 -- no branch around the first 32)
+                *dst = (inside || base + ev.tid + (int64_t)u * SIGT < u_end) ? pf[u] : 0.0;
+                m += pf_dm;
+                const bool over = m >= dim;
+                dst += step + (over ? wrap : 0);
+                m -= over ? dim : 0;
             }
         // (elements PF .. dim - 1 of this lane, if any: loaded here, eight at a time)
-        const int64_t base = t0 * dim;
         for (int u0 = PF; u0 < dim; u0 += 8) {
             double v[8];
 #pragma unroll
@@ -487,76 +525,74 @@ __global__ void __launch_bounds__(SIGT) ls_eval_packed_kernel(LockstepParams q) 
 #pragma unroll
             for (int u = 0; u < 8; ++u)
                 if (u0 + u < dim) {
-                    ev.Ut[j * ldu + m] = base + ev.tid + (int64_t)(u0 + u) * SIGT < u_end ? v[u] : 0.0;
-                    j += dj, m += dm;
-                    if (m >= dim) m -= dim, ++j;
+                    *dst = base + ev.tid + (int64_t)(u0 + u) * SIGT < u_end ? v[u] : 0.0;
+                    m += pf_dm;
+                    const bool over = m >= dim;
+                    dst += step + (over ? wrap : 0);
+                    m -= over ? dim : 0;
                 }
         }
-        const int dpad = 16 * DT - dim;  // (component columns up to the next multiple of 16 stay zero: ev.stage)
-        for (int i = ev.tid; i < SIGT * dpad; i += SIGT) {
-            const int jj = i / dpad;
-            ev.Ut[jj * ldu + dim + (i - jj * dpad)] = 0.0;
-        }
+        LS_TICK(8);
         __syncthreads();
     };
+    if (PF > 0) {
+        // the component columns dim .. 16 DT - 1 of the tile are written once: the column of ones (component dim), zeros
+        // behind it -- pf_store leaves them alone
+        const int dpad = 16 * DT - dim;
+        for (int i = ev.tid; i < SIGT * dpad; i += SIGT) {
+            const int jj = i / dpad, cc = i - jj * dpad;
+            ev.Ut[jj * ldu + dim + cc] = cc == 0 ? 1.0 : 0.0;
+        }
+    }
     // the per-sample scalars of the next tile likewise (issued BEFORE the tile's elements: loads return in order, and these
     // are needed first)
-    double al_n = 0.0, aux_n[LS_GROUP];
+    double al[4];  // sample scalings of samples 16 st + c16 of this wave's 64, st = 0 .. 3: requested at the top of a tile
+                   // (ahead of the next tile's elements: loads return in order), used behind the logits
     auto scalars_load = [&](int64_t t0) {
-        const int64_t n = t0 + ev.tid;
-        const bool in = n < ev.n_end;
-        const int64_t nc = in ? n : ev.n_end - 1;
-        al_n = q.sig.alpha[nc];  // (samples beyond the chunk: their values are not used -- `in` below)
 #pragma unroll
-        for (int g = 0; g < LS_GROUP; ++g) aux_n[g] = q.sig.aux[nc * q.sig.KP + (kbase + g < q.sig.K ? kbase + g : kbase)];
+        for (int st = 0; st < 4; ++st) {
+            const int64_t n = t0 + 64 * ev.wave + 16 * st + c16;
+            al[st] = q.sig.alpha[n < ev.n_end ? n : ev.n_end - 1];  // (samples beyond the chunk: values not used)
+        }
     };
-    scalars_load(ev.n_begin);
     if (PF > 0) pf_load(ev.n_begin);
     for (int64_t t0 = ev.n_begin; t0 < ev.n_end; t0 += SIGT) {
         if (PF > 0) pf_store(t0);
         else ev.stage(t0);  // (ends with a workgroup barrier; rows 64 wave .. 64 wave + 63 are this wave's samples)
-        const int64_t n = t0 + ev.tid;
-        const bool in = n < ev.n_end;
-        const double al = al_n;
-        double auxv[LS_GROUP];
-#pragma unroll
-        for (int g = 0; g < LS_GROUP; ++g) auxv[g] = aux_n[g];
-        if (t0 + SIGT < ev.n_end) {
-            scalars_load(t0 + SIGT);
-            if (PF > 0) pf_load(t0 + SIGT);
+        LS_TICK(0);
+        scalars_load(t0);
+        if (PF > 0 && t0 + SIGT < ev.n_end) pf_load(t0 + SIGT);
+        if (PF == 0) {
+            ev.Ut[ev.tid * ldu + dim] = 1.0;  // (the column of ones of this thread's row: ev.stage zeroed it)
+            __builtin_amdgcn_wave_barrier();
         }
-        double* myrow = ev.Ut + ev.tid * ldu;
-        myrow[dim] = 1.0;
-        // <U_n, y_g> for the group's signatures in one sweep over the row (per signature row_dot's FMA chain; the points'
-        // components by v_readlane -- as LDS broadcasts they were slower: 476 against 458 us per round at c5)
-        double sd[LS_GROUP];
+        LS_TICK(9);
+        // logits of the wave's 64 samples, 16 at a time (KSn k-steps each), and behind each product the weights
+        // exp(beta + alpha + logit) of (sample 16 st + c16, slot q) and, lanes q = 0, (sample, slot 4)
+        {
+            const double* ubase = ev.Ut + (64 * ev.wave + c16) * ldu + qq;
 #pragma unroll
-        for (int g = 0; g < LS_GROUP; ++g) sd[g] = 0.0;
-        int m = 0;
-        for (; m + 4 <= dim; m += 4) {
-            double x[4];
+            for (int st = 0; st < 4; ++st) {
+                d4 sl = (d4){0, 0, 0, 0};
 #pragma unroll
-            for (int u = 0; u < 4; ++u) x[u] = myrow[m + u];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int g = 0; g < LS_GROUP; ++g) sd[g] = __builtin_fma(x[u], ls_lane_value(yg[g], m + u), sd[g]);
-        }
-        for (; m < dim; ++m) {
-            const double x = myrow[m];
-#pragma unroll
-            for (int g = 0; g < LS_GROUP; ++g) sd[g] = __builtin_fma(x, ls_lane_value(yg[g], m), sd[g]);
-        }
-#pragma unroll
-        for (int g = 0; g < LS_GROUP; ++g) {
-            if (!live[g]) continue;  // uniform
-            double wgt = 0.0;
-            if (in) {
-                lin[g] = __builtin_fma(sd[g], auxv[g], lin[g]);
-                wgt = exp((cg[g] + al) + sd[g]);
+                for (int ks = 0; ks < KSMAX; ++ks)
+                    if (FIX ? (ks < 8 || ks < KSn) : ks < KSn) sl = mfma(yl[24 * ks], ubase[16 * st * ldu + 4 * ks], sl);  // (uniform; FIX: dim > 32)
+                const int64_t n = t0 + 64 * ev.wave + 16 * st + c16;
+                const bool in = n < ev.n_end;
+                double* wrow = wt5 + (64 * ev.wave + 16 * st + c16) * 6;
+                if (live_lo) {
+                    double wgt = 0.0;
+                    if (in) wgt = exp((cg_lo + al[st]) + sl[0]);
+                    wrow[qq] = wgt;
+                }
+                if (live_hi) {
+                    double wgt = 0.0;
+                    if (in) wgt = exp((cg_hi + al[st]) + sl[1]);
+                    wrow[4] = wgt;
+                }
             }
-            wt5[ev.tid * 6 + g] = wgt;
         }
+        LS_TICK(1);
         __builtin_amdgcn_wave_barrier();  // (LDS operations of one wave execute in order: its own 64 rows and weights)
         // the wave's 64 samples, four per step: operands one step ahead of the MFMAs that use them
         const double* ub = ev.Ut + (64 * ev.wave + qq) * ldu;
@@ -564,6 +600,7 @@ __global__ void __launch_bounds__(SIGT) ls_eval_packed_kernel(LockstepParams q) 
         // (FIX: the tile counts of the common shape -- three row tiles, three packed tiles -- as compile-time constants; as
         // runtime values every MFMA sits behind a scalar branch of its own)
         const int dt = FIX ? 3 : DT, npk = FIX ? 3 : NPK;
+        LS_TICK(2);
         // the dense leading tiles, signature by signature (one branch per signature and tile, not per step)
         if (dt > 1) {
 #pragma unroll
@@ -591,6 +628,7 @@ __global__ void __launch_bounds__(SIGT) ls_eval_packed_kernel(LockstepParams q) 
                 }
             }
         }
+        LS_TICK(3);
         // the packed last block column, once for the group
         {
             double a[2][3], pu[2][PKMAX], pw[2][PKMAX];
@@ -621,13 +659,14 @@ __global__ void __launch_bounds__(SIGT) ls_eval_packed_kernel(LockstepParams q) 
                     }
             }
         }
+        LS_TICK(4);
         __syncthreads();  // every wave is done with the tile before the next one is staged over it
+        LS_TICK(5);
     }
 #pragma unroll
     for (int g = 0; g < LS_GROUP; ++g) {
         if (!live[g]) continue;
         const int k = kbase + g;
-        const double vlin = ev.block_sum(lin[g]);
         // this signature's (augmented) Hessian sum: the waves' parts to their staging copies, then the fixed-order sum
         double* mine = ev.Ut + ev.wave * (16 * DT) * CORR_LD;
 #pragma unroll
@@ -660,7 +699,7 @@ __global__ void __launch_bounds__(SIGT) ls_eval_packed_kernel(LockstepParams q) 
         __syncthreads();
         double* out = q.part + ((int64_t)k * q.S + s) * LS_REC;
         if (ev.tid == 0) {
-            out[0] = vlin;
+            out[0] = 0.0;  // (the linear term: ls_advance_kernel, LockstepParams::lin_from_sg)
             out[1] = ev.Al[dim * CORR_LD + dim];
         }
         if (ev.wave == 0) out[2 + ev.lane] = ev.lane < dim ? ev.Al[ev.lane * CORR_LD + dim] : 0.0;
@@ -670,6 +709,15 @@ __global__ void __launch_bounds__(SIGT) ls_eval_packed_kernel(LockstepParams q) 
         }
         __syncthreads();  // Al / the staging copies are rewritten for the next signature
     }
+    LS_TICK(6);
+#ifdef SALNMF_DEV_PROFILE
+    if (q.prof != nullptr && ev.lane == 0) {
+        for (int i = 0; i < 7; ++i) atomicAdd(reinterpret_cast<unsigned long long*>(q.prof) + i, (unsigned long long)tks[i]);
+        for (int i = 8; i < 10; ++i) atomicAdd(reinterpret_cast<unsigned long long*>(q.prof) + i, (unsigned long long)tks[i]);
+        atomicAdd(reinterpret_cast<unsigned long long*>(q.prof) + 7, 1ull);
+    }
+#endif
+#undef LS_TICK
 }
 
 // red[k][e] = sum over the S chunk partials, fixed order; only the first `len` entries of a record are live
@@ -778,7 +826,9 @@ __global__ void __launch_bounds__(64) ls_advance_kernel(LockstepParams q) {
     const int i = q.n_evals[k];
     const double y = q.req[k * 64 + lane];
     {
-        double v = red[0];
+        // (the linear term sum_n aux[n][k] <U_n, y>: summed over the samples by the evaluation kernel, or -- the same number
+        // to rounding -- <y, sg_k> with the solve's constant sg = aux^T U)
+        double v = q.lin_from_sg ? ncg::wave_sum(y * q.sg[k * 64 + lane]) : red[0];
         v -= red[1];
         v -= ncg::wave_sum(y * y) / (2 * variance);
         double gg = -red[2 + lane];
