@@ -2601,10 +2601,13 @@ static int lockstep_signature_solves(salnmf_engine* e, const double* U, const do
     // workgroups and more chunks; otherwise one signature per workgroup
     const bool multi = dim <= 48;
     const int groups = multi ? (K + LS_GROUP - 1) / LS_GROUP : K;
-    const int S = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(multi ? 32 : 16, prop.multiProcessorCount / groups), max_chunks));
+    // chunks per signature (group): as many as it takes to fill the chip, within 64 MB of partial records
+    const int64_t s_cap = std::max<int64_t>(1, (int64_t)(64u << 20) / (int64_t)((size_t)LS_GROUP * groups * LS_REC * sizeof(double)));
+    const int S = (int)std::max<int64_t>(1, std::min<int64_t>({multi ? 128 : 16, prop.multiProcessorCount / groups, max_chunks, s_cap}));
     const int64_t chunk = ((n_rows + S - 1) / S + SIGT - 1) / SIGT * SIGT;
     // one allocation: [x0 | req | sg] (K x 64 each), part (K S REC), red (K REC), log_y, log_g (K EVAL 64), log_f (K EVAL), log_H (K EVAL dim^2)
-    const size_t nd = (size_t)3 * K * 64 + (size_t)K * S * LS_REC + (size_t)K * LS_REC + (size_t)2 * K * LS_EVAL_MAX * 64 +
+    const size_t n_part = (size_t)(multi ? LS_GROUP * groups : K) * S * LS_REC;  // (records by (group ordinal, slot, chunk) under the live-group map)
+    const size_t nd = (size_t)3 * K * 64 + n_part + (size_t)K * LS_REC + (size_t)2 * K * LS_EVAL_MAX * 64 +
                       (size_t)K * LS_EVAL_MAX + (size_t)K * LS_EVAL_MAX * dim * dim + (size_t)K * LS_CP;
     if (e->ls_doubles < nd || e->ls_S != S || e->ls_dim != dim) {
         if (e->ls_buf) HIPCK(hipFree(e->ls_buf));
@@ -2636,7 +2639,7 @@ static int lockstep_signature_solves(salnmf_engine* e, const double* U, const do
     q.x0 = b; b += (size_t)K * 64;
     q.req = b; b += (size_t)K * 64;
     q.sg = b; b += (size_t)K * 64;
-    q.part = b; b += (size_t)K * S * LS_REC;
+    q.part = b; b += n_part;
     q.red = b; b += (size_t)K * LS_REC;
     q.log_y = b; b += (size_t)K * LS_EVAL_MAX * 64;
     q.log_g = b; b += (size_t)K * LS_EVAL_MAX * 64;
@@ -2644,6 +2647,7 @@ static int lockstep_signature_solves(salnmf_engine* e, const double* U, const do
     q.log_H = b; b += (size_t)K * LS_EVAL_MAX * dim * dim;
     q.cp = b;
     q.lin_from_sg = multi && dim % 16 != 0;  // (ls_eval_packed_kernel)
+    q.dyn = q.lin_from_sg;
     q.prof = nullptr;
 #ifdef SALNMF_DEV_PROFILE
     static long long* ls_prof = nullptr;  // (development aid: one buffer per process, printed after every solve)
@@ -2690,7 +2694,8 @@ static int lockstep_signature_solves(salnmf_engine* e, const double* U, const do
             else hipLaunchKernelGGL((ls_eval_packed_kernel<5, 0, false, false>), grid, dim3(SIGT), 0, e->stream, q);
         } else if (multi) hipLaunchKernelGGL(ls_eval_multi_kernel, grid, dim3(SIGT), 0, e->stream, q);
         else hipLaunchKernelGGL(ls_eval_kernel, grid, dim3(SIGT), 0, e->stream, q);
-        hipLaunchKernelGGL(ls_reduce_kernel, dim3(K, (rec + 255) / 256), dim3(256), 0, e->stream, q.part, q.red, q.state, S, 0, rec, 0);
+        hipLaunchKernelGGL(ls_reduce_kernel, dim3(K, (rec + 255) / 256), dim3(256), 0, e->stream, q.part, q.red, q.state, S, 0, rec, 0, q.dyn ? S * groups : 0, K,
+                           (int64_t)n_rows);
         HIPCK(hipGetLastError());
         if (shard) CK(allreduce(e, q.red, (size_t)K * LS_REC));
         HIPCK(hipMemsetAsync(q.active, 0, sizeof(int), e->stream));

@@ -50,6 +50,8 @@ struct LockstepParams {
     double* log_g;                 // [K][LS_EVAL_MAX][64]
     double* log_H;                 // [K][LS_EVAL_MAX][dim * dim]
     double* cp;                    // [K][LS_CP]: the solve's state at the top of the last Newton iteration it reached (ncg::Checkpoint)
+    int dyn;                       // the workgroups of a round are shared out among the groups that still have a live signature
+                                   // (LsLive): more, shorter chunks per group as the solves finish (ls_eval_packed_kernel)
     int lin_from_sg;               // the evaluation kernel leaves the linear term sum_n aux[n][k] <U_n, y> to ls_advance_kernel, which forms
                                    // it as <y, sg_k> (sg = aux^T U is the solve's constant anyway): no aux traffic in the rounds
     long long* prof;               // development builds (SALNMF_DEV_PROFILE): [8] shader-clock ticks per section of ls_eval_packed_kernel, or null
@@ -394,6 +396,43 @@ __global__ void __launch_bounds__(SIGT) ls_eval_multi_kernel(LockstepParams q) {
     }
 }
 
+// The rounds' workgroups shared out among the groups of LS_GROUP signatures that still have a live one: with B workgroups
+// and ngl live groups every live group gets Sd = B / ngl chunks of cd samples (a multiple of SIGT).  Early rounds: every
+// group live, Sd = S, the static partition.  Late rounds: the few remaining groups use the whole chip instead of their
+// S workgroups (a round with two of eight groups live took 281 us of a full round's 485 at c5).  Evaluation and reduction
+// derive the same map from the signatures' states; the partial records are indexed (ordinal of the group, slot, chunk).
+struct LsLive {
+    int ngl, Sd, ord, nchunks;  // live groups; chunks per live group; ordinal of THIS group (-1: none live in it); chunks that hold samples
+    int64_t cd;                 // samples per chunk
+};
+__device__ inline LsLive ls_live_map(const int* __restrict__ state, int K, int B, int64_t N, int group) {
+    LsLive m;
+    m.ngl = 0;
+    m.ord = -1;
+    const int groups = (K + LS_GROUP - 1) / LS_GROUP;
+    for (int g = 0; g < groups; ++g) {
+        bool any = false;
+        for (int j = 0; j < LS_GROUP; ++j) any |= g * LS_GROUP + j < K && state[g * LS_GROUP + j] == LS_NEED;
+        if (g == group && any) m.ord = m.ngl;
+        m.ngl += any;
+    }
+    m.Sd = m.ngl > 0 ? B / m.ngl : 0;
+    m.cd = m.Sd > 0 ? ((N + m.Sd - 1) / m.Sd + SIGT - 1) / SIGT * SIGT : 0;
+    m.nchunks = m.cd > 0 ? (int)((N + m.cd - 1) / m.cd) : 0;
+    return m;
+}
+// group index of the live group with ordinal o
+__device__ inline int ls_live_group(const int* __restrict__ state, int K, int o) {
+    const int groups = (K + LS_GROUP - 1) / LS_GROUP;
+    int seen = 0;
+    for (int g = 0; g < groups; ++g) {
+        bool any = false;
+        for (int j = 0; j < LS_GROUP; ++j) any |= g * LS_GROUP + j < K && state[g * LS_GROUP + j] == LS_NEED;
+        if (any && seen++ == o) return g;
+    }
+    return 0;
+}
+
 // ---- dim <= 48, NOT a multiple of 16: the 16-padded tile has a free component column.
 // (i) The staged tile carries a column of ones at component `dim`, so the weighted Gram product that forms the Hessian,
 // sum_n w_n [U_n 1]^T [U_n 1],  also yields the gradient part  sum_n w_n U_n  (column dim) and  sum_n w_n  (entry [dim][dim])
@@ -412,7 +451,17 @@ __global__ void __launch_bounds__(SIGT) ls_eval_multi_kernel(LockstepParams q) {
 //   wt5 [SIGT][6]: the tile's weights, sample-major (slot 5 = 0: the operand of packed columns beyond LS_GROUP w)
 template <int PKMAX, int PF, bool AG, bool FIX>
 __global__ void __launch_bounds__(SIGT) ls_eval_packed_kernel(LockstepParams q) {
-    const int kbase = blockIdx.y * LS_GROUP, s = blockIdx.x;
+    int kbase = blockIdx.y * LS_GROUP, s = blockIdx.x;
+    LsLive lm{};
+    if (q.dyn) {  // (uniform) this workgroup's group and chunk from the map of live groups
+        const int B = gridDim.x * gridDim.y, b = blockIdx.y * gridDim.x + blockIdx.x;
+        lm = ls_live_map(q.state, q.sig.K, B, q.sig.N, -1);
+        if (lm.ngl == 0 || b >= lm.Sd * lm.ngl) return;
+        lm.ord = b / lm.Sd;
+        s = b - lm.ord * lm.Sd;
+        if (s >= lm.nchunks) return;
+        kbase = ls_live_group(q.state, q.sig.K, lm.ord) * LS_GROUP;
+    }
     bool live[LS_GROUP], any = false;
 #pragma unroll
     for (int g = 0; g < LS_GROUP; ++g) {
@@ -424,6 +473,10 @@ __global__ void __launch_bounds__(SIGT) ls_eval_packed_kernel(LockstepParams q) 
     __shared__ double wt5[SIGT * 6], sred[SIGT], ybuf0[64], red[4 * 64];
     SignatureEmbeddingEval ev;
     ls_setup_eval(ev, q, pool, wt5, sred, ybuf0, red, kbase, s);
+    if (q.dyn) {
+        ev.n_begin = (int64_t)s * lm.cd;
+        ev.n_end = ev.n_begin + lm.cd < q.sig.N ? ev.n_begin + lm.cd : q.sig.N;
+    }
     const int dim = q.sig.dim, DT = ev.DT, ldu = ev.ldu;
     const int c16 = ev.lane & 15, qq = ev.lane >> 4;
     const int tail0 = 16 * (DT - 1), w = dim + 1 - tail0;  // the last block column: first component, live columns
@@ -697,7 +750,7 @@ __global__ void __launch_bounds__(SIGT) ls_eval_packed_kernel(LockstepParams q) 
         const int nA = 16 * DT * CORR_LD;
         for (int i = ev.tid; i < nA; i += SIGT) ev.Al[i] = ((ev.Ut[i] + ev.Ut[nA + i]) + ev.Ut[2 * nA + i]) + ev.Ut[3 * nA + i];
         __syncthreads();
-        double* out = q.part + ((int64_t)k * q.S + s) * LS_REC;
+        double* out = q.part + (q.dyn ? ((int64_t)(lm.ord * LS_GROUP + g) * lm.Sd + s) : ((int64_t)k * q.S + s)) * LS_REC;
         if (ev.tid == 0) {
             out[0] = 0.0;  // (the linear term: ls_advance_kernel, LockstepParams::lin_from_sg)
             out[1] = ev.Al[dim * CORR_LD + dim];
@@ -721,8 +774,9 @@ __global__ void __launch_bounds__(SIGT) ls_eval_packed_kernel(LockstepParams q) 
 }
 
 // red[k][e] = sum over the S chunk partials, fixed order; only the first `len` entries of a record are live
+//   dynB > 0: the records were written under the live-group map of a round with dynB workgroups (LsLive)
 __global__ void __launch_bounds__(256) ls_reduce_kernel(const double* __restrict__ part, double* __restrict__ red, const int* __restrict__ state,
-                                                        int S, int first, int len, int all_signatures) {
+                                                        int S, int first, int len, int all_signatures, int dynB = 0, int K = 0, int64_t N = 0) {
     // grid (K, ceil(len / 256)): one entry per thread (a record is 66 + dim^2 doubles: with one workgroup per signature the
     // 17 MB of partials at c5 were read by 40 workgroups, 52 us per round)
     const int k = blockIdx.x;
@@ -730,8 +784,13 @@ __global__ void __launch_bounds__(256) ls_reduce_kernel(const double* __restrict
     const int e = first + (int)blockIdx.y * 256 + (int)threadIdx.x;
     if (e < first + len) {
         double t = 0.0;
-        if (live)
+        if (live && dynB > 0) {
+            const LsLive m = ls_live_map(state, K, dynB, N, k / LS_GROUP);
+            const int64_t base = (int64_t)(m.ord * LS_GROUP + k % LS_GROUP) * m.Sd;
+            for (int s = 0; s < m.nchunks; ++s) t += part[(base + s) * LS_REC + e];
+        } else if (live) {
             for (int s = 0; s < S; ++s) t += part[((int64_t)k * S + s) * LS_REC + e];
+        }
         red[(int64_t)k * LS_REC + e] = t;  // zero for signatures that asked for nothing: the all-reduce covers all K
     }
 }
