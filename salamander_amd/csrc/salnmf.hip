@@ -570,6 +570,18 @@ static void launch_pad_rows(salnmf_engine* e, double* dst, const void* src, int6
     hipLaunchKernelGGL(pad_rows_kernel<T>, dim3(std::max(grid, 1)), dim3(256), 0, e->stream, dst, static_cast<const T*>(src), rows, cols, ld, fill_cols, clip_lo);
 }
 
+// the logit passes of CorrNMF (corr_logit_mfma_kernel): the k-step count is a compile-time constant, dim rounded up to 16
+template <int MODE>
+static void launch_corr_logit(salnmf_engine* e, const CorrParams& p) {
+    const dim3 g(e->cgrid), b(CORR_BLOCK);
+    switch ((e->dim + 15) / 16) {
+        case 1: hipLaunchKernelGGL((corr_logit_mfma_kernel<MODE, 4>), g, b, 0, e->stream, p); break;
+        case 2: hipLaunchKernelGGL((corr_logit_mfma_kernel<MODE, 8>), g, b, 0, e->stream, p); break;
+        case 3: hipLaunchKernelGGL((corr_logit_mfma_kernel<MODE, 12>), g, b, 0, e->stream, p); break;
+        default: hipLaunchKernelGGL((corr_logit_mfma_kernel<MODE, 16>), g, b, 0, e->stream, p); break;
+    }
+}
+
 // ------------------------------------------------------------------------------------ C ABI
 
 extern "C" {
@@ -2434,7 +2446,7 @@ int salnmf_corr_update_sample_scalings(salnmf_engine* e) {
     CorrParams p = corr_params(e);
     p.out = e->alpha;
     p.alpha = nullptr;
-    hipLaunchKernelGGL(corr_logit_kernel<0>, dim3(e->cgrid), dim3(CORR_BLOCK), 0, e->stream, p);
+    launch_corr_logit<0>(e, p);
     HIPCK(hipGetLastError());
     return 0;
 }
@@ -2444,7 +2456,7 @@ int salnmf_corr_compute_exposures(salnmf_engine* e) {
     CorrParams p = corr_params(e);
     p.out = e->H;
     e->h_pending = false;  // H is overwritten in full
-    hipLaunchKernelGGL(corr_logit_kernel<1>, dim3(e->cgrid), dim3(CORR_BLOCK), 0, e->stream, p);
+    launch_corr_logit<1>(e, p);
     HIPCK(hipGetLastError());
     return 0;
 }
@@ -2490,7 +2502,7 @@ int salnmf_corr_update_signature_scalings(salnmf_engine* e) {
     // second_k = sum_n exp(alpha_n + <L_k, U_n>)
     CorrParams p = corr_params(e);
     p.out = e->corrpart;
-    hipLaunchKernelGGL(corr_logit_kernel<2>, dim3(e->cgrid), dim3(CORR_BLOCK), 0, e->stream, p);
+    launch_corr_logit<2>(e, p);
     hipLaunchKernelGGL(sum_partials_kernel, dim3(K), dim3(256), 0, e->stream, e->corrpart, e->cgrid, K, K, second);
     HIPCK(hipGetLastError());
     CK(allreduce(e, first, 128));  // first and second are adjacent

@@ -32,83 +32,116 @@ struct CorrParams {
     int K, KP, dim;
 };
 
-// One pass over the logits  S[n][k] = <L_k, U_n>  (a thin N x K x dim contraction on the VALU:
-// lane = sample, the signature operand is an LDS broadcast), followed by
+// One pass over the logits  S[n][k] = <L_k, U_n>  followed by
 //   MODE 0: alpha_n = log(sum_v X[n][v]) - log(sum_k exp(beta_k + S[n][k]))        (:170-179)
 //   MODE 1: H[n][k] = exp((beta_k + alpha_n) + S[n][k]), pad rows 1, pad columns 0   (:21-25)
 //   MODE 2: partial_k = sum over this workgroup's samples of exp(alpha_n + S[n][k])  (:134-136)
-template <int MODE>
-__global__ void __launch_bounds__(CORR_BLOCK) corr_logit_kernel(CorrParams p) {
-    __shared__ double Ll[CORR_DMAX * CORR_LD];   // L[k][m], zero filled
-    __shared__ double T[CORR_TILE * CORR_LD];    // logit tile [sample][k]
+// The logits on the fp64 MFMA units: S = U . L^T per 16-sample tile of a wave (A[i = sample c16][k = component 4 ks + q]
+// straight from global memory, one tile ahead; B[k][j = signature 16 jt + c16] from an LDS copy of L^T; D[row = sample
+// q + 4 r][col = signature c16]).  The tile of logits goes through a wave-private LDS tile and the exponentials run in
+// ROLLED loops over its elements, with the tile's per-sample scalars in LDS as well (a global load inside such a loop is a
+// round trip per iteration).  The VALU form this replaces (lane = sample, every row read once per wave of the workgroup,
+// FMAs against LDS broadcasts) took 90-120 us per pass at c5's 200 000 x 40 x 40; this one 70-90 us with the two
+// modalities' passes running side by side.
+//   mode 0 / 2 sums (over signatures / over samples) are taken in a fixed order of this kernel's own.
+constexpr int CLM_LD = 80;  // row stride of the LDS copy of L^T: 160 dwords = 32 banks mod 64 -> the two k rows of a half-wave do not collide
+// KSQ: k-steps of the product, dim rounded up to 16 components (compile-time, and all four signature tiles always: an MFMA
+// behind a uniform branch of its own costs the register allocator ~100 accumulator copies -- 6 000 of the kernel's 8 000
+// instructions with runtime counts)
+template <int MODE, int KSQ>
+__global__ void __launch_bounds__(CORR_BLOCK) corr_logit_mfma_kernel(CorrParams p) {
+    __shared__ double Lt[CORR_DMAX * CLM_LD];  // L^T[component][signature], zero filled
+    __shared__ double Tt[4][16 * CORR_LD];      // the waves' tiles of logits [sample][signature]
     __shared__ double bl[CORR_DMAX];
-    const int tid = threadIdx.x;
-    const int s = tid & 63, kg = tid >> 6;
+    __shared__ double arow[4][16];              // the tile's sample scalings (modes 1, 2) / row sums of X (mode 0)
+    __shared__ double wsum[4 * 64];             // (mode 2) the waves' column sums
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c16 = lane & 15, q = lane >> 4;
     const int K = p.K, dim = p.dim;
-    for (int i = tid; i < CORR_DMAX * CORR_LD; i += CORR_BLOCK) {
-        const int k = i / CORR_LD, m = i - k * CORR_LD;
-        Ll[i] = (k < K && m < dim) ? p.L[k * dim + m] : 0.0;
+    for (int i = tid; i < CORR_DMAX * CLM_LD; i += CORR_BLOCK) {
+        const int m = i / CLM_LD, k = i - m * CLM_LD;
+        const bool in = k < K && m < dim;
+        const double v = p.L[in ? k * dim + m : 0];  // (unconditional load, masked afterwards)
+        Lt[i] = in ? v : 0.0;
     }
     if (tid < CORR_DMAX) bl[tid] = (MODE != 2 && tid < K) ? p.beta[tid] : 0.0;
     __syncthreads();
-
-    double colacc = 0.0;  // MODE 2: thread k accumulates its signature's sum over the tiles of this workgroup
-    for (int64_t t0 = (int64_t)blockIdx.x * CORR_TILE; t0 < p.Np; t0 += (int64_t)gridDim.x * CORR_TILE) {
-        const int64_t n = t0 + s;
-        const bool live = n < p.N;
-        double acc[CORR_SLOTS];
+    const double* lb = Lt + q * CLM_LD + c16;
+    double* T = Tt[wave];
+    double colacc = 0.0;  // (mode 2) lane k: the column's sum over this wave's samples
+    const int64_t ntiles = p.Np / 16, tstride = (int64_t)gridDim.x * 4;
+    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    // A operand of a tile: row n0 + c16, components 4 ks + q (clamped addresses; rows beyond N and components beyond dim
+    // are masked when used)
+    double a_next[KSQ];
+    auto load_a = [&](int64_t t) {
+        const int64_t n = t * 16 + c16, nc = n < p.N ? n : p.N - 1;
+        const double* row = p.U + nc * dim;
 #pragma unroll
-        for (int j = 0; j < CORR_SLOTS; ++j) acc[j] = 0.0;
-        for (int m0 = 0; m0 < dim; m0 += 4) {
-            double u[4];
+        for (int ks = 0; ks < KSQ; ++ks) a_next[ks] = row[4 * ks + q < dim ? 4 * ks + q : dim - 1];
+    };
+    if (tile < ntiles) load_a(tile);
+    for (; tile < ntiles; tile += tstride) {
+        const int64_t n0 = tile * 16;
+        const bool rowlive = n0 + c16 < p.N;
+        d4 S[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) u[i] = (live && m0 + i < dim) ? p.U[n * dim + m0 + i] : 0.0;
+        for (int jt = 0; jt < 4; ++jt) S[jt] = (d4){0, 0, 0, 0};
 #pragma unroll
-            for (int j = 0; j < CORR_SLOTS; ++j) {
-                if (4 * j >= K) break;  // uniform over the workgroup
-                const double* lk = Ll + (kg + 4 * j) * CORR_LD + m0;
+        for (int ks = 0; ks < KSQ; ++ks) {
+            const double a = (rowlive && 4 * ks + q < dim) ? a_next[ks] : 0.0;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[j] = __builtin_fma(u[i], lk[i], acc[j]);
-            }
+            for (int jt = 0; jt < 4; ++jt) S[jt] = mfma(a, lb[4 * ks * CLM_LD + 16 * jt], S[jt]);
         }
+        // (the tile's per-sample scalars through LDS: a global load inside the rolled loops below is a round trip per iteration)
+        {
+            const int64_t n = n0 + c16, nc = n < p.N ? n : p.N - 1;
+            const double v = MODE == 0 ? p.xrowsum[nc] : p.alpha[nc];
+            if (q == 0) arow[wave][c16] = v;
+        }
+        if (tile + tstride < ntiles) load_a(tile + tstride);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) T[(q + 4 * r) * CORR_LD + 16 * jt + c16] = S[jt][r];
+        __builtin_amdgcn_wave_barrier();  // (one wave: its LDS operations execute in order)
         if (MODE == 0) {
+            // alpha_n = log(sum_v X[n][v]) - log(sum_k exp(beta_k + S[n][k])): four lanes per sample (signatures sub, sub + 4,
+            // ... in order), then the four
+            const int row = lane >> 2, sub = lane & 3;
             double part = 0.0;
-#pragma unroll
-            for (int j = 0; j < CORR_SLOTS; ++j) {
-                const int k = kg + 4 * j;
-                if (k < K) part += exp(bl[k] + acc[j]);
+#pragma unroll 1
+            for (int k = sub; k < K; k += 4) part += exp(bl[k] + T[row * CORR_LD + k]);
+            part += __shfl_xor(part, 1, 64);
+            part += __shfl_xor(part, 2, 64);
+            const int64_t n = n0 + row;
+            if (sub == 0) p.out[n] = n < p.N ? log(arow[wave][row]) - log(part) : 0.0;
+        } else if (MODE == 1) {
+            // H[n][k] = exp((beta_k + alpha_n) + S[n][k]); pad rows 1, pad columns 0; whole rows of the tile, coalesced
+            const int KP = p.KP, total = 16 * KP;
+#pragma unroll 1
+            for (int e = lane; e < total; e += 64) {
+                const int row = e / KP, col = e - row * KP;
+                const int64_t n = n0 + row;
+                double h = 0.0;
+                if (col < K) h = exp((bl[col] + arow[wave][row]) + T[row * CORR_LD + col]);
+                if (n >= p.N) h = 1.0;
+                p.out[n * KP + col] = h;
             }
-            T[s * CORR_LD + kg] = part;
-            __syncthreads();
-            if (kg == 0 && n < p.Np) {
-                const double tot = ((T[s * CORR_LD] + T[s * CORR_LD + 1]) + T[s * CORR_LD + 2]) + T[s * CORR_LD + 3];
-                p.out[n] = live ? log(p.xrowsum[n]) - log(tot) : 0.0;
-            }
-            __syncthreads();
         } else {
-            const double a = live ? p.alpha[n] : 0.0;
-#pragma unroll
-            for (int j = 0; j < CORR_SLOTS; ++j) {
-                const int k = kg + 4 * j;
-                if (k < K) T[s * CORR_LD + k] = (MODE == 1) ? exp((bl[k] + a) + acc[j]) : (live ? exp(a + acc[j]) : 0.0);
+            // partial_k += sum over the tile's samples of exp(alpha_n + S[n][k]): lane k, the samples in order
+            if (lane < K) {
+#pragma unroll 1
+                for (int row = 0; row < 16; ++row)
+                    if (n0 + row < p.N) colacc += exp(arow[wave][row] + T[row * CORR_LD + lane]);
             }
-            __syncthreads();
-            if (MODE == 1) {
-                const int KP = p.KP;
-                for (int i = tid; i < CORR_TILE * KP; i += CORR_BLOCK) {
-                    const int r = i / KP, c = i - r * KP;
-                    const int64_t nn = t0 + r;
-                    if (nn < p.Np) p.out[nn * KP + c] = (nn >= p.N) ? 1.0 : (c < K ? T[r * CORR_LD + c] : 0.0);
-                }
-            } else if (tid < K) {
-                double t = 0.0;
-                for (int r = 0; r < CORR_TILE; ++r) t += T[r * CORR_LD + tid];  // fixed order
-                colacc += t;
-            }
-            __syncthreads();
         }
+        __builtin_amdgcn_wave_barrier();  // (the tile is rewritten by the next product's stores)
     }
-    if (MODE == 2 && tid < K) p.out[(int64_t)blockIdx.x * K + tid] = colacc;
+    if (MODE == 2) {
+        wsum[wave * 64 + lane] = colacc;
+        __syncthreads();
+        if (tid < K) p.out[(int64_t)blockIdx.x * K + tid] = ((wsum[tid] + wsum[64 + tid]) + wsum[128 + tid]) + wsum[192 + tid];
+    }
 }
 
 // out[n] = sum_v X[n][v] on the padded layout [Np][96] (pads are 0): 16 lanes per row, 6 features each
