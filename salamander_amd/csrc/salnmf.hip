@@ -2601,7 +2601,10 @@ static int ensure_gathered(salnmf_engine* e, size_t rows) {
 // ---- lockstep form of the signature solves (salnmf_corr_lockstep.h): evaluation rounds over (chunks x signatures)
 // workgroups, the solvers replayed from their logs between rounds.  `shard`: the rows are this rank's shard and the
 // reduced sums of every round are all-reduced (objective, gradient and Hessian are sums over samples).
-constexpr int64_t LS_MIN_ROWS = 16384;  // below: the single-kernel form (a round costs three launches and one read-back)
+// below: the single-kernel form (one workgroup per signature passes over all samples for every evaluation; a lockstep solve
+// costs ~0.4 ms of launches and read-backs whatever the size).  Measured crossover 1 500 - 2 000 samples at 10 signatures,
+// lower with more (profiles/r04/corr_sizes.txt: 5 000 x 10: 1.70 -> 0.72 ms per update, 12 000 x 30: 4.73 -> 1.23 ms)
+constexpr int64_t LS_MIN_ROWS = 2048;
 
 static int lockstep_signature_solves(salnmf_engine* e, const double* U, const double* alpha, const double* aux, int64_t n_rows, double variance,
                                      int maxiter, int* status_out, bool shard) {
@@ -2851,6 +2854,8 @@ int salnmf_corr_update_signature_embeddings_from(salnmf_engine* e, int64_t n_all
     CK(upload(e, e->scratch, aux_all, (size_t)n_all * e->K));
     hipLaunchKernelGGL(pad_kernel, dim3(2048), dim3(256), 0, e->stream, e->gaux, e->scratch, n_all, e->K, n_all, e->KP, 0.0, 0.0, 0.0);
     HIPCK(hipGetLastError());
+    // (the form an engine that holds all n_all samples would use: the same bits as its result)
+    if (e->lockstep && n_all >= LS_MIN_ROWS) return lockstep_signature_solves(e, e->gU, e->galpha, e->gaux, n_all, variance, maxiter, status_out, false);
     return launch_signature_solves(e, e->gU, e->galpha, e->gaux, n_all, variance, maxiter, status_out);
 }
 
