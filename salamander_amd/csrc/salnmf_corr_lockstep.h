@@ -31,6 +31,7 @@ namespace salnmf {
 constexpr int LS_EVAL_MAX = 192;                    // evaluations per solve kept in the log; beyond: single-kernel fallback
 constexpr int LS_REC = 2 + 64 + 64 * 64;            // doubles per evaluation record: [lin, ex | r (64) | Hessian (dim x dim, compact)]
 constexpr int LS_NEED = 0, LS_DONE = 1, LS_FALLBACK = SIG_ONLY_VALUE;
+constexpr int LS_WIN = 8;                          // entries of a solve's record that ls_advance_kernel keeps in LDS
 constexpr int LS_CP = 2 * 64 + 8;                   // doubles per checkpoint: xk, g_next (64 each) | 3 scalars | k, flags, cursor, valid
 
 struct LockstepParams {
@@ -813,9 +814,21 @@ struct ReplayEval {
     bool pending;
     double req;          // lane m: component of the point asked for
     double* Hl;          // LDS [64][CORR_LD]: the Hessian sum of the point fixed by prepare_hess
+    double* vb;          // LDS [64]: the vector of a Hessian-vector product
     bool have_H;
+    // the last LS_WIN entries of the record in LDS (one round trip for all of them at the start of the kernel: looked up in
+    // global memory every find costs two dependent round trips, and a resumed replay only asks for recent entries)
+    const double* wy;    // LDS [LS_WIN][64]
+    const double* wg;    // LDS [LS_WIN][64]
+    const double* wf;    // LDS [LS_WIN]
+    int w0;              // first entry of the window
 
-    __device__ inline bool is(int i, double y) const { return __all(lane >= dim || ly[i * 64 + lane] == y); }
+    __device__ inline bool is(int i, double y) const {
+        const double have = i >= w0 ? wy[(i - w0) * 64 + lane] : ly[i * 64 + lane];
+        return __all(lane >= dim || have == y);
+    }
+    __device__ inline double f_at(int i) const { return i >= w0 ? wf[i - w0] : lf[i]; }
+    __device__ inline double g_at(int i) const { return i >= w0 ? wg[(i - w0) * 64 + lane] : lg[i * 64 + lane]; }
     __device__ inline int lookup(double y) {
         if (cursor < n && is(cursor, y)) return cursor++;
         if (cursor > 0 && is(cursor - 1, y)) return cursor - 1;  // the point just evaluated, asked for again (fun, then grad)
@@ -836,16 +849,16 @@ struct ReplayEval {
     }
     __device__ inline double fun(double y) {
         const int i = find_or_ask(y);
-        return i < 0 ? 0.0 : lf[i];
+        return i < 0 ? 0.0 : f_at(i);
     }
     __device__ inline double grad(double y) {
         const int i = find_or_ask(y);
-        return i < 0 ? 0.0 : lg[i * 64 + lane];
+        return i < 0 ? 0.0 : g_at(i);
     }
     __device__ inline void fun_grad(double y, double& f, double& g) {
         const int i = find_or_ask(y);
-        f = i < 0 ? 0.0 : lf[i];
-        g = i < 0 ? 0.0 : lg[i * 64 + lane];
+        f = i < 0 ? 0.0 : f_at(i);
+        g = i < 0 ? 0.0 : g_at(i);
     }
     __device__ inline void prepare_hess(double x) {
         const int i = find_or_ask(x);
@@ -859,9 +872,15 @@ struct ReplayEval {
     // order of SignatureEmbeddingEval::hessp
     __device__ inline double hessp(double v) const {
         if (!have_H) return 0.0;
+        // the vector through LDS, read back as broadcasts (a v_readlane per component stalls the FMA that consumes its
+        // scalar result: ~50 cycles per component against ~10 here; same chain, same order)
+        vb[lane] = v;
+        __builtin_amdgcn_wave_barrier();
         double r = 0.0;
         const double* row = Hl + (lane < dim ? lane : 0) * CORR_LD;
-        for (int j = 0; j < dim; ++j) r = __builtin_fma(row[j], ls_lane_value(v, j), r);  // (v_readlane: j is wave-uniform)
+#pragma unroll 8
+        for (int j = 0; j < dim; ++j) r = __builtin_fma(row[j], vb[j], r);
+        __builtin_amdgcn_wave_barrier();
         return lane < dim ? r + v / variance : 0.0;
     }
     __device__ inline bool exhausted() const { return pending; }
@@ -872,6 +891,8 @@ struct ReplayEval {
 // one wavefront per signature: log the evaluation that has just been reduced, replay the solve, ask or finish
 __global__ void __launch_bounds__(64) ls_advance_kernel(LockstepParams q) {
     __shared__ double Hl[64 * CORR_LD];
+    __shared__ double vbuf[64];
+    __shared__ double wy[LS_WIN * 64], wg[LS_WIN * 64], wf[LS_WIN];
     const int k = blockIdx.x, lane = threadIdx.x;
     if (q.state[k] != LS_NEED) return;
     const int dim = q.sig.dim;
@@ -884,6 +905,21 @@ __global__ void __launch_bounds__(64) ls_advance_kernel(LockstepParams q) {
     // ---- the evaluation at the requested point (same arithmetic as SignatureEmbeddingEval::fun_grad)
     const int i = q.n_evals[k];
     const double y = q.req[k * 64 + lane];
+    const int w0 = i + 1 > LS_WIN ? i + 1 - LS_WIN : 0;  // the window: entries w0 .. i (entry i is the one logged below)
+    {
+        double ty[LS_WIN], tg[LS_WIN], tf[LS_WIN];  // (all loads in flight together)
+#pragma unroll
+        for (int j = 0; j < LS_WIN - 1; ++j) {
+            const int ent = w0 + j < i ? w0 + j : (i > 0 ? i - 1 : 0);
+            ty[j] = ly[ent * 64 + lane], tg[j] = lg[ent * 64 + lane], tf[j] = lf[ent];
+        }
+#pragma unroll
+        for (int j = 0; j < LS_WIN - 1; ++j)
+            if (w0 + j < i) {
+                wy[j * 64 + lane] = ty[j], wg[j * 64 + lane] = tg[j];
+                if (lane == 0) wf[j] = tf[j];
+            }
+    }
     {
         // (the linear term sum_n aux[n][k] <U_n, y>: summed over the samples by the evaluation kernel, or -- the same number
         // to rounding -- <y, sg_k> with the solve's constant sg = aux^T U)
@@ -896,6 +932,9 @@ __global__ void __launch_bounds__(64) ls_advance_kernel(LockstepParams q) {
         ly[i * 64 + lane] = y;
         lg[i * 64 + lane] = lane < dim ? -gg : 0.0;
         if (lane == 0) lf[i] = -v;
+        wy[(i - w0) * 64 + lane] = y;
+        wg[(i - w0) * 64 + lane] = lane < dim ? -gg : 0.0;
+        if (lane == 0) wf[i - w0] = -v;
         for (int e = lane; e < dim * dim; e += 64) lH[(int64_t)i * dim * dim + e] = red[66 + e];
     }
     __threadfence_block();  // the log entries written above are read back below by other lanes of this wave
@@ -913,6 +952,8 @@ __global__ void __launch_bounds__(64) ls_advance_kernel(LockstepParams q) {
     ev.pending = false;
     ev.req = 0.0;
     ev.Hl = Hl;
+    ev.vb = vbuf;
+    ev.wy = wy, ev.wg = wg, ev.wf = wf, ev.w0 = w0;
     ev.have_H = false;
     double x = q.x0[k * 64 + lane];
     // resume at the top of the last Newton iteration the previous rounds reached (its CG solve and the line search's

@@ -33,10 +33,23 @@
 namespace salnmf {
 namespace ncg {
 
+// Sum over the 64 lanes, the same bits in every lane.  Inside a row of 16 lanes by DPP moves (quad permutations, then the
+// row's half mirror and mirror: partners hold equal values after the steps before, so a + b and b + a meet), across the
+// four rows by v_permlane16_swap / v_permlane32_swap of the value with itself: no LDS round trip.  As a butterfly of
+// __shfl_xor (two ds_bpermute per step on doubles) a sum cost ~600 cycles, and a CG iteration takes three of them.
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
+    v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);  // row_half_mirror
+    v += dpp_f64<0x140>(v);  // row_mirror
+    unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    v = __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+    lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
 }
 __device__ __forceinline__ double dot(double a, double b) { return wave_sum(a * b); }
 // x + t * p with the product rounded first (no fused multiply-add): the trial points of a line search and the
