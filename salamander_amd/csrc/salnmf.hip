@@ -2666,8 +2666,8 @@ static int lockstep_signature_solves(salnmf_engine* e, const double* U, const do
     q.prof = nullptr;
 #ifdef SALNMF_DEV_PROFILE
     static long long* ls_prof = nullptr;  // (development aid: one buffer per process, printed after every solve)
-    if (!ls_prof) HIPCK(hipMalloc(&ls_prof, 12 * sizeof(long long)));
-    HIPCK(hipMemsetAsync(ls_prof, 0, 12 * sizeof(long long), e->stream));
+    if (!ls_prof) HIPCK(hipMalloc(&ls_prof, 16 * sizeof(long long)));
+    HIPCK(hipMemsetAsync(ls_prof, 0, 16 * sizeof(long long), e->stream));
     q.prof = ls_prof;
 #endif
     q.state = e->ls_int;
@@ -2736,13 +2736,15 @@ static int lockstep_signature_solves(salnmf_engine* e, const double* U, const do
     if (!finished) return fail("lockstep signature solves did not terminate");
 #ifdef SALNMF_DEV_PROFILE
     {
-        long long h[12];
+        long long h[16];
         HIPCK(hipMemcpyAsync(h, q.prof, sizeof h, hipMemcpyDeviceToHost, e->stream));
         HIPCK(hipStreamSynchronize(e->stream));
         const double w = h[7] > 0 ? (double)h[7] : 1.0;
         fprintf(stderr, "[ls_eval_packed K=%d dim=%d] shader-clock ticks per wave and launch: tile to LDS %.0f + barrier %.0f, load issue %.0f, logit products %.0f, "
                         "weights %.0f, dense %.0f, packed %.0f, end-of-tile barrier %.0f, finish %.0f (%.0f wave-launches)\n", K, dim, h[8] / w, h[0] / w, h[9] / w, h[1] / w,
                 h[2] / w, h[3] / w, h[4] / w, h[5] / w, h[6] / w, w);
+        const double wa = h[14] > 0 ? (double)h[14] : 1.0;
+        fprintf(stderr, "[ls_advance] shader-clock ticks per wave and launch: record + window %.0f, replay %.0f (%.0f wave-launches)\n", h[12] / wa, h[13] / wa, wa);
     }
 #endif
     // runaway solves (log full) are finished by the single-kernel form with its own evaluation budget -- on the rows at hand

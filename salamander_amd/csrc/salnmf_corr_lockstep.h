@@ -801,6 +801,30 @@ __global__ void ls_copy_sg_kernel(const double* __restrict__ red, double* __rest
     if (i < K * 64) sg[i] = red[(int64_t)(i / 64) * LS_REC + 2 + (i & 63)];
 }
 
+// Hl [64][CORR_LD] <- a compact dim x dim Hessian (and, if asked, a copy of it to `copy`): eight loads in flight per lane
+// and round (one load per loop iteration is a memory round trip per iteration: 25 of them for dim 40)
+__device__ inline void ls_fill_hessian(double* Hl, const double* __restrict__ src, double* __restrict__ copy, int dim, int lane) {
+    const int total = dim * dim;
+    int row = lane / dim, col = lane - row * dim;  // position of element e = lane + 64 u, advanced by additions
+    const int drow = 64 / dim, dcol = 64 - drow * dim;
+    for (int e0 = lane; e0 < total + 64 * 7; e0 += 64 * 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[e0 + 64 * u < total ? e0 + 64 * u : total - 1];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (e0 + 64 * u < total) {
+                Hl[row * CORR_LD + col] = v[u];
+                if (copy) copy[e0 + 64 * u] = v[u];
+            }
+            row += drow, col += dcol;
+            if (col >= dim) col -= dim, ++row;
+        }
+        if (e0 - lane + 64 * 8 >= total) break;
+    }
+    __builtin_amdgcn_wave_barrier();  // one wave: its LDS operations execute in order
+}
+
 // The evaluator of the replay: answers from the log of evaluations made so far (by point), asks for the first point it
 // does not know and from then on reports "exhausted", which makes ncg::minimize unwind through its bounded loops.
 struct ReplayEval {
@@ -822,6 +846,7 @@ struct ReplayEval {
     const double* wg;    // LDS [LS_WIN][64]
     const double* wf;    // LDS [LS_WIN]
     int w0;              // first entry of the window
+    int hl_entry;        // the record entry whose Hessian Hl holds (-1: none)
 
     __device__ inline bool is(int i, double y) const {
         const double have = i >= w0 ? wy[(i - w0) * 64 + lane] : ly[i * 64 + lane];
@@ -864,9 +889,9 @@ struct ReplayEval {
         const int i = find_or_ask(x);
         have_H = i >= 0;
         if (!have_H) return;
-        const double* src = lH + (int64_t)i * dim * dim;
-        for (int e = lane; e < dim * dim; e += 64) Hl[(e / dim) * CORR_LD + (e % dim)] = src[e];
-        __builtin_amdgcn_wave_barrier();  // one wave: its LDS operations execute in order
+        if (i == hl_entry) return;  // (the Hessian of the entry just recorded: put there by ls_advance_kernel)
+        ls_fill_hessian(Hl, lH + (int64_t)i * dim * dim, nullptr, dim, lane);
+        hl_entry = i;
     }
     // (Hessian at the fixed point) . v: the logged sum of w_n U_n U_n^T plus the prior's v / variance, in the summation
     // order of SignatureEmbeddingEval::hessp
@@ -895,6 +920,9 @@ __global__ void __launch_bounds__(64) ls_advance_kernel(LockstepParams q) {
     __shared__ double wy[LS_WIN * 64], wg[LS_WIN * 64], wf[LS_WIN];
     const int k = blockIdx.x, lane = threadIdx.x;
     if (q.state[k] != LS_NEED) return;
+#ifdef SALNMF_DEV_PROFILE
+    long long at0 = __builtin_amdgcn_s_memtime(), at1 = 0, at2 = 0;
+#endif
     const int dim = q.sig.dim;
     const double variance = q.sig.variance;
     double* ly = q.log_y + (int64_t)k * LS_EVAL_MAX * 64;
@@ -935,9 +963,12 @@ __global__ void __launch_bounds__(64) ls_advance_kernel(LockstepParams q) {
         wy[(i - w0) * 64 + lane] = y;
         wg[(i - w0) * 64 + lane] = lane < dim ? -gg : 0.0;
         if (lane == 0) wf[i - w0] = -v;
-        for (int e = lane; e < dim * dim; e += 64) lH[(int64_t)i * dim * dim + e] = red[66 + e];
+        ls_fill_hessian(Hl, red + 66, lH + (int64_t)i * dim * dim, dim, lane);  // (to the record and, for the replay, to LDS)
     }
     __threadfence_block();  // the log entries written above are read back below by other lanes of this wave
+#ifdef SALNMF_DEV_PROFILE
+    at1 = __builtin_amdgcn_s_memtime();
+#endif
     // ---- replay
     ReplayEval ev;
     ev.ly = ly;
@@ -954,6 +985,7 @@ __global__ void __launch_bounds__(64) ls_advance_kernel(LockstepParams q) {
     ev.Hl = Hl;
     ev.vb = vbuf;
     ev.wy = wy, ev.wg = wg, ev.wf = wf, ev.w0 = w0;
+    ev.hl_entry = i;
     ev.have_H = false;
     double x = q.x0[k * 64 + lane];
     // resume at the top of the last Newton iteration the previous rounds reached (its CG solve and the line search's
@@ -967,7 +999,16 @@ __global__ void __launch_bounds__(64) ls_advance_kernel(LockstepParams q) {
         cp.old_fval = cpm[128], cp.old_old_fval = cpm[129], cp.update_l1norm = cpm[130];
         cp.k = (int)cpm[131], cp.have_old_old = (int)cpm[132], cp.have_g_next = (int)cpm[133], cp.tag = (int)cpm[134];
     }
-    const int st = ncg::minimize(ev, x, dim, q.sig.maxiter, nullptr, &cp);
+    int n_newton = 0;
+    const int st = ncg::minimize(ev, x, dim, q.sig.maxiter, &n_newton, &cp);
+#ifdef SALNMF_DEV_PROFILE
+    at2 = __builtin_amdgcn_s_memtime();
+    if (q.prof != nullptr && lane == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(q.prof) + 12, (unsigned long long)(at1 - at0));
+        atomicAdd(reinterpret_cast<unsigned long long*>(q.prof) + 13, (unsigned long long)(at2 - at1));
+        atomicAdd(reinterpret_cast<unsigned long long*>(q.prof) + 14, 1ull);
+    }
+#endif
     if (ev.pending) {
         if (cp.valid) {
             cpm[lane] = cp.xk, cpm[64 + lane] = cp.g_next;
