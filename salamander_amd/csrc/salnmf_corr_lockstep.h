@@ -278,8 +278,18 @@ __global__ void __launch_bounds__(1024) ls_reduce_sg_kernel(const double* __rest
     __shared__ double sub[16][64];
     const int k = blockIdx.x, m = threadIdx.x & 63, w = threadIdx.x >> 6;
     double t = 0.0;
-    if (m < dim)
-        for (int s = w; s < nparts; s += 16) t += part2[((int64_t)s * K + k) * 64 + m];
+    if (m < dim) {
+        // (eight loads in flight per round: one per iteration is a memory round trip per iteration)
+        int s = w;
+        for (; s + 16 * 7 < nparts; s += 16 * 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part2[((int64_t)(s + 16 * u) * K + k) * 64 + m];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t += v[u];
+        }
+        for (; s < nparts; s += 16) t += part2[((int64_t)s * K + k) * 64 + m];
+    }
     sub[w][m] = t;
     __syncthreads();
     if (w == 0) {
@@ -788,9 +798,25 @@ __global__ void __launch_bounds__(256) ls_reduce_kernel(const double* __restrict
         if (live && dynB > 0) {
             const LsLive m = ls_live_map(state, K, dynB, N, k / LS_GROUP);
             const int64_t base = (int64_t)(m.ord * LS_GROUP + k % LS_GROUP) * m.Sd;
-            for (int s = 0; s < m.nchunks; ++s) t += part[(base + s) * LS_REC + e];
+            int s = 0;
+            for (; s + 8 <= m.nchunks; s += 8) {  // (eight loads in flight per round)
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = part[(base + s + u) * LS_REC + e];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t += v[u];
+            }
+            for (; s < m.nchunks; ++s) t += part[(base + s) * LS_REC + e];
         } else if (live) {
-            for (int s = 0; s < S; ++s) t += part[((int64_t)k * S + s) * LS_REC + e];
+            int s = 0;
+            for (; s + 8 <= S; s += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = part[((int64_t)k * S + s + u) * LS_REC + e];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t += v[u];
+            }
+            for (; s < S; ++s) t += part[((int64_t)k * S + s) * LS_REC + e];
         }
         red[(int64_t)k * LS_REC + e] = t;  // zero for signatures that asked for nothing: the all-reduce covers all K
     }
