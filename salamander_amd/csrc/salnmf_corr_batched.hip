@@ -121,16 +121,34 @@ __global__ void __launch_bounds__(BT_BLOCK, 1) corr_sample_embeddings_batched_ke
         sol[i] = live ? p.beta[mo][k] : 0.0;
     }
     __syncthreads();
-    for (int i = tid; i < Lds::IMG1; i += BT_BLOCK) {
+    // the two operand images of L: eight unconditional loads (clamped term / component, masked afterwards) in flight per
+    // round -- one guarded load per loop iteration is a memory round trip per iteration, 27 of them in front of every launch
+    auto fill_image = [&](double* img, int count, auto term_comp) {
+        for (int i0 = tid; i0 < count; i0 += 8 * BT_BLOCK) {
+            double v[8];
+            bool in[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * BT_BLOCK < count ? i0 + u * BT_BLOCK : count - 1;
+                int term, comp;
+                term_comp(i, term, comp);
+                in[u] = term < T && comp < dim;
+                const int tt = term < T ? term : T - 1, cc = comp < dim ? comp : dim - 1;
+                v[u] = p.L[tmod[tt]][tk[tt] * dim + cc];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i0 + u * BT_BLOCK < count) img[i0 + u * BT_BLOCK] = in[u] ? v[u] : 0.0;
+        }
+    };
+    fill_image(img1, Lds::IMG1, [&](int i, int& term, int& comp) {
         const int l = i & 63, blk = i >> 6, ks = blk % NJ, mt = blk / NJ;
-        const int term = 16 * mt + (l & 15), comp = 4 * ks + (l >> 4);
-        img1[i] = (term < T && comp < dim) ? p.L[tmod[term]][tk[term] * dim + comp] : 0.0;
-    }
-    for (int i = tid; i < Lds::IMG2; i += BT_BLOCK) {
+        term = 16 * mt + (l & 15), comp = 4 * ks + (l >> 4);
+    });
+    fill_image(img2, Lds::IMG2, [&](int i, int& term, int& comp) {
         const int l = i & 63, blk = i >> 6, ks2 = blk % NE, ct = blk / NE;
-        const int term = 4 * ks2 + (l >> 4), comp = 16 * ct + (l & 15);
-        img2[i] = (term < T && comp < dim) ? p.L[tmod[term]][tk[term] * dim + comp] : 0.0;
-    }
+        term = 4 * ks2 + (l >> 4), comp = 16 * ct + (l & 15);
+    });
     __syncthreads();
     // from here on the waves run independently (no workgroup barrier below)
     const int64_t wave_id = (int64_t)blockIdx.x * BT_WAVES + wave;
