@@ -570,10 +570,12 @@ static void launch_pad_rows(salnmf_engine* e, double* dst, const void* src, int6
     hipLaunchKernelGGL(pad_rows_kernel<T>, dim3(std::max(grid, 1)), dim3(256), 0, e->stream, dst, static_cast<const T*>(src), rows, cols, ld, fill_cols, clip_lo);
 }
 
+// workgroups of a logit pass: two per CU at most (each opens with the staging of L^T)
+static inline int corr_logit_grid(const salnmf_engine* e) { return std::min(e->cgrid, 2 * e->cus); }
 // the logit passes of CorrNMF (corr_logit_mfma_kernel): the k-step count is a compile-time constant, dim rounded up to 16
 template <int MODE>
 static void launch_corr_logit(salnmf_engine* e, const CorrParams& p) {
-    const dim3 g(e->cgrid), b(CORR_BLOCK);
+    const dim3 g(corr_logit_grid(e)), b(CORR_BLOCK);
     switch ((e->dim + 15) / 16) {
         case 1: hipLaunchKernelGGL((corr_logit_mfma_kernel<MODE, 4>), g, b, 0, e->stream, p); break;
         case 2: hipLaunchKernelGGL((corr_logit_mfma_kernel<MODE, 8>), g, b, 0, e->stream, p); break;
@@ -2503,7 +2505,7 @@ int salnmf_corr_update_signature_scalings(salnmf_engine* e) {
     CorrParams p = corr_params(e);
     p.out = e->corrpart;
     launch_corr_logit<2>(e, p);
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(K), dim3(256), 0, e->stream, e->corrpart, e->cgrid, K, K, second);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(K), dim3(256), 0, e->stream, e->corrpart, corr_logit_grid(e), K, K, second);
     HIPCK(hipGetLastError());
     CK(allreduce(e, first, 128));  // first and second are adjacent
     hipLaunchKernelGGL(corr_log_ratio_kernel, dim3(1), dim3(64), 0, e->stream, first, second, K, e->beta);

@@ -57,11 +57,20 @@ __global__ void __launch_bounds__(CORR_BLOCK) corr_logit_mfma_kernel(CorrParams 
     __shared__ double wsum[4 * 64];             // (mode 2) the waves' column sums
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c16 = lane & 15, q = lane >> 4;
     const int K = p.K, dim = p.dim;
-    for (int i = tid; i < CORR_DMAX * CLM_LD; i += CORR_BLOCK) {
-        const int m = i / CLM_LD, k = i - m * CLM_LD;
-        const bool in = k < K && m < dim;
-        const double v = p.L[in ? k * dim + m : 0];  // (unconditional load, masked afterwards)
-        Lt[i] = in ? v : 0.0;
+    // (L^T: ten unconditional loads in flight per lane and round, masked afterwards -- one load per loop iteration is a memory
+    // round trip per iteration, twenty of them in front of every workgroup's first tile)
+    for (int i0 = tid; i0 < CORR_DMAX * CLM_LD; i0 += 10 * CORR_BLOCK) {
+        double v[10];
+        bool in[10];
+#pragma unroll
+        for (int u = 0; u < 10; ++u) {
+            const int i = i0 + u * CORR_BLOCK, m = i / CLM_LD, k = i - m * CLM_LD;
+            in[u] = i < CORR_DMAX * CLM_LD && k < K && m < dim;
+            v[u] = p.L[in[u] ? k * dim + m : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < 10; ++u)
+            if (i0 + u * CORR_BLOCK < CORR_DMAX * CLM_LD) Lt[i0 + u * CORR_BLOCK] = in[u] ? v[u] : 0.0;
     }
     if (tid < CORR_DMAX) bl[tid] = (MODE != 2 && tid < K) ? p.beta[tid] : 0.0;
     __syncthreads();
