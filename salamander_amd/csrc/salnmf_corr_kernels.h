@@ -176,8 +176,17 @@ __global__ void __launch_bounds__(256) colsum_partial_kernel(const double* __res
     const int64_t chunk = (N + gridDim.x - 1) / gridDim.x;
     const int64_t lo = (int64_t)blockIdx.x * chunk, hi = (lo + chunk < N) ? lo + chunk : N;
     double s = 0.0;
-    if (g < groups)
-        for (int64_t n = lo + g; n < hi; n += groups) s += A[n * ld + c];
+    if (g < groups) {
+        int64_t n = lo + g;
+        for (; n + 7 * groups < hi; n += 8 * groups) {  // (eight loads in flight per round, added in the same order)
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = A[(n + (int64_t)u * groups) * ld + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; n < hi; n += groups) s += A[n * ld + c];
+    }
     red[threadIdx.x] = s;
     __syncthreads();
     if (g == 0) {
