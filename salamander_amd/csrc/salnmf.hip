@@ -2611,8 +2611,7 @@ constexpr int64_t LS_MIN_ROWS = 2048;
 static int lockstep_signature_solves(salnmf_engine* e, const double* U, const double* alpha, const double* aux, int64_t n_rows, double variance,
                                      int maxiter, int* status_out, bool shard) {
     const int K = e->K, dim = e->dim;
-    hipDeviceProp_t prop;
-    HIPCK(hipGetDeviceProperties(&prop, e->device));
+    const int n_cus = e->cus;  // (cached at salnmf_create: a properties query per solve costs as much as a small solve)
     const int64_t max_chunks = (n_rows + SIGT - 1) / SIGT;
     // dim <= 48: LS_GROUP signatures share a staged tile of U (salnmf_corr_lockstep.h), so there are fewer, longer rows of
     // workgroups and more chunks; otherwise one signature per workgroup
@@ -2620,7 +2619,7 @@ static int lockstep_signature_solves(salnmf_engine* e, const double* U, const do
     const int groups = multi ? (K + LS_GROUP - 1) / LS_GROUP : K;
     // chunks per signature (group): as many as it takes to fill the chip, within 64 MB of partial records
     const int64_t s_cap = std::max<int64_t>(1, (int64_t)(64u << 20) / (int64_t)((size_t)LS_GROUP * groups * LS_REC * sizeof(double)));
-    const int S = (int)std::max<int64_t>(1, std::min<int64_t>({multi ? 128 : 16, prop.multiProcessorCount / groups, max_chunks, s_cap}));
+    const int S = (int)std::max<int64_t>(1, std::min<int64_t>({multi ? 128 : 16, n_cus / groups, max_chunks, s_cap}));
     const int64_t chunk = ((n_rows + S - 1) / S + SIGT - 1) / SIGT * SIGT;
     // one allocation: [x0 | req | sg] (K x 64 each), part (K S REC), red (K REC), log_y, log_g (K EVAL 64), log_f (K EVAL), log_H (K EVAL dim^2)
     const size_t n_part = (size_t)(multi ? LS_GROUP * groups : K) * S * LS_REC;  // (records by (group ordinal, slot, chunk) under the live-group map)
@@ -2682,7 +2681,7 @@ static int lockstep_signature_solves(salnmf_engine* e, const double* U, const do
     if (multi) {
         // sg = aux^T U as one MFMA product, four workgroups per CU; their partial sums [wg][K][64] borrow
         // the front of q.part (K S LS_REC doubles)
-        const int nwg = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)4 * prop.multiProcessorCount, (n_rows + 255) / 256, (int64_t)S * LS_REC / 64}));
+        const int nwg = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)4 * n_cus, (n_rows + 255) / 256, (int64_t)S * LS_REC / 64}));
         const int64_t rows_per_wg = ((n_rows + nwg - 1) / nwg + 255) / 256 * 256;
         hipLaunchKernelGGL(ls_begin_mfma_kernel, dim3(nwg), dim3(256), 0, e->stream, q, q.part, rows_per_wg);
         hipLaunchKernelGGL(ls_reduce_sg_kernel, dim3(K), dim3(1024), 0, e->stream, q.part, q.red, nwg, K, dim);
