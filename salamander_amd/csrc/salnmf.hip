@@ -2711,10 +2711,9 @@ static int lockstep_signature_solves(salnmf_engine* e, const double* U, const do
         } else if (multi) hipLaunchKernelGGL(ls_eval_multi_kernel, grid, dim3(SIGT), 0, e->stream, q);
         else hipLaunchKernelGGL(ls_eval_kernel, grid, dim3(SIGT), 0, e->stream, q);
         hipLaunchKernelGGL(ls_reduce_kernel, dim3(K, (rec + 255) / 256), dim3(256), 0, e->stream, q.part, q.red, q.state, S, 0, rec, 0, q.dyn ? S * groups : 0, K,
-                           (int64_t)n_rows);
+                           (int64_t)n_rows, q.active);
         HIPCK(hipGetLastError());
         if (shard) CK(allreduce(e, q.red, (size_t)K * LS_REC));
-        HIPCK(hipMemsetAsync(q.active, 0, sizeof(int), e->stream));
         hipLaunchKernelGGL(ls_advance_kernel, dim3(K), dim3(64), 0, e->stream, q);
         HIPCK(hipGetLastError());
         HIPCK(hipMemcpyAsync(hactive + (r & 1), q.active, sizeof(int), hipMemcpyDeviceToHost, e->stream));

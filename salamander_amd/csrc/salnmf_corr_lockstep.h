@@ -787,7 +787,11 @@ __global__ void __launch_bounds__(SIGT) ls_eval_packed_kernel(LockstepParams q) 
 // red[k][e] = sum over the S chunk partials, fixed order; only the first `len` entries of a record are live
 //   dynB > 0: the records were written under the live-group map of a round with dynB workgroups (LsLive)
 __global__ void __launch_bounds__(256) ls_reduce_kernel(const double* __restrict__ part, double* __restrict__ red, const int* __restrict__ state,
-                                                        int S, int first, int len, int all_signatures, int dynB = 0, int K = 0, int64_t N = 0) {
+                                                        int S, int first, int len, int all_signatures, int dynB = 0, int K = 0, int64_t N = 0,
+                                                        int* active = nullptr) {
+    // (the round's count of signatures that still ask for an evaluation starts from zero: ls_advance_kernel adds to it --
+    // here instead of a memset launch of its own between the two kernels)
+    if (active != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *active = 0;
     // grid (K, ceil(len / 256)): one entry per thread (a record is 66 + dim^2 doubles: with one workgroup per signature the
     // 17 MB of partials at c5 were read by 40 workgroups, 52 us per round)
     const int k = blockIdx.x;
