@@ -2705,7 +2705,9 @@ static int lockstep_signature_solves(salnmf_engine* e, const double* U, const do
             const int npk = (LS_GROUP * tail_cols + 15) / 16;
             // <3, 40, ..>: three row tiles and three packed tiles as compile-time constants, the next tile of U prefetched
             // into 40 registers per lane (c5's shape: dim 33 .. 40)
-            if (npk == 3 && dim > 32 && dim <= 40) hipLaunchKernelGGL((ls_eval_packed_kernel<3, 40, true, true>), grid, dim3(SIGT), 0, e->stream, q);
+            // (even dim: the tile by LDS-DMA, per wave, in double-buffered halves -- no staging registers, no barrier in the loop)
+            if (npk == 3 && dim > 32 && dim <= 40 && dim % 2 == 0) hipLaunchKernelGGL((ls_eval_packed_kernel<3, 0, true, true, true>), grid, dim3(SIGT), 0, e->stream, q);
+            else if (npk == 3 && dim > 32 && dim <= 40) hipLaunchKernelGGL((ls_eval_packed_kernel<3, 40, true, true>), grid, dim3(SIGT), 0, e->stream, q);
             else if (npk <= 3) hipLaunchKernelGGL((ls_eval_packed_kernel<3, 0, false, false>), grid, dim3(SIGT), 0, e->stream, q);
             else hipLaunchKernelGGL((ls_eval_packed_kernel<5, 0, false, false>), grid, dim3(SIGT), 0, e->stream, q);
         } else if (multi) hipLaunchKernelGGL(ls_eval_multi_kernel, grid, dim3(SIGT), 0, e->stream, q);

@@ -460,7 +460,7 @@ __device__ inline int ls_live_group(const int* __restrict__ state, int K, int o)
 // (iii) PF: the next tile of U is on its way to registers while this tile's products run.  FIX: the common tile counts as
 // compile-time constants.  582 -> 458 us per round at c5 for (ii) + (iii) (profiles/r04/lockstep_packed.md).
 //   wt5 [SIGT][6]: the tile's weights, sample-major (slot 5 = 0: the operand of packed columns beyond LS_GROUP w)
-template <int PKMAX, int PF, bool AG, bool FIX>
+template <int PKMAX, int PF, bool AG, bool FIX, bool DMA = false>
 __global__ void __launch_bounds__(SIGT) ls_eval_packed_kernel(LockstepParams q) {
     int kbase = blockIdx.y * LS_GROUP, s = blockIdx.x;
     LsLive lm{};
@@ -480,7 +480,7 @@ __global__ void __launch_bounds__(SIGT) ls_eval_packed_kernel(LockstepParams q) 
         any |= live[g];
     }
     if (!any) return;
-    __shared__ double pool[SIG_POOL];
+    __shared__ __attribute__((aligned(16))) double pool[SIG_POOL];  // (16 bytes: the LDS-DMA variant writes it in 16-byte pieces)
     __shared__ double wt5[SIGT * 6], sred[SIGT], ybuf0[64], red[4 * 64];
     SignatureEmbeddingEval ev;
     ls_setup_eval(ev, q, pool, wt5, sred, ybuf0, red, kbase, s);
@@ -488,7 +488,8 @@ __global__ void __launch_bounds__(SIGT) ls_eval_packed_kernel(LockstepParams q) 
         ev.n_begin = (int64_t)s * lm.cd;
         ev.n_end = ev.n_begin + lm.cd < q.sig.N ? ev.n_begin + lm.cd : q.sig.N;
     }
-    const int dim = q.sig.dim, DT = ev.DT, ldu = ev.ldu;
+    // (DMA: rows of 50 doubles = 25 sixteen-byte pieces, so that a row starts on a piece boundary)
+    const int dim = q.sig.dim, DT = ev.DT, ldu = DMA ? 50 : ev.ldu;
     const int c16 = ev.lane & 15, qq = ev.lane >> 4;
     const int tail0 = 16 * (DT - 1), w = dim + 1 - tail0;  // the last block column: first component, live columns
     const int NPK = (LS_GROUP * w + 15) / 16;               // packed tiles (<= PKMAX: the launcher's choice)
@@ -619,54 +620,74 @@ __global__ void __launch_bounds__(SIGT) ls_eval_packed_kernel(LockstepParams q) 
             al[st] = q.sig.alpha[n < ev.n_end ? n : ev.n_end - 1];  // (samples beyond the chunk: values not used)
         }
     };
-    if (PF > 0) pf_load(ev.n_begin);
-    for (int64_t t0 = ev.n_begin; t0 < ev.n_end; t0 += SIGT) {
-        if (PF > 0) pf_store(t0);
-        else ev.stage(t0);  // (ends with a workgroup barrier; rows 64 wave .. 64 wave + 63 are this wave's samples)
-        LS_TICK(0);
-        scalars_load(t0);
-        if (PF > 0 && t0 + SIGT < ev.n_end) pf_load(t0 + SIGT);
-        if (PF == 0) {
-            ev.Ut[ev.tid * ldu + dim] = 1.0;  // (the column of ones of this thread's row: ev.stage zeroed it)
-            __builtin_amdgcn_wave_barrier();
-        }
-        LS_TICK(9);
-        // logits of the wave's 64 samples, 16 at a time (KSn k-steps each), and behind each product the weights
+    // The products of one block of this wave's samples: NST tiles of 16 (a wave's 64 rows of a staged tile, or the 32 rows of
+    // a DMA half).  rows: the block's first row in LDS; wrows: its weights; n_first: its first sample; alv: sample scalings
+    auto compute = [&](auto NSTC, const double* rows, double* wrows, int64_t n_first, const double (&alv)[4]) {
+        constexpr int NST = decltype(NSTC)::value, NSG = 4 * NST;
+        // logits of the block's samples, 16 at a time (KSn k-steps each), and behind each product the weights
         // exp(beta + alpha + logit) of (sample 16 st + c16, slot q) and, lanes q = 0, (sample, slot 4)
         {
-            const double* ubase = ev.Ut + (64 * ev.wave + c16) * ldu + qq;
+            const double* ubase = rows + c16 * ldu + qq;
 #pragma unroll
-            for (int st = 0; st < 4; ++st) {
+            for (int st = 0; st < NST; ++st) {
                 d4 sl = (d4){0, 0, 0, 0};
 #pragma unroll
                 for (int ks = 0; ks < KSMAX; ++ks)
                     if (FIX ? (ks < 8 || ks < KSn) : ks < KSn) sl = mfma(yl[24 * ks], ubase[16 * st * ldu + 4 * ks], sl);  // (uniform; FIX: dim > 32)
-                const int64_t n = t0 + 64 * ev.wave + 16 * st + c16;
+                const int64_t n = n_first + 16 * st + c16;
                 const bool in = n < ev.n_end;
-                double* wrow = wt5 + (64 * ev.wave + 16 * st + c16) * 6;
+                double* wrow = wrows + (16 * st + c16) * 6;
                 if (live_lo) {
                     double wgt = 0.0;
-                    if (in) wgt = exp((cg_lo + al[st]) + sl[0]);
+                    if (in) wgt = exp((cg_lo + alv[st]) + sl[0]);
                     wrow[qq] = wgt;
                 }
                 if (live_hi) {
                     double wgt = 0.0;
-                    if (in) wgt = exp((cg_hi + al[st]) + sl[1]);
+                    if (in) wgt = exp((cg_hi + alv[st]) + sl[1]);
                     wrow[4] = wgt;
                 }
             }
         }
         LS_TICK(1);
-        __builtin_amdgcn_wave_barrier();  // (LDS operations of one wave execute in order: its own 64 rows and weights)
-        // the wave's 64 samples, four per step: operands one step ahead of the MFMAs that use them
-        const double* ub = ev.Ut + (64 * ev.wave + qq) * ldu;
-        const double* wb = wt5 + (64 * ev.wave + qq) * 6;
+        __builtin_amdgcn_wave_barrier();  // (LDS operations of one wave execute in order: its own rows and weights)
+        // four samples per step: operands one step ahead of the MFMAs that use them
+        const double* ub = rows + qq * ldu;
+        const double* wb = wrows + qq * 6;
         // (FIX: the tile counts of the common shape -- three row tiles, three packed tiles -- as compile-time constants; as
         // runtime values every MFMA sits behind a scalar branch of its own)
         const int dt = FIX ? 3 : DT, npk = FIX ? 3 : NPK;
         LS_TICK(2);
-        // the dense leading tiles, signature by signature (one branch per signature and tile, not per step)
-        if (dt > 1) {
+        // the dense leading tiles.  DMA (blocks of 32 samples): step-outer, the group's signatures side by side -- one
+        // operand-fetch prologue per block instead of one per signature; else signature by signature (one branch per
+        // signature and block, not per step)
+        if (DMA && dt > 1) {
+            double a[2][2], wv[2][LS_GROUP];
+            auto fetch = [&](int buf, int sgrp) {
+                const double* ur = ub + 4 * sgrp * ldu;
+                a[buf][0] = ur[c16];
+                a[buf][1] = dt > 2 ? ur[16 + c16] : 0.0;
+#pragma unroll
+                for (int g = 0; g < LS_GROUP; ++g) wv[buf][g] = wb[4 * sgrp * 6 + g];
+            };
+            fetch(0, 0);
+#pragma unroll
+            for (int sgrp = 0; sgrp < NSG; ++sgrp) {
+                const int cur = sgrp & 1;
+                if (sgrp + 1 < NSG) fetch(cur ^ 1, sgrp + 1);
+#pragma unroll
+                for (int g = 0; g < LS_GROUP; ++g) {
+                    if (!live[g]) continue;
+                    const double b0 = wv[cur][g] * a[cur][0];
+                    if (AG) mfma_agpr(dense[g][0], a[cur][0], b0); else dense[g][0] = mfma(a[cur][0], b0, dense[g][0]);
+                    if (dt > 2) {
+                        const double b1 = wv[cur][g] * a[cur][1];
+                        if (AG) mfma_agpr(dense[g][1], a[cur][0], b1); else dense[g][1] = mfma(a[cur][0], b1, dense[g][1]);
+                        if (AG) mfma_agpr(dense[g][2], a[cur][1], b1); else dense[g][2] = mfma(a[cur][1], b1, dense[g][2]);
+                    }
+                }
+            }
+        } else if (dt > 1) {
 #pragma unroll
             for (int g = 0; g < LS_GROUP; ++g) {
                 if (!live[g]) continue;
@@ -679,9 +700,9 @@ __global__ void __launch_bounds__(SIGT) ls_eval_packed_kernel(LockstepParams q) 
                 };
                 fetch(0, 0);
 #pragma unroll
-                for (int sgrp = 0; sgrp < 16; ++sgrp) {
+                for (int sgrp = 0; sgrp < NSG; ++sgrp) {
                     const int cur = sgrp & 1;
-                    if (sgrp + 1 < 16) fetch(cur ^ 1, sgrp + 1);
+                    if (sgrp + 1 < NSG) fetch(cur ^ 1, sgrp + 1);
                     const double b0 = wv[cur] * a[cur][0];
                     if (AG) mfma_agpr(dense[g][0], a[cur][0], b0); else dense[g][0] = mfma(a[cur][0], b0, dense[g][0]);
                     if (dt > 2) {
@@ -710,9 +731,9 @@ __global__ void __launch_bounds__(SIGT) ls_eval_packed_kernel(LockstepParams q) 
             };
             fetch(0, 0);
 #pragma unroll
-            for (int sgrp = 0; sgrp < 16; ++sgrp) {
+            for (int sgrp = 0; sgrp < NSG; ++sgrp) {
                 const int cur = sgrp & 1;
-                if (sgrp + 1 < 16) fetch(cur ^ 1, sgrp + 1);
+                if (sgrp + 1 < NSG) fetch(cur ^ 1, sgrp + 1);
 #pragma unroll
                 for (int p = 0; p < PKMAX; ++p)
                     if (p < npk) {
@@ -724,8 +745,86 @@ __global__ void __launch_bounds__(SIGT) ls_eval_packed_kernel(LockstepParams q) 
             }
         }
         LS_TICK(4);
+    };
+    if constexpr (DMA) {
+        // ---- the tile by LDS-DMA, per wave, double-buffered in halves of 32 samples.  Every wave stages and consumes its OWN
+        // rows: global_load_lds_dwordx4 puts lane l's 16 bytes at base + 16 l, so one instruction moves 64 pieces (2.56 rows of
+        // 25 pieces; the five pad pieces of a row -- the column of ones, zeros -- are written once and skipped) from global
+        // memory to LDS without passing through registers; half k + 1 travels while half k is multiplied, and no workgroup
+        // barrier is left in the loop.  Rows of samples beyond the chunk keep older (finite) values: their weights are 0.
+        double* myreg = ev.Ut + 64 * ev.wave * ldu;
+        for (int i = ev.lane; i < 64 * ldu; i += 64) myreg[i] = 0.0;
+        __builtin_amdgcn_wave_barrier();
+        myreg[ev.lane * ldu + dim] = 1.0;
+        __syncthreads();  // (wt5 zeroed above by all threads)
+        const int64_t nunits = (ev.n_end - ev.n_begin + 31) / 32;
+        const int hp = dim / 2;  // data pieces per row
+        // piece 64 i + lane of a half's image: its offset in the unit's 32 x dim block of U (doubles), -1 for the pad pieces
+        // and beyond the 32 rows (thirteen per lane, computed once)
+        int poff[13];
+        {
+            int row = ev.lane / 25, slot = ev.lane - 25 * row;
+#pragma unroll
+            for (int i = 0; i < 13; ++i) {
+                poff[i] = (row < 32 && slot < hp) ? row * dim + 2 * slot : -1;
+                row += 2, slot += 14;
+                if (slot >= 25) slot -= 25, ++row;
+            }
+        }
+        auto issue = [&](int64_t u, int half) {
+            const int64_t base = ev.n_begin + 32 * u;
+            const double* src = q.sig.U + base * dim;
+            double* dst = myreg + half * 32 * ldu;
+            const int64_t lim = (q.sig.N - base) * dim;  // (rows of the unit beyond N are not requested)
+#pragma unroll
+            for (int i = 0; i < 13; ++i)
+                if (poff[i] >= 0 && poff[i] < lim)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + poff[i]), (__attribute__((address_space(3))) void*)(dst + 128 * i), 16, 0,
+                                                     0);
+        };
+        double al_next[4] = {0.0, 0.0, 0.0, 0.0};
+        auto scal = [&](int64_t u) {
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const int64_t n = ev.n_begin + 32 * u + 16 * st + c16;
+                al_next[st] = q.sig.alpha[n < ev.n_end ? n : ev.n_end - 1];
+            }
+        };
+        int64_t u = ev.wave;
+        int half = 0;
+        if (u < nunits) {
+            issue(u, 0);
+            scal(u);
+        }
+        for (; u < nunits; u += 4, half ^= 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (this half and its scalars have arrived)
+            LS_TICK(8);
+            double alv[4] = {al_next[0], al_next[1], 0.0, 0.0};
+            if (u + 4 < nunits) {
+                issue(u + 4, half ^ 1);
+                scal(u + 4);
+            }
+            LS_TICK(0);
+            compute(std::integral_constant<int, 2>{}, myreg + half * 32 * ldu, wt5 + 64 * ev.wave * 6, ev.n_begin + 32 * u, alv);
+        }
+        __syncthreads();  // every wave is done with its rows: the finish below uses the tile buffer as staging
+    } else {
+    if (PF > 0) pf_load(ev.n_begin);
+    for (int64_t t0 = ev.n_begin; t0 < ev.n_end; t0 += SIGT) {
+        if (PF > 0) pf_store(t0);
+        else ev.stage(t0);  // (ends with a workgroup barrier; rows 64 wave .. 64 wave + 63 are this wave's samples)
+        LS_TICK(0);
+        scalars_load(t0);
+        if (PF > 0 && t0 + SIGT < ev.n_end) pf_load(t0 + SIGT);
+        if (PF == 0) {
+            ev.Ut[ev.tid * ldu + dim] = 1.0;  // (the column of ones of this thread's row: ev.stage zeroed it)
+            __builtin_amdgcn_wave_barrier();
+        }
+        LS_TICK(9);
+        compute(std::integral_constant<int, 4>{}, ev.Ut + 64 * ev.wave * ldu, wt5 + 64 * ev.wave * 6, t0 + 64 * ev.wave, al);
         __syncthreads();  // every wave is done with the tile before the next one is staged over it
         LS_TICK(5);
+    }
     }
 #pragma unroll
     for (int g = 0; g < LS_GROUP; ++g) {
