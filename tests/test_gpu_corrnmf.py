@@ -569,7 +569,7 @@ def test_embedding_solves_terminate_on_non_finite_input():
      # every shape class of the grouped evaluation kernels (salnmf_corr_lockstep.h): row tiles 1 / 2 / 3, packed tiles 1 .. 5,
      # dim a multiple of 16 (the unpacked form), groups that are not full
      (17000, 7, 20), (17000, 11, 30), (16500, 6, 45), (16500, 9, 36), (17000, 13, 33), (17000, 4, 15), (17000, 5, 16), (16500, 6, 32),
-     (16500, 7, 48), (17000, 8, 37)],
+     (16500, 7, 48), (17000, 8, 37), (17000, 11, 38), (2500, 40, 40)],  # (38, 40: the LDS-DMA variant; 2 500: a partial last half)
 )
 def test_lockstep_signature_solves_agree_with_the_single_kernel_form(N, K, dim):
     """From 16 384 samples on the signature solves advance in lockstep rounds (evaluation over chunks x signatures, the
