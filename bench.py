@@ -57,7 +57,8 @@ FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X fp32 matrix peak (MI355X_MICROARCH.md); 
 def cpu_baseline(X, W0, H0, max_steps=500, budget_s=150.0):
     """The oracle's update_WH on the host cores from the shared init: 3 untimed warm-up steps on copies, then up
     to ``max_steps`` timed steps (stopping early at a multiple of 10 once ``budget_s`` is spent).  Returns the
-    baseline record and (steps, objective after those steps, seconds) for time_to_kl."""
+    baseline record and (steps, objective after those steps, seconds, W, H after those steps -- sample-major, as the engine
+    holds them) for time_to_kl and the north star's parity gate."""
     from oracle import klnmf_oracle as orc
 
     Xt = np.asfortranarray(X.T)  # the layouts the reference computes on
@@ -88,7 +89,7 @@ def cpu_baseline(X, W0, H0, max_steps=500, budget_s=150.0):
         "sample": f"{n} timed update_WH steps from the shared init (after 3 warm-up steps) of the NumPy oracle on the full "
         f"96x{X.shape[0]} k={K} workload, numpy {np.__version__}, {dt:.1f} s",
     }
-    return rec, (n, target, dt)
+    return rec, (n, target, dt, np.ascontiguousarray(W.T), np.ascontiguousarray(H.T))
 
 
 def device_loop_to_target(e, target, limit):
@@ -114,15 +115,28 @@ def device_loop_to_target(e, target, limit):
         slot = 1 + slot % 250
 
 
-def time_to_kl(sal, X, W0, H0, cpu_steps, target, cpu_seconds, device):
+def parity_gate(e, W0, H0, cpu_steps, W_cpu, H_cpu):
+    """BASELINE.json's acceptance figure: W, H within 1e-4 rel-L2 of the CPU path after EQUAL iterations from the same init
+    (``_utils_klnmf.py:281-361`` restated by the oracle, run by ``cpu_baseline`` on this box)."""
+    e.upload_W(W0), e.upload_H(H0)
+    e.kl_step(cpu_steps)
+    W, H = e.download_W(), e.download_H()
+    rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    rw, rh = rel(W, W_cpu), rel(H, H_cpu)
+    return {"parity_steps": cpu_steps, "rel_l2_W": rw, "rel_l2_H": rh, "parity_gate": 1e-4, "parity_ok": bool(max(rw, rh) <= 1e-4)}
+
+
+def time_to_kl(sal, X, W0, H0, cpu_steps, target, cpu_seconds, device, W_cpu=None, H_cpu=None):
     """Wall-clock until the device-resident loop (objective every 10 steps, as fit does) is at or below the KL
-    the CPU path reached after ``cpu_steps`` steps from the same init; then the same through KLNMF.fit."""
+    the CPU path reached after ``cpu_steps`` steps from the same init; then the same through KLNMF.fit.  With the CPU
+    path's factors: the north star's parity gate after the same number of steps (``parity_gate``)."""
     N = X.shape[0]
     e = sal.Engine(N, V, K, device=device)
     e.upload_X(X), e.upload_W(W0), e.upload_H(H0)
     e.kl_step(300)  # (20 ms of work: the GPU's clocks are back up after the idle minutes of the CPU baseline) ...
     e.upload_W(W0), e.upload_H(H0)  # ... and the loop starts from the shared init
     steps, obj, loop_s = device_loop_to_target(e, target, cpu_steps + 100)
+    gate = parity_gate(e, W0, H0, cpu_steps, W_cpu, H_cpu) if W_cpu is not None else {}
     e.close()
     adata = sal.AnnData(X.copy())
     model = sal.models.KLNMF(K, "custom", min_iterations=steps, max_iterations=steps, device=device)
@@ -142,6 +156,7 @@ def time_to_kl(sal, X, W0, H0, cpu_steps, target, cpu_seconds, device):
         "gpu_loop_protocol": "objective every 10 steps, evaluated inside the first update of the next block, which is queued before the deciding objective is read (kept block, rolled back at the target)",
         "gpu_fit_seconds_end_to_end": fit_s,
         "fit_objective_last": float(model.history["objective_function"][-1]) if model.history["objective_function"] else None,
+        **gate,
     }
 
 
@@ -328,7 +343,7 @@ def problem_rows(start, stop):
     return np.concatenate(Xs), np.concatenate(Hs)
 
 
-def validate_exchange(engine, dist, W0, H0, local_rank, steps=3, reference="rccl"):
+def validate_exchange(engine, dist, W0, H0, ctrl, steps=3, reference="rccl"):
     """A few steps from the same start through the reference collective and through the peer-to-peer exchange: W must
     agree to rounding (the two add the ranks' numerators in different orders) and, with the exchange, be bit-identical on
     all ranks.  The reference is the engine's RCCL communicator, or -- where that could not be created -- the split step
@@ -358,7 +373,7 @@ def validate_exchange(engine, dist, W0, H0, local_rank, steps=3, reference="rccl
         good = 1.0 if rel < 1e-11 else 0.0
     except RuntimeError as exc:  # e.g. an exchange that gave up waiting for a peer
         out["error"] = str(exc)
-    t = torch.tensor([digest, -digest, good], dtype=torch.float64, device=f"cuda:{local_rank}")
+    t = torch.tensor([digest, -digest, good], dtype=torch.float64, device=ctrl)
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
     same = bool(t[0].item() == -t[1].item())
     out.update({"p2p_valid": bool(t[2].item() == 1.0 and same), "p2p_vs_rccl_rel_l2_W": rel, "p2p_W_identical_on_all_ranks": same})
@@ -381,6 +396,11 @@ def main():
     ap.add_argument("--busy-seconds", type=float, default=2.5, help="repeat the K-step block until the GPU was busy this long")
     ap.add_argument("--no-p2p", action="store_true", help="N > 1: RCCL all-reduce only, do not try the peer-to-peer exchange")
     ap.add_argument("--simulate-no-rccl", action="store_true", help="rehearsal aid: behave as if the engine's RCCL communicator could not be created")
+    ap.add_argument("--rehearse-one-device", action="store_true",
+                    help="N > 1 on a ONE-GPU box: every rank's engine on device 0, control plane over gloo, the engine's RCCL communicator "
+                    "treated as absent (two RCCL ranks cannot share a GPU), the K x V exchange by the peer-to-peer protocol between the "
+                    "processes -- the whole --gpus N flow of this file except the xGMI hop and RCCL.  The line says so "
+                    "(config.rehearsal); its numbers are N processes time-sharing one GPU, NOT a scaling measurement")
     ap.add_argument("--rehearse-sharded", action="store_true",
                     help="--gpus 1 only: run the N > 1 code path (process group, RCCL communicator in the engine, c3's row blocks, "
                     "one-GPU reference) at world size 1 -- a rehearsal of what the driver launches on a multi-GPU node")
@@ -411,8 +431,16 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29555")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.rehearse_one_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    # the HIP device of this rank's engine, and where the control plane's small tensors live (gloo reduces host tensors)
+    device = 0 if args.rehearse_one_device else local_rank
+    ctrl = "cpu" if args.rehearse_one_device else f"cuda:{device}"
+    if args.rehearse_one_device:
+        args.simulate_no_rccl = True
 
     strong = sharded and not args.weak
     if not sharded:
@@ -430,7 +458,7 @@ def main():
         n_total = n_local * world
         X, W0, H0 = synthetic_problem(V, n_local, K, seed=rank)
 
-    engine = sal.Engine(n_local, V, K, device=local_rank)
+    engine = sal.Engine(n_local, V, K, device=device)
     rccl_ok = True
     if sharded:
         from salamander_amd.distributed import attach_communicator, broadcast_from_rank0
@@ -456,13 +484,13 @@ def main():
     # N > 1: the K x V all-reduce of every step goes either through RCCL or through the engine's peer-to-peer exchange
     # (salnmf_p2p_kernels.h).  Both are run; the exchange's result is checked against the RCCL result before it is timed,
     # and the line reports the faster VALID mode as `value` with both timings under config.exchange.
-    exchange = None
+    exchange = {"p2p_connected": False, "rccl_communicator": rccl_ok} if sharded else None
     if sharded and not (args.no_p2p and rccl_ok):
         from salamander_amd.distributed import attach_peer_exchange
 
-        exchange = {"p2p_connected": bool(attach_peer_exchange(engine, n_total, required=False)), "rccl_communicator": rccl_ok}
+        exchange["p2p_connected"] = bool(attach_peer_exchange(engine, n_total, required=False))
         if exchange["p2p_connected"]:
-            exchange.update(validate_exchange(engine, dist, W0, H0, local_rank, reference="rccl" if rccl_ok else "host"))
+            exchange.update(validate_exchange(engine, dist, W0, H0, ctrl, reference="rccl" if rccl_ok else "host"))
             if not exchange["p2p_valid"] and rccl_ok:
                 engine.set_p2p(False)
             engine.upload_W(W0)
@@ -481,9 +509,17 @@ def main():
     def max_over_ranks(x):
         if dist is None:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([x], dtype=torch.float64, device=ctrl)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
+
+    def gather(obj):
+        """Every rank's object, in rank order (a list of one without a process group)."""
+        if dist is None or world == 1:
+            return [obj]
+        out = [None] * world
+        dist.all_gather_object(out, obj)
+        return out
 
     # untimed: warm-up steps, and one profiling pass so that every event / lazily sized buffer exists
     engine.kl_step(args.warmup)
@@ -540,28 +576,47 @@ def main():
         # node says whether compute, the exchange's wire time or the ranks' skew (wait_for_peer_flags) is the long pole
         if exchange.get("p2p_valid"):
             was_p2p = exchange_mode == "p2p"
+            # (every collective below is entered by every rank whatever happened on it: a rank's failure is a row of the
+            # table, not a missing participant -- the timeline must never cost the headline line, nor hang it)
+            err = None
             try:
                 if not was_p2p:
                     engine.set_p2p(True)
+            except Exception as exc:
+                err = f"{type(exc).__name__}: {exc}"
+            errs = gather(err)
+            if all(x is None for x in errs):
                 barrier()
-                mine = engine.profile_sharded_steps(args.steps)
+                try:
+                    mine = engine.profile_sharded_steps(args.steps)
+                except Exception as exc:
+                    mine = {"error": f"{type(exc).__name__}: {exc}"}
                 mine["rank"] = rank
-                if dist is not None and world > 1:
-                    rows = [None] * world
-                    dist.all_gather_object(rows, mine)
-                else:
-                    rows = [mine]
-                exchange["timeline_us_per_rank"] = rows
+                exchange["timeline_us_per_rank"] = gather(mine)
                 exchange["timeline_protocol"] = (
                     f"{args.steps} steps per rank through the peer-to-peer tail; step / fused_pass / tail_exchange_launch from HIP events "
                     "on the dispatches, the rest averaged over the tail's row workgroups from in-kernel 100 MHz stamps"
                 )
-            except Exception as exc:  # the timeline must never cost the headline line
-                exchange["timeline_error"] = f"{type(exc).__name__}: {exc}"
-            finally:
-                if not was_p2p:
+            else:
+                exchange["timeline_error"] = errs
+            if not was_p2p:
+                try:
                     engine.set_p2p(False)
-                barrier()
+                except Exception as exc:
+                    exchange["timeline_error"] = f"{type(exc).__name__}: {exc}"
+            barrier()
+        # what the exchange layers themselves say about this job: the RCCL communicator's own rank count (ncclCommCount, not the
+        # number this script passed), the peer-to-peer exchange's mapped inboxes, and each rank's device / PCI bus id
+        try:
+            seen = engine.comm_observed()
+        except Exception as exc:
+            seen = {"error": f"{type(exc).__name__}: {exc}"}
+        seen["rank"], seen["local_rank"], seen["pid"] = rank, local_rank, os.getpid()
+        rows = gather(seen)
+        exchange["ranks"] = rows
+        exchange["rccl_nranks"] = min((r.get("rccl_nranks", -1) for r in rows), default=-1)
+        exchange["p2p_nranks"] = min((r.get("p2p_nranks", 0) for r in rows), default=0)
+        exchange["distinct_devices"] = len({r.get("pci_bus_id") for r in rows if r.get("pci_bus_id")})
 
     # untimed: kernel durations from HIP events bound to the dispatches of every 2nd step of 200 (100 samples each)
     barrier()
@@ -573,65 +628,108 @@ def main():
     gpu_sections["kernel_samples"] = time.perf_counter() - t_sec
     barrier()
 
+    # From here on nothing may cost the headline line (the timed blocks above are the measurement): what only rank 0 does is
+    # wrapped on rank 0, and what all ranks do together is wrapped with the collectives OUTSIDE the guarded part, so that a
+    # rank that failed still meets the others.
     one_gpu = None
     if strong and not args.no_one_gpu_reference:
         # the same problem on ONE GPU (rank 0's), the figure the N-GPU value is to be compared with
         if rank == 0:
-            Xa, Ha = problem_rows(0, n_total)
-            e1 = sal.Engine(n_total, V, K, device=local_rank)
-            e1.upload_X(Xa), e1.upload_W(W0), e1.upload_H(Ha)
-            del Xa, Ha
-            e1.kl_step(5)
-            e1.sync()
-            ts = []
-            for _ in range(5):
-                t0 = time.perf_counter()
-                e1.kl_step(args.steps)
+            try:
+                Xa, Ha = problem_rows(0, n_total)
+                e1 = sal.Engine(n_total, V, K, device=device)
+                e1.upload_X(Xa), e1.upload_W(W0), e1.upload_H(Ha)
+                del Xa, Ha
+                e1.kl_step(5)
                 e1.sync()
-                ts.append((time.perf_counter() - t0) / args.steps)
-            e1.close()
-            t1 = statistics.median(ts)
-            one_gpu = {
-                "n_gpus": 1,
-                "n_samples": n_total,
-                "ms_per_step": t1 * 1e3,
-                "steps_per_s": 1.0 / t1,
-                "speedup_of_this_run": (args.steps / median) * t1,
-                "how": f"rank 0 alone, median of 5 blocks of {args.steps} steps, same 10^6-sample problem",
-            }
+                ts = []
+                for _ in range(5):
+                    t0 = time.perf_counter()
+                    e1.kl_step(args.steps)
+                    e1.sync()
+                    ts.append((time.perf_counter() - t0) / args.steps)
+                e1.close()
+                t1 = statistics.median(ts)
+                one_gpu = {
+                    "n_gpus": 1,
+                    "n_samples": n_total,
+                    "ms_per_step": t1 * 1e3,
+                    "steps_per_s": 1.0 / t1,
+                    "speedup_of_this_run": (args.steps / median) * t1,
+                    "how": f"rank 0 alone, median of 5 blocks of {args.steps} steps, same {n_total}-sample problem"
+                    + (" (the other ranks' engines idle on the SAME device: rehearsal)" if args.rehearse_one_device else ""),
+                }
+            except Exception as exc:
+                one_gpu = {"error": f"{type(exc).__name__}: {exc}"}
         barrier()
 
     # N > 1 (and the rehearsal): the other half of the metric for the sharded problem.  Rank 0 times the NumPy oracle on the
     # WHOLE problem (a few steps: one step of 96 x 10^6 takes seconds) and broadcasts the KL it reached; then all ranks
     # run the sharded device loop to that target together (the objectives are all-reduced: every rank takes the same
-    # decision).
+    # decision), and once more for exactly the CPU path's number of steps: the north star's parity gate on the sharded run
+    # (W, replicated, on every rank; H on rank 0's rows).
     sharded_cpu, sharded_ttk = None, None
     if strong and not args.no_cpu_baseline:
         box = [None]
+        W_cpu = H_cpu = None
         if rank == 0:
-            Xa, Ha = problem_rows(0, n_total)
-            rec, (n_cpu, target, cpu_s) = cpu_baseline(Xa, W0, Ha, args.cpu_steps_sharded, args.cpu_budget)
-            del Xa, Ha
-            box = [(rec, n_cpu, target, cpu_s)]
+            try:
+                Xa, Ha = problem_rows(0, n_total)
+                rec, (n_cpu, target, cpu_s, W_cpu, H_cpu) = cpu_baseline(Xa, W0, Ha, args.cpu_steps_sharded, args.cpu_budget)
+                del Xa, Ha
+                H_cpu = H_cpu[:n_local].copy()
+                box = [(rec, n_cpu, target, cpu_s)]
+            except Exception as exc:
+                box = [{"error": f"{type(exc).__name__}: {exc}"}]
         if world > 1:
             dist.broadcast_object_list(box, src=0)
-        sharded_cpu, n_cpu, target, cpu_s = box[0]
-        engine.upload_W(W0)
-        engine.upload_H(H0)
-        barrier()
-        steps, obj, loop_s = device_loop_to_target(engine, target, n_cpu + 100)
-        loop_s = max_over_ranks(loop_s)
-        sharded_ttk = {
-            "target": f"KL the NumPy oracle reaches after {n_cpu} update_WH steps on the whole {V}x{n_total} problem from the shared init",
-            "cpu_steps": n_cpu,
-            "target_kl": target,
-            "cpu_seconds": cpu_s,
-            "gpu_steps_to_target": steps,
-            "gpu_objective_there": obj,
-            "reached": bool(obj <= target * (1 + 1e-12)),
-            "gpu_loop_seconds": loop_s,
-            "gpu_loop_protocol": "sharded device loop on all ranks, objective (all-reduced) every 10 steps; maximum over ranks",
-        }
+        if isinstance(box[0], dict):
+            sharded_cpu = box[0]
+        else:
+            sharded_cpu, n_cpu, target, cpu_s = box[0]
+            steps = obj = None
+            loop_s, err, gate = float("nan"), None, None
+            barrier()
+            try:
+                engine.upload_W(W0)
+                engine.upload_H(H0)
+                steps, obj, loop_s = device_loop_to_target(engine, target, n_cpu + 100)
+                engine.upload_W(W0)
+                engine.upload_H(H0)
+                engine.kl_step(n_cpu)
+                Wg = engine.download_W()
+                digest = float(np.frombuffer(Wg.tobytes(), dtype=np.uint32).astype(np.uint64).sum() % (1 << 52))
+                gate = {"W_digest": digest}
+                if rank == 0:
+                    rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+                    gate.update({"rel_l2_W": rel(Wg, W_cpu), "rel_l2_H_rank0_rows": rel(engine.download_H(), H_cpu)})
+            except Exception as exc:
+                err = f"{type(exc).__name__}: {exc}"
+            loop_s = max_over_ranks(loop_s)
+            rows = gather((err, gate))
+            errs = [r[0] for r in rows if r[0] is not None]
+            if errs or steps is None:
+                sharded_ttk = {"error": errs or ["failed on another rank"]}
+            else:
+                same_W = len({r[1]["W_digest"] for r in rows}) == 1
+                g0 = rows[0][1]
+                sharded_ttk = {
+                    "target": f"KL the NumPy oracle reaches after {n_cpu} update_WH steps on the whole {V}x{n_total} problem from the shared init",
+                    "cpu_steps": n_cpu,
+                    "target_kl": target,
+                    "cpu_seconds": cpu_s,
+                    "gpu_steps_to_target": steps,
+                    "gpu_objective_there": obj,
+                    "reached": bool(obj <= target * (1 + 1e-12)),
+                    "gpu_loop_seconds": loop_s,
+                    "gpu_loop_protocol": "sharded device loop on all ranks, objective (all-reduced) every 10 steps; maximum over ranks",
+                    "parity_steps": n_cpu,
+                    "rel_l2_W": g0["rel_l2_W"],
+                    "rel_l2_H_rank0_rows": g0["rel_l2_H_rank0_rows"],
+                    "W_identical_on_all_ranks": same_W,
+                    "parity_gate": 1e-4,
+                    "parity_ok": bool(max(g0["rel_l2_W"], g0["rel_l2_H_rank0_rows"]) <= 1e-4 and same_W),
+                }
         barrier()
 
     if rank == 0:
@@ -718,6 +816,13 @@ def main():
         if sharded_cpu is not None:
             line["cpu_baseline"] = sharded_cpu
             line["time_to_kl"] = sharded_ttk
+            if sharded_ttk and "rel_l2_W" in sharded_ttk:
+                line["parity"] = {k: sharded_ttk[k] for k in ("parity_steps", "rel_l2_W", "rel_l2_H_rank0_rows", "W_identical_on_all_ranks", "parity_gate", "parity_ok")}
+        if args.rehearse_one_device:
+            line["config"]["rehearsal"] = (
+                f"{world} ranks as processes on ONE GPU (device 0), control plane gloo, no RCCL, peer-to-peer exchange between the "
+                "processes: a rehearsal of the --gpus N flow, NOT a scaling measurement"
+            )
         if not sharded:
             # the other single-GPU configurations FIRST, the CPU baseline (100 s of NumPy on the host cores, the GPU idle)
             # last: a utilisation trace of this process shows the device at work for the first part of the run, then nothing
@@ -733,11 +838,13 @@ def main():
                 line["extra"] = extra
             if not args.no_cpu_baseline:
                 t_cpu = time.perf_counter()
-                rec, (n_cpu, target, cpu_s) = cpu_baseline(X, W0, H0, args.cpu_steps, args.cpu_budget)
+                rec, (n_cpu, target, cpu_s, W_cpu, H_cpu) = cpu_baseline(X, W0, H0, args.cpu_steps, args.cpu_budget)
                 line["cpu_baseline"] = rec
                 cpu_wall = time.perf_counter() - t_cpu
                 t_sec = time.perf_counter()
-                line["time_to_kl"] = time_to_kl(sal, X, W0, H0, n_cpu, target, cpu_s, local_rank)
+                line["time_to_kl"] = time_to_kl(sal, X, W0, H0, n_cpu, target, cpu_s, local_rank, W_cpu, H_cpu)
+                # the north star's gate, also at the top level of the line: W, H after the SAME number of steps as the CPU path
+                line["parity"] = {k: line["time_to_kl"][k] for k in ("parity_steps", "rel_l2_W", "rel_l2_H", "parity_gate", "parity_ok")}
                 gpu_sections["time_to_kl"] = time.perf_counter() - t_sec
                 line["cpu_baseline_wall_seconds"] = cpu_wall
         # where this process's wall clock went: the GPU works in the sections listed (the timed blocks are pure device

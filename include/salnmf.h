@@ -332,6 +332,20 @@ int salnmf_comm_init(salnmf_engine* e, const char* id, int n_ranks, int rank);
 /* Number of ranks, this engine's rank, and the number of samples over all shards (n_samples of this engine
  * when no communicator is attached).  Any output may be NULL. */
 int salnmf_comm_info(salnmf_engine* e, int* n_ranks, int* rank, int64_t* n_samples_total);
+/* What the exchange layers THEMSELVES report about this engine, as opposed to what the caller passed to comm_init /
+ * p2p_connect (the reference has no counterpart: SURVEY.md 8e; a benchmark line that claims N ranks quotes these):
+ *   rccl_nranks, rccl_rank, rccl_device : ncclCommCount / ncclCommUserRank / ncclCommCuDevice of the attached
+ *       communicator; -1 without a communicator (or if the RCCL in the process lacks the query)
+ *   p2p_nranks        : ranks of the connected peer-to-peer exchange (0 when not connected)
+ *   p2p_inboxes_mapped: inboxes this engine holds a mapping of, its own included (== p2p_nranks when connected)
+ *   peer_devices      : SALNMF_P2P_MAX_RANKS ints, the HIP device (as this process numbers them) on which rank r's inbox
+ *       lives, -1 for ranks beyond p2p_nranks or where the runtime cannot tell for an IPC mapping
+ *   device, pci_bus_id: this engine's HIP device and its PCI bus id ("0000:05:00.0", SALNMF_PCI_BUS_ID_BYTES incl. NUL)
+ * Any output may be NULL. */
+#define SALNMF_P2P_MAX_RANKS 8
+#define SALNMF_PCI_BUS_ID_BYTES 32
+int salnmf_comm_observed(salnmf_engine* e, int* rccl_nranks, int* rccl_rank, int* rccl_device, int* p2p_nranks, int* p2p_inboxes_mapped,
+                         int* peer_devices /* SALNMF_P2P_MAX_RANKS */, int* device, char* pci_bus_id /* SALNMF_PCI_BUS_ID_BYTES */);
 
 /* Peer-to-peer exchange for the small all-reduces (the K x V numerator, the MvNMF line-search sums, objective scalars):
  * every rank stores its vector straight into an inbox on each peer of the node (hipIpc-mapped uncached memory, xGMI

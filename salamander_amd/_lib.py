@@ -87,6 +87,7 @@ SIGNATURES = {
     "salnmf_comm_unique_id": (c_int, [ctypes.c_char_p]),
     "salnmf_comm_init": (c_int, [_P, ctypes.c_char_p, c_int, c_int]),
     "salnmf_comm_info": (c_int, [_P, POINTER(c_int), POINTER(c_int), POINTER(c_int64)]),
+    "salnmf_comm_observed": (c_int, [_P, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int), ctypes.c_char_p]),
     "salnmf_p2p_export": (c_int, [_P, c_int, c_int64, ctypes.c_char_p]),
     "salnmf_set_p2p_timeout_ms": (c_int, [_P, c_int64]),
     "salnmf_p2p_connect": (c_int, [_P, c_int, c_int, ctypes.c_char_p, c_int64]),

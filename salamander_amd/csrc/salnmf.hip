@@ -70,6 +70,10 @@ struct RcclApi {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    // optional (salnmf_comm_observed): what the communicator itself says about its size, this rank and its device
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommCuDevice)(const ncclComm_t, int*) = nullptr;
 };
 static RcclApi g_rccl;
 static std::mutex g_rccl_mutex;
@@ -98,6 +102,9 @@ static int rccl_bind() {
     SALNMF_BIND(GetErrorString, "ncclGetErrorString")
 #undef SALNMF_BIND
     if (!ok) return fail("the RCCL library in this process lacks a symbol this engine needs");
+    *(void**)(&api.CommCount) = dlsym(h, "ncclCommCount");
+    *(void**)(&api.CommUserRank) = dlsym(h, "ncclCommUserRank");
+    *(void**)(&api.CommCuDevice) = dlsym(h, "ncclCommCuDevice");
     g_rccl = api;
     return 0;
 }
@@ -1732,7 +1739,7 @@ static int mv_wide_logdet(salnmf_engine* e, const double* W, double delta, int s
 // numerator of (W, H) -> Gblk, rowsums_H -> red + K V, A = W Y_minus, B = W |Y| -> mvA, mvB, log det(W) -> scal[3]
 static int mv_wide_prepare(salnmf_engine* e, double delta) {
     CK(flush_H_scale(e));  // (the column sums below read H as it is)
-    CK(blocked_numerators(e));
+    CK(blocked_numerators(e, false));  // update_W_unconstrained takes no weights (mvnmf.py:37-66): as the narrow path
     hipLaunchKernelGGL(colsum_kernel, dim3(e->K), dim3(256), 0, e->stream, e->H, e->N, e->KP, e->red + (size_t)e->K * e->V);
     HIPCK(hipGetLastError());
     hipLaunchKernelGGL(mv_prepare_W_wide_kernel, dim3(1), dim3(MV_BLOCK), 0, e->stream, e->W, e->K, e->V, delta, e->mvA, e->mvB, e->scal + 3);
@@ -2305,7 +2312,7 @@ int salnmf_mv_step_objective(salnmf_engine* e, int n_steps, int n_given, double 
         e->keep_valid = false;
         double f = 0.0;
         for (int i = 0; i < n_steps; ++i) {
-            CK(blocked_update_H(e, e->H));  // MvNMF._update_H (mvnmf.py:162-165): in place, unweighted
+            CK(blocked_update_H(e, e->H, kEps, false));  // MvNMF._update_H (mvnmf.py:162-165): in place, unweighted
             e->h_pending = false;
             CK(mv_wide_update_W(e, n_given, lam, delta, gamma_inout, &f));
         }
@@ -3160,6 +3167,47 @@ int salnmf_comm_info(salnmf_engine* e, int* n_ranks, int* rank, int64_t* n_sampl
     return 0;
 }
 
+int salnmf_comm_observed(salnmf_engine* e, int* rccl_nranks, int* rccl_rank, int* rccl_device, int* p2p_nranks, int* p2p_inboxes_mapped,
+                         int* peer_devices, int* device, char* pci_bus_id) {
+    if (!e) return fail("null engine");
+    HIPCK(hipSetDevice(e->device));
+    int cnt = -1, urank = -1, cdev = -1;
+    if (e->comm) {  // asked of the communicator, not echoed from salnmf_comm_init's arguments
+        if (g_rccl.CommCount && g_rccl.CommCount(e->comm, &cnt) != ncclSuccess) cnt = -1;
+        if (g_rccl.CommUserRank && g_rccl.CommUserRank(e->comm, &urank) != ncclSuccess) urank = -1;
+        if (g_rccl.CommCuDevice && g_rccl.CommCuDevice(e->comm, &cdev) != ncclSuccess) cdev = -1;
+    }
+    if (rccl_nranks) *rccl_nranks = cnt;
+    if (rccl_rank) *rccl_rank = urank;
+    if (rccl_device) *rccl_device = cdev;
+    int mapped = 0;
+    for (int r = 0; r < P2P_MAX_RANKS; ++r) {
+        int dev = -1;
+        if (e->p2p.connected && r < e->p2p.n_ranks && e->p2p.inbox[r]) {
+            ++mapped;
+            hipPointerAttribute_t attr;
+            // (the device an inbox lives on as THIS process numbers it; an IPC mapping of a peer process's memory may not
+            // resolve, which leaves -1)
+            if (hipPointerGetAttributes(&attr, e->p2p.inbox[r]) == hipSuccess)
+                dev = attr.device;
+            else
+                (void)hipGetLastError();
+        }
+        if (peer_devices) peer_devices[r] = dev;
+    }
+    if (p2p_nranks) *p2p_nranks = e->p2p.connected ? e->p2p.n_ranks : 0;
+    if (p2p_inboxes_mapped) *p2p_inboxes_mapped = mapped;
+    if (device) *device = e->device;
+    if (pci_bus_id) {
+        memset(pci_bus_id, 0, SALNMF_PCI_BUS_ID_BYTES);
+        if (hipDeviceGetPCIBusId(pci_bus_id, SALNMF_PCI_BUS_ID_BYTES - 1, e->device) != hipSuccess) {
+            (void)hipGetLastError();
+            pci_bus_id[0] = 0;
+        }
+    }
+    return 0;
+}
+
 int salnmf_p2p_export(salnmf_engine* e, int n_ranks, int64_t max_count, char* handle_out) {
     if (e && split(e)) return single_block(e, "a sample-sharded engine");
     if (!e || !handle_out) return fail("null argument");
@@ -3327,24 +3375,28 @@ int salnmf_profile_sharded_steps(salnmf_engine* e, int n_steps, int n_given, dou
     const size_t count = (size_t)e->K * e->V;
     if (!(p2p_usable(e, count) && e->K <= P2P_MAX_WG)) return fail("the sharded timeline needs the peer-to-peer exchange (salnmf_p2p_connect, salnmf_set_p2p)");
     if (e->wkl || e->wlh) return fail("the sharded timeline profiles the unweighted step");
+    // (with every signature given the step has no W update, hence no exchange launch: there would be nothing to report but zeros)
+    if (n_given < 0 || n_given >= e->K) return fail("the sharded timeline needs a step with an exchange: n_given must be in 0..K-1");
     CK(ensure_events(e, (size_t)4 * n_steps + 2));
     unsigned long long* dstamps = nullptr;
     const size_t n_stamps = (size_t)n_steps * 6 * P2P_MAX_WG;
     HIPCK(hipMalloc(&dstamps, n_stamps * sizeof(unsigned long long)));
-    HIPCK(hipMemsetAsync(dstamps, 0, n_stamps * sizeof(unsigned long long), e->stream));
     hipEvent_t first = e->events[4 * (size_t)n_steps], last = e->events[4 * (size_t)n_steps + 1];
-    int rc = 0;
-    HIPCK(hipEventRecord(first, e->stream));
+    int rc = 0;  // (from here on every exit path frees dstamps)
+    if (hipMemsetAsync(dstamps, 0, n_stamps * sizeof(unsigned long long), e->stream) != hipSuccess) rc = fail("hipMemsetAsync failed");
+    if (!rc && hipEventRecord(first, e->stream) != hipSuccess) rc = fail("hipEventRecord failed");
     e->p2p.stamps = dstamps;
     for (int i = 0; i < n_steps && !rc; ++i) rc = kl_step_once(e, n_given, &e->events[4 * (size_t)i]);
     e->p2p.stamps = nullptr;
     if (!rc && hipEventRecord(last, e->stream) != hipSuccess) rc = fail("hipEventRecord failed");
-    if (!rc && hipStreamSynchronize(e->stream) != hipSuccess) rc = fail("hipStreamSynchronize failed");
+    // (also after a failed launch: nothing may still be writing stamps when the buffer is freed)
+    if (hipStreamSynchronize(e->stream) != hipSuccess && !rc) rc = fail("hipStreamSynchronize failed");
     std::vector<unsigned long long> st(n_stamps);
     if (!rc && hipMemcpy(st.data(), dstamps, n_stamps * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) rc = fail("stamp download failed");
     (void)hipFree(dstamps);
     if (rc) return rc;
     CK(check_abort(e));
+    if (st[0] == 0 || st[5] == 0) return fail("no exchange launch wrote its stamps: the steps did not take the peer-to-peer tail");
     double fused = 0, tail = 0, seg[5] = {0, 0, 0, 0, 0}, wait_max = 0;
     for (int i = 0; i < n_steps; ++i) {
         float a = 0, b = 0;

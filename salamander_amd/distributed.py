@@ -144,7 +144,13 @@ def host_collective_steps(engine, n_steps: int, n_given: int = 0, group=None) ->
         engine.kl_step_partial()
         if n_given < engine.K:  # all signatures given: W is untouched, nothing to exchange
             buf = engine.numerator()
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+            if getattr(buf, "is_cuda", False) and dist.get_backend(group) == "gloo":
+                # a host-side control plane (rehearsals of several ranks on one GPU): the reduction goes through host memory
+                host = buf.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+                buf.copy_(host)
+            else:
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
             engine.after_collective()
             engine.kl_step_finish(n_given, _lib.CLIP_ALL)
 

@@ -375,6 +375,20 @@ class Engine:
         _lib.check(self._lib.salnmf_comm_info(self._h, ctypes.byref(n), ctypes.byref(r), ctypes.byref(t)))
         return n.value, r.value, t.value
 
+    def comm_observed(self) -> dict:
+        """What the exchange layers themselves report (``include/salnmf.h: salnmf_comm_observed``): the RCCL communicator's own
+        rank count / rank / device (-1 without one), the peer-to-peer exchange's rank count and mapped inboxes, this engine's
+        device and PCI bus id."""
+        ints = [ctypes.c_int() for _ in range(6)]
+        peers = (ctypes.c_int * 8)()
+        bus = ctypes.create_string_buffer(32)
+        _lib.check(self._lib.salnmf_comm_observed(self._h, *[ctypes.byref(i) for i in ints[:5]], peers, ctypes.byref(ints[5]), bus))
+        keys = ("rccl_nranks", "rccl_rank", "rccl_device", "p2p_nranks", "p2p_inboxes_mapped", "device")
+        out = {k: i.value for k, i in zip(keys, ints)}
+        out["p2p_peer_devices"] = [int(v) for v in peers][: max(out["p2p_nranks"], 0)]
+        out["pci_bus_id"] = bus.value.decode()
+        return out
+
     def p2p_export(self, n_ranks: int, max_count: int | None = None) -> bytes:
         """Allocate this engine's inbox of the peer-to-peer exchange (``include/salnmf.h``) and return its IPC handle.
 

@@ -150,6 +150,30 @@ def test_wide_mvnmf_steps_and_function_level_api_match_the_oracle(V, N, K, n_giv
     e.close()
 
 
+@pytest.mark.parametrize("V", [96, 288])
+def test_mvnmf_steps_ignore_sample_weights_on_narrow_and_wide_engines(V):
+    """MvNMF takes no sample weights (``mvnmf.py:37-66,162-165`` pass none): an engine on which ``set_weights`` is active
+    computes the same MvNMF steps as one without, on one feature block and on several (the wide passes used to
+    weight the numerators and the H update but not the objective)."""
+    N, K, lam, delta = 1100, 8, 0.7, 1.0
+    X, W0, H0 = problem(V, N, K, seed=V + 1)
+    rng = np.random.default_rng(V)
+    e = Engine(N, V, K)
+    e.upload_X(X), e.upload_W(W0), e.upload_H(H0)
+    e.set_weights(rng.uniform(0.3, 3.0, N), rng.uniform(0.0, 0.5, N))
+    W, H, g = W0.T, H0.T, 1.0
+    for _ in range(4):
+        W, H, g = orc.mvnmf_step(X.T, W, H, lam, delta, g, 0)
+    gamma = e.mv_step(1, 0, lam, delta, 1.0)
+    gamma, obj = e.mv_step_objective(3, 0, lam, delta, gamma)
+    assert np.isclose(gamma, g, rtol=1e-12)
+    assert rel_l2(e.download_W(), W.T) < 1e-7 and rel_l2(e.download_H(), H.T) < 1e-7
+    assert np.isclose(obj, orc.kl_divergence_penalized(X.T, W, H, lam, delta), rtol=1e-9)
+    Wu = e.mv_update_W_unconstrained(0, lam, delta)
+    assert rel_l2(Wu, orc.update_W_unconstrained(X.T, W, H, lam, delta, 0).T) < 1e-7
+    e.close()
+
+
 def test_wide_mvnmf_model_fit_matches_the_oracle_fit():
     """``MvNMF(10).fit`` on 288 features: same iterations, history and factors as the restated reference loop."""
     V, N, K = 288, 1200, 10
