@@ -190,6 +190,10 @@ int salnmf_mv_line_search(salnmf_engine* e, double lam, double delta, double* ga
  * scalars once per call and resolves a rejected first trial on the classic path.  0 = the classic form: one host decision
  * per step, two passes over the samples.  Same results bit for bit. */
 int salnmf_set_mv_queued(salnmf_engine* e, int on);
+/* The update passes copy W (38 KB at K = 50) into every workgroup's LDS once per launch.  Default (1): by LDS-DMA
+ * (global_load_lds_dwordx4, no registers) where n_features == 96 and W is 16-byte aligned; 0: through registers (the
+ * form of rounds 1-4; any other layout takes it anyway).  Same results bit for bit (W is copied, not computed). */
+int salnmf_set_w_dma(salnmf_engine* e, int on);
 int salnmf_mv_step_objective(salnmf_engine* e, int n_steps, int n_given, double lam, double delta,
                              double* gamma_inout, double* objective_out, int more_follows);
 /* only MvNMF._update_W (:190-195) / only _update_H (= salnmf_update_H) for the

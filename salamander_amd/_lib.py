@@ -47,6 +47,7 @@ SIGNATURES = {
     "salnmf_set_batched_sample_solves": (c_int, [_P, c_int]),
     "salnmf_set_small_cohort_tiles": (c_int, [_P, c_int]),
     "salnmf_set_mv_queued": (c_int, [_P, c_int]),
+    "salnmf_set_w_dma": (c_int, [_P, c_int]),
     "salnmf_set_precision": (c_int, [_P, c_int]),
     "salnmf_update_H": (c_int, [_P]),
     "salnmf_update_W": (c_int, [_P, c_int, c_int]),

@@ -249,6 +249,7 @@ struct salnmf_engine {
     int ls_S = 0, ls_dim = 0;
     bool lockstep = true;  // salnmf_set_lockstep(e, 0) forces the single-kernel form
     bool batched_samples = true;  // salnmf_set_batched_sample_solves(e, 0) forces one wavefront per sample
+    bool w_dma = true;           // salnmf_set_w_dma(e, 0): the update passes stage W through registers instead of by LDS-DMA
     bool mv_queued = true;       // salnmf_set_mv_queued(e, 0): MvNMF steps with the host's line-search decision per step (the classic form)
     unsigned* mvflag = nullptr;  // device word of the queued MvNMF steps: non-zero = a trial was rejected on the device
     int small_max_tiles = SMALL_TILES_DEFAULT;  // salnmf_set_small_cohort_tiles: up to this many tiles salnmf_kl_step runs as one workgroup
@@ -359,6 +360,7 @@ static FusedParams fused_params(salnmf_engine* e) {
     p.ldw = e->V;
     p.K = e->K;
     p.ntiles = e->ntiles;
+    p.wdma = e->w_dma ? 1 : 0;
     return p;
 }
 
@@ -1205,6 +1207,12 @@ static int chunked_kl_step_once(salnmf_engine* e, int n_given) {
 int salnmf_set_lockstep(salnmf_engine* e, int on) {
     if (!e) return fail("null engine");
     e->lockstep = on != 0;
+    return 0;
+}
+
+int salnmf_set_w_dma(salnmf_engine* e, int on) {
+    if (!e) return fail("null engine");
+    e->w_dma = on != 0;
     return 0;
 }
 

@@ -138,6 +138,7 @@ struct FusedParams {
     int ldw;                // row stride of W (= V unless W points at one block of a wider matrix)
     int K;
     int64_t ntiles;
+    int wdma;               // W -> LDS by LDS-DMA where the layout allows it (stage_W_dma_issue); 0: through registers (stage_W)
     // feature blocks (n_features > 96; fused_kernel<..., BLOCKED>, update_H pass only): U = R W^T is a sum over the
     // 96-feature blocks.  ublock = 1: first block, store U into Uacc; 2: add Uacc, store; 3: last block, add Uacc and
     // update H with the total.  Uacc is [Np][KP] like H.
@@ -325,6 +326,33 @@ __device__ __forceinline__ void stage_W(double* Wl, const double* W, int K, int 
         const double w = (k < K) ? ((v < V) ? wreg[j] : 1.0) : 0.0;
         if (k < WROWS) Wl[k * WS + v] = w;
     }
+}
+
+// The same image by LDS-DMA (global_load_lds_dwordx4: lane l's 16 bytes go from its global address straight to LDS at
+// base + 16 l, no register in between) for the common case V == ldw == 96, W 16-byte aligned.  A row of W is 48 pieces
+// of 16 bytes, a row of the image 49 (WS = 98 doubles: the 49th piece is the stride padding, which nothing reads), so piece
+// s of the image is row s / 49, piece s % 49, and instruction i of wave w moves pieces 64 (4 i + w) .. + 63.  Only ISSUES
+// the loads (2 address registers live, against stage_W's 24 values per lane): the caller waits for them
+// (s_waitcnt vmcnt(0)) and joins the workgroup barrier.  The zero rows k >= K are plain stores.
+template <int WROWS>
+__device__ __forceinline__ void stage_W_dma_issue(double* Wl, const double* W, int K, int tid) {
+    static_assert(WS == VMAX + 2, "a row of the image = 48 data pieces + 1 pad piece");
+    constexpr int PPR = WS / 2;                                  // pieces per image row
+    constexpr int NI = (WROWS * PPR + BLOCK - 1) / BLOCK;        // instructions per wave
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int npieces = K * PPR;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int s0 = 64 * (WAVES * i + wave);                  // (wave-uniform) first piece of this instruction
+        const int s = s0 + lane;
+        const int k = s / PPR, c = s - k * PPR;
+        if (s0 < npieces) {                                      // (uniform branch: no instruction for rows beyond K)
+            if (s < npieces && c < PPR - 1)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + k * VMAX + 2 * c),
+                                                 (__attribute__((address_space(3))) void*)(Wl + 2 * s0), 16, 0, 0);
+        }
+    }
+    for (int i = K * WS + tid; i < WROWS * WS; i += BLOCK) Wl[i] = 0.0;
 }
 
 // Sum over one tile (accumulator layout: rows n = q+4r, columns v = 16vt+c16) of the per-sample weighted
@@ -1280,9 +1308,26 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
     } else {
         // (the first tile's loads issued ahead of the staging instead: 69.7 -> 71.9 us per step at c2 -- the prologue's
         // registers then overlap the tile's, 234 -> 256 VGPRs + 24 spill copies; profiles/r03/ab_step_variants.txt)
-        stage_W<G_::WROWS>(Wl, p.W, K, V, p.ldw, tid);
-        __syncthreads();
-        if (tile < nfull) load_tile(tile);
+        // Round 5: for the common layout W travels by LDS-DMA (no registers, 13 instructions per wave at K = 50 against 24
+        // loads + 24 LDS stores): 69.5 -> 69.0 us per step at c2, 79.9 -> 79.4 at c3's shard (alternating blocks on one
+        // engine, profiles/r05/w_dma.md).  The barrier is the bare instruction: __syncthreads() carries a workgroup fence
+        // that hipcc lowers to s_waitcnt vmcnt(0) anyway; here the DMA pieces (counted by vmcnt like any load) and the zero
+        // rows' ds_writes are waited for by hand, and LDS is coherent within the CU.
+        // Measured and dropped in the same A/B: the first tile's loads queued BEHIND the DMA (+2.3 us at c2 whether the wait
+        // is for everything or a counted vmcnt(24) that leaves X in flight: the waves' 20 KB of cold loads each then sit in
+        // the CU's memory pipeline in front of the other waves' DMA pieces, and the barrier waits for the last of those);
+        // only the H tile behind the DMA (+0.5 us at K = 50, -1.0 at K = 30).
+        if (p.wdma && V == VMAX && p.ldw == VMAX && (reinterpret_cast<uintptr_t>(p.W) & 15) == 0) {  // (uniform)
+            stage_W_dma_issue<G_::WROWS>(Wl, p.W, K, tid);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");  // (no LDS read of W is hoisted above the barrier)
+            if (tile < nfull) load_tile(tile);
+        } else {
+            stage_W<G_::WROWS>(Wl, p.W, K, V, p.ldw, tid);
+            __syncthreads();
+            if (tile < nfull) load_tile(tile);
+        }
     }
     for (; tile < nfull; tile += tstride) {
         using std::integral_constant;

@@ -127,6 +127,10 @@ class Engine:
         """Signature-embedding solves in lockstep rounds (default from 16 384 samples on) or one workgroup per signature."""
         _lib.check(self._lib.salnmf_set_lockstep(self._h, int(bool(on))))
 
+    def set_w_dma(self, on: bool = True):
+        """W into the workgroups' LDS by LDS-DMA (default) or through registers (``include/salnmf.h: salnmf_set_w_dma``)."""
+        _lib.check(self._lib.salnmf_set_w_dma(self._h, int(bool(on))))
+
     def set_mv_queued(self, on: bool = True):
         """MvNMF steps queued ahead of the host with the line-search decision on the device (default) or the classic form
         (``include/salnmf.h: salnmf_set_mv_queued``)."""

@@ -20,6 +20,11 @@ Outputs (all float64):
   corr_synth.npz    correlated NMF (row f1): every function of _utils_corrnmf and a 3-update CorrNMFDet
                     trajectory on synthetic counts, K in {7, 12} -- run with ``--corr`` (only this file is
                     regenerated; the embedding solves go through the installed SciPy, as in the reference)
+  corr_c5.npz       the embedding solves at the instantiations config c5 uses -- run with ``--corr-c5``
+                    (~15 min: the reference's Hessian is a Python triple loop without numba): joint sample solves with
+                    ns_signatures [40, 40], dim 40, V = 96 / 83 at the start and after two reference-executed updates of
+                    MultimodalCorrNMF on 256 samples (with that trajectory's final state), and signature solves over
+                    2 304 samples (the size from which the engine's lockstep rounds run), 5 signatures, dim 40
 """
 
 from __future__ import annotations
@@ -207,6 +212,91 @@ def corr_golden(uk, uc):
     print("corr_synth.npz written (scipy", scipy.__version__ + ")")
 
 
+def corr_c5_golden(uk, uc):
+    """corr_c5.npz: the reference's embedding solves at config c5's instantiations (80 terms x dim 40 per sample solve,
+    dim 40 signature solves over thousands of samples).  Inputs that only need to be *some* matrix (embeddings) are drawn
+    in float32 precision so that the file compresses; everything the reference computed is stored in full."""
+    import time
+
+    import scipy
+
+    out = {}
+    f32 = lambda a: a.astype(np.float32).astype(np.float64)
+    t0 = time.time()
+    # ---- (i) MultimodalCorrNMF at c5's shape on 256 samples: three updates in the order of mmcorrnmf.py:443-453, the
+    # joint sample solve's inputs and outputs kept for the first and the third
+    rng = np.random.default_rng(50)
+    N, Ks, Vs, dim = 256, [40, 40], [96, 83], 40
+    U = f32(rng.normal(0, 0.3, (N, dim)))
+    var = 0.7
+    Xs, Ws, betas, Ls, alphas = [], [], [], [], [None, None]
+    for m, (K, V) in enumerate(zip(Ks, Vs)):
+        X, W0, _ = synthetic(V, N, K, 51 + m)
+        Xs.append(X.T.copy())
+        Ws.append(W0.T.copy())
+        betas.append(f32(rng.normal(0, 0.3, K)))
+        Ls.append(f32(rng.normal(0, 0.3, (K, dim))))
+        out.update({f"mm{m}_X": Xs[m], f"mm{m}_W0": Ws[m], f"mm{m}_beta0": betas[m], f"mm{m}_L0": Ls[m]})
+    out.update(mm_U0=U, mm_var0=var)
+    elbos = []
+    for it in (1, 2, 3):
+        auxs, Hs = [], []
+        for m in range(2):
+            alphas[m] = uc.update_sample_scalings(Xs[m], betas[m], Ls[m], U)
+        for m in range(2):
+            Hs.append(uc.compute_exposures(betas[m], alphas[m], Ls[m], U))
+            auxs.append(uc.compute_aux(Xs[m], Ws[m], Hs[m]))
+        for m in range(2):
+            betas[m] = uc.update_signature_scalings(auxs[m], alphas[m], Ls[m], U)
+        outer_U = np.einsum("Dm,Dn->Dmn", U, U)
+        for m in range(2):
+            Ln = Ls[m].copy()
+            for k in range(Ks[m]):
+                # (the reference updates the embeddings matrix row by row in place; a row's solve reads only its own row)
+                Ln[k] = uc.update_embedding(Ls[m][k].copy(), U, betas[m][k], alphas[m], var, auxs[m][k], outer_U)
+            Ls[m] = Ln
+            print(f"  update {it}: signature embeddings of modality {m} done ({time.time() - t0:.0f} s)", flush=True)
+        L_all, beta_all, aux_all = np.concatenate(Ls), np.concatenate(betas), np.concatenate(auxs)
+        outer_L = np.einsum("Km,Kn->Kmn", L_all, L_all)
+        Un = U.copy()
+        for d in range(N):
+            scalings = np.concatenate([np.repeat(alphas[m][d], Ks[m]) for m in range(2)])
+            Un[d] = uc.update_embedding(U[d].copy(), L_all, scalings, beta_all, var, aux_all[:, d], outer_L, options={"maxiter": 3})
+        if it in (1, 3):
+            for m in range(2):
+                out.update({f"s{it}_mm{m}_beta": betas[m], f"s{it}_mm{m}_alpha": alphas[m].copy(), f"s{it}_mm{m}_L": Ls[m], f"s{it}_mm{m}_aux": auxs[m]})
+            out.update({f"s{it}_U": U.copy(), f"s{it}_U_upd": Un.copy(), f"s{it}_var": var})
+        U = Un
+        var = float(np.clip(np.mean(np.concatenate([L_all, U]) ** 2), uk.EPSILON, None))
+        for m in range(2):
+            Ws[m] = uk.update_W(Xs[m].T, Ws[m].T, Hs[m].T, n_given_signatures=0).T
+        elbos.append(sum(uc.elbo_corrnmf(Xs[m], Ws[m], Hs[m], Ls[m], U, var, penalize_sample_embeddings=False) for m in range(2)))
+        print(f"  update {it} done ({time.time() - t0:.0f} s)", flush=True)
+    for m in range(2):
+        out.update({f"mm{m}_W3": Ws[m], f"mm{m}_beta3": betas[m], f"mm{m}_alpha3": alphas[m], f"mm{m}_L3": Ls[m], f"mm{m}_H3": Hs[m]})
+    out.update(mm_U3=U, mm_var3=var, mm_llh_plus_signature_priors=np.array(elbos))
+    # ---- (ii) signature solves over 2 304 samples (ragged against every tile size; from 2 048 on the engine takes lockstep
+    # rounds with the packed evaluation kernel), 5 signatures = one group, dim 40, default options as corrnmf_det.py:88-141
+    rng = np.random.default_rng(60)
+    N, K, dim, var = 2304, 5, 40, 0.6
+    X, W0, _ = synthetic(96, N, K, 61)
+    X, W = X.T.copy(), W0.T.copy()
+    U = f32(rng.normal(0, 0.3, (N, dim)))
+    L = f32(rng.normal(0, 0.3, (K, dim)))
+    beta = f32(rng.normal(0, 0.3, K))
+    alpha = uc.update_sample_scalings(X, beta, L, U)
+    aux = uc.compute_aux(X, W, uc.compute_exposures(beta, alpha, L, U))
+    outer_U = np.einsum("Dm,Dn->Dmn", U, U)
+    Ln = L.copy()
+    for k in range(K):
+        Ln[k] = uc.update_embedding(L[k].copy(), U, beta[k], alpha, var, aux[k], outer_U)
+        print(f"  signature solve {k} over {N} samples done ({time.time() - t0:.0f} s)", flush=True)
+    out.update(g_U=U, g_L=L, g_beta=beta, g_alpha=alpha, g_aux=aux, g_var=var, g_L_upd=Ln)
+    out["scipy_version"] = np.array(scipy.__version__)
+    np.savez_compressed(os.path.join(HERE, "corr_c5.npz"), **out)
+    print("corr_c5.npz written (scipy", scipy.__version__ + f", {time.time() - t0:.0f} s)")
+
+
 def main():
     if not os.path.isdir(REF):
         print("no /root/reference here: nothing to do")
@@ -214,6 +304,9 @@ def main():
     uk, mv = load_reference()
     if "--corr" in sys.argv:
         corr_golden(uk, load_reference_corrnmf())
+        return
+    if "--corr-c5" in sys.argv:
+        corr_c5_golden(uk, load_reference_corrnmf())
         return
     EPS = uk.EPSILON
     copy_ref_fixtures()

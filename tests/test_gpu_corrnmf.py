@@ -678,3 +678,32 @@ def test_batched_sample_solves_agree_with_one_wavefront_per_sample(N, K, dim, ma
         assert co.embedding_objective(Ua[n], L, alpha[n], beta, 0.8, aux[:, n]) < f0
     # at full convergence the last line search works at rounding level: success vs 'precision loss' may differ
     assert (sa == sb).mean() >= (0.97 if maxiter > 0 else 0.8)
+
+
+# ------------------------------------------------------------------ the lockstep kernels against vectors the REFERENCE produced
+@pytest.mark.parametrize("lockstep", [True, False])
+def test_c5_instantiation_signature_solves_match_reference_executed_vectors(lockstep):
+    """Five signatures (one group of the packed evaluation kernel), dim 40 (the LDS-DMA variant, ``ls_eval_packed_kernel``
+    with three row tiles), 2 304 samples -- above the 2 048 from which the solves run as lockstep rounds: against the
+    reference's ``update_embedding`` results for the same problems (``tests/golden/corr_c5.npz``, made by
+    ``make_golden.py --corr-c5``), and the one-workgroup-per-signature kernel beside it.  Measured on an MI355X:
+    max |diff| 2.5e-15 / 2.3e-15 (lockstep / single kernel), all five solves converged; asserted at 1e-11."""
+    from test_oracle_corrnmf import load_c5_signature_solve
+
+    r, var = load_c5_signature_solve()
+    N, dim = r["U"].shape
+    K = len(r["beta"])
+    e = Engine(N, 96, K)
+    e.set_lockstep(lockstep)
+    e.corr_configure(dim)
+    e.corr_upload(_lib.CORR_SIGNATURE_SCALINGS, r["beta"])
+    e.corr_upload(_lib.CORR_SAMPLE_SCALINGS, r["alpha"])
+    e.corr_upload(_lib.CORR_SIGNATURE_EMBEDDINGS, r["L"])
+    e.corr_upload(_lib.CORR_SAMPLE_EMBEDDINGS, r["U"])
+    e.corr_upload(_lib.CORR_AUX, np.ascontiguousarray(r["aux"].T))
+    status = e.corr_update_signature_embeddings(var, 0, return_status=True)
+    got = e.corr_download(_lib.CORR_SIGNATURE_EMBEDDINGS)
+    e.close()
+    err = np.abs(got - r["L_upd"]).max()
+    print(f"c5 signature solves, lockstep={lockstep}: max |diff| {err:.2e}, status {status}")
+    assert err < 1e-11

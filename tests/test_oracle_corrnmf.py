@@ -246,3 +246,62 @@ def test_reference_executed_joint_sample_solve():
     mods, U, U_upd, var = load_mm_synth()
     got = co.mm_update_sample_embeddings([m["aux"] for m in mods], [m["L"] for m in mods], U, [m["beta"] for m in mods], [m["alpha"] for m in mods], var)
     assert np.allclose(got, U_upd, rtol=1e-6, atol=1e-9)
+
+
+# ------------------------------------------------------------------ the instantiations config c5 uses (corr_c5.npz)
+CORR_C5 = os.path.join(os.path.dirname(__file__), "golden", "corr_c5.npz")
+
+
+def load_c5_sample_solve(it):
+    """Inputs and the reference-executed result of the joint sample solve of update ``it`` (1 or 3) of MultimodalCorrNMF at
+    c5's shape: ns_signatures [40, 40], dim 40, 256 samples (``tests/golden/make_golden.py --corr-c5``)."""
+    g = np.load(CORR_C5)
+    mods = [{k: g[f"s{it}_mm{m}_{k}"] for k in ("beta", "alpha", "L", "aux")} for m in range(2)]
+    return mods, g[f"s{it}_U"], g[f"s{it}_U_upd"], float(g[f"s{it}_var"])
+
+
+def load_c5_signature_solve():
+    g = np.load(CORR_C5)
+    return {k: g["g_" + k] for k in ("U", "L", "beta", "alpha", "aux", "L_upd")}, float(g["g_var"])
+
+
+def load_c5_trajectory():
+    g = np.load(CORR_C5)
+    start = {"Xs": [g["mm0_X"], g["mm1_X"]], "Ws": [g["mm0_W0"], g["mm1_W0"]], "betas": [g["mm0_beta0"], g["mm1_beta0"]],
+             "Ls": [g["mm0_L0"], g["mm1_L0"]], "U": g["mm_U0"], "var": float(g["mm_var0"])}
+    end = {"Ws": [g["mm0_W3"], g["mm1_W3"]], "betas": [g["mm0_beta3"], g["mm1_beta3"]], "alphas": [g["mm0_alpha3"], g["mm1_alpha3"]],
+           "Ls": [g["mm0_L3"], g["mm1_L3"]], "Hs": [g["mm0_H3"], g["mm1_H3"]], "U": g["mm_U3"], "var": float(g["mm_var3"]),
+           "llh_plus_signature_priors": g["mm_llh_plus_signature_priors"]}
+    return start, end
+
+
+@pytest.mark.parametrize("it", [1, 3])
+def test_c5_shape_joint_sample_solves_match_reference_executed_vectors(it):
+    """80 terms x dim 40, maxiter 3 (``mmcorrnmf.py:398-428``): the restated solve against what the reference's
+    ``update_embedding`` returned for the same 256 problems -- at the random start and on the state two updates later."""
+    mods, U, U_upd, var = load_c5_sample_solve(it)
+    got = co.mm_update_sample_embeddings([m["aux"] for m in mods], [m["L"] for m in mods], U, [m["beta"] for m in mods], [m["alpha"] for m in mods], var)
+    assert np.allclose(got, U_upd, rtol=1e-9, atol=1e-12)
+
+
+def test_c5_shape_signature_solves_over_2304_samples_match_reference_executed_vectors():
+    """dim 40 signature solves (``corrnmf_det.py:88-141``, ``mmcorrnmf.py:319-334``) over 2 304 samples."""
+    r, var = load_c5_signature_solve()
+    got = co.update_signature_embeddings(r["aux"], r["L"], r["U"], r["beta"], r["alpha"], var)
+    assert np.allclose(got, r["L_upd"], rtol=1e-8, atol=1e-11)
+
+
+def test_c5_shape_three_updates_match_the_reference_executed_trajectory():
+    """Three ``MultimodalCorrNMF._update_parameters`` (``mmcorrnmf.py:443-453``) at c5's shape on 256 samples."""
+    s, e = load_c5_trajectory()
+    Ws, betas, Ls, U, var = s["Ws"], s["betas"], s["Ls"], s["U"], s["var"]
+    alphas = [None, None]
+    for _ in range(3):
+        Ws, betas, alphas, Ls, U, var, Hs = co.mm_step(s["Xs"], Ws, betas, alphas, Ls, U, var)
+    for m in range(2):
+        assert np.allclose(Ws[m], e["Ws"][m], rtol=1e-6, atol=1e-12) and np.allclose(Hs[m], e["Hs"][m], rtol=1e-6)
+        assert np.allclose(betas[m], e["betas"][m], rtol=0, atol=1e-8) and np.allclose(alphas[m], e["alphas"][m], rtol=0, atol=1e-8)
+        assert np.allclose(Ls[m], e["Ls"][m], rtol=1e-5, atol=1e-7)
+    assert np.allclose(U, e["U"], rtol=1e-5, atol=1e-7) and np.isclose(var, e["var"], rtol=1e-8)
+    llh = sum(co.elbo_corrnmf(s["Xs"][m], Ws[m], Hs[m], Ls[m], U, var, penalize_sample_embeddings=False) for m in range(2))
+    assert np.isclose(llh, float(e["llh_plus_signature_priors"][-1]), rtol=1e-9)
