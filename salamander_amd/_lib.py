@@ -12,7 +12,8 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsalnmf.so")
+# (SALNMF_LIB: a development hook of this loader -- tools/ A/B runs of two builds of the library in one gpurun call)
+LIB_PATH = os.environ.get("SALNMF_LIB") or os.path.join(_HERE, "lib", "libsalnmf.so")
 
 UNIQUE_ID_BYTES = 128
 P2P_HANDLE_BYTES = 64

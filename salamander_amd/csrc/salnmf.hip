@@ -249,6 +249,7 @@ struct salnmf_engine {
     int ls_S = 0, ls_dim = 0;
     bool lockstep = true;  // salnmf_set_lockstep(e, 0) forces the single-kernel form
     bool batched_samples = true;  // salnmf_set_batched_sample_solves(e, 0) forces one wavefront per sample
+    unsigned long long* fk_prof = nullptr;  // (SALNMF_DEV_PROFILE builds) section clocks of the fused passes, printed by salnmf_destroy
     bool w_dma = true;           // salnmf_set_w_dma(e, 0): the update passes stage W through registers instead of by LDS-DMA
     bool mv_queued = true;       // salnmf_set_mv_queued(e, 0): MvNMF steps with the host's line-search decision per step (the classic form)
     unsigned* mvflag = nullptr;  // device word of the queued MvNMF steps: non-zero = a trial was rejected on the device
@@ -341,6 +342,7 @@ static int launch_forward(salnmf_engine* e, const FwdParams& p, int grid = 0, hi
     return 0;
 }
 
+constexpr size_t FK_PROF_ROWS = 4096;  // (SALNMF_DEV_PROFILE) waves of the largest grid
 static FusedParams fused_params(salnmf_engine* e) {
     FusedParams p{};  // (the optional parts -- MvNMF side workgroup, in-launch KL sum, persistent mode -- are off)
     p.X = e->X;
@@ -361,6 +363,11 @@ static FusedParams fused_params(salnmf_engine* e) {
     p.K = e->K;
     p.ntiles = e->ntiles;
     p.wdma = e->w_dma ? 1 : 0;
+#ifdef SALNMF_DEV_PROFILE
+    if (!e->fk_prof && hipMalloc(&e->fk_prof, FK_PROF_ROWS * (FK_NSEC + 1) * sizeof(unsigned long long)) == hipSuccess)
+        (void)hipMemset(e->fk_prof, 0, FK_PROF_ROWS * (FK_NSEC + 1) * sizeof(unsigned long long));
+    p.prof = e->fk_prof;
+#endif
     return p;
 }
 
@@ -611,6 +618,36 @@ void salnmf_destroy(salnmf_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+#ifdef SALNMF_DEV_PROFILE
+    if (e->fk_prof) {  // section clocks of every fused pass this engine launched (salnmf_kernels.h: FK_TICK)
+        std::vector<unsigned long long> rows(FK_PROF_ROWS * (FK_NSEC + 1));
+        unsigned long long t[FK_NSEC + 1] = {};
+        size_t nw = 0;
+        if (hipMemcpy(rows.data(), e->fk_prof, rows.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+            for (size_t w = 0; w < FK_PROF_ROWS; ++w) {
+                if (rows[w * (FK_NSEC + 1) + FK_NSEC] == 0 && rows[w * (FK_NSEC + 1)] == 0) continue;
+                ++nw;
+                for (int i = 0; i <= FK_NSEC; ++i) t[i] += rows[w * (FK_NSEC + 1) + i];
+            }
+        }
+        if (t[FK_NSEC] > 0) {
+            static const char* names[FK_NSEC] = {"prologue", "a.stage_H", "a.P_product", "a.KL_terms", "a.divisions", "a.prefetch+R_transpose", "a.G_phase",
+                                                 "a.U_phase+H_update", "b.stage_H", "b.P_product", "b.KL_terms", "b.divisions", "b.prefetch+R_transpose",
+                                                 "b.G_phase", "b.U_phase+H_update", "epilogue"};
+            unsigned long long tot = 0;
+            for (int i = 0; i < FK_NSEC; ++i) tot += t[i];
+            fprintf(stderr, "[salnmf dev profile] fused passes of engine N=%lld K=%d: %zu waves, %llu (wave, tile) pairs, %.0f shader-clock cycles per wave in all\n",
+                    (long long)e->N, e->K, nw, t[FK_NSEC], (double)tot / nw);
+            for (int i = 0; i < FK_NSEC; ++i)
+                if (t[i]) {
+                    const bool per_tile = i != 0 && i != FK_NSEC - 1;
+                    fprintf(stderr, "  %-24s %6.2f %%  %9.0f cycles per %s\n", names[i], 100.0 * t[i] / tot, (double)t[i] / (per_tile ? (double)t[FK_NSEC] : (double)nw),
+                            per_tile ? "(wave, tile)" : "wave and launch x launches");
+                }
+        }
+        (void)hipFree(e->fk_prof);
+    }
+#endif
     if (e->comm) ncclCommDestroy(e->comm);
     for (int r = 0; r < P2P_MAX_RANKS; ++r)
         if (e->p2p.inbox[r] && e->p2p.inbox[r] != e->p2p.local) (void)hipIpcCloseMemHandle(e->p2p.inbox[r]);

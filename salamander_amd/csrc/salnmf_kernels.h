@@ -139,6 +139,9 @@ struct FusedParams {
     int K;
     int64_t ntiles;
     int wdma;               // W -> LDS by LDS-DMA where the layout allows it (stage_W_dma_issue); 0: through registers (stage_W)
+    // development builds (SALNMF_DEV_PROFILE): [waves of the grid][FK_NSEC + 1] shader-clock cycles per section of the pass
+    // summed over the launches (+ the wave's number of tiles), or null -- printed by salnmf_destroy (profiles/r05/mvj_sections.md)
+    unsigned long long* prof;
     // feature blocks (n_features > 96; fused_kernel<..., BLOCKED>, update_H pass only): U = R W^T is a sum over the
     // 96-feature blocks.  ublock = 1: first block, store U into Uacc; 2: add Uacc, store; 3: last block, add Uacc and
     // update H with the total.  Uacc is [Np][KP] like H.
@@ -668,9 +671,22 @@ __device__ __forceinline__ double lhalf_update(double h, double u, double wl, do
 //   run back to back: X stays in registers, H' in the wave's LDS tile.  Per entry the arithmetic is the two passes'; the
 //   tile -> wave mapping and the slab order are those of an update_H pass with its side workgroup (salnmf.hip: the
 //   stand-alone numerator pass of an MvNMF step runs on the same number of tile workgroups), so the bits are the same.
+// Section clocks of a development build: s_memtime at the phase boundaries of a tile (each read drains the wave's LDS queue,
+// so the software pipelining across a boundary is lost: the table says where the time goes, the sum is a few per cent
+// above the production kernel's).  Sections: 0 prologue; per half h (0: the whole tile or the update_H half, 1: MVJ's
+// numerator half) 1 + 7 h + {0 stage H, 1 P product, 2 KL terms, 3 divisions, 4 prefetch issue + R transpose, 5 G phase,
+// 6 U phase + H update}; 15 epilogue.
+constexpr int FK_NSEC = 16;
 template <int KS, int KTM, int KR, bool DO_G, bool DO_U, bool DO_STATS, bool WTS = false, bool PERSIST = false, bool BLOCKED = false, bool RGIVEN = false,
           bool MVJ = false>
 __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
+#ifdef SALNMF_DEV_PROFILE
+    unsigned long long tks[FK_NSEC] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tk0 = __builtin_amdgcn_s_memtime(), tk1, ntl = 0;
+    // (sched_barrier on both sides: the machine scheduler moves nothing across a boundary)
+#define FK_TICK(i) do { __builtin_amdgcn_sched_barrier(0); tk1 = __builtin_amdgcn_s_memtime(); tks[i] += tk1 - tk0; tk0 = tk1; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define FK_TICK(i) do { } while (0)
+#endif
     static_assert(!MVJ || (DO_G && DO_U && DO_STATS && !WTS && !PERSIST && !BLOCKED && !RGIVEN), "MVJ: the unweighted MvNMF pass pair");
     static_assert(!RGIVEN || (WTS && !DO_STATS && !PERSIST && !BLOCKED), "given ratio: the weighted-capable plain passes only");
     static_assert(!PERSIST || (DO_G && DO_U && !DO_STATS && !WTS), "the persistent mode is the plain joint step");
@@ -810,6 +826,8 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
             }
         }
         __builtin_amdgcn_wave_barrier();
+        constexpr int FKB = 1 + 7 * (HALF == 2 ? 1 : 0);
+        FK_TICK(FKB + 0);
 
         // (DO_STATS) the x-only constants of this lane's KL terms (tile_kl); they land under the P product
         double cv[4] = {0.0, 0.0, 0.0, 0.0};
@@ -855,6 +873,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
             }
         }
 
+        FK_TICK(FKB + 1);
         // (joint step with the objective: the KL terms first, before the G operands below take their registers)
         constexpr bool JKL = TG && TU && DO_STATS;  // (never with MVJ: a half has one of the two)
         if (JKL) {
@@ -879,6 +898,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
             const double none[4] = {0.0, 0.0, 0.0, 0.0};
             (HALF == 2 ? klacc_b : klacc) += tile_kl<false>(x, pr, none, cv, ltab, n0, N, V, q, c16);
         }
+        FK_TICK(FKB + 2);
         // ---- R = X / P in place (rows n = q + 4r, columns v = 16vt + c16); pads give 0 / P = 0
         // (div_path's sequence, six quotients at a time and stage by stage: independent chains next to each other)
 #pragma unroll
@@ -906,6 +926,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         asm volatile("" : "+v"(pr[3][2]), "+v"(pr[3][3]), "+v"(pr[4][0]), "+v"(pr[4][1]), "+v"(pr[4][2]), "+v"(pr[4][3]), "+v"(pr[5][0]),
                      "+v"(pr[5][1]), "+v"(pr[5][2]), "+v"(pr[5][3]));
 
+        FK_TICK(FKB + 3);
         // prefetch the next tile: X and the staging registers are free from here on, and the loads
         // get the G and U phases to land
         if (HALF != 1 && tile + tstride < nfull) load_tile(tile + tstride);  // (MVJ: X serves the second half too)
@@ -918,6 +939,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
                 for (int r = 0; r < 4; ++r) Rl[(q + 4 * r) * RS + 16 * vt + c16] = pr[vt][r];
         }
 
+        FK_TICK(FKB + 4);
         // ---- G += (w_kl . Ht)^T . R   (A = H[n=4r+q][k=16kt+c16], B = register r of R)
         if (TG) {
             if (wkl) {
@@ -969,7 +991,10 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
                     for (int r = 0; r < 4; ++r) urem[4 * j + r] = __builtin_fma(pr[vt][r], wj[j][vt], urem[4 * j + r]);
         }
         __builtin_amdgcn_wave_barrier();
-
+        FK_TICK(FKB + 5);
+#ifdef SALNMF_DEV_PROFILE
+        if (HALF != 1) ++ntl;
+#endif
 
         if (TU) {
             // ---- U = R . W^T   (A = R[n=c16][v=4s+q], B = W[k=16kt+c16][v=4s+q])
@@ -1046,6 +1071,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
 #pragma unroll
                         for (int kt = 0; kt < KT; ++kt) ua[4 * r * KP + 16 * kt] = u[kt][r];
                     if (KR > 0 && rem_owner) *uar = urem[0];
+                    FK_TICK(FKB + 6);
                     return;  // (of the tile lambda)
                 }
             }
@@ -1113,6 +1139,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
                 }
             }
         }
+        FK_TICK(FKB + 6);
     };
 
     if (DO_G) {
@@ -1329,6 +1356,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
             if (tile < nfull) load_tile(tile);
         }
     }
+    FK_TICK(0);
     for (; tile < nfull; tile += tstride) {
         using std::integral_constant;
         if constexpr (MVJ) {
@@ -1538,6 +1566,15 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         }
     }
     }  // step
+    FK_TICK(15);
+#ifdef SALNMF_DEV_PROFILE
+    if (p.prof != nullptr && (threadIdx.x & 63) == 0) {  // (one row per wave of the grid: no atomics, launches are serialised)
+        unsigned long long* row = p.prof + ((size_t)blockIdx.x * WAVES + (threadIdx.x >> 6)) * (FK_NSEC + 1);
+        for (int i = 0; i < FK_NSEC; ++i) row[i] += tks[i];
+        row[FK_NSEC] += ntl;
+    }
+#endif
+#undef FK_TICK
 }
 
 // ----------------------------------------------------------------------------------------------
