@@ -198,6 +198,11 @@ def extra_c4(sal, device):
         "us_per_step_max": max(blocks) * 1e6,
         "algorithmic_flops_per_step": flops,
         "frac_of_fp64_mfma_peak": flops / t / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+        # the reference's algorithm forms 6 products of 2 V K N per iteration (update_H 2, numerator 2, f0 and the first trial's
+        # f1 one each); the one-pass step shares P between update_H and the trial's KL and between the numerator and f0, so
+        # the kernel EXECUTES 4 products = 8 V K N on the matrix cores (SQ_INSTS_MFMA agrees: profiles/r05/mvj_sections.md)
+        "executed_mfma_flops_per_step": 8.0 * V * Kc * N_C2,
+        "frac_of_fp64_mfma_peak_executed": 8.0 * V * Kc * N_C2 / t / 1e12 / FP64_MFMA_PEAK_TFLOPS,
         "gamma_after": g,
     }
 

@@ -2149,6 +2149,15 @@ static int mv_steps_queued(salnmf_engine* e, int n_steps, int n_given, double la
     if (!e->KLpart2) HIPCK(hipMalloc(&e->KLpart2, (size_t)e->grid * sizeof(double)));
     if (!e->mvflag) HIPCK(hipMalloc(&e->mvflag, 16));
     const int total = mv_side_total(e), nwg = total - 1;
+    // A sample-sharded engine (round 5) runs the same queue with the sums over the samples all-reduced: per step the tail
+    // (local reduction only), ONE exchange of [G | rowsums_H | KL of the numerator half | KL of the previous step's trial]
+    // (K V + K + 2 doubles: the peer-to-peer kernel, or RCCL), the root / first trial / f0 kernel -- which takes the
+    // device-side decision from the all-reduced sums, the same bits on every rank -- and the MVJ pass.  Every rank queues
+    // the same launches and exchanges whatever the flag says, so the exchanges stay in step.
+    const bool sh = sharded(e);
+    const int K = e->K, V = e->V;
+    const size_t nred = (size_t)K * V + K + 2;
+    double* const trial_kl = sh ? e->red + (size_t)K * V + K + 1 : e->scal + 2;  // where an MVJ pass leaves its trial's KL
     double g = *gamma, f_last = 0.0;
     bool ahead = resume;
     int done = 0;
@@ -2181,6 +2190,28 @@ static int mv_steps_queued(salnmf_engine* e, int n_steps, int n_given, double la
             t.rootCs = e->cs;
             t.rootLam = lam;
             t.mv_flag = e->mvflag;
+            if (sh) {
+                // local sums only; the root, the trial and the decision follow the exchange
+                t.rootA = nullptr;
+                hipLaunchKernelGGL(tail_kernel, dim3(e->K), dim3(TAIL_BLOCK), 0, e->stream, t);
+                HIPCK(hipGetLastError());
+                CK(allreduce(e, e->red, nred));
+                MvRootParams root{e->mvA, e->mvB, e->red, e->red + K * V, e->red + K * V + K, e->scal + 3, e->scal + mv_f0_slot(i), lam, n_given};
+                root.mv_flag = e->mvflag;
+                if (i > first) {
+                    root.dec_f0 = e->scal + mv_f0_slot(i - 1);
+                    root.dec_kl = trial_kl;
+                    root.dec_logdet = e->scal + 3;
+                    root.dec_lam = lam;
+                    root.dec_code = (unsigned)(i - first);
+                }
+                if (!spec)
+                    LAUNCH_WITH_EVENT(mv_trial_light_kernel<true>, dim3(1), dim3(MV_BLOCK), e->stream, e->evTrial, e->W, e->Wunc, 1.0, 0, K, V, e->Wtrial,
+                                      e->cs, root);
+                else
+                    hipLaunchKernelGGL(mv_trial_light_kernel<true>, dim3(1), dim3(MV_BLOCK), 0, e->stream, e->W, e->Wunc, 1.0, 0, K, V, e->Wtrial, e->cs, root);
+                HIPCK(hipGetLastError());
+            } else {
             if (i > first) {  // (gamma of a step behind accepted first trials is >= the call's gamma: the `gamma > 1e-16` half of mvnmf.py:84 holds)
                 t.dec_f0 = e->scal + mv_f0_slot(i - 1);
                 t.dec_kl = e->scal + 2;
@@ -2193,6 +2224,7 @@ static int mv_steps_queued(salnmf_engine* e, int n_steps, int n_given, double la
             else
                 hipLaunchKernelGGL(tail_kernel, dim3(e->K), dim3(TAIL_BLOCK), 0, e->stream, t);
             HIPCK(hipGetLastError());
+            }
             if (!spec) {
                 classic_last = true;
                 break;
@@ -2205,7 +2237,7 @@ static int mv_steps_queued(salnmf_engine* e, int n_steps, int n_given, double la
             sp.Hout = e->Halt;
             sp.KLpart = e->KLpart2;  // the update_H half's partials: the trial's KL, summed inside the launch -> scal[2]
             sp.KLpartB = e->KLpart;  // the numerator half's: f0 of the next step, reduced by its tail
-            sp.kl_out = e->scal + 2;
+            sp.kl_out = trial_kl;  // (sharded: this rank's share, all-reduced with the next tail's sums)
             sp.kl_counter = e->klcnt;
             sp.skip_flag = e->mvflag;
             mv_side_params(e, sp, e->Wtrial, delta);
@@ -2218,6 +2250,12 @@ static int mv_steps_queued(salnmf_engine* e, int n_steps, int n_given, double la
             std::swap(e->H, e->Halt);
             e->h_pending = false;
             ++queued;
+        }
+        if (sh && queued > 0 && !classic_last) {
+            // the last queued trial's KL has not been through an exchange yet (the next step's would have carried it): one
+            // scalar all-reduce, into the slot the host reads (after a rejection further up it is a stale value nobody uses)
+            HIPCK(hipMemcpyAsync(e->scal + 2, trial_kl, sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+            CK(allreduce(e, e->scal + 2, 1));
         }
         // one read for the whole batch: the flag and the scalars
         unsigned code = 0;
@@ -2372,7 +2410,7 @@ int salnmf_mv_step_objective(salnmf_engine* e, int n_steps, int n_given, double 
     if (!resume) CK(mv_settle(e));
     e->mv_ahead = false;
     e->keep_valid = false;  // (the MvNMF steps use the second H buffer themselves)
-    if (e->mv_queued && !sharded(e) && n_given < e->K && n_steps > 0)
+    if (e->mv_queued && n_given < e->K && n_steps > 0)
         return mv_steps_queued(e, n_steps, n_given, lam, delta, gamma_inout, objective_out, more_follows != 0, resume);
     bool ahead = resume;  // this step's update_H pass, W-only algebra and numerator pass already ran during the previous step
     for (int i = 0; i < n_steps; ++i) {

@@ -41,6 +41,16 @@ struct MvRootParams {
     double* f0_out;
     double lam;
     int n_given;
+    // optional (steps queued ahead of the host on a SAMPLE-SHARDED engine: salnmf.hip, mv_steps_queued): the device-side
+    // line-search decision that tail_kernel takes on an unsharded engine (TailParams::mv_flag, dec_*), here in the kernel
+    // that follows the all-reduce of [G | rowsums_H | KL | the previous trial's KL] -- the operands are the all-reduced
+    // sums, the same bits on every rank, so every rank takes the same decision.
+    unsigned* mv_flag;
+    const double* dec_f0;
+    const double* dec_kl;
+    const double* dec_logdet;
+    double dec_lam;
+    unsigned dec_code;
 };
 
 // the part of a line-search trial the forward pass needs (mvnmf.py:80-81, 85-88): blend, row sums, normalise, clip.
@@ -55,6 +65,22 @@ __global__ void __launch_bounds__(MV_BLOCK)
     constexpr int PT = (MV_KMAX * MV_VMAX + MV_BLOCK - 1) / MV_BLOCK;
     double a[PT], b[PT];
     const int total = K * V;
+    if (ROOT && r.mv_flag != nullptr) {  // (tail_kernel's prologue, expression for expression)
+        __shared__ int mv_exit;
+        if (threadIdx.x == 0) {
+            int ex = __hip_atomic_load((gsync_t*)r.mv_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+            if (!ex && r.dec_f0 != nullptr) {
+                const double f1 = __dadd_rn(r.dec_kl[0], __dmul_rn(r.dec_lam, r.dec_logdet[0]));
+                if (f1 > r.dec_f0[0]) {
+                    ex = 1;
+                    __hip_atomic_store((gsync_t*)r.mv_flag, r.dec_code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            mv_exit = ex;
+        }
+        __syncthreads();
+        if (mv_exit) return;
+    }
     if constexpr (ROOT) {
         if (threadIdx.x == 0) *r.f0_out = *r.kl + r.lam * *r.logdet;
         double wa[PT], wb[PT], wg[PT];

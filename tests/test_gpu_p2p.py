@@ -181,3 +181,99 @@ def test_peer_exchange_argument_checks():
         ref.profile_sharded_steps(2, 0)
     with pytest.raises(RuntimeError, match="cannot be switched off"):
         e.set_p2p(False)
+
+
+# ------------------------------------------------------------------ MvNMF steps queued ahead of the host on sharded engines (round 5)
+MV_CASES = {
+    # problems whose line search backtracks at several step indices (found with the oracle: tests/golden/make_golden.py's search,
+    # larger cohorts): gammas 1, 1, .96, .74, .71, .68, .65, .78, .75, .72 and 1, 1, 1, 1, .61, .38, .23, .18, .14, .11
+    "mixed": dict(N=330, K=3, lam=2163.8587982671297, delta=0.18254529653645993, mean=26.27523189893783, seed=2003),
+    "late": dict(N=150, K=8, lam=2533.9897774426486, delta=0.05722437618654012, mean=11.53329221488821, seed=2002),
+}
+MV_STEPS = 10
+
+
+def _mv_problem(case):
+    from oracle import klnmf_oracle as orc
+
+    c = MV_CASES[case]
+    X, W0, H0 = orc.synthetic_problem(V, c["N"], c["K"], seed=c["seed"], mean_mutations=c["mean"])
+    return X.clip(orc.EPSILON), W0, H0, c
+
+
+def _mv_worker(rank, world, port, out_dir, case):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+
+    from salamander_amd.distributed import attach_peer_exchange, shard_bounds
+    from salamander_amd.engine import Engine
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        X, W0, H0, c = _mv_problem(case)
+        a, b = shard_bounds(c["N"], world, rank)
+        e = Engine(b - a, V, c["K"])
+        e.upload_X(X[a:b])
+        attach_peer_exchange(e)
+        out = {}
+        for queued in (True, False):
+            e.set_mv_queued(queued)
+            for mode in ("one", "blocks", "single"):
+                e.upload_W(W0), e.upload_H(H0[a:b])
+                gamma, gs, fs = 1.0, [], []
+                if mode == "one":
+                    gamma, f = e.mv_step_objective(MV_STEPS, 0, c["lam"], c["delta"], gamma)
+                    gs, fs = [gamma], [f]
+                elif mode == "blocks":
+                    left = MV_STEPS
+                    while left > 0:
+                        n = min(3, left)
+                        gamma, f = e.mv_step_objective(n, 0, c["lam"], c["delta"], gamma, more_follows=left > n)
+                        gs.append(gamma), fs.append(f)
+                        left -= n
+                else:
+                    for _ in range(MV_STEPS):
+                        gamma = e.mv_step(1, 0, c["lam"], c["delta"], gamma)
+                        gs.append(gamma)
+                tag = f"{'q' if queued else 'c'}_{mode}"
+                out[tag + "_W"], out[tag + "_H"], out[tag + "_g"], out[tag + "_f"] = e.download_W(), e.download_H(), np.array(gs), np.array(fs)
+                out[tag + "_obj"] = e.mv_objective(c["lam"], c["delta"])
+        np.savez(os.path.join(out_dir, f"mv{rank}.npz"), a=a, b=b, **out)
+        dist.barrier()
+        e.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,case", [(2, "mixed"), (3, "mixed"), (2, "late"), (3, "late")])
+def test_sharded_mvnmf_steps_queued_ahead_of_the_host_equal_the_classic_form(tmp_path, world, case):
+    """Round 5: sample-sharded engines take the queued form too -- per step a tail, ONE exchange of
+    [G | rowsums_H | KL | the previous trial's KL], the root / trial kernel with the device-side line-search decision, and one
+    pass over the samples -- instead of two passes and a host decision per step.  Ranks as processes on one GPU, peer-to-peer
+    exchange: bit for bit the classic sharded form (all steps in one call, blocks of three that leave the engines ahead,
+    step by step; first trials rejected in the middle of a queue, as its last step and as its first), W identical on all
+    ranks, and the unsharded oracle's gamma sequence."""
+    from oracle import klnmf_oracle as orc
+
+    mp.spawn(_mv_worker, args=(world, _free_port(), str(tmp_path), case), nprocs=world, join=True)
+    parts = [np.load(os.path.join(tmp_path, f"mv{r}.npz")) for r in range(world)]
+    X, W0, H0, c = _mv_problem(case)
+    W, H, g, gs = W0.T, H0.T, 1.0, []
+    for _ in range(MV_STEPS):
+        W, H, g = orc.mvnmf_step(X.T, W, H, c["lam"], c["delta"], g, 0)
+        gs.append(g)
+    assert min(gs) < 1.0 and max(gs[1:]) >= gs[1]  # (the case does reject first trials)
+    for mode in ("one", "blocks", "single"):
+        for p in parts:
+            for key in ("W", "H", "g", "f", "obj"):
+                assert np.array_equal(p[f"q_{mode}_{key}"], p[f"c_{mode}_{key}"]), (mode, key)
+            assert np.array_equal(p[f"q_{mode}_W"], parts[0][f"q_{mode}_W"])  # replicated W: the same bits on every rank
+            assert np.array_equal(p[f"q_{mode}_W"], parts[0]["q_one_W"]) and np.array_equal(p[f"q_{mode}_H"], p["q_one_H"])
+        got = parts[0][f"q_{mode}_g"]
+        want = {"one": gs[-1:], "blocks": [gs[2], gs[5], gs[8], gs[9]], "single": gs}[mode]
+        assert np.allclose(got, want, rtol=1e-12), (mode, got, want)
+    assert rel_l2(parts[0]["q_one_W"], W.T) < 1e-7
+    assert rel_l2(np.concatenate([p["q_one_H"] for p in parts], axis=0), H.T) < 1e-7
+    assert np.isclose(float(parts[0]["q_one_obj"]), orc.kl_divergence_penalized(X.T, W, H, c["lam"], c["delta"]), rtol=1e-9)

@@ -989,6 +989,52 @@ def test_mvnmf_queued_steps_equal_the_classic_form_bit_for_bit(golden, tag):
     assert np.isclose(ref[0], g[f"{tag}_gammas"][-1], rtol=1e-12) and rel_l2(ref[1], g[f"{tag}_W"].T) < 1e-7
 
 
+@pytest.mark.parametrize("tag", ["bt1", "bt2"])
+def test_mvnmf_queued_form_edge_cases_equal_the_classic_form(golden, tag):
+    """the queued form's host bookkeeping at its corners, against the classic form bit for bit -- (i) a batch
+    whose FIRST queued step is rejected with more steps queued behind it (one step, then the rest in one call); (ii) a
+    rejection on the LAST queued step of a call that leaves the engine ahead (``more_follows``), found by cutting the
+    trajectory right behind every step whose gamma dropped; (iii) an entry gamma of 1e-17, where ``gamma > 1e-16``
+    (mvnmf.py:84) overrides the device's verdict and every trial is accepted."""
+    g = golden.mv
+    lam, delta, steps, ng = g[f"{tag}_par"]
+    steps, ng = int(steps), int(ng)
+    gam = g[f"{tag}_gammas"]
+    drops = [i for i in range(steps) if gam[i] < min(1.0, 1.2 * (gam[i - 1] if i else 1.0))]  # steps that backtracked
+    assert drops
+    plans = [[1, steps - 1]]                                    # (i)
+    plans += [[d + 1, steps - d - 1] for d in drops if 0 < d + 1 < steps]  # (ii): the call ends ON a rejected step, engine left ahead
+    for plan in plans:
+        outs = []
+        for queued in (True, False):
+            e = make_engine(g[f"{tag}_X"], g[f"{tag}_W0"], g[f"{tag}_H0"])
+            e.set_mv_queued(queued)
+            gamma, fs, left = 1.0, [], steps
+            for n in plan:
+                left -= n
+                gamma, f = e.mv_step_objective(n, ng, lam, delta, gamma, more_follows=left > 0)
+                fs.append(f)
+            outs.append((gamma, fs, e.download_W(), e.download_H()))
+            e.close()
+        (gq, fq, Wq, Hq), (gc, fc, Wc, Hc) = outs
+        assert gq == gc and fq == fc and np.array_equal(Wq, Wc) and np.array_equal(Hq, Hc), plan
+        assert np.isclose(gq, gam[-1], rtol=1e-12) and rel_l2(Wq, g[f"{tag}_W"].T) < 1e-7
+    # (iii) gamma <= 1e-16 on entry: no trial can be rejected
+    outs = []
+    for queued in (True, False):
+        e = make_engine(g[f"{tag}_X"], g[f"{tag}_W0"], g[f"{tag}_H0"])
+        e.set_mv_queued(queued)
+        g1, f1 = e.mv_step_objective(3, ng, lam, delta, 1e-17, more_follows=True)
+        g2, f2 = e.mv_step_objective(3, ng, lam, delta, g1)
+        outs.append((g1, g2, f1, f2, e.download_W(), e.download_H()))
+        e.close()
+    assert outs[0][:4] == outs[1][:4] and np.array_equal(outs[0][4], outs[1][4]) and np.array_equal(outs[0][5], outs[1][5])
+    W, H, gg = g[f"{tag}_W0"], g[f"{tag}_H0"], 1e-17
+    for _ in range(6):
+        W, H, gg = orc.mvnmf_step(g[f"{tag}_X"], W, H, lam, delta, gg, ng)
+    assert np.isclose(outs[0][1], gg, rtol=1e-12) and rel_l2(outs[0][4], W.T) < 1e-7
+
+
 @pytest.mark.parametrize("N,K", [(17003, 33), (900, 17), (40000, 50), (5000, 8)])
 def test_mvnmf_queued_steps_on_more_shapes(N, K):
     X, W0, H0 = orc.synthetic_problem(96, N, K, seed=N % 97)
