@@ -73,8 +73,10 @@ int salnmf_device_count(void);
  * chain of forward launches, the last of which forms the ratio X / (H W) (or the objective), and the update passes run
  * once per chunk on that ratio.  On feature blocks also: MvNMF (the step in its plain form, salnmf_mv_wide_kernels.h),
  * CorrNMF (its two passes over X block by block; everything else is K- and dim-sized) and the device-side
- * initialisation except the separableNMF selection.  The fp32 fast mode and sample sharding answer with an error in both
- * cases, MvNMF / CorrNMF / the initialisation on more than 64 signatures too. */
+ * initialisation incl. the separableNMF selection.  On signature chunks also: MvNMF (round 5: the same plain form, its
+ * K x K algebra -- Gram matrix, elimination, log det, A and B -- in global memory; mvnmf.py:116-126 has no limit on
+ * n_signatures).  The fp32 fast mode and sample sharding answer with an error in both cases, CorrNMF and the device-side
+ * initialisation on more than 64 signatures too. */
 int salnmf_create(int device, int n_features, int64_t n_samples, int n_signatures,
                   salnmf_engine** out);
 void salnmf_destroy(salnmf_engine* e);

@@ -249,6 +249,7 @@ struct salnmf_engine {
     int ls_S = 0, ls_dim = 0;
     bool lockstep = true;  // salnmf_set_lockstep(e, 0) forces the single-kernel form
     bool batched_samples = true;  // salnmf_set_batched_sample_solves(e, 0) forces one wavefront per sample
+    double* mvS = nullptr;       // (MvNMF on signature chunks) [K][2K] scratch of the global-memory elimination
     unsigned long long* fk_prof = nullptr;  // (SALNMF_DEV_PROFILE builds) section clocks of the fused passes, printed by salnmf_destroy
     bool w_dma = true;           // salnmf_set_w_dma(e, 0): the update passes stage W through registers instead of by LDS-DMA
     bool mv_queued = true;       // salnmf_set_mv_queued(e, 0): MvNMF steps with the host's line-search decision per step (the classic form)
@@ -506,8 +507,11 @@ static int ensure_xlogx(salnmf_engine* e) {
 // materialise a pending rescale of H (needed only by readers that cannot apply it on the fly)
 static int flush_H_scale(salnmf_engine* e) {
     if (!e->h_pending) return 0;
-    hipLaunchKernelGGL(scale_H_kernel, dim3(2048), dim3(256), 0, e->stream, e->H, e->cs, (int64_t)e->Np * e->KP, e->KP);
-    HIPCK(hipGetLastError());
+    for (int ci = 0; ci < e->NC; ++ci) {  // (signature chunks: chunk ci's columns are the signatures from kc[ci].k0 on)
+        hipLaunchKernelGGL(scale_H_kernel, dim3(2048), dim3(256), 0, e->stream, e->H + (size_t)ci * e->Np * e->KP, e->cs + e->kc[(size_t)ci].k0,
+                           (int64_t)e->Np * e->KP, e->KP);
+        HIPCK(hipGetLastError());
+    }
     e->h_pending = false;
     return 0;
 }
@@ -657,7 +661,7 @@ void salnmf_destroy(salnmf_engine* e) {
     if (e->p2p.abort_dev) (void)hipFree(e->p2p.abort_dev);
     double* bufs[] = {e->PR, e->wones, e->wzeros, e->Gblk, e->Uacc, e->xlx, e->X, e->H, e->W, e->wkl, e->wlh, e->Gpart, e->Hsumpart, e->KLpart, e->red,
                       e->objpart, e->scal, e->Wunc, e->Wtrial, e->mvA, e->mvB, e->cs, e->scratch, e->Halt, e->KLpart2, e->Wkeep, e->Hkeep, e->objring,
-                      e->alpha, e->beta, e->Lemb, e->Uemb, e->aux, e->xrowsum, e->corrpart, e->gU, e->galpha, e->gaux};
+                      e->alpha, e->beta, e->Lemb, e->Uemb, e->aux, e->xrowsum, e->corrpart, e->gU, e->galpha, e->gaux, e->mvS};
     for (double* b : bufs)
         if (b) (void)hipFree(b);
     if (e->hpin) release_pinned(e->hpin, 1);  // (one block: hpin, and the abort word behind it)
@@ -780,11 +784,14 @@ int salnmf_create(int device, int n_features, int64_t n_samples, int n_signature
     ALLOC(e->Wtrial, K * V);
     ALLOC(e->mvA, K * V);
     ALLOC(e->mvB, K * V);
-    ALLOC(e->cs, KP);
+    // (signature chunks: one entry per signature, compact, + a chunk's width of filler behind the last one -- a chunk's
+    // passes read KP entries from its first signature on)
+    const size_t ncs = e->NC > 1 ? K + KP : KP;
+    ALLOC(e->cs, ncs);
 #undef ALLOC
     {
-        std::vector<double> ones(KP, 1.0);
-        if (hipMemcpy(e->cs, ones.data(), KP * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+        std::vector<double> ones(ncs, 1.0);
+        if (hipMemcpy(e->cs, ones.data(), ncs * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
             return cleanup(fail("hipMemcpy failed"));
     }
     if (acquire_pinned((void**)&e->hpin, 1) != hipSuccess) return cleanup(fail("hipHostMalloc failed"));
@@ -1166,11 +1173,14 @@ static int blocked_kl_step_once(salnmf_engine* e, int n_given) {
 // the chunks, so it is formed FIRST, by a chain of forward launches through e->PR (each adds its chunk's product; the
 // last one turns the sum into what is needed: the ratio X / P, the divergence, the per-sample divergences or P itself);
 // the update passes then run on the given ratio, once per chunk, each with the geometry of its chunk's size.
-static FwdParams chunk_fwd_params(salnmf_engine* e, const salnmf_engine::Chunk& c, int ci) {
+//   W, hscale (MvNMF line-search trials): the signature matrix instead of e->W, and H read as clip(H * hscale[k]) -- both
+//   compact over all signatures
+static FwdParams chunk_fwd_params(salnmf_engine* e, const salnmf_engine::Chunk& c, int ci, const double* W = nullptr, const double* hscale = nullptr) {
     FwdParams p{};
     p.X = e->X;
     p.H = e->H + (size_t)ci * e->Np * e->KP;
-    p.W = e->W + (size_t)c.k0 * e->V;
+    p.W = (W ? W : e->W) + (size_t)c.k0 * e->V;
+    p.hscale = hscale ? hscale + c.k0 : nullptr;
     p.xlx = e->xlx;
     p.N = e->N;
     p.V = e->V;
@@ -1181,10 +1191,10 @@ static FwdParams chunk_fwd_params(salnmf_engine* e, const salnmf_engine::Chunk& 
 }
 // the chain: chunks 0 .. NC-2 accumulate into e->PR (mode 2), the last chunk runs `last_mode` with `last` as its template
 // (out, weights) on top of the accumulated product
-static int chunk_chain(salnmf_engine* e, int last_mode, const FwdParams& last) {
+static int chunk_chain(salnmf_engine* e, int last_mode, const FwdParams& last, const double* W = nullptr, const double* hscale = nullptr) {
     for (int ci = 0; ci < e->NC; ++ci) {
         const auto& c = e->kc[(size_t)ci];
-        FwdParams p = chunk_fwd_params(e, c, ci);
+        FwdParams p = chunk_fwd_params(e, c, ci, W, hscale);
         p.pin = ci == 0 ? nullptr : e->PR;
         const bool is_last = ci == e->NC - 1;
         if (is_last) {
@@ -1207,7 +1217,9 @@ static int chunk_ratio(salnmf_engine* e) {  // e->PR = X / (H W)
 }
 // the update passes of every chunk on the ratio in e->PR: H half (do_u) into the chunk's columns of H, in place; W half
 // (do_g): numerator slabs, reduced and applied to the chunk's rows of W by the ordinary tail
-static int chunk_passes(salnmf_engine* e, bool do_g, bool do_u, int n_given, int clip_mode) {
+//   weighted = false: MvNMF's passes (no sample weights: mvnmf.py:56,162-165); g_only: the numerator rows are reduced into
+//   e->red and W is left alone (the MvNMF W step takes its own root from them)
+static int chunk_passes(salnmf_engine* e, bool do_g, bool do_u, int n_given, int clip_mode, bool weighted = true, bool g_only = false) {
     for (int ci = 0; ci < e->NC; ++ci) {
         const auto& c = e->kc[(size_t)ci];
         const int given = std::max(0, std::min(c.K, n_given - c.k0));  // given rows inside this chunk
@@ -1219,13 +1231,14 @@ static int chunk_passes(salnmf_engine* e, bool do_g, bool do_u, int n_given, int
         p.W = e->W + (size_t)c.k0 * e->V;
         p.K = c.K;
         p.hscale = nullptr;
+        if (!weighted) p.wkl = p.wlh = nullptr;
         CK(weight_arrays(e, p));
         FusedSel sel{c.KS, c.KTM, c.KR, g, do_u, false, true, false, false};
         sel.RGIVEN = true;
         if (launch_fused_inst(sel, p, e->grid, e->stream, nullptr, nullptr)) return fail("no kernel instantiation for KS=%d KTM=%d KR=%d", c.KS, c.KTM, c.KR);
         HIPCK(hipGetLastError());
         if (g) {
-            TailParams t = tail_params(e, e->grid, e->red + (size_t)c.k0 * e->V, given, clip_mode, 1, false);
+            TailParams t = tail_params(e, e->grid, e->red + (size_t)c.k0 * e->V, given, clip_mode, g_only ? 0 : 1, false);
             t.W = t.Wout = e->W + (size_t)c.k0 * e->V;
             t.K = c.K;
             hipLaunchKernelGGL(tail_kernel, dim3(c.K), dim3(TAIL_BLOCK), 0, e->stream, t);
@@ -1525,7 +1538,7 @@ static int objective_partials(salnmf_engine* e, const double* W, const double* h
         // l-half penalty, klnmf.py:75-79), the other chunks' shares come from a small kernel each
         FwdParams last = p;
         last.out = e->objpart;
-        CK(chunk_chain(e, 0, last));
+        CK(chunk_chain(e, 0, last, W, hscale));
         int n = e->fgrid;
         if (p.wlh) {
             for (int ci = 0; ci + 1 < e->NC; ++ci) {
@@ -1766,24 +1779,70 @@ static int mv_logdet_to_slot(salnmf_engine* e, const double* W, double delta, in
     return 0;
 }
 
-// ---- MvNMF on more than 96 features (feature blocks, one signature chunk): the step of mvnmf.py:197-210 in its plain form
-// -- update_H over the blocks, the blocked numerator passes, the W-only algebra, root, and a host-driven line search
-// whose objectives are forward passes over the blocks.  No speculation: a 288- or 1 536-feature problem spends its time
-// in the passes over the samples, which are the KLNMF path's (csrc/salnmf_mv_wide_kernels.h has the kernels).
-static inline bool mv_wide(const salnmf_engine* e) { return e->NB > 1 && e->NC == 1; }
+// ---- MvNMF on more than 96 features (feature blocks, one signature chunk) or on more than 64 signatures (signature chunks,
+// one feature block; round 5): the step of mvnmf.py:197-210 in its plain form -- update_H over the blocks / chunks, the
+// numerator passes, the W-only algebra, root, and a host-driven line search whose objectives are the KLNMF path's forward
+// passes.  No speculation: such a problem spends its time in the passes over the samples
+// (csrc/salnmf_mv_wide_kernels.h has the kernels).
+static inline bool mv_wide(const salnmf_engine* e) { return (e->NB > 1) != (e->NC > 1); }
 static int mv_wide_check(const salnmf_engine* e) {
-    if (e->NC > 1) return single_block(e, "MvNMF");
-    if (sharded(e)) return fail("MvNMF on more than %d features is not available on a sample-sharded engine", VMAX);
+    if (e->NB > 1 && e->NC > 1) return fail("MvNMF is not available for n_features > %d together with n_signatures > %d", VMAX, KC);
+    if (sharded(e)) return fail("MvNMF on more than %d features or more than %d signatures is not available on a sample-sharded engine", VMAX, KC);
+    return 0;
+}
+// (signature chunks) the K x 2K scratch of the global-memory elimination
+static int ensure_mv_scratch(salnmf_engine* e) {
+    if (e->mvS) return 0;
+    if (e->K > MVM_KMAX) return fail("MvNMF supports up to %d signatures (this engine has %d)", MVM_KMAX, e->K);
+    HIPCK(hipMalloc(&e->mvS, (size_t)2 * e->K * e->K * sizeof(double)));
     return 0;
 }
 static int mv_wide_logdet(salnmf_engine* e, const double* W, double delta, int slot) {
+    if (e->NC > 1) {
+        CK(ensure_mv_scratch(e));
+        hipLaunchKernelGGL(mv_many_gram_kernel<false>, dim3(e->K), dim3(256), 0, e->stream, W, e->K, e->V, delta, e->mvS);
+        HIPCK(hipGetLastError());
+        hipLaunchKernelGGL(mv_many_eliminate_kernel<false>, dim3(1), dim3(MVM_BLOCK), 0, e->stream, e->mvS, e->K, e->scal + slot);
+        HIPCK(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(mv_logdet_wide_kernel, dim3(1), dim3(MV_BLOCK), 0, e->stream, W, e->K, e->V, delta, e->scal + slot);
     HIPCK(hipGetLastError());
     return 0;
 }
-// numerator of (W, H) -> Gblk, rowsums_H -> red + K V, A = W Y_minus, B = W |Y| -> mvA, mvB, log det(W) -> scal[3]
+// update_H of an MvNMF step (MvNMF._update_H, mvnmf.py:162-165: in place, unweighted) on a split engine
+static int mv_wide_update_H(salnmf_engine* e) {
+    if (e->NC > 1) {
+        CK(flush_H_scale(e));
+        CK(chunk_ratio(e));
+        return chunk_passes(e, false, true, 0, 0, false);
+    }
+    CK(blocked_update_H(e, e->H, kEps, false));
+    e->h_pending = false;
+    return 0;
+}
+// numerator of (W, H) -> Gblk (feature blocks) / red (signature chunks), rowsums_H -> red + K V, A = W Y_minus, B = W |Y|
+// -> mvA, mvB, log det(W) -> scal[3]
 static int mv_wide_prepare(salnmf_engine* e, double delta) {
     CK(flush_H_scale(e));  // (the column sums below read H as it is)
+    if (e->NC > 1) {
+        CK(ensure_mv_scratch(e));
+        CK(chunk_ratio(e));
+        CK(chunk_passes(e, true, false, 0, 0, false, true));  // every row's numerator, W untouched
+        for (int ci = 0; ci < e->NC; ++ci) {
+            const auto& c = e->kc[(size_t)ci];
+            hipLaunchKernelGGL(colsum_kernel, dim3(c.K), dim3(256), 0, e->stream, e->H + (size_t)ci * e->Np * e->KP, e->N, e->KP,
+                               e->red + (size_t)e->K * e->V + c.k0);
+            HIPCK(hipGetLastError());
+        }
+        hipLaunchKernelGGL(mv_many_gram_kernel<true>, dim3(e->K), dim3(256), 0, e->stream, e->W, e->K, e->V, delta, e->mvS);
+        HIPCK(hipGetLastError());
+        hipLaunchKernelGGL(mv_many_eliminate_kernel<true>, dim3(1), dim3(MVM_BLOCK), 0, e->stream, e->mvS, e->K, e->scal + 3);
+        HIPCK(hipGetLastError());
+        hipLaunchKernelGGL(mv_many_AB_kernel, dim3(e->K), dim3(128), 0, e->stream, e->mvS, e->W, e->K, e->V, e->mvA, e->mvB);
+        HIPCK(hipGetLastError());
+        return 0;
+    }
     CK(blocked_numerators(e, false));  // update_W_unconstrained takes no weights (mvnmf.py:37-66): as the narrow path
     hipLaunchKernelGGL(colsum_kernel, dim3(e->K), dim3(256), 0, e->stream, e->H, e->N, e->KP, e->red + (size_t)e->K * e->V);
     HIPCK(hipGetLastError());
@@ -1793,7 +1852,7 @@ static int mv_wide_prepare(salnmf_engine* e, double delta) {
 }
 static int mv_wide_root(salnmf_engine* e, double lam, int n_given) {
     hipLaunchKernelGGL(mv_trial_row_wide_kernel<true>, dim3(e->K), dim3(256), 0, e->stream, e->W, e->Wunc, 1.0, 0, e->K, e->V, e->Wtrial, e->cs, e->mvA,
-                       e->mvB, e->Gblk, e->red + (size_t)e->K * e->V, lam, n_given);
+                       e->mvB, e->NC > 1 ? e->red : e->Gblk, e->red + (size_t)e->K * e->V, lam, n_given);
     HIPCK(hipGetLastError());
     return 0;
 }
@@ -1827,6 +1886,7 @@ static int mv_wide_line_search(salnmf_engine* e, double lam, double delta, doubl
     *gamma = std::min(1.0, 1.2 * g);  // mvnmf.py:91
     std::swap(e->W, e->Wtrial);
     e->h_pending = true;  // H <- clip(H * colsum), applied by the readers until the next update_H pass writes H in full
+    if (e->NC > 1) CK(flush_H_scale(e));  // (the chunked passes read H as it is: the rescale is a pass of its own there)
     return 0;
 }
 static int mv_wide_update_W(salnmf_engine* e, int n_given, double lam, double delta, double* gamma, double* f_accepted) {
@@ -2395,8 +2455,7 @@ int salnmf_mv_step_objective(salnmf_engine* e, int n_steps, int n_given, double 
         e->keep_valid = false;
         double f = 0.0;
         for (int i = 0; i < n_steps; ++i) {
-            CK(blocked_update_H(e, e->H, kEps, false));  // MvNMF._update_H (mvnmf.py:162-165): in place, unweighted
-            e->h_pending = false;
+            CK(mv_wide_update_H(e));
             CK(mv_wide_update_W(e, n_given, lam, delta, gamma_inout, &f));
         }
         if (objective_out) {

@@ -125,3 +125,76 @@ __global__ void __launch_bounds__(256) mv_trial_row_wide_kernel(const double* __
 }
 
 }  // namespace salnmf
+
+// ---- MvNMF with more than 64 signatures (signature chunks, round 5): the K x K part no longer fits one workgroup's LDS
+// (K = 512: 2 MB), so it runs in global memory -- Gram matrix W W^T + delta I, Gauss-Jordan elimination without pivoting
+// (symmetric positive definite for delta > 0, as in salnmf_mv_device.h) on the matrix augmented with the identity, log det
+// from the pivots, then A = Y_minus W and B = |Y| W.  Plain kernels: the K^3 work is 2.7e8 multiply-adds at K = 512, small
+// beside the passes over the samples of an engine that large.  Reference arithmetic: mvnmf.py:19-24, :48-54; the reference
+// has no limit on n_signatures (mvnmf.py:116-126).
+namespace salnmf {
+
+constexpr int MVM_BLOCK = 1024;
+constexpr int MVM_KMAX = 512;
+
+// S[i][0..K) = (W W^T + delta I)[i][:], S[i][K..2K) = identity row (AUG) -- one workgroup per row, the dot products in
+// the order v = 0 .. V-1
+template <bool AUG>
+__global__ void __launch_bounds__(256) mv_many_gram_kernel(const double* __restrict__ W, int K, int V, double delta, double* __restrict__ S) {
+    const int i = blockIdx.x, ld = AUG ? 2 * K : K;
+    for (int j = threadIdx.x; j < K; j += 256) {
+        double s = 0.0;
+        for (int v = 0; v < V; ++v) s = __builtin_fma(W[(int64_t)i * V + v], W[(int64_t)j * V + v], s);
+        S[(int64_t)i * ld + j] = i == j ? s + delta : s;
+        if (AUG) S[(int64_t)i * ld + K + j] = i == j ? 1.0 : 0.0;
+    }
+}
+
+// One workgroup.  AUG: Gauss-Jordan on [K][2K] -- afterwards the right half is the inverse; else forward elimination of the
+// trailing block only (the pivots are all a log det needs).  logdet_out = sum_p log(pivot_p), p in order.
+template <bool AUG>
+__global__ void __launch_bounds__(MVM_BLOCK) mv_many_eliminate_kernel(double* __restrict__ S, int K, double* __restrict__ logdet_out) {
+    __shared__ double f[MVM_KMAX];          // column p of the matrix (the row multipliers)
+    __shared__ double prow[2 * MVM_KMAX];   // row p divided by the pivot
+    __shared__ double lp[MVM_KMAX];         // log of the pivots
+    const int tid = threadIdx.x, ld = AUG ? 2 * K : K;
+    for (int p = 0; p < K; ++p) {
+        const double pivot = S[(int64_t)p * ld + p];
+        const int c0 = AUG ? 0 : p, r0 = AUG ? 0 : p + 1;
+        for (int c = c0 + tid; c < ld; c += MVM_BLOCK) prow[c] = S[(int64_t)p * ld + c] / pivot;
+        for (int r = r0 + tid; r < K; r += MVM_BLOCK) f[r] = S[(int64_t)r * ld + p];
+        if (tid == 0) lp[p] = log(pivot);
+        __syncthreads();
+        const int ncol = ld - c0, nrow = K - r0;
+        for (int64_t i = tid; i < (int64_t)nrow * ncol; i += MVM_BLOCK) {
+            const int r = r0 + (int)(i / ncol), c = c0 + (int)(i % ncol);
+            double* dst = S + (int64_t)r * ld + c;
+            if (r == p) *dst = prow[c];
+            else *dst = __builtin_fma(-f[r], prow[c], *dst);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        double t = 0.0;
+        for (int k = 0; k < K; ++k) t += lp[k];
+        *logdet_out = t;
+    }
+}
+
+// A[k][v] = sum_m max(0, -Y[m][k]) W[m][v], B[k][v] = sum_m |Y[m][k]| W[m][v] (mvnmf.py:50-53), Y = the right half of the
+// eliminated augmented matrix; one workgroup per signature row, m in order
+__global__ void __launch_bounds__(128) mv_many_AB_kernel(const double* __restrict__ S, const double* __restrict__ W, int K, int V, double* __restrict__ A,
+                                                         double* __restrict__ B) {
+    const int k = blockIdx.x, v = threadIdx.x;
+    if (v >= V) return;
+    double a = 0.0, b = 0.0;
+    for (int m = 0; m < K; ++m) {
+        const double y = S[(int64_t)m * 2 * K + K + k], w = W[(int64_t)m * V + v];
+        a = __builtin_fma(fmax(0.0, -y), w, a);
+        b = __builtin_fma(fabs(y), w, b);
+    }
+    A[(int64_t)k * V + v] = a;
+    B[(int64_t)k * V + v] = b;
+}
+
+}  // namespace salnmf
