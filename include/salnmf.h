@@ -261,7 +261,7 @@ int salnmf_corr_update_sample_embeddings_multi(salnmf_engine* const* engines, in
  * what the reference uses here; status_out has n_signatures ints or is NULL. */
 int salnmf_corr_update_signature_embeddings(salnmf_engine* e, double variance, int maxiter,
                                             int* status_out);
-/* From 16 384 samples on, the signature solves run in LOCKSTEP (csrc/salnmf_corr_lockstep.h): one evaluation round
+/* From 2 048 samples on, the signature solves run in LOCKSTEP (csrc/salnmf_corr_lockstep.h): one evaluation round
  * per launch over (chunks x signatures) workgroups, the K Newton-CG solvers replayed from their evaluation logs
  * between rounds -- 3x faster than one workgroup per signature at c5, and shardable: a sample-sharded engine
  * all-reduces the 1 + dim + dim^2 sums per signature of every round.  0 forces the single-kernel form; the two agree

@@ -2955,13 +2955,14 @@ static int launch_signature_solves(salnmf_engine* e, const double* U, const doub
 }
 
 // A signature embedding depends on ALL samples (its objective, gradient and Hessian are sums over samples), and
-// its Newton-CG solve takes data-dependent decisions after every one of them.  With the sample axis sharded, the
-// sample-side inputs of the solves -- U (N x dim), alpha (N) and aux (N x K) -- are gathered ONCE per update
-// (all-gather with per-rank counts = one broadcast per rank inside an RCCL group), after which every rank runs all
-// K solves on identical inputs in the same sample order as an unsharded engine: bit-identical signature embeddings
-// on every rank without any exchange inside the solves.  (The alternative -- an all-reduce of 1 + dim +
-// dim(dim+1)/2 doubles per evaluation -- needs the K solvers advanced in lockstep as resumable state machines and
-// puts hundreds of latency-bound collectives on the critical path; at c5 the gather is 130 MB per update.)
+// its Newton-CG solve takes data-dependent decisions after every one of them.  With the sample axis sharded there are two
+// forms (salnmf_corr_update_signature_embeddings picks):
+//   * from LS_MIN_ROWS samples per rank on (every BASELINE-sized cohort) the K solvers advance in LOCKSTEP rounds on the
+//     local rows and the 1 + dim + dim^2 sums per signature of every round are all-reduced (lockstep_signature_solves):
+//     identical sums, hence identical decisions and embeddings, on every rank;
+//   * smaller cohorts gather the sample-side inputs -- U (N x dim), alpha (N) and aux (N x K) -- ONCE per update
+//     (all-gather with per-rank counts = one broadcast per rank inside an RCCL group, below), after which every rank runs
+//     all K solves on identical inputs in the sample order of an unsharded engine.
 static int gather_sample_side(salnmf_engine* e) {
     CK(ensure_gathered(e, (size_t)e->N_total));
     NCCLCK(ncclGroupStart());

@@ -407,12 +407,9 @@ bool launch(const SampleEmbeddingParams& p, hipStream_t stream) {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess) return false;
     // more than 64 KB of dynamic LDS needs the attribute, per function AND per device (a process may hold engines on several)
-    static bool attr_set[64] = {};
-    if (dev < 0 || dev >= 64) return false;
-    if (!attr_set[dev]) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lds::bytes) != hipSuccess) return false;
-        attr_set[dev] = true;
-    }
+    // Set per launch: the call is a host-side table update (no device work), and a flag that remembers it would have to be
+    // guarded -- two host threads driving engines could otherwise see the flag before the attribute is in place.
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lds::bytes) != hipSuccess) return false;
     // one workgroup per CU; every wave gets a contiguous range of at least 16 samples (one per slot) where N allows
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int64_t max_waves = (int64_t)cus * BT_WAVES;

@@ -124,7 +124,7 @@ class Engine:
         _lib.check(self._lib.salnmf_set_precision(self._h, _lib.PRECISIONS[precision]))
 
     def set_lockstep(self, on: bool = True):
-        """Signature-embedding solves in lockstep rounds (default from 16 384 samples on) or one workgroup per signature."""
+        """Signature-embedding solves in lockstep rounds (default from 2 048 samples on) or one workgroup per signature."""
         _lib.check(self._lib.salnmf_set_lockstep(self._h, int(bool(on))))
 
     def set_w_dma(self, on: bool = True):

@@ -107,8 +107,9 @@ class CorrNMFDet(CorrNMF):
     # ------------------------------------------------------------------ device-resident loop used by fit()
     # With ``distributed=True`` ``adata`` is this rank's shard of the samples.  The engine then all-reduces the
     # numerator of the signature update, the two sums of the signature scalings, the Poisson term and the sum of
-    # squares of the sample embeddings, and gathers U / alpha / aux once per update for the signature-embedding
-    # solves (a signature embedding depends on all samples; every rank solves all of them on identical inputs).
+    # squares of the sample embeddings; the signature-embedding solves (a signature embedding depends on all samples) run as
+    # lockstep rounds on the local rows with every round's sums all-reduced -- from 2 048 samples per rank on; smaller
+    # cohorts gather U / alpha / aux once per update and every rank solves all of them on identical inputs.
     def _resident_variance(self) -> float:
         """update_variance on the resident embeddings (corrnmf_det.py:65-69)."""
         ss_sig, ss_samples = self._engine.corr_embedding_sumsq()

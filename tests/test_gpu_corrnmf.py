@@ -572,7 +572,7 @@ def test_embedding_solves_terminate_on_non_finite_input():
      (16500, 7, 48), (17000, 8, 37), (17000, 11, 38), (2500, 40, 40)],  # (38, 40: the LDS-DMA variant; 2 500: a partial last half)
 )
 def test_lockstep_signature_solves_agree_with_the_single_kernel_form(N, K, dim):
-    """From 16 384 samples on the signature solves advance in lockstep rounds (evaluation over chunks x signatures, the
+    """From 2 048 samples on the signature solves advance in lockstep rounds (evaluation over chunks x signatures, the
     solvers replayed from their logs).  Same problems, same solver, the sums of an evaluation in a different order:
     the embeddings agree with the one-workgroup-per-signature kernel far inside the solver's own tolerance and the
     status codes are the same; two of the solves are checked against SciPy as well."""
