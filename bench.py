@@ -505,8 +505,13 @@ def main():
         if not rccl_ok:
             engine.set_p2p(True)
 
+    failures = []  # engine errors inside timed blocks (an exchange that gave up waiting for a peer): see timed_block
+
     def barrier():
-        engine.sync()
+        try:
+            engine.sync()
+        except RuntimeError as exc:  # (reported through the block's time, below: every rank still joins the collective)
+            failures.append(str(exc))
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -540,23 +545,48 @@ def main():
         # last step before all ranks have computed theirs) and the block's time is the MAXIMUM over the ranks: the
         # moment the whole job is done.  The closing barrier still runs, but its own latency (a collective launch of
         # 30-50 us: 2 us per step at K = 20) is a cost of measuring, not of the K steps, and is not counted.
+        # An engine error inside the block (a peer-to-peer exchange that gave up) does not leave this rank's collectives
+        # unmatched: the block's time becomes infinite, which the MAX over the ranks hands to everybody, and every rank
+        # leaves the series of blocks at the same point (the caller falls back to RCCL).
         barrier()
         t0 = time.perf_counter()
-        engine.kl_step(args.steps)
-        local_sync()
-        dt = time.perf_counter() - t0
+        try:
+            engine.kl_step(args.steps)
+            local_sync()
+            dt = time.perf_counter() - t0
+        except RuntimeError as exc:
+            failures.append(str(exc))
+            dt = float("inf")
         barrier()
         return max_over_ranks(dt)
 
     def timed_blocks():
         first = timed_block()
+        if math.isinf(first):
+            return first, 0, [], first
         n_blocks = int(min(1000, max(5, math.ceil(args.busy_seconds / max(first, 1e-6)))))
-        blocks = [timed_block() for _ in range(n_blocks)]
+        blocks = []
+        for _ in range(n_blocks):
+            blocks.append(timed_block())
+            if math.isinf(blocks[-1]):
+                return first, len(blocks), blocks, float("inf")
         return first, n_blocks, blocks, statistics.median(blocks)
 
     gpu_sections = {}  # wall-clock seconds of the sections in which the GPU is the one that works (launch gaps included)
     t_sec = time.perf_counter()
     first, n_blocks, blocks, median = timed_blocks()
+    if math.isinf(median) and exchange is not None and exchange.get("p2p_valid") and rccl_ok:
+        # the peer-to-peer exchange failed under load although it had passed its validation: every rank saw the infinite
+        # block (MAX over ranks), so every rank comes here; the run goes on through RCCL and the line says so
+        exchange["p2p_failed_during_timing"] = failures[-1] if failures else "on another rank"
+        exchange["p2p_valid"] = False
+        engine.set_p2p(False)
+        engine.upload_W(W0)
+        engine.upload_H(H0)
+        engine.kl_step(args.warmup)
+        first, n_blocks, blocks, median = timed_blocks()
+    if math.isinf(median):
+        raise SystemExit(f"bench: the timed steps failed: {failures[-1] if failures else 'on another rank'}")
     gpu_sections["timed_blocks"] = time.perf_counter() - t_sec
     exchange_mode = "rccl" if sharded else None
     if exchange is not None and exchange.get("p2p_valid") and not rccl_ok:
@@ -568,8 +598,15 @@ def main():
         engine.set_p2p(False)
         engine.kl_step(args.warmup)
         r_first, r_n, r_blocks, r_median = timed_blocks()
-        exchange["rccl_ms_per_step"] = r_median / args.steps * 1e3
-        if r_median < median:
+        exchange["rccl_ms_per_step"] = None if math.isinf(r_median) else r_median / args.steps * 1e3
+        if math.isinf(r_median):  # (RCCL itself failed: the peer-to-peer figure stands; the engine's state is restored)
+            exchange["rccl_failed_during_timing"] = failures[-1] if failures else "on another rank"
+            engine.set_p2p(True)
+            engine.upload_W(W0)
+            engine.upload_H(H0)
+            engine.kl_step(args.warmup)
+            exchange_mode = "p2p"
+        elif r_median < median:
             first, n_blocks, blocks, median = r_first, r_n, r_blocks, r_median
         else:
             engine.set_p2p(True)
@@ -637,11 +674,18 @@ def main():
     # wrapped on rank 0, and what all ranks do together is wrapped with the collectives OUTSIDE the guarded part, so that a
     # rank that failed still meets the others.
     one_gpu = None
+    whole = []  # rank 0: the whole problem, drawn once for the one-GPU reference and the CPU baseline (36 s of NumPy at 10^6)
+
+    def whole_problem():
+        if not whole:
+            whole.extend(problem_rows(0, n_total))
+        return whole[0], whole[1]
+
     if strong and not args.no_one_gpu_reference:
         # the same problem on ONE GPU (rank 0's), the figure the N-GPU value is to be compared with
         if rank == 0:
             try:
-                Xa, Ha = problem_rows(0, n_total)
+                Xa, Ha = whole_problem()
                 e1 = sal.Engine(n_total, V, K, device=device)
                 e1.upload_X(Xa), e1.upload_W(W0), e1.upload_H(Ha)
                 del Xa, Ha
@@ -679,9 +723,10 @@ def main():
         W_cpu = H_cpu = None
         if rank == 0:
             try:
-                Xa, Ha = problem_rows(0, n_total)
+                Xa, Ha = whole_problem()
                 rec, (n_cpu, target, cpu_s, W_cpu, H_cpu) = cpu_baseline(Xa, W0, Ha, args.cpu_steps_sharded, args.cpu_budget)
                 del Xa, Ha
+                whole.clear()
                 H_cpu = H_cpu[:n_local].copy()
                 box = [(rec, n_cpu, target, cpu_s)]
             except Exception as exc:

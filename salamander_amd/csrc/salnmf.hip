@@ -319,6 +319,7 @@ static int weight_arrays(salnmf_engine* e, FusedParams& p) {
 // ev_start / ev_stop (profiling only): bound to the dispatch itself, so that their elapsed time is the kernel's own
 // duration, as rocprofv3 reports it -- events recorded around the launch add their barrier packets to it.
 // The instantiations live in salnmf_fused_inst.hip / salnmf_forward_inst.hip (salnmf_launch.h).
+static int flush_H_scale(salnmf_engine* e);
 template <bool DO_G, bool DO_U, bool DO_STATS>
 static int launch_fused(salnmf_engine* e, const FusedParams& p, int grid = 0, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
     // per-sample weights select the WTS instantiation (KLNMF only: the MvNMF / CorrNMF passes, which are the
@@ -329,6 +330,13 @@ static int launch_fused(salnmf_engine* e, const FusedParams& p, int grid = 0, hi
     const FusedSel sel{e->KS, e->KTM, e->KR, DO_G, DO_U, DO_STATS, wts, false};
     FusedParams pw = p;
     if (wts) CK(weight_arrays(e, pw));
+    if (DO_G && DO_U && !DO_STATS && !wts && pw.hscale != nullptr) {
+        // the plain joint step reads its H tiles by LDS-DMA (fused_kernel: HDMA), i.e. as they are in memory: a pending
+        // rescale (an accepted MvNMF trial, salnmf_set_H_scale) is applied as a pass of its own first
+        if (pw.hscale != e->cs || pw.H != e->H || !e->h_pending) return fail("internal: the joint step cannot apply a foreign exposure scale on the fly");
+        CK(flush_H_scale(e));
+        pw.hscale = nullptr;
+    }
     if (launch_fused_inst(sel, pw, grid > 0 ? grid : e->grid, e->stream, ev_start, ev_stop))
         return fail("no kernel instantiation for KS=%d KTM=%d KR=%d", e->KS, e->KTM, e->KR);
     HIPCK(hipGetLastError());

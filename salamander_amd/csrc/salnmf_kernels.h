@@ -697,7 +697,20 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
     constexpr int KB = 16 * KTM;                                   // first remainder column
     constexpr int NVP = KR == 0 ? 0 : (KR == 1 ? 4 : (KR == 2 ? 8 : 16));  // 4*KR values, padded to a power of two
     static_assert(KR >= 0 && KR <= 4 && KB + KR <= KP, "remainder columns must fit the padded layout");
-    __shared__ __attribute__((aligned(16))) double lds[G_::LDS_DOUBLES + KP + (DO_STATS ? LOGTAB_DOUBLES : 0) + (WTS ? WAVES * 32 : 0)];
+    // Rows of W any phase reads: the P product 4 KS (its k-steps), the U product and the remainder columns 16 KTM + KR.
+    // (Round 5: K = 50 stages 52 rows, not the 64 of the padded layout: 9 KB of LDS that the second H buffer below needs.)
+    constexpr int WROWS = 4 * KS > 16 * KTM + KR ? 4 * KS : 16 * KTM + KR;
+    static_assert(WROWS <= G_::WROWS, "never more rows than the padded layout");
+    // HDMA (round 5, the plain joint step only): the NEXT tile's H travels straight from global memory into a second LDS
+    // tile by LDS-DMA (global_load_lds_dwordx4) instead of through 32 prefetch registers and a staging pass at the top of
+    // the tile -- a row of the tile is KP / 2 pieces of 16 bytes, a row of the LDS image one more (LS = KP + 2), as for W.
+    // hipcc tracks LDS-DMA writes against vmcnt itself, so the first read of the new tile waits for exactly these loads.
+    // Needs the tile's rows as they are in memory: the host applies a pending rescale of H before launching this variant.
+    constexpr bool HDMA_FITS = (WROWS * WS + WAVES * (2 * G_::HL + G_::RL) + KP) * 8 <= 160 * 1024;
+    constexpr bool HDMA = DO_G && DO_U && !DO_STATS && !WTS && !PERSIST && !BLOCKED && !RGIVEN && !MVJ && HDMA_FITS;
+    constexpr int REGION = (HDMA ? 2 : 1) * G_::HL + G_::RL;  // per wave: [H tile | R tile | (HDMA) second H tile]
+    constexpr int LDSD = WROWS * WS + WAVES * REGION;
+    __shared__ __attribute__((aligned(16))) double lds[LDSD + KP + (DO_STATS ? LOGTAB_DOUBLES : 0) + (WTS ? WAVES * 32 : 0)];
 
     // MvNMF update_H pass: the grid's last workgroup may be the one that does the W-only algebra instead of tiles
     constexpr bool MVU = DO_U && DO_STATS && (!DO_G || MVJ);
@@ -707,7 +720,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
     if (DO_STATS && p.skip_flag != nullptr && __hip_atomic_load((gsync_t*)p.skip_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     const int nwg = (int)gridDim.x - ((MVU && p.sideW != nullptr) ? 1 : 0);  // workgroups that process tiles
     if (MVU && p.sideW != nullptr && (int)blockIdx.x == nwg) {
-        static_assert(!MVU || KP * (MV_WS + 2 * MV_LD + 1) + 1 <= G_::LDS_DOUBLES, "the W-only algebra must fit this geometry's LDS");
+        static_assert(!MVU || KP * (MV_WS + 2 * MV_LD + 1) + 1 <= LDSD, "the W-only algebra must fit this geometry's LDS");
         const int K = p.K;  // <= KP: the three matrices are packed by K rows
         double* Wl = lds;
         double* S = Wl + K * MV_WS;
@@ -731,10 +744,14 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
     const double* __restrict__ const wlh = WTS ? p.wlh : nullptr;
 
     double* Wl = lds;
-    double* Hl = lds + G_::WROWS * WS + wave * (G_::HL + G_::RL);
-    double* Rl = Hl + G_::HL;
+    double* Hl = lds + WROWS * WS + wave * REGION;  // (HDMA: the tile being worked on; changes places with Hnx after every tile)
+    double* const Rl = lds + WROWS * WS + wave * REGION + G_::HL;
+    double* Hnx = Hl + (HDMA ? G_::HL + G_::RL : 0);
+    // (HDMA) the same two tiles as wave-uniform addresses for the DMA's M0, and which of them receives the next tile
+    double* const Hdma0 = lds + WROWS * WS + __builtin_amdgcn_readfirstlane(wave) * REGION;
+    int hsel = 0;
 
-    double* hsl = lds + G_::LDS_DOUBLES;  // [KP] copy of hscale
+    double* hsl = lds + LDSD;  // [KP] copy of hscale
     if (p.hscale && tid < KP) hsl[tid] = p.hscale[tid];
     double* ltab = hsl + KP;              // (DO_STATS) table of log_pos
     if (DO_STATS) stage_logtab(ltab, tid);
@@ -763,8 +780,8 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
     // profiles/r03/ab_step_variants.txt.)
     // The joint step with the objective folded in (DO_STATS) does the same: its numerator is summed in the plain step's order.
     constexpr bool COOP = DO_G && DO_U && !RGIVEN && !MVJ;  // (with per-sample weights too: process_tile_coop honours them)
-    using CO_ = EpiGeo<KT, KR, G_::LDS_DOUBLES>;
-    static_assert(CO_::COOP_DOUBLES <= (WAVES - 1) * (G_::HL + G_::RL), "the cooperative tile's numerator park must fit the idle waves' LDS");
+    using CO_ = EpiGeo<KT, KR, LDSD>;
+    static_assert(CO_::COOP_DOUBLES <= (WAVES - 1) * REGION, "the cooperative tile's numerator park must fit the idle waves' LDS");
     const int64_t nleft = p.ntiles % tstride;
     const bool coop = COOP && nleft > 0 && nleft <= (int64_t)gridDim.x && p.hscale == nullptr;
     const int64_t nfull = coop ? p.ntiles - nleft : p.ntiles;  // tiles of the one-wave-per-tile rounds
@@ -783,11 +800,46 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
     double x[VT][4];
     d2 wpre = (d2){1.0, 0.0};  // (WTS) {w_kl, w_lhalf} of row (lane & 15) of the prefetched tile
 
-    auto load_tile = [&](int64_t t) __attribute__((always_inline)) {
-        const int64_t n0 = t * 16;
-        const d2* hsrc = reinterpret_cast<const d2*>(p.H + n0 * KP) + lane;
+    // (HDMA) piece 64 i + lane of the LDS image of an H tile: its offset in the tile's [16][KP] block (doubles), -1 for the pad
+    // piece of a row and beyond the sixteen rows
+    constexpr int HPR = LS / 2, HNI = (16 * HPR + 63) / 64;
+    // (the pad piece of a row receives a copy of the row's last data piece: nothing reads it, and the instruction needs no
+    // lane mask -- only the last instruction, whose lanes run past the sixteenth row, has one)
+    int hoff[HDMA ? HNI : 1];
+    if (HDMA) {
 #pragma unroll
-        for (int j = 0; j < HV; ++j) hpre[j] = hsrc[64 * j];
+        for (int i = 0; i < HNI; ++i) {
+            const int sp = 64 * i + lane, row = sp / HPR, c = sp - row * HPR;
+            hoff[i] = row < 16 ? row * KP + 2 * (c < HPR - 1 ? c : HPR - 2) : -1;
+        }
+    }
+    auto load_tile_H = [&](int64_t t) __attribute__((always_inline)) {
+        const int64_t n0 = t * 16;
+        if constexpr (HDMA) {
+            // As inline assembly, not through __builtin_amdgcn_global_load_lds: around the builtin hipcc put s_waitcnt vmcnt(0)
+            // in front of the X loads of the launch's first tile (one more memory round trip in the prologue) and between the
+            // pieces on the register-staged path, yet none in front of the tile's first LDS read -- its bookkeeping of LDS-DMA
+            // is of no use here, so the pieces are invisible to it and process_half waits for them by count.  That is sound
+            // because vmcnt completes in issue order and no wait hipcc computes spans a DMA group: it waits for X loads (issued
+            // right behind the group, volatile + memory clobber keep them there) and for nothing younger before the next group.
+            const double* hsrc = p.H + n0 * KP;
+            const unsigned m0base = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(Hdma0 + hsel * (G_::HL + G_::RL));
+#pragma unroll
+            for (int i = 0; i < HNI; ++i)
+                if (64 * (i + 1) <= 16 * HPR || hoff[i] >= 0)  // (compile-time true for all but the last instruction)
+                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                                 :
+                                 : "v"(hsrc + hoff[i]), "s"(__builtin_amdgcn_readfirstlane(m0base + 1024u * i))
+                                 : "memory");
+            hsel ^= 1;
+        } else {
+            const d2* hsrc = reinterpret_cast<const d2*>(p.H + n0 * KP) + lane;
+#pragma unroll
+            for (int j = 0; j < HV; ++j) hpre[j] = hsrc[64 * j];
+        }
+    };
+    auto load_tile_X = [&](int64_t t) __attribute__((always_inline)) {
+        const int64_t n0 = t * 16;
         const double* xsrc = p.X + (n0 + q) * VMAX + c16;
 #pragma unroll
         for (int vt = 0; vt < VT; ++vt)
@@ -798,6 +850,12 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
             wpre[1] = p.wlh_eff[n0 + c16];
         }
     };
+    // (H first: process_half's counted wait for the DMA pieces relies on the X loads being the younger ones)
+    auto load_tile = [&](int64_t t) __attribute__((always_inline)) {
+        load_tile_H(t);
+        load_tile_X(t);
+    };
+    bool x_first = false;  // (HDMA) the tile about to be processed was loaded X first (the register-staged prologue only)
 
     // HALF 0: the whole tile as the template switches say; (MVJ) HALF 1: the update_H half, HALF 2: the numerator half on
     // the H' that half 1 left in the wave's LDS tile (no staging, no rescale, X still in registers)
@@ -809,7 +867,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         // holding 8 weights per lane across the tile pushed the weighted joint kernel past its 512 registers
         if (WTS) *reinterpret_cast<d2*>(wgt + 2 * c16) = wpre;  // (the four q groups write the same values)
         // ---- stage the H tile (wave private; LDS ops of one wave are executed in order)
-        if (HALF != 2 && p.hscale) {
+        if (!HDMA && HALF != 2 && p.hscale) {
             // MvNMF: H is read as clip(H * colsum(W_trial)) (a line-search trial, or the rescale of an accepted
             // one that no pass has materialised yet).  Applied here, where the prefetched tile is consumed
             // anyway, from the LDS copy of the scale
@@ -819,11 +877,22 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
                 hpre[j][1] = clip_lo(hpre[j][1] * hsl[hcol[j] + 1], kEps);
             }
         }
-        if (HALF != 2) {
+        if (!HDMA && HALF != 2) {
 #pragma unroll
             for (int j = 0; j < HV; ++j) {
                 *reinterpret_cast<d2*>(Hl + hrow[j] * LS + hcol[j]) = hpre[j];
             }
+        }
+        if (HDMA) {
+            // This tile's H was sent to LDS by load_tile's DMA, which hipcc does NOT order against the LDS reads below (checked
+            // in the ISA: no vmcnt in front of the first ds_read).  vmcnt counts in issue order, and behind this tile's DMA pieces
+            // were issued its 24 X loads and, except for the launch's first tile, the previous tile's H stores: "at most 24
+            // outstanding" therefore means the DMA pieces (and the first X loads, issued a whole tile ago) have landed, while
+            // the stores of the tile just finished stay in flight.
+            static_assert(VT * 4 == 24, "the X tile is 24 loads per lane");
+            if (x_first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (uniform; its DMA pieces are the youngest loads)
+            else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            x_first = false;
         }
         __builtin_amdgcn_wave_barrier();
         constexpr int FKB = 1 + 7 * (HALF == 2 ? 1 : 0);
@@ -1170,8 +1239,8 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
         const int lane = tid & 63, wave = tid >> 6, c16 = lane & 15, q = lane >> 4;
-        double* Hs = lds + G_::WROWS * WS;  // wave 0's H tile and R tile serve as the shared ones
-        double* cslab = lds + G_::WROWS * WS + (G_::HL + G_::RL);  // the LDS regions of waves 1..3 are free meanwhile
+        double* Hs = lds + WROWS * WS;  // wave 0's H tile and R tile serve as the shared ones
+        double* cslab = lds + WROWS * WS + REGION;  // the LDS regions of waves 1..3 are free meanwhile
         double* Rs = Hs + G_::HL;
         const int wv = __builtin_amdgcn_readfirstlane(wave);
         // loads first (they fly while the slower waves of the workgroup arrive): the H tile, 16 bytes per thread and
@@ -1330,7 +1399,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         // the first tile (its H rows were written by this very wave in the previous step) flies during the wait
         if (tile < nfull) load_tile(tile);
         if (step > 0 && !persist_wait_W(p.sync, p.abort_host, (unsigned)step * (unsigned)K, lds, tid)) return;
-        stage_W<G_::WROWS, true>(Wl, p.Wmut, K, V, V, tid);  // sc1 loads: rows published by other workgroups
+        stage_W<WROWS, true>(Wl, p.Wmut, K, V, V, tid);  // sc1 loads: rows published by other workgroups
         __syncthreads();
     } else {
         // (the first tile's loads issued ahead of the staging instead: 69.7 -> 71.9 us per step at c2 -- the prologue's
@@ -1345,15 +1414,26 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         // the CU's memory pipeline in front of the other waves' DMA pieces, and the barrier waits for the last of those);
         // only the H tile behind the DMA (+0.5 us at K = 50, -1.0 at K = 30).
         if (p.wdma && V == VMAX && p.ldw == VMAX && (reinterpret_cast<uintptr_t>(p.W) & 15) == 0) {  // (uniform)
-            stage_W_dma_issue<G_::WROWS>(Wl, p.W, K, tid);
+            stage_W_dma_issue<WROWS>(Wl, p.W, K, tid);
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");  // (no LDS read of W is hoisted above the barrier)
             if (tile < nfull) load_tile(tile);
         } else {
-            stage_W<G_::WROWS>(Wl, p.W, K, V, p.ldw, tid);
+            stage_W<WROWS>(Wl, p.W, K, V, p.ldw, tid);
             __syncthreads();
-            if (tile < nfull) load_tile(tile);
+            if (tile < nfull) {
+                if (HDMA) {
+                    // X first, then the DMA pieces of H, on this (rare) path: were the two prologues to end in the same
+                    // sequence, hipcc would merge their tails and put an s_waitcnt vmcnt(0) between the DMA pieces and the X
+                    // loads of BOTH (seen in the ISA): one more memory round trip in front of every launch's first tile
+                    load_tile_X(tile);
+                    load_tile_H(tile);
+                    x_first = true;
+                } else {
+                    load_tile(tile);
+                }
+            }
         }
     }
     FK_TICK(0);
@@ -1364,6 +1444,11 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
             process_half(tile, integral_constant<int, 2>{});
         } else {
             process_half(tile, integral_constant<int, 0>{});
+        }
+        if (HDMA) {  // the tile prefetched meanwhile becomes the current one
+            double* t = Hl;
+            Hl = Hnx;
+            Hnx = t;
         }
     }
     if (COOP && coop && (int64_t)blockIdx.x < nleft) process_tile_coop(nfull + blockIdx.x);
@@ -1383,7 +1468,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         // contributions in the fixed order wave 0 + 1 + 2 + 3 and stores its tiles: 128-byte row segments.
         // ROUNDS = 2 (feature halves) only where the parked tiles do not fit (KT = 4).
         constexpr int REMD = CO_::REMD, ROUNDS = CO_::ROUNDS, VTR = CO_::VTR, NT = CO_::NT;
-        static_assert(3 * NT * 256 + REMD <= G_::LDS_DOUBLES, "parked accumulator tiles must fit in LDS");
+        static_assert(3 * NT * 256 + REMD <= LDSD, "parked accumulator tiles must fit in LDS");
         auto owned = [](int o) constexpr { return o < NT ? (NT - o + 3) / 4 : 0; };   // tiles owned by wave o
         auto pbase = [&](int o) constexpr { int b = 0; for (int i = 0; i < o; ++i) b += 3 * owned(i); return b; };
         double* remL = lds + 3 * NT * 256;  // [WAVES][KR][VMAX]
@@ -1394,7 +1479,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         double cc[ROUNDS][CO_::MAXI][4];
         double crem[2] = {0.0, 0.0};
         if (COOP && coopwg) {
-            const double* cl = lds + G_::WROWS * WS + (G_::HL + G_::RL);
+            const double* cl = lds + WROWS * WS + REGION;
 #pragma unroll
             for (int half = 0; half < ROUNDS; ++half)
 #pragma unroll

@@ -488,7 +488,7 @@ def test_distributed_multimodal_model_world_size_one():
 # ---------------------------------------------------------------------------------------------------------------
 # The instantiations config c5 uses, against vectors the REFERENCE produced (tests/golden/corr_c5.npz: make_golden.py
 # --corr-c5 executes _utils_corrnmf.update_embedding) -- not against the box's SciPy
-def _c5_engines(mods, U):
+def _c5_vector_engines(mods, U):
     engines = []
     for m, V in zip(mods, (96, 83)):
         e = Engine(U.shape[0], V, len(m["beta"]))
@@ -514,7 +514,7 @@ def test_c5_instantiation_joint_sample_solves_match_reference_executed_vectors(i
     from test_oracle_corrnmf import load_c5_sample_solve
 
     mods, U, U_upd, var = load_c5_sample_solve(it)
-    engines = _c5_engines(mods, U)
+    engines = _c5_vector_engines(mods, U)
     for e in engines:
         e.set_batched_sample_solves(batched)
     status = Engine.corr_update_sample_embeddings_multi(engines, var, 3, return_status=True)
