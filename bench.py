@@ -872,6 +872,11 @@ def main():
             line["time_to_kl"] = sharded_ttk
             if sharded_ttk and "rel_l2_W" in sharded_ttk:
                 line["parity"] = {k: sharded_ttk[k] for k in ("parity_steps", "rel_l2_W", "rel_l2_H_rank0_rows", "W_identical_on_all_ranks", "parity_gate", "parity_ok")}
+        if one_gpu and "steps_per_s" in one_gpu:
+            # strong scaling: the N-GPU value is to be compared with ONE GPU on the SAME 10^6-sample problem (measured in this very
+            # run, on rank 0's GPU) -- not with the N = 1 line of this script, which is c2, a ten times smaller problem
+            line["one_gpu_same_problem_value"] = one_gpu["steps_per_s"]
+            line["speedup_vs_one_gpu_same_problem"] = one_gpu["speedup_of_this_run"]
         if args.rehearse_one_device:
             line["config"]["rehearsal"] = (
                 f"{world} ranks as processes on ONE GPU (device 0), control plane gloo, no RCCL, peer-to-peer exchange between the "
