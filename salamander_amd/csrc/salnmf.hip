@@ -1779,1832 +1779,10 @@ int salnmf_reconstruct(salnmf_engine* e, double* out) {
     return rc;
 }
 
-// ------------------------------------------------------------------------------------ MvNMF
-
-static int mv_logdet_to_slot(salnmf_engine* e, const double* W, double delta, int slot) {
-    hipLaunchKernelGGL(mv_logdet_kernel, dim3(1), dim3(MV_BLOCK), 0, e->stream, W, e->K, e->V, delta, e->scal + slot);
-    HIPCK(hipGetLastError());
-    return 0;
-}
-
-// ---- MvNMF on more than 96 features (feature blocks, one signature chunk) or on more than 64 signatures (signature chunks,
-// one feature block; round 5): the step of mvnmf.py:197-210 in its plain form -- update_H over the blocks / chunks, the
-// numerator passes, the W-only algebra, root, and a host-driven line search whose objectives are the KLNMF path's forward
-// passes.  No speculation: such a problem spends its time in the passes over the samples
-// (csrc/salnmf_mv_wide_kernels.h has the kernels).
-static inline bool mv_wide(const salnmf_engine* e) { return (e->NB > 1) != (e->NC > 1); }
-static int mv_wide_check(const salnmf_engine* e) {
-    if (e->NB > 1 && e->NC > 1) return fail("MvNMF is not available for n_features > %d together with n_signatures > %d", VMAX, KC);
-    if (sharded(e)) return fail("MvNMF on more than %d features or more than %d signatures is not available on a sample-sharded engine", VMAX, KC);
-    return 0;
-}
-// (signature chunks) the K x 2K scratch of the global-memory elimination
-static int ensure_mv_scratch(salnmf_engine* e) {
-    if (e->mvS) return 0;
-    if (e->K > MVM_KMAX) return fail("MvNMF supports up to %d signatures (this engine has %d)", MVM_KMAX, e->K);
-    HIPCK(hipMalloc(&e->mvS, (size_t)2 * e->K * e->K * sizeof(double)));
-    return 0;
-}
-static int mv_wide_logdet(salnmf_engine* e, const double* W, double delta, int slot) {
-    if (e->NC > 1) {
-        CK(ensure_mv_scratch(e));
-        hipLaunchKernelGGL(mv_many_gram_kernel<false>, dim3(e->K), dim3(256), 0, e->stream, W, e->K, e->V, delta, e->mvS);
-        HIPCK(hipGetLastError());
-        hipLaunchKernelGGL(mv_many_eliminate_kernel<false>, dim3(1), dim3(MVM_BLOCK), 0, e->stream, e->mvS, e->K, e->scal + slot);
-        HIPCK(hipGetLastError());
-        return 0;
-    }
-    hipLaunchKernelGGL(mv_logdet_wide_kernel, dim3(1), dim3(MV_BLOCK), 0, e->stream, W, e->K, e->V, delta, e->scal + slot);
-    HIPCK(hipGetLastError());
-    return 0;
-}
-// update_H of an MvNMF step (MvNMF._update_H, mvnmf.py:162-165: in place, unweighted) on a split engine
-static int mv_wide_update_H(salnmf_engine* e) {
-    if (e->NC > 1) {
-        CK(flush_H_scale(e));
-        CK(chunk_ratio(e));
-        return chunk_passes(e, false, true, 0, 0, false);
-    }
-    CK(blocked_update_H(e, e->H, kEps, false));
-    e->h_pending = false;
-    return 0;
-}
-// numerator of (W, H) -> Gblk (feature blocks) / red (signature chunks), rowsums_H -> red + K V, A = W Y_minus, B = W |Y|
-// -> mvA, mvB, log det(W) -> scal[3]
-static int mv_wide_prepare(salnmf_engine* e, double delta) {
-    CK(flush_H_scale(e));  // (the column sums below read H as it is)
-    if (e->NC > 1) {
-        CK(ensure_mv_scratch(e));
-        CK(chunk_ratio(e));
-        CK(chunk_passes(e, true, false, 0, 0, false, true));  // every row's numerator, W untouched
-        for (int ci = 0; ci < e->NC; ++ci) {
-            const auto& c = e->kc[(size_t)ci];
-            hipLaunchKernelGGL(colsum_kernel, dim3(c.K), dim3(256), 0, e->stream, e->H + (size_t)ci * e->Np * e->KP, e->N, e->KP,
-                               e->red + (size_t)e->K * e->V + c.k0);
-            HIPCK(hipGetLastError());
-        }
-        hipLaunchKernelGGL(mv_many_gram_kernel<true>, dim3(e->K), dim3(256), 0, e->stream, e->W, e->K, e->V, delta, e->mvS);
-        HIPCK(hipGetLastError());
-        hipLaunchKernelGGL(mv_many_eliminate_kernel<true>, dim3(1), dim3(MVM_BLOCK), 0, e->stream, e->mvS, e->K, e->scal + 3);
-        HIPCK(hipGetLastError());
-        hipLaunchKernelGGL(mv_many_AB_kernel, dim3(e->K), dim3(128), 0, e->stream, e->mvS, e->W, e->K, e->V, e->mvA, e->mvB);
-        HIPCK(hipGetLastError());
-        return 0;
-    }
-    CK(blocked_numerators(e, false));  // update_W_unconstrained takes no weights (mvnmf.py:37-66): as the narrow path
-    hipLaunchKernelGGL(colsum_kernel, dim3(e->K), dim3(256), 0, e->stream, e->H, e->N, e->KP, e->red + (size_t)e->K * e->V);
-    HIPCK(hipGetLastError());
-    hipLaunchKernelGGL(mv_prepare_W_wide_kernel, dim3(1), dim3(MV_BLOCK), 0, e->stream, e->W, e->K, e->V, delta, e->mvA, e->mvB, e->scal + 3);
-    HIPCK(hipGetLastError());
-    return 0;
-}
-static int mv_wide_root(salnmf_engine* e, double lam, int n_given) {
-    hipLaunchKernelGGL(mv_trial_row_wide_kernel<true>, dim3(e->K), dim3(256), 0, e->stream, e->W, e->Wunc, 1.0, 0, e->K, e->V, e->Wtrial, e->cs, e->mvA,
-                       e->mvB, e->NC > 1 ? e->red : e->Gblk, e->red + (size_t)e->K * e->V, lam, n_given);
-    HIPCK(hipGetLastError());
-    return 0;
-}
-// line_search (mvnmf.py:69-92) from the resident (W, H) with W_unconstrained in Wunc.  trial_ready: the first trial (the
-// normalised, clipped W_unconstrained) and its column sums are in Wtrial / cs already; have_logdet: scal[3] = log det(W).
-static int mv_wide_line_search(salnmf_engine* e, double lam, double delta, double* gamma, bool trial_ready, bool have_logdet, double* f_accepted) {
-    CK(flush_H_scale(e));
-    CK(objective_to_slot(e, e->W, nullptr, false, 0));  // KL(X || W H), unweighted (mvnmf.py:27-34)
-    if (!have_logdet) CK(mv_wide_logdet(e, e->W, delta, 3));
-    double g = *gamma;
-    bool blend = false;
-    for (;;) {
-        if (blend || !trial_ready) {
-            hipLaunchKernelGGL(mv_trial_row_wide_kernel<false>, dim3(e->K), dim3(256), 0, e->stream, e->W, e->Wunc, g, blend ? 1 : 0, e->K, e->V, e->Wtrial,
-                               e->cs, nullptr, nullptr, nullptr, nullptr, 0.0, 0);
-            HIPCK(hipGetLastError());
-        }
-        CK(mv_wide_logdet(e, e->Wtrial, delta, 4));
-        CK(objective_to_slot(e, e->Wtrial, e->cs, false, 2));  // KL(X || W_trial clip(H * colsum))
-        double v[5];
-        CK(read_scalars(e, 0, 5, v));
-        const double f0 = v[0] + lam * v[3], f1 = v[2] + lam * v[4];
-        if (f_accepted) *f_accepted = f1;
-        if (f1 > f0 && g > 1e-16) {  // mvnmf.py:84
-            g *= 0.8;
-            blend = true;
-            continue;
-        }
-        break;
-    }
-    *gamma = std::min(1.0, 1.2 * g);  // mvnmf.py:91
-    std::swap(e->W, e->Wtrial);
-    e->h_pending = true;  // H <- clip(H * colsum), applied by the readers until the next update_H pass writes H in full
-    if (e->NC > 1) CK(flush_H_scale(e));  // (the chunked passes read H as it is: the rescale is a pass of its own there)
-    return 0;
-}
-static int mv_wide_update_W(salnmf_engine* e, int n_given, double lam, double delta, double* gamma, double* f_accepted) {
-    if (n_given >= e->K) return 0;
-    CK(mv_wide_prepare(e, delta));
-    CK(mv_wide_root(e, lam, n_given));
-    return mv_wide_line_search(e, lam, delta, gamma, true, true, f_accepted);
-}
-
-int salnmf_mv_objective(salnmf_engine* e, double lam, double delta, double* out) {
-    if (e && split(e)) CK(mv_wide_check(e));
-    if (!e || !out) return fail("null argument");
-    CK(enter(e));
-    CK(objective_to_slot(e, e->W, nullptr, false, 0));
-    if (mv_wide(e))
-        CK(mv_wide_logdet(e, e->W, delta, 3));
-    else
-        CK(mv_logdet_to_slot(e, e->W, delta, 3));
-    double v[4];
-    CK(read_scalars(e, 0, 4, v));
-    *out = v[0] + lam * v[3];
-    return 0;
-}
-
-// Launch with `ev` bound to the kernel's own completion signal: a hipEventRecord behind the launch would put a
-// barrier packet of its own into the queue, which costs the stream ~7 us per record (profiles/r02/mv_timeline_*.txt).
-#define LAUNCH_WITH_EVENT(kernel, grid, block, stream, ev, ...) \
-    hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, nullptr, ev, 0, __VA_ARGS__)
-
-// MvNMF._update_W (mvnmf.py:190-195) on the current (W, H).
-// Two streams: everything that depends on W alone -- Gram matrix, Cholesky, inverse, A = W Y_minus, B = W |Y|,
-// log det, and later the log det of a trial W -- is single-workgroup latency-bound work and runs on stream2
-// while the passes over the samples (which leave one CU free, mv_grid / mv_fgrid) run on the main stream.
-//   w_ready: the caller recorded evW on the main stream after the last write of W and already started
-//            mv_prepare_W on stream2 (mv_step does, so that it also overlaps the update_H pass)
-// The MvNMF side streams exist only in engines that run MvNMF steps (HIP multiplexes a process's streams onto a few
-// hardware queues: an engine that only ever runs KL or CorrNMF steps should not hold three of them).
-static int ensure_side_streams(salnmf_engine* e) {
-    if (!e->stream2) HIPCK(hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking));
-    if (!e->stream3) HIPCK(hipStreamCreateWithFlags(&e->stream3, hipStreamNonBlocking));
-    return 0;
-}
-
-// An MvNMF update_H pass whose last workgroup runs the W-only algebra (fused_kernel<!G, U, STATS>: sideW): `total`
-// workgroups are launched, `total - 1` of them process tiles.  One per CU at most, so that the side workgroup starts at once.
-static inline int mv_side_total(const salnmf_engine* e) { return std::min(e->cus, e->grid + 1); }
-
-static void mv_side_params(salnmf_engine* e, FusedParams& p, const double* W, double delta) {
-    p.sideW = W;
-    p.sideDelta = delta;
-    p.sideA = e->mvA;
-    p.sideB = e->mvB;
-    p.sideLogdet = e->scal + 3;
-}
-
-static int mv_start_prepare_W(salnmf_engine* e, double delta, bool record_w_event) {
-    CK(ensure_side_streams(e));
-    if (record_w_event) HIPCK(hipEventRecord(e->evW, e->stream));  // else: recorded when W was last written
-    HIPCK(hipStreamWaitEvent(e->stream2, e->evW, 0));
-    LAUNCH_WITH_EVENT(mv_prepare_W_kernel, dim3(1), dim3(MV_BLOCK), e->stream2, e->evPrepW, e->W, e->K, e->V, delta, e->mvA, e->mvB,
-                      e->scal + 3);
-    HIPCK(hipGetLastError());
-    return 0;
-}
-
-// The numerator pass of one MvNMF W update on (W, H): G = (X/(WH)) @ H.T partials and the KL partial, reduced
-// together with the row sums of H (from the preceding update_H pass) by one tail launch and all-reduced.
-//   grid: e->mv_grid leaves one CU per XCD to the side stream's kernels; the steady state of mv_step has nothing on the
-//   side stream and uses the whole chip (e->grid)
-//   hsum_parts: workgroups of the preceding update_H pass (rows of Hsumpart)
-static int mv_numerator_pass(salnmf_engine* e, const double* W, const double* H, const double* hscale, int grid, int hsum_parts) {
-    CK(ensure_xlogx(e));
-    FusedParams p = fused_params(e);
-    p.wkl = nullptr;  // the MvNMF path is unweighted (mvnmf.py:56)
-    p.wlh = nullptr;
-    p.W = W;
-    p.H = const_cast<double*>(H);
-    p.Hout = const_cast<double*>(H);
-    p.hscale = hscale;
-    CK((launch_fused<true, false, true>(e, p, grid)));
-    e->mv_slabs = grid;        // what the tail that follows (now or after the line-search decision) has to reduce
-    e->mv_hparts = hsum_parts;
-    return 0;
-}
-
-// The tail of a numerator pass: G slabs, row sums of H and KL partials reduced in one launch (-> e->red).  with_root: the
-// same launch also evaluates the closed-form root and the first trial of the line search (tail_kernel: rootA; needs the
-// row sums from the preceding update_H pass and an unsharded engine); ev: bound to the launch's completion.
-static int mv_tail(salnmf_engine* e, bool with_root, double lam, int n_given, hipEvent_t ev) {
-    TailParams t = tail_params(e, e->mv_slabs, e->red, n_given, 0, 0, true, e->mv_hparts);
-    if (with_root) {
-        t.rootA = e->mvA;
-        t.rootB = e->mvB;
-        t.rootLogdet = e->scal + 3;
-        t.rootF0 = e->scal + 1;
-        t.rootWunc = e->Wunc;
-        t.rootWtrial = e->Wtrial;
-        t.rootCs = e->cs;
-        t.rootLam = lam;
-    }
-    if (ev)
-        hipExtLaunchKernelGGL(tail_kernel, dim3(e->K), dim3(TAIL_BLOCK), 0, e->stream, nullptr, ev, 0, t);
-    else
-        hipLaunchKernelGGL(tail_kernel, dim3(e->K), dim3(TAIL_BLOCK), 0, e->stream, t);
-    HIPCK(hipGetLastError());
-    return 0;
-}
-
-//   speculate: the caller will run another step right after this one.  Everything the NEXT step can do before this
-//            step's line search is decided is queued behind the first trial, assuming it will be accepted (the common
-//            case):
-//              * that step's update_H pass with the trial as W, reading H as clip(H * colsum) on the fly and writing a
-//                second H buffer.  Its P = H' W_trial is exactly what KL(W_trial, H') -- the trial's objective --
-//                needs, so the pass evaluates the trial as well (KL partials from P before the division) and the
-//                separate forward pass over the samples is not run at all;
-//              * its W-only algebra on stream2, and its numerator pass + tail on the main stream.
-//            The scalars come back on a side stream while the numerator pass runs; on acceptance the buffers are
-//            swapped and *speculated = true tells the caller that the next step starts at its closed-form root, otherwise
-//            everything speculative is dropped and the backtracking loop evaluates its trials with the forward kernel.
-//   w_ready:  A, B and the log det of the current W are produced on the MAIN stream already (the side workgroup of the
-//            preceding update_H pass); otherwise mv_prepare_W_kernel is started on stream2 here and waited for
-//   g_ready:  (in) the numerator pass of THIS step was queued by the previous call's speculation (its tail was not)
-static int mv_update_W_impl(salnmf_engine* e, int n_given, double lam, double delta, double* gamma, bool have_hsum, bool w_ready,
-                            bool speculate = false, bool* speculated = nullptr, bool g_ready = false, double* f_accepted = nullptr,
-                            double* wunc_out = nullptr, const double* wunc_given = nullptr) {
-    // wunc_out (salnmf_mv_update_W_unconstrained): stop behind the closed-form root and hand W_unconstrained back; the
-    // resident state is not changed.  wunc_given (salnmf_mv_line_search): the line search of mvnmf.py:69-92 from the
-    // resident (W, H) with the caller's W_unconstrained instead of the root.
-    // f_accepted: the line search's value at the accepted point (mvnmf.py:82,89), which IS the model's objective of the
-    // state this call leaves behind (kl_divergence_penalized of the normalised W and the rescaled H, mvnmf.py:27-34,149-156)
-    if (speculated) *speculated = false;
-    if (n_given >= e->K) return 0;
-    CK(ensure_side_streams(e));
-    const int K = e->K, V = e->V;
-    if (wunc_given) {
-        CK(flush_H_scale(e));
-        HIPCK(hipMemcpyAsync(e->Wunc, wunc_given, (size_t)K * V * sizeof(double), hipMemcpyHostToDevice, e->stream));
-        // f0 = KL(X || W H) + lam log det(W W^T + delta I) -> scal[1]  (mvnmf.py:79)
-        CK(objective_to_slot(e, e->W, nullptr, false, 0));
-        CK(mv_logdet_to_slot(e, e->W, delta, 3));
-        hipLaunchKernelGGL(combine_scalar_kernel, dim3(1), dim3(1), 0, e->stream, e->scal + 1, (const double*)e->scal, lam, (const double*)(e->scal + 3));
-        HIPCK(hipGetLastError());
-        HIPCK(hipStreamSynchronize(e->stream));  // (the caller's array is free again)
-    }
-    if (!g_ready && !wunc_given) {
-        CK(flush_H_scale(e));  // a stand-alone call after an earlier step; inside mv_step the update_H pass consumed it
-        if (!w_ready) CK(mv_start_prepare_W(e, delta, true));
-        // the rowsums_H partials come from the preceding update_H pass (have_hsum) or, for a stand-alone _update_W,
-        // from a column-sum kernel over the current H.  Inside mv_step (w_ready: the W-only algebra ran in that pass's
-        // side workgroup, on this stream) the numerator pass has the whole chip, as the speculative one has: the same
-        // slab order, hence the same bits of W, whether the steps come in one call or one by one; a stand-alone call
-        // leaves one CU per XCD to the W-only kernel on stream2.
-        if (w_ready)  // (on as many tile workgroups as a pass with the side workgroup: one slab order for every form of the step)
-            CK(mv_numerator_pass(e, e->W, e->H, nullptr, mv_side_total(e) - 1, mv_side_total(e) - 1));
-        else
-            CK(mv_numerator_pass(e, e->W, e->H, nullptr, e->mv_grid, e->mv_grid));
-    }
-    // The tail of the numerator pass -- which the previous call's speculation queued WITHOUT its tail (g_ready), so that
-    // the tail runs after the line-search decision and can carry the closed-form root and the first trial of THIS step
-    // in the same launch (inside mv_step on an unsharded engine: one kernel and one boundary less per step).  A, B and
-    // the log det it reads come from the side workgroup of the preceding update_H pass (same stream), or from stream2.
-    const bool root_in_tail = have_hsum && !sharded(e) && !wunc_given;
-    if (!w_ready && !wunc_given) HIPCK(hipStreamWaitEvent(e->stream, e->evPrepW, 0));
-    // (a non-speculative first trial is followed by the log det of the trial on stream2: the tail's completion is its event)
-    if (!wunc_given) CK(mv_tail(e, root_in_tail, lam, n_given, root_in_tail && !speculate ? e->evTrial : nullptr));
-    if (!root_in_tail && !wunc_given) {
-        // the rowsums_H partials came from the preceding update_H pass (have_hsum) or, for a stand-alone _update_W,
-        // come from a column-sum kernel over the current H
-        if (!have_hsum) {
-            hipLaunchKernelGGL(colsum_kernel, dim3(K), dim3(256), 0, e->stream, e->H, e->N, e->KP, e->red + K * V);
-            HIPCK(hipGetLastError());
-        }
-        CK(allreduce(e, e->red, (size_t)K * V + K + 1));
-    }
-    // otherwise: W_unconstrained from A, B and the reduced sums, f0 = KL + lam * logdet(W) -> scal[1], inside the first
-    // trial kernel below
-    const MvRootParams root{e->mvA, e->mvB, e->red, e->red + K * V, e->red + K * V + K, e->scal + 3, e->scal + 1, lam, n_given};
-    double g = *gamma;
-    bool blend = false;
-    for (;;) {
-        const bool spec = speculate && !blend;
-        // trial W: normalise + clip and the column sums for H on the main stream
-        if (!blend && root_in_tail)
-            ;  // (done by the tail launch above)
-        else if (spec)
-            hipLaunchKernelGGL(mv_trial_light_kernel<true>, dim3(1), dim3(MV_BLOCK), 0, e->stream, e->W, e->Wunc, 1.0, 0, K, V, e->Wtrial, e->cs, root);
-        else if (!blend && wunc_given)  // the first trial is the caller's W_unconstrained, normalised and clipped (mvnmf.py:80-81)
-            LAUNCH_WITH_EVENT(mv_trial_light_kernel<false>, dim3(1), dim3(MV_BLOCK), e->stream, e->evTrial, e->W, e->Wunc, 1.0, 0, K,
-                              V, e->Wtrial, e->cs, root);
-        else if (!blend)
-            LAUNCH_WITH_EVENT(mv_trial_light_kernel<true>, dim3(1), dim3(MV_BLOCK), e->stream, e->evTrial, e->W, e->Wunc, 1.0, 0, K,
-                              V, e->Wtrial, e->cs, root);
-        else
-            LAUNCH_WITH_EVENT(mv_trial_light_kernel<false>, dim3(1), dim3(MV_BLOCK), e->stream, e->evTrial, e->W, e->Wunc, g, 1, K, V,
-                              e->Wtrial, e->cs, root);
-        HIPCK(hipGetLastError());
-        if (wunc_out) return download(e, wunc_out, e->Wunc, (size_t)K * V);  // (W, H untouched; the trial buffers are scratch)
-        double v[5];
-        if (spec) {
-            CK(ensure_halt(e));
-            if (!e->KLpart2) HIPCK(hipMalloc(&e->KLpart2, (size_t)e->grid * sizeof(double)));
-            // The next step's update_H (+ row sums of the new H), which also evaluates this trial: KL(W_trial, H') -> scal[2],
-            // summed inside the launch by the workgroup that finishes last.  The grid's last workgroup does no tiles: it
-            // runs the next step's W-only algebra on the trial (A, B; its log det -> scal[3] is this trial's log det as
-            // well) -- nothing of the steady state is left on a second stream, so nothing here waits for another queue.
-            const int total = mv_side_total(e), nwg = total - 1;
-            FusedParams sp = fused_params(e);
-            sp.wkl = nullptr;
-            sp.wlh = nullptr;
-            sp.W = e->Wtrial;
-            sp.hscale = e->cs;
-            sp.Hout = e->Halt;
-            sp.KLpart = e->KLpart2;
-            mv_side_params(e, sp, e->Wtrial, delta);
-            if (!sharded(e)) {
-                sp.kl_out = e->scal + 2;
-                sp.kl_counter = e->klcnt;
-                CK((launch_fused<false, true, true>(e, sp, total, nullptr, e->evObj)));  // evObj = the pass's own completion signal
-            } else {
-                CK((launch_fused<false, true, true>(e, sp, total)));
-                hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, e->KLpart2, nwg, 1, 1, e->scal + 2, nullptr);
-                HIPCK(hipGetLastError());
-                CK(allreduce(e, e->scal + 2, 1));
-                HIPCK(hipEventRecord(e->evObj, e->stream));
-            }
-            // ... and its numerator pass (W_trial as W, the new H) on the whole chip: it runs while the scalars travel to the
-            // host.  Its tail waits for the decision (see above).
-            CK(mv_numerator_pass(e, e->Wtrial, e->Halt, nullptr, nwg, nwg));
-            HIPCK(hipStreamWaitEvent(e->stream3, e->evObj, 0));
-            HIPCK(hipMemcpyAsync(e->hpin, e->scal, 5 * sizeof(double), hipMemcpyDeviceToHost, e->stream3));
-            HIPCK(hipStreamSynchronize(e->stream3));
-            for (int i = 0; i < 5; ++i) v[i] = e->hpin[i];
-            v[4] = v[3];  // the trial's log det came from the side workgroup
-        } else {
-            // the trial's log det -> scal[4] on stream2, beside KL(W_trial, clip(H * colsum)) by the forward pass
-            HIPCK(hipStreamWaitEvent(e->stream2, e->evTrial, 0));
-            LAUNCH_WITH_EVENT(mv_logdet_kernel, dim3(1), dim3(MV_BLOCK), e->stream2, e->evLogdet, e->Wtrial, K, V, delta, e->scal + 4);
-            HIPCK(hipGetLastError());
-            CK(objective_to_slot(e, e->Wtrial, e->cs, false, 2, e->mv_fgrid));
-            HIPCK(hipStreamWaitEvent(e->stream, e->evLogdet, 0));
-            CK(read_scalars(e, 0, 5, v));
-        }
-        const double f0 = v[1], f1 = v[2] + lam * v[4];
-        if (f_accepted) *f_accepted = f1;  // (of the last trial: the accepted one when the loop ends)
-        if (f1 > f0 && g > 1e-16) {  // mvnmf.py:84
-            // (a rejected speculation is simply dropped: it wrote scratch buffers only -- Halt, the numerator slabs, A, B
-            // and scal[3], which the next non-speculative step recomputes for the W it starts from -- and everything that
-            // read the trial buffer ran on this stream, ahead of the blend that overwrites it)
-            g *= 0.8;
-            blend = true;
-            continue;
-        }
-        if (spec) {
-            // accepted at the first trial: the speculative passes are the first half of the next step
-            *gamma = std::min(1.0, 1.2 * g);
-            std::swap(e->W, e->Wtrial);
-            std::swap(e->H, e->Halt);  // written in full from clip(H * cs): nothing pending
-            // (no evW: the next step's W-only algebra ran already; a later stand-alone start records its own)
-            e->h_pending = false;
-            if (speculated) *speculated = true;
-            return 0;
-        }
-        break;
-    }
-    *gamma = std::min(1.0, 1.2 * g);  // mvnmf.py:91
-    // accept: W <- W_trial, H <- clip(H * colsum).  The rescale of H is not a pass of its own: every reader of H
-    // applies clip(H * cs) on the fly until the next update_H pass writes H in full (flush_H_scale otherwise)
-    std::swap(e->W, e->Wtrial);  // no copy: the trial buffer becomes W
-    HIPCK(hipEventRecord(e->evW, e->stream));  // W is final for the next step's W-only kernels
-    e->h_pending = true;
-    return 0;
-}
-
-// ---- MvNMF steps queued ahead of the host (unsharded engines, at least one free signature).
-// Per step TWO launches: the tail of the previous numerator half (reduce, closed-form root, first trial, f0) and the MVJ
-// pass (fused_kernel<.., MVJ>: update_H with the trial -- which evaluates the trial -- and the numerator half on the new H,
-// the next step's W-only algebra in its last workgroup).  The line-search decision of step i is taken ON THE DEVICE, in the
-// prologue of step i + 1's tail (TailParams::dec_*): accepted -> go on; rejected -> the flag is set and everything queued
-// behind returns at once.  The host queues a whole call's steps with the buffer roles alternating as if every first trial
-// were accepted (the common case), reads the flag and the scalars once at the end, and resolves a rejected step on the
-// classic path (blends evaluated by the forward kernel, mvnmf.py:84-90), then queues the rest.  The decision compares the
-// same doubles with the same operations as the host's, so the result is the classic form's bit for bit.
-static inline int mv_f0_slot(int step) { return (step & 1) ? 9 : 1; }  // f0 by step parity: a tail reads the previous step's while it writes its own
-
-// the backtracking part of line_search (mvnmf.py:84-90) from the resident (W, H), W_unconstrained in Wunc and f0 given;
-// g: the gamma the rejected first trial left (already multiplied by 0.8).  Accepts: W <- the blend's trial, H pending.
-static int mv_backtrack(salnmf_engine* e, double lam, double delta, double f0, double* g_io, double* f_accepted) {
-    const int K = e->K, V = e->V;
-    const MvRootParams root{e->mvA, e->mvB, e->red, e->red + K * V, e->red + K * V + K, e->scal + 3, e->scal + 1, lam, 0};
-    double g = *g_io;
-    for (;;) {
-        LAUNCH_WITH_EVENT(mv_trial_light_kernel<false>, dim3(1), dim3(MV_BLOCK), e->stream, e->evTrial, e->W, e->Wunc, g, 1, K, V, e->Wtrial, e->cs, root);
-        HIPCK(hipGetLastError());
-        HIPCK(hipStreamWaitEvent(e->stream2, e->evTrial, 0));
-        LAUNCH_WITH_EVENT(mv_logdet_kernel, dim3(1), dim3(MV_BLOCK), e->stream2, e->evLogdet, e->Wtrial, K, V, delta, e->scal + 4);
-        HIPCK(hipGetLastError());
-        CK(objective_to_slot(e, e->Wtrial, e->cs, false, 2, e->mv_fgrid));
-        HIPCK(hipStreamWaitEvent(e->stream, e->evLogdet, 0));
-        double v[5];
-        CK(read_scalars(e, 0, 5, v));
-        const double f1 = v[2] + lam * v[4];
-        if (f_accepted) *f_accepted = f1;
-        if (f1 > f0 && g > 1e-16) {
-            g *= 0.8;
-            continue;
-        }
-        break;
-    }
-    *g_io = g;
-    std::swap(e->W, e->Wtrial);
-    HIPCK(hipEventRecord(e->evW, e->stream));
-    e->h_pending = true;
-    return 0;
-}
-
-static int mv_steps_queued(salnmf_engine* e, int n_steps, int n_given, double lam, double delta, double* gamma, double* f_out, bool more_follows,
-                           bool resume) {
-    CK(ensure_side_streams(e));
-    CK(ensure_halt(e));
-    if (!e->KLpart2) HIPCK(hipMalloc(&e->KLpart2, (size_t)e->grid * sizeof(double)));
-    if (!e->mvflag) HIPCK(hipMalloc(&e->mvflag, 16));
-    const int total = mv_side_total(e), nwg = total - 1;
-    // A sample-sharded engine (round 5) runs the same queue with the sums over the samples all-reduced: per step the tail
-    // (local reduction only), ONE exchange of [G | rowsums_H | KL of the numerator half | KL of the previous step's trial]
-    // (K V + K + 2 doubles: the peer-to-peer kernel, or RCCL), the root / first trial / f0 kernel -- which takes the
-    // device-side decision from the all-reduced sums, the same bits on every rank -- and the MVJ pass.  Every rank queues
-    // the same launches and exchanges whatever the flag says, so the exchanges stay in step.
-    const bool sh = sharded(e);
-    const int K = e->K, V = e->V;
-    const size_t nred = (size_t)K * V + K + 2;
-    double* const trial_kl = sh ? e->red + (size_t)K * V + K + 1 : e->scal + 2;  // where an MVJ pass leaves its trial's KL
-    double g = *gamma, f_last = 0.0;
-    bool ahead = resume;
-    int done = 0;
-    while (done < n_steps) {
-        HIPCK(hipMemsetAsync(e->mvflag, 0, sizeof(unsigned), e->stream));
-        if (!ahead) {
-            // the first half of step `done`: update_H (+ the W-only algebra of W in the side workgroup), numerator pass
-            FusedParams p = fused_params(e);
-            p.wkl = nullptr;  // MvNMF._update_H passes no weights (mvnmf.py:162-165)
-            p.wlh = nullptr;
-            p.KLpart = nullptr;
-            mv_side_params(e, p, e->W, delta);
-            CK((launch_fused<false, true, true>(e, p, total)));
-            e->h_pending = false;
-            CK(mv_numerator_pass(e, e->W, e->H, nullptr, nwg, nwg));
-        }
-        // queue: tail_i (decides step i - 1, root + trial of step i), MVJ pass_i (evaluates trial i, first half of step i + 1)
-        const int first = done;
-        int queued = 0;       // steps whose MVJ pass is queued (their trial's decision is pending or on the device)
-        bool classic_last = false;
-        for (int i = first; i < n_steps; ++i) {
-            const bool spec = (i + 1 < n_steps) || more_follows;
-            TailParams t = tail_params(e, e->mv_slabs, e->red, n_given, 0, 0, true, e->mv_hparts);
-            t.rootA = e->mvA;
-            t.rootB = e->mvB;
-            t.rootLogdet = e->scal + 3;
-            t.rootF0 = e->scal + mv_f0_slot(i);
-            t.rootWunc = e->Wunc;
-            t.rootWtrial = e->Wtrial;
-            t.rootCs = e->cs;
-            t.rootLam = lam;
-            t.mv_flag = e->mvflag;
-            if (sh) {
-                // local sums only; the root, the trial and the decision follow the exchange
-                t.rootA = nullptr;
-                hipLaunchKernelGGL(tail_kernel, dim3(e->K), dim3(TAIL_BLOCK), 0, e->stream, t);
-                HIPCK(hipGetLastError());
-                CK(allreduce(e, e->red, nred));
-                MvRootParams root{e->mvA, e->mvB, e->red, e->red + K * V, e->red + K * V + K, e->scal + 3, e->scal + mv_f0_slot(i), lam, n_given};
-                root.mv_flag = e->mvflag;
-                if (i > first) {
-                    root.dec_f0 = e->scal + mv_f0_slot(i - 1);
-                    root.dec_kl = trial_kl;
-                    root.dec_logdet = e->scal + 3;
-                    root.dec_lam = lam;
-                    root.dec_code = (unsigned)(i - first);
-                }
-                if (!spec)
-                    LAUNCH_WITH_EVENT(mv_trial_light_kernel<true>, dim3(1), dim3(MV_BLOCK), e->stream, e->evTrial, e->W, e->Wunc, 1.0, 0, K, V, e->Wtrial,
-                                      e->cs, root);
-                else
-                    hipLaunchKernelGGL(mv_trial_light_kernel<true>, dim3(1), dim3(MV_BLOCK), 0, e->stream, e->W, e->Wunc, 1.0, 0, K, V, e->Wtrial, e->cs, root);
-                HIPCK(hipGetLastError());
-            } else {
-            if (i > first) {  // (gamma of a step behind accepted first trials is >= the call's gamma: the `gamma > 1e-16` half of mvnmf.py:84 holds)
-                t.dec_f0 = e->scal + mv_f0_slot(i - 1);
-                t.dec_kl = e->scal + 2;
-                t.dec_logdet = e->scal + 3;
-                t.dec_lam = lam;
-                t.dec_code = (unsigned)(i - first);  // 1 + index within this batch of the step whose trial is rejected
-            }
-            if (!spec)
-                hipExtLaunchKernelGGL(tail_kernel, dim3(e->K), dim3(TAIL_BLOCK), 0, e->stream, nullptr, e->evTrial, 0, t);
-            else
-                hipLaunchKernelGGL(tail_kernel, dim3(e->K), dim3(TAIL_BLOCK), 0, e->stream, t);
-            HIPCK(hipGetLastError());
-            }
-            if (!spec) {
-                classic_last = true;
-                break;
-            }
-            FusedParams sp = fused_params(e);
-            sp.wkl = nullptr;
-            sp.wlh = nullptr;
-            sp.W = e->Wtrial;
-            sp.hscale = e->cs;
-            sp.Hout = e->Halt;
-            sp.KLpart = e->KLpart2;  // the update_H half's partials: the trial's KL, summed inside the launch -> scal[2]
-            sp.KLpartB = e->KLpart;  // the numerator half's: f0 of the next step, reduced by its tail
-            sp.kl_out = trial_kl;  // (sharded: this rank's share, all-reduced with the next tail's sums)
-            sp.kl_counter = e->klcnt;
-            sp.skip_flag = e->mvflag;
-            mv_side_params(e, sp, e->Wtrial, delta);
-            const FusedSel sel{e->KS, e->KTM, e->KR, true, true, true, false, false, false, false, true};
-            if (launch_fused_inst(sel, sp, total, e->stream, nullptr, nullptr)) return fail("no kernel instantiation for KS=%d KTM=%d KR=%d", e->KS, e->KTM, e->KR);
-            HIPCK(hipGetLastError());
-            e->mv_slabs = nwg;
-            e->mv_hparts = nwg;
-            std::swap(e->W, e->Wtrial);  // as if accepted (undone below if it was not)
-            std::swap(e->H, e->Halt);
-            e->h_pending = false;
-            ++queued;
-        }
-        if (sh && queued > 0 && !classic_last) {
-            // the last queued trial's KL has not been through an exchange yet (the next step's would have carried it): one
-            // scalar all-reduce, into the slot the host reads (after a rejection further up it is a stale value nobody uses)
-            HIPCK(hipMemcpyAsync(e->scal + 2, trial_kl, sizeof(double), hipMemcpyDeviceToDevice, e->stream));
-            CK(allreduce(e, e->scal + 2, 1));
-        }
-        // one read for the whole batch: the flag and the scalars
-        unsigned code = 0;
-        double v[16];
-        HIPCK(hipMemcpyAsync(e->hpin, e->scal, 16 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-        HIPCK(hipMemcpyAsync(reinterpret_cast<char*>(e->hpin) + 16 * sizeof(double), e->mvflag, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
-        HIPCK(hipStreamSynchronize(e->stream));
-        CK(check_abort(e));
-        for (int i = 0; i < 16; ++i) v[i] = e->hpin[i];
-        memcpy(&code, reinterpret_cast<char*>(e->hpin) + 16 * sizeof(double), sizeof code);
-        // which queued step (if any) is open: rejected on the device, or the last queued one (nobody has compared its f1
-        // with its f0 yet).  The steps before it were accepted on the device.
-        int open = -1;
-        if (code != 0) open = first + (int)code - 1;
-        else if (queued > 0 && !classic_last) open = first + queued - 1;  // (a classic last step's tail decided the last queued one)
-        for (int i = first; i < (open >= 0 ? open : first + queued); ++i) g = std::min(1.0, 1.2 * g);
-        if (open >= 0) {
-            // the open step's MVJ pass was the last one to write scal[2], scal[3] (everything behind a rejection returned at once)
-            const double f0 = v[mv_f0_slot(open)], f1 = v[2] + lam * v[3];
-            const bool rejected = (code != 0 || f1 > f0) && g > 1e-16;  // mvnmf.py:84
-            // the pointer swaps of the steps behind the open one (and, if rejected, its own) are undone
-            const int undo = first + queued - open - (rejected ? 0 : 1);
-            if (undo & 1) {
-                std::swap(e->W, e->Wtrial);
-                std::swap(e->H, e->Halt);
-            }
-            if (rejected) {
-                // (W, H) = the state the open step started its line search from: H unscaled with its scale in cs, W_unconstrained
-                // in Wunc; the numerator slabs, A, B, log det and the second H buffer hold the dropped speculation
-                g *= 0.8;
-                CK(mv_backtrack(e, lam, delta, f0, &g, &f_last));
-                ahead = false;
-            } else {
-                f_last = f1;
-                ahead = true;  // its MVJ pass is the first half of the next step
-            }
-            g = std::min(1.0, 1.2 * g);
-            done = open + 1;
-            if (done < n_steps || !classic_last) continue;
-        }
-        if (classic_last) {
-            // the call's last step without a continuation: its trial is evaluated by the forward kernel (no pass follows)
-            const int i = n_steps - 1;
-            HIPCK(hipStreamWaitEvent(e->stream2, e->evTrial, 0));
-            LAUNCH_WITH_EVENT(mv_logdet_kernel, dim3(1), dim3(MV_BLOCK), e->stream2, e->evLogdet, e->Wtrial, e->K, e->V, delta, e->scal + 4);
-            HIPCK(hipGetLastError());
-            CK(objective_to_slot(e, e->Wtrial, e->cs, false, 2, e->mv_fgrid));
-            HIPCK(hipStreamWaitEvent(e->stream, e->evLogdet, 0));
-            double w[16];
-            CK(read_scalars(e, 0, 16, w));
-            const double f0 = w[mv_f0_slot(i)], f1 = w[2] + lam * w[4];
-            f_last = f1;
-            if (f1 > f0 && g > 1e-16) {
-                g *= 0.8;
-                CK(mv_backtrack(e, lam, delta, f0, &g, &f_last));
-            } else {
-                std::swap(e->W, e->Wtrial);
-                HIPCK(hipEventRecord(e->evW, e->stream));
-                e->h_pending = true;
-            }
-            g = std::min(1.0, 1.2 * g);
-            done = n_steps;
-            ahead = false;
-        }
-    }
-    *gamma = g;
-    if (f_out) *f_out = f_last;
-    if (ahead) {  // (only with more_follows)
-        e->mv_ahead = true;
-        e->mv_ahead_delta = delta;
-        e->mv_ahead_given = n_given;
-    }
-    return 0;
-}
-
-int salnmf_mv_update_W(salnmf_engine* e, int n_given, double lam, double delta, double* gamma_inout) {
-    if (e && split(e)) CK(mv_wide_check(e));
-    if (!e || !gamma_inout) return fail("null argument");
-    e->keep_valid = false;  // (the MvNMF steps use the second H buffer themselves)
-    CK(enter(e));
-    if (mv_wide(e)) return mv_wide_update_W(e, n_given, lam, delta, gamma_inout, nullptr);
-    return mv_update_W_impl(e, n_given, lam, delta, gamma_inout, false, false);
-}
-
-int salnmf_mv_logdet(salnmf_engine* e, double delta, double* out) {
-    if (e && split(e)) CK(mv_wide_check(e));
-    if (!e || !out) return fail("null argument");
-    CK(enter(e));
-    if (mv_wide(e))
-        CK(mv_wide_logdet(e, e->W, delta, 3));
-    else
-        CK(mv_logdet_to_slot(e, e->W, delta, 3));
-    return read_scalars(e, 3, 1, out);
-}
-
-int salnmf_mv_update_W_unconstrained(salnmf_engine* e, int n_given, double lam, double delta, double* Wunc_out) {
-    if (e && split(e)) CK(mv_wide_check(e));
-    if (!e || !Wunc_out) return fail("null argument");
-    if (n_given < 0 || n_given > e->K) return fail("n_given out of range");
-    CK(enter(e));
-    if (n_given >= e->K) return download(e, Wunc_out, e->W, (size_t)e->K * e->V);  // every column given: W itself (mvnmf.py:61)
-    if (mv_wide(e)) {
-        CK(mv_wide_prepare(e, delta));
-        CK(mv_wide_root(e, lam, n_given));
-        return download(e, Wunc_out, e->Wunc, (size_t)e->K * e->V);  // (W, H untouched; the trial buffers are scratch)
-    }
-    double gamma = 1.0;
-    return mv_update_W_impl(e, n_given, lam, delta, &gamma, false, false, false, nullptr, false, nullptr, Wunc_out, nullptr);
-}
-
-int salnmf_mv_line_search(salnmf_engine* e, double lam, double delta, double* gamma_inout, const double* Wunc) {
-    if (e && split(e)) CK(mv_wide_check(e));
-    if (!e || !gamma_inout || !Wunc) return fail("null argument");
-    e->keep_valid = false;
-    CK(enter(e));
-    if (mv_wide(e)) {
-        HIPCK(hipMemcpyAsync(e->Wunc, Wunc, (size_t)e->K * e->V * sizeof(double), hipMemcpyHostToDevice, e->stream));
-        HIPCK(hipStreamSynchronize(e->stream));  // (the caller's array is free again)
-        return mv_wide_line_search(e, lam, delta, gamma_inout, false, false, nullptr);
-    }
-    return mv_update_W_impl(e, 0, lam, delta, gamma_inout, false, false, false, nullptr, false, nullptr, nullptr, Wunc);
-}
-
-int salnmf_mv_step(salnmf_engine* e, int n_steps, int n_given, double lam, double delta, double* gamma_inout) {
-    return salnmf_mv_step_objective(e, n_steps, n_given, lam, delta, gamma_inout, nullptr, 0);
-}
-
-int salnmf_mv_step_objective(salnmf_engine* e, int n_steps, int n_given, double lam, double delta, double* gamma_inout, double* objective_out,
-                             int more_follows) {
-    if (e && split(e)) CK(mv_wide_check(e));
-    if (!e || !gamma_inout) return fail("null argument");
-    if (n_steps < 1 && objective_out) return fail("n_steps must be positive");
-    if (n_given < 0 || n_given > e->K) return fail("n_given out of range");
-    HIPCK(hipSetDevice(e->device));
-    if (mv_wide(e)) {
-        CK(enter(e));
-        e->keep_valid = false;
-        double f = 0.0;
-        for (int i = 0; i < n_steps; ++i) {
-            CK(mv_wide_update_H(e));
-            CK(mv_wide_update_W(e, n_given, lam, delta, gamma_inout, &f));
-        }
-        if (objective_out) {
-            if (n_given >= e->K) return salnmf_mv_objective(e, lam, delta, objective_out);
-            *objective_out = f;  // the line search's value at the accepted point = the objective of the state left behind
-        }
-        return 0;
-    }
-    // an engine left ahead by the previous call continues from there if this call is the continuation it speculated on
-    const bool resume = e->mv_ahead && n_steps > 0 && e->mv_ahead_delta == delta && e->mv_ahead_given == n_given;
-    if (!resume) CK(mv_settle(e));
-    e->mv_ahead = false;
-    e->keep_valid = false;  // (the MvNMF steps use the second H buffer themselves)
-    if (e->mv_queued && n_given < e->K && n_steps > 0)
-        return mv_steps_queued(e, n_steps, n_given, lam, delta, gamma_inout, objective_out, more_follows != 0, resume);
-    bool ahead = resume;  // this step's update_H pass, W-only algebra and numerator pass already ran during the previous step
-    for (int i = 0; i < n_steps; ++i) {
-        const bool update_W = n_given < e->K;
-        if (!ahead) {
-            FusedParams p = fused_params(e);
-            p.wkl = nullptr;  // MvNMF._update_H passes no weights (mvnmf.py:162-165)
-            p.wlh = nullptr;
-            p.KLpart = nullptr;  // row sums of the new H only
-            // update_H + row sums of the new H; the pass's last workgroup runs the W-only algebra of the W step beside
-            // it (an accepted speculation ran both already, for exactly this W)
-            if (update_W) {
-                mv_side_params(e, p, e->W, delta);
-                CK((launch_fused<false, true, true>(e, p, mv_side_total(e))));
-            } else {
-                CK((launch_fused<false, true, true>(e, p)));
-            }
-            e->h_pending = false;
-        }
-        const bool was_ahead = ahead;
-        CK(mv_update_W_impl(e, n_given, lam, delta, gamma_inout, true, true, i + 1 < n_steps || more_follows != 0, &ahead, was_ahead, objective_out));
-    }
-    if (ahead) {  // (only with more_follows: the last step's speculation was accepted)
-        e->mv_ahead = true;
-        e->mv_ahead_delta = delta;
-        e->mv_ahead_given = n_given;
-    }
-    // (all signatures given: no line search ran -- the objective as a pass of its own)
-    if (objective_out && n_given >= e->K) return salnmf_mv_objective(e, lam, delta, objective_out);
-    return 0;
-}
-
-// ------------------------------------------------------------------------------------ CorrNMF (row f1)
-
-int salnmf_corr_configure(salnmf_engine* e, int dim_embeddings) {
-    // feature blocks (n_features > 96): the two passes over X run block by block (corr_compute_aux, corr_poisson_llh);
-    // everything else of CorrNMF is K- and dim-sized
-    if (e && e->NC > 1) return single_block(e, "CorrNMF");
-    if (!e) return fail("null engine");
-    if (dim_embeddings < 1 || dim_embeddings > CORR_DMAX) return fail("dim_embeddings must be in [1, %d], got %d", CORR_DMAX, dim_embeddings);
-    CK(enter(e));
-    HIPCK(hipStreamSynchronize(e->stream));
-    double** bufs[] = {&e->alpha, &e->beta, &e->Lemb, &e->Uemb, &e->aux, &e->xrowsum, &e->corrpart};
-    for (double** b : bufs) {
-        if (*b) HIPCK(hipFree(*b));
-        *b = nullptr;
-    }
-    e->dim = 0;
-    const size_t Np = e->Np, K = e->K, d = dim_embeddings;
-    e->cgrid = (int)std::min<int64_t>(1024, (e->Np + CORR_TILE - 1) / CORR_TILE);
-    HIPCK(hipMalloc(&e->alpha, Np * sizeof(double)));
-    HIPCK(hipMalloc(&e->beta, K * sizeof(double)));
-    HIPCK(hipMalloc(&e->Lemb, K * d * sizeof(double)));
-    HIPCK(hipMalloc(&e->Uemb, (size_t)e->N * d * sizeof(double)));
-    HIPCK(hipMalloc(&e->aux, Np * e->KP * sizeof(double)));
-    HIPCK(hipMalloc(&e->xrowsum, Np * sizeof(double)));
-    HIPCK(hipMalloc(&e->corrpart, (size_t)e->cgrid * 64 * sizeof(double)));
-    HIPCK(hipMemsetAsync(e->alpha, 0, Np * sizeof(double), e->stream));
-    HIPCK(hipMemsetAsync(e->beta, 0, K * sizeof(double), e->stream));
-    HIPCK(hipMemsetAsync(e->Lemb, 0, K * d * sizeof(double), e->stream));
-    HIPCK(hipMemsetAsync(e->Uemb, 0, (size_t)e->N * d * sizeof(double), e->stream));
-    HIPCK(hipMemsetAsync(e->aux, 0, Np * e->KP * sizeof(double), e->stream));
-    e->dim = dim_embeddings;
-    e->xrowsum_valid = false;
-    return 0;
-}
-
-static int corr_ready(salnmf_engine* e) {
-    if (!e) return fail("null engine");
-    if (e->dim == 0) return fail("salnmf_corr_configure has not been called on this engine");
-    CK(enter(e));
-    return 0;
-}
-
-int salnmf_corr_upload(salnmf_engine* e, int which, const double* src) {
-    CK(corr_ready(e));
-    if (!src) return fail("null argument");
-    switch (which) {
-        case SALNMF_CORR_SIGNATURE_SCALINGS: return upload(e, e->beta, src, (size_t)e->K);
-        case SALNMF_CORR_SAMPLE_SCALINGS: return upload_padded(e, e->alpha, src, 1, 1, 0.0, 0.0, 0.0);
-        case SALNMF_CORR_SIGNATURE_EMBEDDINGS: return upload(e, e->Lemb, src, (size_t)e->K * e->dim);
-        case SALNMF_CORR_SAMPLE_EMBEDDINGS: return upload(e, e->Uemb, src, (size_t)e->N * e->dim);
-        case SALNMF_CORR_AUX: return upload_padded(e, e->aux, src, e->K, e->KP, 0.0, 0.0, 0.0);
-        default: return fail("unknown CorrNMF buffer %d", which);
-    }
-}
-
-int salnmf_corr_download(salnmf_engine* e, int which, double* dst) {
-    CK(corr_ready(e));
-    if (!dst) return fail("null argument");
-    switch (which) {
-        case SALNMF_CORR_SIGNATURE_SCALINGS: return download(e, dst, e->beta, (size_t)e->K);
-        case SALNMF_CORR_SAMPLE_SCALINGS: return download(e, dst, e->alpha, (size_t)e->N);
-        case SALNMF_CORR_SIGNATURE_EMBEDDINGS: return download(e, dst, e->Lemb, (size_t)e->K * e->dim);
-        case SALNMF_CORR_SAMPLE_EMBEDDINGS: return download(e, dst, e->Uemb, (size_t)e->N * e->dim);
-        case SALNMF_CORR_AUX: return download_padded(e, dst, e->aux, e->K, e->KP);
-        default: return fail("unknown CorrNMF buffer %d", which);
-    }
-}
-
-static CorrParams corr_params(salnmf_engine* e) {
-    CorrParams p;
-    p.alpha = e->alpha;
-    p.beta = e->beta;
-    p.L = e->Lemb;
-    p.U = e->Uemb;
-    p.xrowsum = e->xrowsum;
-    p.out = nullptr;
-    p.N = e->N;
-    p.Np = e->Np;
-    p.K = e->K;
-    p.KP = e->KP;
-    p.dim = e->dim;
-    return p;
-}
-
-int salnmf_corr_update_sample_scalings(salnmf_engine* e) {
-    CK(corr_ready(e));
-    if (!e->xrowsum_valid) {
-        for (int b = 0; b < e->NB; ++b)  // (block b's sum joins the earlier blocks')
-            hipLaunchKernelGGL(rowsum_X_kernel, dim3(1024), dim3(256), 0, e->stream, e->X + (size_t)b * e->Np * VMAX, e->Np, VMAX, b > 0 ? 1 : 0, e->xrowsum);
-        HIPCK(hipGetLastError());
-        e->xrowsum_valid = true;
-    }
-    CorrParams p = corr_params(e);
-    p.out = e->alpha;
-    p.alpha = nullptr;
-    launch_corr_logit<0>(e, p);
-    HIPCK(hipGetLastError());
-    return 0;
-}
-
-int salnmf_corr_compute_exposures(salnmf_engine* e) {
-    CK(corr_ready(e));
-    CorrParams p = corr_params(e);
-    p.out = e->H;
-    e->h_pending = false;  // H is overwritten in full
-    launch_corr_logit<1>(e, p);
-    HIPCK(hipGetLastError());
-    return 0;
-}
-
-int salnmf_corr_compute_aux(salnmf_engine* e) {
-    CK(corr_ready(e));
-    if (e->NB > 1) {
-        // U = R W^T summed over the feature blocks, aux = H * U unclipped by the last block's launch; the numerators of
-        // update_signatures block by block into Gblk (applied by salnmf_corr_update_signatures)
-        CK(blocked_update_H(e, e->aux, 0.0, false));
-        return blocked_numerators(e, false);
-    }
-    FusedParams p = fused_params(e);
-    p.wkl = nullptr;  // CorrNMF is unweighted (corrnmf_det.py:80-85)
-    p.wlh = nullptr;
-    p.Hout = e->aux;
-    p.hfloor = 0.0;
-    CK((launch_fused<true, true, false>(e, p)));
-    // the same pass produced G = (X/(HW))^T H for update_signatures: reduce it now (all ranks), apply later
-    CK(launch_tail(e, e->grid, e->red, 0, 0, 0));
-    return allreduce(e, e->red, (size_t)e->K * e->V);
-}
-
-int salnmf_corr_update_signatures(salnmf_engine* e, int n_given) {
-    CK(corr_ready(e));
-    if (n_given < 0 || n_given > e->K) return fail("n_given out of range");
-    if (n_given >= e->K) return 0;  // _utils_klnmf.py:204-205
-    if (e->NB > 1) return blocked_finish_W(e, n_given, SALNMF_CLIP_NON_GIVEN);
-    return launch_tail(e, 0, e->red, n_given, SALNMF_CLIP_NON_GIVEN, 1);
-}
-
-int salnmf_corr_update_signature_scalings(salnmf_engine* e) {
-    CK(corr_ready(e));
-    const int K = e->K;
-    // first_k = sum_n aux[n][k]
-    const int pgrid = (int)std::min<int64_t>(512, (e->N + 255) / 256);
-    CK(ensure_scratch(e, (size_t)512 * 64 + 2 * 64));
-    double* part = e->scratch;
-    double* first = e->scratch + (size_t)512 * 64;
-    double* second = first + 64;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(pgrid), dim3(256), 0, e->stream, e->aux, e->N, e->KP, part);
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(K), dim3(256), 0, e->stream, part, pgrid, e->KP, K, first);
-    // second_k = sum_n exp(alpha_n + <L_k, U_n>)
-    CorrParams p = corr_params(e);
-    p.out = e->corrpart;
-    launch_corr_logit<2>(e, p);
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(K), dim3(256), 0, e->stream, e->corrpart, corr_logit_grid(e), K, K, second);
-    HIPCK(hipGetLastError());
-    CK(allreduce(e, first, 128));  // first and second are adjacent
-    hipLaunchKernelGGL(corr_log_ratio_kernel, dim3(1), dim3(64), 0, e->stream, first, second, K, e->beta);
-    HIPCK(hipGetLastError());
-    return 0;
-}
-
-static int sample_embeddings_impl(salnmf_engine* const* engines, int n_engines, double variance, int maxiter, int* status_out) {
-    if (!engines || n_engines < 1 || n_engines > CORR_MODS) return fail("between 1 and %d engines expected", CORR_MODS);
-    salnmf_engine* e0 = engines[0];
-    CK(corr_ready(e0));
-    if (!(variance > 0.0)) return fail("variance must be positive");
-    SampleEmbeddingParams p;
-    int terms = 0;
-    for (int i = 0; i < CORR_MODS; ++i) {
-        salnmf_engine* e = engines[i < n_engines ? i : 0];
-        if (i < n_engines) {
-            if (!e || e->dim == 0) return fail("engine %d is not configured for CorrNMF", i);
-            if (e->device != e0->device || e->N != e0->N || e->dim != e0->dim)
-                return fail("engine %d differs from engine 0 in device, n_samples or dim_embeddings", i);
-            terms += e->K;
-        }
-        p.aux[i] = e->aux;
-        p.alpha[i] = e->alpha;
-        p.beta[i] = e->beta;
-        p.L[i] = e->Lemb;
-        p.K[i] = i < n_engines ? e->K : 0;
-        p.KP[i] = e->KP;
-    }
-    if (terms > CORR_TERMS) return fail("at most %d signatures over all modalities, got %d", CORR_TERMS, terms);
-    p.n_mod = n_engines;
-    p.U = e0->Uemb;
-    p.status = nullptr;
-    p.variance = variance;
-    p.N = e0->N;
-    p.dim = e0->dim;
-    p.maxiter = maxiter > 0 ? maxiter : 200 * e0->dim;  // scipy's default: 200 * len(x0)
-    // the modalities' engines have their own streams: everything they queued must be complete first
-    for (int i = 1; i < n_engines; ++i) HIPCK(hipStreamSynchronize(engines[i]->stream));
-    int* dstatus = nullptr;
-    if (status_out) {
-        HIPCK(hipMalloc(&dstatus, (size_t)e0->N * sizeof(int)));
-        p.status = dstatus;
-    }
-    // sixteen solves per wavefront on the fp64 MFMA units where an instantiation covers the shape (csrc/salnmf_corr_batched.hip:
-    // <= 80 terms, dim <= 48), else one wavefront per sample
-    if (!(e0->batched_samples && launch_sample_embeddings_batched(p, terms, e0->stream))) {
-        const int grid = (int)std::min<int64_t>((e0->N + 3) / 4, 8192);
-        const size_t lds_bytes = (size_t)terms * (e0->dim | 1) * sizeof(double);  // the term matrix (corr_sample_embeddings_kernel)
-        if (terms <= 64)
-            hipLaunchKernelGGL(corr_sample_embeddings_kernel<1>, dim3(grid), dim3(CORR_BLOCK), lds_bytes, e0->stream, p);
-        else
-            hipLaunchKernelGGL(corr_sample_embeddings_kernel<2>, dim3(grid), dim3(CORR_BLOCK), lds_bytes, e0->stream, p);
-    }
-    int rc = 0;
-    if (hipGetLastError() != hipSuccess) rc = fail("corr_sample_embeddings_kernel launch failed");
-    // the sample embeddings are shared: every modality's engine gets the result
-    for (int i = 1; i < n_engines && !rc; ++i)
-        if (hipMemcpyAsync(engines[i]->Uemb, e0->Uemb, (size_t)e0->N * e0->dim * sizeof(double), hipMemcpyDeviceToDevice, e0->stream) != hipSuccess)
-            rc = fail("copy of the shared sample embeddings failed");
-    if (!rc && (status_out || n_engines > 1)) {
-        if (status_out && hipMemcpyAsync(status_out, dstatus, (size_t)e0->N * sizeof(int), hipMemcpyDeviceToHost, e0->stream) != hipSuccess)
-            rc = fail("status download failed");
-        if (!rc && hipStreamSynchronize(e0->stream) != hipSuccess) rc = fail("hipStreamSynchronize failed");
-    }
-    if (dstatus) (void)hipFree(dstatus);
-    return rc;
-}
-
-int salnmf_corr_update_sample_embeddings(salnmf_engine* e, double variance, int maxiter, int* status_out) {
-    return sample_embeddings_impl(&e, 1, variance, maxiter, status_out);
-}
-
-int salnmf_corr_update_sample_embeddings_multi(salnmf_engine* const* engines, int n_engines, double variance, int maxiter,
-                                               int* status_out) {
-    return sample_embeddings_impl(engines, n_engines, variance, maxiter, status_out);
-}
-
-// room for the gathered sample-side inputs of the signature-embedding solves
-static int ensure_gathered(salnmf_engine* e, size_t rows) {
-    if (e->g_rows >= rows && e->g_dim == e->dim) return 0;
-    for (double** b : {&e->gU, &e->galpha, &e->gaux}) {
-        if (*b) HIPCK(hipFree(*b));
-        *b = nullptr;
-    }
-    e->g_rows = 0;
-    HIPCK(hipMalloc(&e->gU, rows * e->dim * sizeof(double)));
-    HIPCK(hipMalloc(&e->galpha, rows * sizeof(double)));
-    HIPCK(hipMalloc(&e->gaux, rows * e->KP * sizeof(double)));
-    e->g_rows = rows;
-    e->g_dim = e->dim;
-    return 0;
-}
-
-// ---- lockstep form of the signature solves (salnmf_corr_lockstep.h): evaluation rounds over (chunks x signatures)
-// workgroups, the solvers replayed from their logs between rounds.  `shard`: the rows are this rank's shard and the
-// reduced sums of every round are all-reduced (objective, gradient and Hessian are sums over samples).
-// below: the single-kernel form (one workgroup per signature passes over all samples for every evaluation; a lockstep solve
-// costs ~0.4 ms of launches and read-backs whatever the size).  Measured crossover 1 500 - 2 000 samples at 10 signatures,
-// lower with more (profiles/r04/corr_sizes.txt: 5 000 x 10: 1.70 -> 0.72 ms per update, 12 000 x 30: 4.73 -> 1.23 ms)
-constexpr int64_t LS_MIN_ROWS = 2048;
-
-static int lockstep_signature_solves(salnmf_engine* e, const double* U, const double* alpha, const double* aux, int64_t n_rows, double variance,
-                                     int maxiter, int* status_out, bool shard) {
-    const int K = e->K, dim = e->dim;
-    const int n_cus = e->cus;  // (cached at salnmf_create: a properties query per solve costs as much as a small solve)
-    const int64_t max_chunks = (n_rows + SIGT - 1) / SIGT;
-    // dim <= 48: LS_GROUP signatures share a staged tile of U (salnmf_corr_lockstep.h), so there are fewer, longer rows of
-    // workgroups and more chunks; otherwise one signature per workgroup
-    const bool multi = dim <= 48;
-    const int groups = multi ? (K + LS_GROUP - 1) / LS_GROUP : K;
-    // chunks per signature (group): as many as it takes to fill the chip, within 64 MB of partial records
-    const int64_t s_cap = std::max<int64_t>(1, (int64_t)(64u << 20) / (int64_t)((size_t)LS_GROUP * groups * LS_REC * sizeof(double)));
-    const int S = (int)std::max<int64_t>(1, std::min<int64_t>({multi ? 128 : 16, n_cus / groups, max_chunks, s_cap}));
-    const int64_t chunk = ((n_rows + S - 1) / S + SIGT - 1) / SIGT * SIGT;
-    // one allocation: [x0 | req | sg] (K x 64 each), part (K S REC), red (K REC), log_y, log_g (K EVAL 64), log_f (K EVAL), log_H (K EVAL dim^2)
-    const size_t n_part = (size_t)(multi ? LS_GROUP * groups : K) * S * LS_REC;  // (records by (group ordinal, slot, chunk) under the live-group map)
-    const size_t nd = (size_t)3 * K * 64 + n_part + (size_t)K * LS_REC + (size_t)2 * K * LS_EVAL_MAX * 64 +
-                      (size_t)K * LS_EVAL_MAX + (size_t)K * LS_EVAL_MAX * dim * dim + (size_t)K * LS_CP;
-    if (e->ls_doubles < nd || e->ls_S != S || e->ls_dim != dim) {
-        if (e->ls_buf) HIPCK(hipFree(e->ls_buf));
-        e->ls_buf = nullptr;
-        e->ls_doubles = 0;
-        HIPCK(hipMalloc(&e->ls_buf, nd * sizeof(double)));
-        e->ls_doubles = nd;
-        e->ls_S = S;
-        e->ls_dim = dim;
-    }
-    if (!e->ls_int) HIPCK(hipMalloc(&e->ls_int, (size_t)(3 * 64 + 8) * sizeof(int)));
-    LockstepParams q;
-    q.sig.aux = aux;
-    q.sig.alpha = alpha;
-    q.sig.beta = e->beta;
-    q.sig.U = U;
-    q.sig.L = e->Lemb;
-    q.sig.only = nullptr;
-    q.sig.variance = variance;
-    q.sig.N = n_rows;
-    q.sig.Np = n_rows;
-    q.sig.K = K;
-    q.sig.KP = e->KP;
-    q.sig.dim = dim;
-    q.sig.maxiter = maxiter > 0 ? maxiter : 200 * dim;
-    q.S = S;
-    q.chunk = chunk;
-    double* b = e->ls_buf;
-    q.x0 = b; b += (size_t)K * 64;
-    q.req = b; b += (size_t)K * 64;
-    q.sg = b; b += (size_t)K * 64;
-    q.part = b; b += n_part;
-    q.red = b; b += (size_t)K * LS_REC;
-    q.log_y = b; b += (size_t)K * LS_EVAL_MAX * 64;
-    q.log_g = b; b += (size_t)K * LS_EVAL_MAX * 64;
-    q.log_f = b; b += (size_t)K * LS_EVAL_MAX;
-    q.log_H = b; b += (size_t)K * LS_EVAL_MAX * dim * dim;
-    q.cp = b;
-    q.lin_from_sg = multi && dim % 16 != 0;  // (ls_eval_packed_kernel)
-    q.dyn = q.lin_from_sg;
-    q.prof = nullptr;
-#ifdef SALNMF_DEV_PROFILE
-    static long long* ls_prof = nullptr;  // (development aid: one buffer per process, printed after every solve)
-    if (!ls_prof) HIPCK(hipMalloc(&ls_prof, 16 * sizeof(long long)));
-    HIPCK(hipMemsetAsync(ls_prof, 0, 16 * sizeof(long long), e->stream));
-    q.prof = ls_prof;
-#endif
-    q.state = e->ls_int;
-    q.n_evals = e->ls_int + 64;
-    q.sig.status = e->ls_int + 128;
-    q.active = e->ls_int + 192;
-    int* hactive = reinterpret_cast<int*>(e->hpin);
-    const dim3 grid(S, groups);
-    // start: sg = sum_n aux[n][k] U[n][:] and the first requests (the start points)
-    if (multi) {
-        // sg = aux^T U as one MFMA product, four workgroups per CU; their partial sums [wg][K][64] borrow
-        // the front of q.part (K S LS_REC doubles)
-        const int nwg = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)4 * n_cus, (n_rows + 255) / 256, (int64_t)S * LS_REC / 64}));
-        const int64_t rows_per_wg = ((n_rows + nwg - 1) / nwg + 255) / 256 * 256;
-        hipLaunchKernelGGL(ls_begin_mfma_kernel, dim3(nwg), dim3(256), 0, e->stream, q, q.part, rows_per_wg);
-        hipLaunchKernelGGL(ls_reduce_sg_kernel, dim3(K), dim3(1024), 0, e->stream, q.part, q.red, nwg, K, dim);
-    } else {
-        hipLaunchKernelGGL(ls_begin_kernel, grid, dim3(SIGT), 0, e->stream, q);
-        hipLaunchKernelGGL(ls_reduce_kernel, dim3(K, 1), dim3(256), 0, e->stream, q.part, q.red, q.state, S, 2, 64, 1);
-    }
-    HIPCK(hipGetLastError());
-    if (shard) CK(allreduce(e, q.red, (size_t)K * LS_REC));
-    hipLaunchKernelGGL(ls_copy_sg_kernel, dim3((K * 64 + 255) / 256), dim3(256), 0, e->stream, q.red, q.sg, K);
-    HIPCK(hipGetLastError());
-    const int rec = 66 + dim * dim;
-    for (hipEvent_t& ev : e->ls_ev)
-        if (!ev) HIPCK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    // one round: evaluation at every live signature's requested point, fixed-order sum of the partials, the solvers advance;
-    // the number of signatures that still want an evaluation travels to the host behind it (slot and event r & 1)
-    auto launch_round = [&](int r) -> int {
-        if (multi && dim % 16 != 0) {
-            // the last block column's live columns of the group's signatures side by side (ls_eval_packed_kernel)
-            const int tail_cols = dim + 1 - 16 * ((dim + 15) / 16 - 1);
-            const int npk = (LS_GROUP * tail_cols + 15) / 16;
-            // <3, 40, ..>: three row tiles and three packed tiles as compile-time constants, the next tile of U prefetched
-            // into 40 registers per lane (c5's shape: dim 33 .. 40)
-            // (even dim: the tile by LDS-DMA, per wave, in double-buffered halves -- no staging registers, no barrier in the loop)
-            if (npk == 3 && dim > 32 && dim <= 40 && dim % 2 == 0) hipLaunchKernelGGL((ls_eval_packed_kernel<3, 0, true, true, true>), grid, dim3(SIGT), 0, e->stream, q);
-            else if (npk == 3 && dim > 32 && dim <= 40) hipLaunchKernelGGL((ls_eval_packed_kernel<3, 40, true, true>), grid, dim3(SIGT), 0, e->stream, q);
-            else if (npk <= 3) hipLaunchKernelGGL((ls_eval_packed_kernel<3, 0, false, false>), grid, dim3(SIGT), 0, e->stream, q);
-            else hipLaunchKernelGGL((ls_eval_packed_kernel<5, 0, false, false>), grid, dim3(SIGT), 0, e->stream, q);
-        } else if (multi) hipLaunchKernelGGL(ls_eval_multi_kernel, grid, dim3(SIGT), 0, e->stream, q);
-        else hipLaunchKernelGGL(ls_eval_kernel, grid, dim3(SIGT), 0, e->stream, q);
-        hipLaunchKernelGGL(ls_reduce_kernel, dim3(K, (rec + 255) / 256), dim3(256), 0, e->stream, q.part, q.red, q.state, S, 0, rec, 0, q.dyn ? S * groups : 0, K,
-                           (int64_t)n_rows, q.active);
-        HIPCK(hipGetLastError());
-        if (shard) CK(allreduce(e, q.red, (size_t)K * LS_REC));
-        hipLaunchKernelGGL(ls_advance_kernel, dim3(K), dim3(64), 0, e->stream, q);
-        HIPCK(hipGetLastError());
-        HIPCK(hipMemcpyAsync(hactive + (r & 1), q.active, sizeof(int), hipMemcpyDeviceToHost, e->stream));
-        HIPCK(hipEventRecord(e->ls_ev[r & 1], e->stream));
-        return 0;
-    };
-    // The host only decides whether another round is needed.  Round r + 1 is queued BEFORE round r's count is read: if
-    // everything had finished it is a no-op on the device (the kernels return for signatures that want nothing), and
-    // otherwise the round trip of the count hides behind it (25 us per round before).
-    bool finished = false;
-    CK(launch_round(0));
-    for (int round = 0; round < LS_EVAL_MAX + 2; ++round) {
-        if (round + 1 < LS_EVAL_MAX + 2) CK(launch_round(round + 1));
-        HIPCK(hipEventSynchronize(e->ls_ev[round & 1]));
-        if (hactive[round & 1] == 0) {
-            finished = true;
-            break;
-        }
-    }
-    if (!finished) return fail("lockstep signature solves did not terminate");
-#ifdef SALNMF_DEV_PROFILE
-    {
-        long long h[16];
-        HIPCK(hipMemcpyAsync(h, q.prof, sizeof h, hipMemcpyDeviceToHost, e->stream));
-        HIPCK(hipStreamSynchronize(e->stream));
-        const double w = h[7] > 0 ? (double)h[7] : 1.0;
-        fprintf(stderr, "[ls_eval_packed K=%d dim=%d] shader-clock ticks per wave and launch: tile to LDS %.0f + barrier %.0f, load issue %.0f, logit products %.0f, "
-                        "weights %.0f, dense %.0f, packed %.0f, end-of-tile barrier %.0f, finish %.0f (%.0f wave-launches)\n", K, dim, h[8] / w, h[0] / w, h[9] / w, h[1] / w,
-                h[2] / w, h[3] / w, h[4] / w, h[5] / w, h[6] / w, w);
-        const double wa = h[14] > 0 ? (double)h[14] : 1.0;
-        fprintf(stderr, "[ls_advance] shader-clock ticks per wave and launch: record + window %.0f, replay %.0f (%.0f wave-launches)\n", h[12] / wa, h[13] / wa, wa);
-    }
-#endif
-    // runaway solves (log full) are finished by the single-kernel form with its own evaluation budget -- on the rows at hand
-    // (a sharded engine reaches this point on every rank alike, the decisions being identical)
-    std::vector<int> st(64 * 3);
-    HIPCK(hipMemcpyAsync(st.data(), e->ls_int, st.size() * sizeof(int), hipMemcpyDeviceToHost, e->stream));
-    HIPCK(hipStreamSynchronize(e->stream));
-    bool fallback = false;
-    for (int k = 0; k < K; ++k) fallback |= st[k] == LS_FALLBACK;
-    if (fallback) {
-        if (shard) return fail("a signature-embedding solve exceeded %d evaluations on a sample-sharded engine", LS_EVAL_MAX);
-        SignatureEmbeddingParams p = q.sig;
-        p.only = q.state;
-        hipLaunchKernelGGL(corr_signature_embeddings_kernel, dim3(K), dim3(SIGT), 0, e->stream, p);
-        HIPCK(hipGetLastError());
-        HIPCK(hipMemcpyAsync(st.data() + 128, q.sig.status, (size_t)K * sizeof(int), hipMemcpyDeviceToHost, e->stream));
-        HIPCK(hipStreamSynchronize(e->stream));
-    }
-    if (status_out)
-        for (int k = 0; k < K; ++k) status_out[k] = st[128 + k];
-    return 0;
-}
-
-// One Newton-CG solve per signature over n_rows samples whose embeddings / scalings / aux rows are at U, alpha, aux
-static int launch_signature_solves(salnmf_engine* e, const double* U, const double* alpha, const double* aux, int64_t n_rows,
-                                   double variance, int maxiter, int* status_out) {
-    SignatureEmbeddingParams p;
-    p.aux = aux;
-    p.alpha = alpha;
-    p.beta = e->beta;
-    p.U = U;
-    p.L = e->Lemb;
-    p.status = nullptr;
-    p.only = nullptr;
-    p.variance = variance;
-    p.N = n_rows;
-    p.Np = n_rows;
-    p.K = e->K;
-    p.KP = e->KP;
-    p.dim = e->dim;
-    p.maxiter = maxiter > 0 ? maxiter : 200 * e->dim;
-    int* dstatus = nullptr;
-    if (status_out) {
-        HIPCK(hipMalloc(&dstatus, (size_t)e->K * sizeof(int)));
-        p.status = dstatus;
-    }
-    hipLaunchKernelGGL(corr_signature_embeddings_kernel, dim3(e->K), dim3(SIGT), 0, e->stream, p);
-    int rc = 0;
-    if (hipGetLastError() != hipSuccess) rc = fail("corr_signature_embeddings_kernel launch failed");
-    if (!rc && status_out) {
-        if (hipMemcpyAsync(status_out, dstatus, (size_t)e->K * sizeof(int), hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
-            hipStreamSynchronize(e->stream) != hipSuccess)
-            rc = fail("status download failed");
-    }
-    if (dstatus) (void)hipFree(dstatus);
-    return rc;
-}
-
-// A signature embedding depends on ALL samples (its objective, gradient and Hessian are sums over samples), and
-// its Newton-CG solve takes data-dependent decisions after every one of them.  With the sample axis sharded there are two
-// forms (salnmf_corr_update_signature_embeddings picks):
-//   * from LS_MIN_ROWS samples per rank on (every BASELINE-sized cohort) the K solvers advance in LOCKSTEP rounds on the
-//     local rows and the 1 + dim + dim^2 sums per signature of every round are all-reduced (lockstep_signature_solves):
-//     identical sums, hence identical decisions and embeddings, on every rank;
-//   * smaller cohorts gather the sample-side inputs -- U (N x dim), alpha (N) and aux (N x K) -- ONCE per update
-//     (all-gather with per-rank counts = one broadcast per rank inside an RCCL group, below), after which every rank runs
-//     all K solves on identical inputs in the sample order of an unsharded engine.
-static int gather_sample_side(salnmf_engine* e) {
-    CK(ensure_gathered(e, (size_t)e->N_total));
-    NCCLCK(ncclGroupStart());
-    int64_t off = 0;
-    for (int r = 0; r < e->n_ranks; ++r) {
-        const size_t n = (size_t)e->shard_N[r];
-        NCCLCK(ncclBroadcast(e->Uemb, e->gU + off * e->dim, n * e->dim, ncclDouble, r, e->comm, e->stream));
-        NCCLCK(ncclBroadcast(e->alpha, e->galpha + off, n, ncclDouble, r, e->comm, e->stream));
-        NCCLCK(ncclBroadcast(e->aux, e->gaux + off * e->KP, n * e->KP, ncclDouble, r, e->comm, e->stream));
-        off += (int64_t)n;
-    }
-    NCCLCK(ncclGroupEnd());
-    return 0;
-}
-
-int salnmf_corr_update_signature_embeddings(salnmf_engine* e, double variance, int maxiter, int* status_out) {
-    CK(corr_ready(e));
-    if (!(variance > 0.0)) return fail("variance must be positive");
-    if (sharded(e) && !e->comm) return fail("the sharded signature-embedding solves gather through the RCCL communicator: call salnmf_comm_init");
-    if (e->comm) {
-        // sample-sharded: with enough samples the solves run in lockstep on the local rows and the sums of every
-        // evaluation are all-reduced (1 + dim + dim^2 per signature); small problems gather the sample side once
-        // and solve on identical inputs
-        if (e->lockstep && e->N_total >= LS_MIN_ROWS * e->n_ranks)
-            return lockstep_signature_solves(e, e->Uemb, e->alpha, e->aux, e->N, variance, maxiter, status_out, true);
-        CK(gather_sample_side(e));
-        return launch_signature_solves(e, e->gU, e->galpha, e->gaux, e->N_total, variance, maxiter, status_out);
-    }
-    if (e->lockstep && e->N >= LS_MIN_ROWS) return lockstep_signature_solves(e, e->Uemb, e->alpha, e->aux, e->N, variance, maxiter, status_out, false);
-    return launch_signature_solves(e, e->Uemb, e->alpha, e->aux, e->N, variance, maxiter, status_out);
-}
-
-int salnmf_corr_update_signature_embeddings_from(salnmf_engine* e, int64_t n_all, const double* U_all, const double* alpha_all,
-                                                 const double* aux_all, double variance, int maxiter, int* status_out) {
-    CK(corr_ready(e));
-    if (!U_all || !alpha_all || !aux_all) return fail("null argument");
-    if (n_all < 1) return fail("n_all must be positive");
-    if (!(variance > 0.0)) return fail("variance must be positive");
-    CK(ensure_gathered(e, (size_t)n_all));
-    CK(upload(e, e->gU, U_all, (size_t)n_all * e->dim));
-    CK(upload(e, e->galpha, alpha_all, (size_t)n_all));
-    CK(ensure_scratch(e, (size_t)n_all * e->K));
-    CK(upload(e, e->scratch, aux_all, (size_t)n_all * e->K));
-    hipLaunchKernelGGL(pad_kernel, dim3(2048), dim3(256), 0, e->stream, e->gaux, e->scratch, n_all, e->K, n_all, e->KP, 0.0, 0.0, 0.0);
-    HIPCK(hipGetLastError());
-    // (the form an engine that holds all n_all samples would use: the same bits as its result)
-    if (e->lockstep && n_all >= LS_MIN_ROWS) return lockstep_signature_solves(e, e->gU, e->galpha, e->gaux, n_all, variance, maxiter, status_out, false);
-    return launch_signature_solves(e, e->gU, e->galpha, e->gaux, n_all, variance, maxiter, status_out);
-}
-
-int salnmf_corr_embedding_sumsq(salnmf_engine* e, double* out2) {
-    CK(corr_ready(e));
-    if (!out2) return fail("null argument");
-    const int g = 256;
-    CK(ensure_scratch(e, (size_t)2 * g));
-    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(g), dim3(256), 0, e->stream, e->Lemb, (int64_t)e->K * e->dim, e->scratch);
-    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(g), dim3(256), 0, e->stream, e->Uemb, e->N * (int64_t)e->dim, e->scratch + g);
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, e->scratch, g, 1, 1, e->scal + 5);
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, e->scratch + g, g, 1, 1, e->scal + 6);
-    HIPCK(hipGetLastError());
-    CK(allreduce(e, e->scal + 6, 1));  // the sample embeddings are sharded, the signature embeddings replicated
-    return read_scalars(e, 5, 2, out2);
-}
-
-int salnmf_corr_poisson_llh(salnmf_engine* e, double* out) {
-    if (!e || !out) return fail("null argument");
-    CK(enter(e));
-    if (!e->lgam_valid) {
-        const int g = 1024;
-        CK(ensure_scratch(e, (size_t)g + 1));
-        CK(ensure_scratch(e, (size_t)g * e->NB + 1));
-        for (int b = 0; b < e->NB; ++b)
-            hipLaunchKernelGGL(lgamma_partial_kernel, dim3(g), dim3(256), 0, e->stream, e->X + (size_t)b * e->Np * VMAX, e->N, block_width(e, b), VMAX,
-                               e->scratch + (size_t)b * g);
-        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, e->scratch, g * e->NB, 1, 1, e->scal + 5);
-        HIPCK(hipGetLastError());
-        CK(allreduce(e, e->scal + 5, 1));
-        double v;
-        CK(read_scalars(e, 5, 1, &v));
-        e->lgam_sum = v;
-        e->lgam_valid = true;
-    }
-    FwdParams p;
-    CK(fwd_params(e, p));
-    p.wkl = nullptr;
-    p.wlh = nullptr;
-    for (int b = 0; b < e->NB; ++b) {  // (a sum over the features: one pass per feature block)
-        FwdParams pb = p;
-        pb.X = e->X + (size_t)b * e->Np * VMAX;
-        pb.W = e->W + (size_t)VMAX * b;
-        pb.V = block_width(e, b);
-        pb.out = e->objpart + (size_t)b * e->fgrid;
-        CK(launch_forward<3>(e, pb));
-    }
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, e->objpart, e->fgrid * e->NB, 1, 1, e->scal + 6);
-    HIPCK(hipGetLastError());
-    CK(allreduce(e, e->scal + 6, 1));
-    double v;
-    CK(read_scalars(e, 6, 1, &v));
-    *out = v - e->lgam_sum;
-    return 0;
-}
-
-// ------------------------------------------------------------------------------------ initialisation (row f3)
-
-// one 96 x 96 diagonal block of X^T X (and the block's sum of X) -> host[GRAM_PART + 1], all-reduced over the shards
-static int gram_diagonal_block(salnmf_engine* e, const double* Xb, std::vector<double>& host) {
-    const int nparts = e->grid * WAVES;
-    CK(ensure_scratch(e, (size_t)nparts * GRAM_PART + nparts + GRAM_PART + 2));
-    double* part = e->scratch;
-    double* xpart = part + (size_t)nparts * GRAM_PART;
-    double* red = xpart + nparts;  // [GRAM_PART | 1]
-    hipLaunchKernelGGL(gram_kernel, dim3(e->grid), dim3(BLOCK), 0, e->stream, Xb, e->ntiles, part, xpart);
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(GRAM_PART), dim3(256), 0, e->stream, part, nparts, GRAM_PART, GRAM_PART, red);
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, e->stream, xpart, nparts, 1, 1, red + GRAM_PART);
-    HIPCK(hipGetLastError());
-    CK(allreduce(e, red, (size_t)GRAM_PART + 1));  // sample-sharded engines: the Gram matrix of ALL samples
-    host.resize((size_t)GRAM_PART + 1);
-    return download(e, host.data(), red, host.size());
-}
-
-int salnmf_init_gram(salnmf_engine* e, double* gram_out, double* xsum_out) {
-    if (e && e->NC > 1) return single_block(e, "the device-side initialisation");
-    if (!e || !gram_out) return fail("null argument");
-    CK(enter(e));
-    const int V = e->V;
-    std::vector<double> host;
-    double xsum = 0.0;
-    for (int b = 0; b < e->NB; ++b) {  // the diagonal blocks (one block: the whole matrix)
-        CK(gram_diagonal_block(e, e->X + (size_t)b * e->Np * VMAX, host));
-        const int o = VMAX * b;
-        int idx = 0;
-        for (int vt = 0; vt < VT; ++vt)
-            for (int wt = vt; wt < VT; ++wt, ++idx)
-                for (int r = 0; r < 4; ++r)
-                    for (int lane = 0; lane < 64; ++lane) {
-                        const int i = o + 16 * vt + (lane >> 4) + 4 * r, j = o + 16 * wt + (lane & 15);
-                        if (i < V && j < V) {
-                            const double g = host[((size_t)idx * 4 + r) * 64 + lane];
-                            // a diagonal tile holds both triangles; off-diagonal tiles are mirrored
-                            gram_out[(size_t)i * V + j] = g;
-                            if (vt != wt) gram_out[(size_t)j * V + i] = g;
-                        }
-                    }
-        xsum += host[GRAM_PART];
-    }
-    // n_features > 96: the off-diagonal blocks Xa^T Xb, a < b, half a block (18 of its 36 tiles) per launch
-    if (e->NB > 1) {
-        const int nparts = e->grid * WAVES;
-        CK(ensure_scratch(e, (size_t)nparts * GRAMX_PART + GRAMX_PART));
-        double* part = e->scratch;
-        double* red = part + (size_t)nparts * GRAMX_PART;
-        host.resize(GRAMX_PART);
-        for (int a = 0; a < e->NB; ++a)
-            for (int b = a + 1; b < e->NB; ++b)
-                for (int half = 0; half < 2; ++half) {
-                    const double* Xa = e->X + (size_t)a * e->Np * VMAX;
-                    const double* Xb = e->X + (size_t)b * e->Np * VMAX;
-                    if (half == 0)
-                        hipLaunchKernelGGL(gram_cross_kernel<0>, dim3(e->grid), dim3(BLOCK), 0, e->stream, Xa, Xb, e->ntiles, part);
-                    else
-                        hipLaunchKernelGGL(gram_cross_kernel<1>, dim3(e->grid), dim3(BLOCK), 0, e->stream, Xa, Xb, e->ntiles, part);
-                    hipLaunchKernelGGL(sum_partials_kernel, dim3(GRAMX_PART), dim3(256), 0, e->stream, part, nparts, GRAMX_PART, GRAMX_PART, red);
-                    HIPCK(hipGetLastError());
-                    CK(allreduce(e, red, (size_t)GRAMX_PART));
-                    CK(download(e, host.data(), red, host.size()));
-                    for (int vt = 0; vt < 3; ++vt)
-                        for (int wt = 0; wt < VT; ++wt)
-                            for (int r = 0; r < 4; ++r)
-                                for (int lane = 0; lane < 64; ++lane) {
-                                    const int i = VMAX * a + 48 * half + 16 * vt + (lane >> 4) + 4 * r, j = VMAX * b + 16 * wt + (lane & 15);
-                                    if (i < V && j < V) {
-                                        const double g = host[((size_t)(VT * vt + wt) * 4 + r) * 64 + lane];
-                                        gram_out[(size_t)i * V + j] = g;
-                                        gram_out[(size_t)j * V + i] = g;
-                                    }
-                                }
-                }
-    }
-    if (xsum_out) *xsum_out = xsum;
-    return 0;
-}
-
-int salnmf_init_project(salnmf_engine* e, const double* B, double* posneg_out) {
-    if (e && e->NC > 1) return single_block(e, "the device-side initialisation");
-    if (!e || !B || !posneg_out) return fail("null argument");
-    CK(enter(e));
-    const int K = e->K, V = e->V, KP = e->KP;
-    const int pgrid = (int)std::min<int64_t>(1024, e->ntiles);
-    CK(ensure_scratch(e, (size_t)K * V + (size_t)pgrid * 2 * KP + 2 * KP));
-    double* dB = e->scratch;
-    double* part = dB + (size_t)K * V;
-    double* red = part + (size_t)pgrid * 2 * KP;
-    CK(upload(e, dB, B, (size_t)K * V));
-    e->h_pending = false;  // H is overwritten in full
-    const size_t lds = ((size_t)KP * PROJ_LD + 16 * PROJ_LD + 256) * sizeof(double);
-    for (int b = 0; b < e->NB; ++b)  // (feature blocks: the projection is a sum over them, accumulated in H)
-        hipLaunchKernelGGL(init_project_kernel, dim3(pgrid), dim3(256), lds, e->stream, e->X + (size_t)b * e->Np * VMAX, dB + (size_t)VMAX * b, e->H, e->N,
-                           e->ntiles, block_width(e, b), V, K, KP, part, b == 0 ? 1 : 0, b == e->NB - 1 ? 1 : 0);
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(2 * KP), dim3(256), 0, e->stream, part, pgrid, 2 * KP, 2 * KP, red);
-    HIPCK(hipGetLastError());
-    CK(allreduce(e, red, (size_t)2 * KP));
-    std::vector<double> host((size_t)2 * KP);
-    CK(download(e, host.data(), red, host.size()));
-    for (int j = 0; j < K; ++j) {
-        posneg_out[j] = host[j];
-        posneg_out[K + j] = host[KP + j];
-    }
-    return 0;
-}
-
-int salnmf_init_finish(salnmf_engine* e, const double* scale, const int* take_neg, const double* post, double zero_below, double fill) {
-    if (e && e->NC > 1) return single_block(e, "the device-side initialisation");
-    if (!e || !scale || !take_neg || !post) return fail("null argument");
-    CK(enter(e));
-    const int K = e->K;
-    CK(ensure_scratch(e, (size_t)3 * K + 8));
-    double* dscale = e->scratch;
-    double* dpost = dscale + K;
-    int* dneg = reinterpret_cast<int*>(dpost + K);
-    CK(upload(e, dscale, scale, (size_t)K));
-    CK(upload(e, dpost, post, (size_t)K));
-    HIPCK(hipMemcpyAsync(dneg, take_neg, (size_t)K * sizeof(int), hipMemcpyHostToDevice, e->stream));
-    HIPCK(hipStreamSynchronize(e->stream));
-    InitFinishParams p;
-    p.H = e->H;
-    p.scale = dscale;
-    p.take_neg = dneg;
-    p.post = dpost;
-    p.zero_below = zero_below;
-    p.fill = fill;
-    p.N = e->N;
-    p.Np = e->Np;
-    p.K = K;
-    p.KP = e->KP;
-    hipLaunchKernelGGL(init_finish_kernel, dim3(2048), dim3(256), 0, e->stream, p);
-    HIPCK(hipGetLastError());
-    HIPCK(hipStreamSynchronize(e->stream));  // the scratch operands may be reused by the next call
-    return 0;
-}
-
-int salnmf_init_flat(salnmf_engine* e, const double* post) {
-    if (e && e->NC > 1) return single_block(e, "the device-side initialisation");
-    if (!e || !post) return fail("null argument");
-    CK(enter(e));
-    e->h_pending = false;
-    CK(ensure_scratch(e, (size_t)e->K));
-    CK(upload(e, e->scratch, post, (size_t)e->K));
-    hipLaunchKernelGGL(init_flat_kernel, dim3(1024), dim3(256), 0, e->stream, e->X, e->H, e->N, e->Np, e->K, e->KP, e->scratch, e->NB);
-    HIPCK(hipGetLastError());
-    HIPCK(hipStreamSynchronize(e->stream));  // the scratch operand may be reused by the next call
-    return 0;
-}
-
-int salnmf_init_separable(salnmf_engine* e, int n_select, int64_t* chosen_out, double* norms_out) {
-    if (e && e->NC > 1) return single_block(e, "the device-side initialisation");
-    if (!e || !chosen_out) return fail("null argument");
-    if (n_select < 1 || (int64_t)n_select > e->N) return fail("n_select must be in [1, n_samples]");
-    if (sharded(e)) return fail("the separableNMF selection needs all samples on one engine: not available on a sharded engine");
-    CK(enter(e));
-    const int grid = (int)std::min<int64_t>(1024, (e->N + 15) / 16);
-    const bool wide = e->NB > 1;  // rows of R over all feature blocks (sep_pass_wide_kernel)
-    const int ldr = e->NB * VMAX;
-    const size_t nR = (size_t)e->Np * ldr, nstate = wide ? (size_t)ldr + 2 : (size_t)SEP_STATE;
-    CK(ensure_scratch(e, nR + nstate + 2 * (size_t)grid + 2 * (size_t)n_select));
-    double* R = e->scratch;
-    double* state = R + nR;
-    double* pval = state + nstate;
-    long long* pidx = reinterpret_cast<long long*>(pval + grid);
-    long long* chosen = pidx + grid;
-    double* norms = reinterpret_cast<double*>(chosen + n_select);
-    auto pass = [&](bool init) {
-        if (wide) {
-            if (init) hipLaunchKernelGGL(sep_pass_wide_kernel<true>, dim3(grid), dim3(SEP_BLOCK), 0, e->stream, e->X, R, e->N, e->Np, e->V, ldr, state, pval, pidx);
-            else hipLaunchKernelGGL(sep_pass_wide_kernel<false>, dim3(grid), dim3(SEP_BLOCK), 0, e->stream, e->X, R, e->N, e->Np, e->V, ldr, state, pval, pidx);
-        } else {
-            if (init) hipLaunchKernelGGL(sep_pass_kernel<true>, dim3(grid), dim3(SEP_BLOCK), 0, e->stream, e->X, R, e->N, e->V, state, pval, pidx);
-            else hipLaunchKernelGGL(sep_pass_kernel<false>, dim3(grid), dim3(SEP_BLOCK), 0, e->stream, e->X, R, e->N, e->V, state, pval, pidx);
-        }
-    };
-    pass(true);
-    HIPCK(hipGetLastError());
-    for (int k = 0; k < n_select; ++k) {
-        hipLaunchKernelGGL(sep_select_kernel, dim3(1), dim3(256), 0, e->stream, R, pval, pidx, grid, state, chosen, norms, k, ldr);
-        HIPCK(hipGetLastError());
-        if (k + 1 < n_select) {
-            pass(false);
-            HIPCK(hipGetLastError());
-        }
-    }
-    static_assert(sizeof(long long) == sizeof(int64_t), "index type");
-    HIPCK(hipMemcpyAsync(chosen_out, chosen, (size_t)n_select * sizeof(int64_t), hipMemcpyDeviceToHost, e->stream));
-    if (norms_out) HIPCK(hipMemcpyAsync(norms_out, norms, (size_t)n_select * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-    HIPCK(hipStreamSynchronize(e->stream));
-    return check_abort(e);
-}
-
-// ------------------------------------------------------------------------------------ multi-GPU
-
-int salnmf_comm_unique_id(char* out_id) {
-    if (!out_id) return fail("null argument");
-    static_assert(sizeof(ncclUniqueId) <= SALNMF_UNIQUE_ID_BYTES, "id size");
-    CK(rccl_bind());
-    ncclUniqueId id;
-    NCCLCK(ncclGetUniqueId(&id));
-    memset(out_id, 0, SALNMF_UNIQUE_ID_BYTES);
-    memcpy(out_id, &id, sizeof id);
-    return 0;
-}
-
-int salnmf_comm_init(salnmf_engine* e, const char* id_bytes, int n_ranks, int rank) {
-    if (e && split(e)) return single_block(e, "a sample-sharded engine");
-    if (!e || !id_bytes) return fail("null argument");
-    if (e->comm) return fail("communicator already attached");
-    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail("rank %d out of range for %d ranks", rank, n_ranks);
-    CK(enter(e));
-    CK(rccl_bind());
-    ncclUniqueId id;
-    memcpy(&id, id_bytes, sizeof id);
-    NCCLCK(ncclCommInitRank(&e->comm, n_ranks, id, rank));
-    e->n_ranks = n_ranks;
-    e->rank = rank;
-    // every rank learns every shard's size (the gathers of the CorrNMF signature solves need the counts)
-    int64_t* dn = nullptr;
-    HIPCK(hipMalloc(&dn, (size_t)(n_ranks + 1) * sizeof(int64_t)));
-    int rc = 0;
-    if (hipMemcpyAsync(dn + n_ranks, &e->N, sizeof(int64_t), hipMemcpyHostToDevice, e->stream) != hipSuccess) rc = fail("hipMemcpy failed");
-    if (!rc && ncclAllGather(dn + n_ranks, dn, 1, ncclInt64, e->comm, e->stream) != ncclSuccess) rc = fail("ncclAllGather of the shard sizes failed");
-    e->shard_N.assign(n_ranks, 0);
-    if (!rc && (hipMemcpyAsync(e->shard_N.data(), dn, (size_t)n_ranks * sizeof(int64_t), hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
-                hipStreamSynchronize(e->stream) != hipSuccess))
-        rc = fail("download of the shard sizes failed");
-    (void)hipFree(dn);
-    if (rc) return rc;
-    e->N_total = 0;
-    for (int64_t n : e->shard_N) e->N_total += n;
-    return 0;
-}
-
-int salnmf_comm_info(salnmf_engine* e, int* n_ranks, int* rank, int64_t* n_samples_total) {
-    if (!e) return fail("null engine");
-    if (n_ranks) *n_ranks = e->n_ranks;
-    if (rank) *rank = e->rank;
-    if (n_samples_total) *n_samples_total = sharded(e) ? e->N_total : e->N;
-    return 0;
-}
-
-int salnmf_comm_observed(salnmf_engine* e, int* rccl_nranks, int* rccl_rank, int* rccl_device, int* p2p_nranks, int* p2p_inboxes_mapped,
-                         int* peer_devices, int* device, char* pci_bus_id) {
-    if (!e) return fail("null engine");
-    HIPCK(hipSetDevice(e->device));
-    int cnt = -1, urank = -1, cdev = -1;
-    if (e->comm) {  // asked of the communicator, not echoed from salnmf_comm_init's arguments
-        if (g_rccl.CommCount && g_rccl.CommCount(e->comm, &cnt) != ncclSuccess) cnt = -1;
-        if (g_rccl.CommUserRank && g_rccl.CommUserRank(e->comm, &urank) != ncclSuccess) urank = -1;
-        if (g_rccl.CommCuDevice && g_rccl.CommCuDevice(e->comm, &cdev) != ncclSuccess) cdev = -1;
-    }
-    if (rccl_nranks) *rccl_nranks = cnt;
-    if (rccl_rank) *rccl_rank = urank;
-    if (rccl_device) *rccl_device = cdev;
-    int mapped = 0;
-    for (int r = 0; r < P2P_MAX_RANKS; ++r) {
-        int dev = -1;
-        if (e->p2p.connected && r < e->p2p.n_ranks && e->p2p.inbox[r]) {
-            ++mapped;
-            hipPointerAttribute_t attr;
-            // (the device an inbox lives on as THIS process numbers it; an IPC mapping of a peer process's memory may not
-            // resolve, which leaves -1)
-            if (hipPointerGetAttributes(&attr, e->p2p.inbox[r]) == hipSuccess)
-                dev = attr.device;
-            else
-                (void)hipGetLastError();
-        }
-        if (peer_devices) peer_devices[r] = dev;
-    }
-    if (p2p_nranks) *p2p_nranks = e->p2p.connected ? e->p2p.n_ranks : 0;
-    if (p2p_inboxes_mapped) *p2p_inboxes_mapped = mapped;
-    if (device) *device = e->device;
-    if (pci_bus_id) {
-        memset(pci_bus_id, 0, SALNMF_PCI_BUS_ID_BYTES);
-        if (hipDeviceGetPCIBusId(pci_bus_id, SALNMF_PCI_BUS_ID_BYTES - 1, e->device) != hipSuccess) {
-            (void)hipGetLastError();
-            pci_bus_id[0] = 0;
-        }
-    }
-    return 0;
-}
-
-int salnmf_p2p_export(salnmf_engine* e, int n_ranks, int64_t max_count, char* handle_out) {
-    if (e && split(e)) return single_block(e, "a sample-sharded engine");
-    if (!e || !handle_out) return fail("null argument");
-    if (e->p2p.local) return fail("the peer-to-peer inbox is exported already");
-    if (n_ranks < 1 || n_ranks > P2P_MAX_RANKS) return fail("peer-to-peer exchange supports 1..%d ranks, not %d", P2P_MAX_RANKS, n_ranks);
-    if (max_count < 1 || max_count > (int64_t)P2P_MAX_WG * P2P_BLOCK) return fail("max_count must be in 1..%d", P2P_MAX_WG * P2P_BLOCK);
-    static_assert(sizeof(hipIpcMemHandle_t) == SALNMF_P2P_HANDLE_BYTES, "handle size");
-    CK(enter(e));
-    e->p2p.max_count = (size_t)max_count;
-    e->p2p.slot = (size_t)max_count + P2P_MAX_WG;
-    e->p2p.n_ranks = n_ranks;
-    const size_t bytes = 2 * (size_t)n_ranks * e->p2p.slot * sizeof(double);
-    HIPCK(hipExtMallocWithFlags((void**)&e->p2p.local, bytes, hipDeviceMallocUncached));
-    HIPCK(hipMemset(e->p2p.local, 0, bytes));
-    HIPCK(hipMalloc(&e->p2p.abort_dev, sizeof(unsigned)));
-    HIPCK(hipMemset(e->p2p.abort_dev, 0, sizeof(unsigned)));
-    HIPCK(hipDeviceSynchronize());  // the flags are zero before any peer can learn the handle
-    hipIpcMemHandle_t h;
-    HIPCK(hipIpcGetMemHandle(&h, e->p2p.local));
-    memcpy(handle_out, &h, sizeof h);
-    return 0;
-}
-
-int salnmf_p2p_connect(salnmf_engine* e, int rank, int n_ranks, const char* handles, int64_t n_samples_total) {
-    if (!e || !handles) return fail("null argument");
-    if (!e->p2p.local) return fail("salnmf_p2p_export first");
-    if (e->p2p.connected) return fail("peer-to-peer exchange already connected");
-    if (n_ranks != e->p2p.n_ranks || rank < 0 || rank >= n_ranks) return fail("rank %d of %d does not match the exported inbox (%d ranks)", rank, n_ranks, e->p2p.n_ranks);
-    if (e->comm && (e->n_ranks != n_ranks || e->rank != rank)) return fail("rank %d of %d contradicts the RCCL communicator (%d of %d)", rank, n_ranks, e->rank, e->n_ranks);
-    if (n_samples_total < e->N) return fail("n_samples_total %lld is smaller than this shard (%lld)", (long long)n_samples_total, (long long)e->N);
-    CK(enter(e));
-    for (int r = 0; r < n_ranks; ++r) {
-        if (r == rank) {
-            e->p2p.inbox[r] = e->p2p.local;
-            continue;
-        }
-        hipIpcMemHandle_t h;
-        memcpy(&h, handles + (size_t)r * sizeof h, sizeof h);
-        void* ptr = nullptr;
-        hipError_t rc = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
-        if (rc != hipSuccess) {
-            for (int q = 0; q < r; ++q)
-                if (q != rank && e->p2p.inbox[q]) (void)hipIpcCloseMemHandle(e->p2p.inbox[q]);
-            for (double*& b : e->p2p.inbox) b = nullptr;
-            return fail("hipIpcOpenMemHandle of rank %d's inbox failed: %s", r, hipGetErrorString(rc));
-        }
-        e->p2p.inbox[r] = static_cast<double*>(ptr);
-    }
-    e->n_ranks = n_ranks;
-    e->rank = rank;
-    if (!e->comm) e->N_total = n_samples_total;
-    e->p2p.connected = true;
-    e->p2p.on = true;
-    return 0;
-}
-
-int salnmf_set_p2p_timeout_ms(salnmf_engine* e, int64_t timeout_ms) {
-    if (!e) return fail("null engine");
-    if (timeout_ms < 1) return fail("timeout_ms must be positive");
-    e->p2p.timeout_ticks = (unsigned long long)timeout_ms * 100000ull;  // the exchange kernels count the 100 MHz clock
-    return 0;
-}
-
-int salnmf_set_p2p(salnmf_engine* e, int on) {
-    if (!e) return fail("null engine");
-    if (on && !e->p2p.connected) return fail("peer-to-peer exchange is not connected");
-    if (on && e->p2p.abort_dev) {
-        unsigned gave_up = 0;
-        HIPCK(hipMemcpy(&gave_up, e->p2p.abort_dev, sizeof gave_up, hipMemcpyDeviceToHost));
-        if (gave_up) return fail("the peer-to-peer exchange gave up earlier on this engine and cannot be switched on again");
-    }
-    if (!on && e->p2p.connected && !e->comm) return fail("without an RCCL communicator the peer-to-peer exchange cannot be switched off");
-    e->p2p.on = on != 0;
-    if (!on && e->pabort && *e->pabort == 2u) {
-        // an exchange gave up: RCCL takes over and the caller uploads W and H again.  (The exchange stays unusable on every
-        // rank after that: the ranks' sequence numbers are no longer known to agree.)
-        HIPCK(hipStreamSynchronize(e->stream));
-        *e->pabort = 0;
-    }
-    return 0;
-}
-
-void* salnmf_device_ptr(salnmf_engine* e, int which) {
-    if (!e) return nullptr;
-    if (enter(e)) return nullptr;
-    switch (which) {
-        case SALNMF_BUF_G: return e->red;
-        case SALNMF_BUF_W: return e->W;
-        case SALNMF_BUF_H:
-            if (flush_H_scale(e)) return nullptr;
-            return e->H;
-        case SALNMF_BUF_X: return e->X;
-        case SALNMF_BUF_OBJ: return e->scal;
-        case SALNMF_BUF_RED: return e->red;
-        default: return nullptr;
-    }
-}
-
-void* salnmf_stream(salnmf_engine* e) { return e ? (void*)e->stream : nullptr; }
-
-int salnmf_sync(salnmf_engine* e) {
-    if (!e) return fail("null engine");
-    CK(enter(e));
-    HIPCK(hipStreamSynchronize(e->stream));
-    return check_abort(e);
-}
-
-// ------------------------------------------------------------------------------------ measurement
-
-static int ensure_events(salnmf_engine* e, size_t n) {
-    while (e->events.size() < n) {
-        hipEvent_t ev;
-        HIPCK(hipEventCreate(&ev));
-        e->events.push_back(ev);
-    }
-    return 0;
-}
-
-int salnmf_profile_kl_steps(salnmf_engine* e, int n_steps, int n_given, int sample_stride, double* total_ms,
-                            double* fused_avg_ms, double* tail_avg_ms) {
-    if (e && split(e)) return single_block(e, "the profiling entry points");
-    if (!e) return fail("null engine");
-    if (n_steps < 1 || n_steps > 1000000) return fail("n_steps out of range");
-    if (sample_stride < 1) sample_stride = 1;
-    CK(enter(e));
-    const int n_samples = (n_steps + sample_stride - 1) / sample_stride;
-    CK(ensure_events(e, (size_t)4 * n_samples + 2));
-    hipEvent_t first = e->events[4 * (size_t)n_samples], last = e->events[4 * (size_t)n_samples + 1];
-    HIPCK(hipEventRecord(first, e->stream));
-    for (int i = 0; i < n_steps; ++i) {
-        // every sample_stride-th step carries events (bound to its two dispatches: their own durations)
-        hipEvent_t* ev = (i % sample_stride == 0) ? &e->events[4 * (size_t)(i / sample_stride)] : nullptr;
-        CK(kl_step_once(e, n_given, ev));
-    }
-    HIPCK(hipEventRecord(last, e->stream));
-    HIPCK(hipStreamSynchronize(e->stream));
-    double fused = 0, tail = 0;
-    for (int i = 0; i < n_samples; ++i) {
-        float a = 0, b = 0;
-        HIPCK(hipEventElapsedTime(&a, e->events[4 * (size_t)i], e->events[4 * (size_t)i + 1]));
-        HIPCK(hipEventElapsedTime(&b, e->events[4 * (size_t)i + 2], e->events[4 * (size_t)i + 3]));
-        fused += a;
-        tail += b;
-    }
-    float tot = 0;
-    HIPCK(hipEventElapsedTime(&tot, first, last));
-    if (total_ms) *total_ms = tot;
-    if (fused_avg_ms) *fused_avg_ms = fused / n_samples;
-    if (tail_avg_ms) *tail_avg_ms = tail / n_samples;
-    return 0;
-}
-
-// n_steps sharded joint steps with HIP events bound to every step's two dispatches and the in-kernel stamps of the
-// tail's exchange (salnmf_p2p_kernels.h: tail_p2p_kernel): where a sharded step's microseconds go, rank by rank.
-//   out[0] step (wall clock of the stream / n_steps)   out[1] fused pass   out[2] tail + exchange launch   (events)
-//   per row workgroup of the tail, averaged over rows and steps (s_memrealtime, 100 MHz):
-//   out[3] local slab reduction  out[4] stores to the peers + flags  out[5] wait for the peers' flags
-//   out[6] read + sum of the peers' rows  out[7] W row finish   out[8] the longest wait of any row and step
-// all in microseconds.  Needs the peer-to-peer exchange (a world of one rank included: the rehearsal).
-int salnmf_profile_sharded_steps(salnmf_engine* e, int n_steps, int n_given, double* out9) {
-    if (!e || !out9) return fail("null argument");
-    if (split(e)) return single_block(e, "the profiling entry points");
-    if (n_steps < 1 || n_steps > 4096) return fail("n_steps out of range");
-    CK(enter(e));
-    const size_t count = (size_t)e->K * e->V;
-    if (!(p2p_usable(e, count) && e->K <= P2P_MAX_WG)) return fail("the sharded timeline needs the peer-to-peer exchange (salnmf_p2p_connect, salnmf_set_p2p)");
-    if (e->wkl || e->wlh) return fail("the sharded timeline profiles the unweighted step");
-    // (with every signature given the step has no W update, hence no exchange launch: there would be nothing to report but zeros)
-    if (n_given < 0 || n_given >= e->K) return fail("the sharded timeline needs a step with an exchange: n_given must be in 0..K-1");
-    CK(ensure_events(e, (size_t)4 * n_steps + 2));
-    unsigned long long* dstamps = nullptr;
-    const size_t n_stamps = (size_t)n_steps * 6 * P2P_MAX_WG;
-    HIPCK(hipMalloc(&dstamps, n_stamps * sizeof(unsigned long long)));
-    hipEvent_t first = e->events[4 * (size_t)n_steps], last = e->events[4 * (size_t)n_steps + 1];
-    int rc = 0;  // (from here on every exit path frees dstamps)
-    if (hipMemsetAsync(dstamps, 0, n_stamps * sizeof(unsigned long long), e->stream) != hipSuccess) rc = fail("hipMemsetAsync failed");
-    if (!rc && hipEventRecord(first, e->stream) != hipSuccess) rc = fail("hipEventRecord failed");
-    e->p2p.stamps = dstamps;
-    for (int i = 0; i < n_steps && !rc; ++i) rc = kl_step_once(e, n_given, &e->events[4 * (size_t)i]);
-    e->p2p.stamps = nullptr;
-    if (!rc && hipEventRecord(last, e->stream) != hipSuccess) rc = fail("hipEventRecord failed");
-    // (also after a failed launch: nothing may still be writing stamps when the buffer is freed)
-    if (hipStreamSynchronize(e->stream) != hipSuccess && !rc) rc = fail("hipStreamSynchronize failed");
-    std::vector<unsigned long long> st(n_stamps);
-    if (!rc && hipMemcpy(st.data(), dstamps, n_stamps * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) rc = fail("stamp download failed");
-    (void)hipFree(dstamps);
-    if (rc) return rc;
-    CK(check_abort(e));
-    if (st[0] == 0 || st[5] == 0) return fail("no exchange launch wrote its stamps: the steps did not take the peer-to-peer tail");
-    double fused = 0, tail = 0, seg[5] = {0, 0, 0, 0, 0}, wait_max = 0;
-    for (int i = 0; i < n_steps; ++i) {
-        float a = 0, b = 0;
-        HIPCK(hipEventElapsedTime(&a, e->events[4 * (size_t)i], e->events[4 * (size_t)i + 1]));
-        HIPCK(hipEventElapsedTime(&b, e->events[4 * (size_t)i + 2], e->events[4 * (size_t)i + 3]));
-        fused += a;
-        tail += b;
-        for (int k = 0; k < e->K; ++k) {
-            const unsigned long long* s6 = st.data() + ((size_t)i * P2P_MAX_WG + k) * 6;
-            for (int j = 0; j < 5; ++j) seg[j] += (double)(s6[j + 1] - s6[j]) * 0.01;  // 100 MHz ticks -> us
-            wait_max = std::max(wait_max, (double)(s6[3] - s6[2]) * 0.01);
-        }
-    }
-    float tot = 0;
-    HIPCK(hipEventElapsedTime(&tot, first, last));
-    out9[0] = tot * 1e3 / n_steps;
-    out9[1] = fused * 1e3 / n_steps;
-    out9[2] = tail * 1e3 / n_steps;
-    for (int j = 0; j < 5; ++j) out9[3 + j] = seg[j] / ((double)n_steps * e->K);
-    out9[8] = wait_max;
-    return 0;
-}
-
-// average duration of the forward kernel: mode 0 = W@H + objective terms, mode 2 = W@H alone (written
-// to a scratch reconstruction buffer)
-static int profile_forward(salnmf_engine* e, int mode, int n_calls, double* avg_ms) {
-    if (!e) return fail("null engine");
-    if (split(e)) return single_block(e, "the profiling entry points");
-    if (n_calls < 1 || n_calls > 100000) return fail("n_calls out of range");
-    CK(enter(e));
-    CK(ensure_events(e, (size_t)2 * n_calls));
-    FwdParams p;
-    CK(fwd_params(e, p));
-    double* recon = nullptr;
-    if (mode == 2) {
-        HIPCK(hipMalloc(&recon, (size_t)e->Np * VMAX * sizeof(double)));
-        p.out = recon;
-    }
-    int rc = 0;
-    for (int i = 0; i < n_calls && !rc; ++i) {
-        // (events bound to the dispatch: the kernel's own duration)
-        hipEvent_t a = e->events[2 * (size_t)i], b = e->events[2 * (size_t)i + 1];
-        rc = (mode == 2) ? launch_forward<2>(e, p, 0, a, b) : launch_forward<0>(e, p, 0, a, b);
-    }
-    if (hipStreamSynchronize(e->stream) != hipSuccess && !rc) rc = fail("hipStreamSynchronize failed");
-    double s = 0;
-    for (int i = 0; i < n_calls && !rc; ++i) {
-        float a = 0;
-        if (hipEventElapsedTime(&a, e->events[2 * (size_t)i], e->events[2 * (size_t)i + 1]) != hipSuccess) rc = fail("hipEventElapsedTime failed");
-        s += a;
-    }
-    if (recon) (void)hipFree(recon);
-    if (!rc && avg_ms) *avg_ms = s / n_calls;
-    return rc;
-}
-
-int salnmf_profile_objective(salnmf_engine* e, int n_calls, double* avg_ms) { return profile_forward(e, 0, n_calls, avg_ms); }
-int salnmf_profile_reconstruct(salnmf_engine* e, int n_calls, double* avg_ms) { return profile_forward(e, 2, n_calls, avg_ms); }
+#include "salnmf_host_mv.h"  // MvNMF entry points and their host-side logic
+#include "salnmf_host_corr.h"  // CorrNMF / MultimodalCorrNMF entry points
+#include "salnmf_host_init.h"  // device-side initialisation entry points
+#include "salnmf_host_dist.h"  // multi-GPU entry points
+#include "salnmf_host_profile.h"  // measurement entry points
 
 }  // extern "C"

@@ -4,7 +4,7 @@
 // Reference arithmetic: src/salamander/models/_utils_corrnmf.py:11-25 (compute_exposures),
 // :103-138 (update_signature_scalings), :141-179 (update_sample_scalings);
 // _utils_klnmf.py:98-160 (poisson_llh).  aux itself (:28-52) is the U phase of fused_kernel
-// with an H-multiply epilogue, see salnmf_corr_compute_aux in salnmf.hip.
+// with an H-multiply epilogue, see salnmf_corr_compute_aux in salnmf_host_corr.h.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

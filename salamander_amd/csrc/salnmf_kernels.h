@@ -1936,7 +1936,7 @@ struct TailParams {
     double* __restrict__ hsum_out;         // [K]
     const double* __restrict__ kl_part;    // [nparts] or null: partials of the KL divergence (tile_kl: x-only constants included)
     double* __restrict__ kl_out;           // [1]
-    // optional (MvNMF, steps queued ahead of the host: salnmf.hip, mv_steps_queued): the line-search decision of the
+    // optional (MvNMF, steps queued ahead of the host: salnmf_host_mv.h, mv_steps_queued): the line-search decision of the
     // PREVIOUS step on the device.  mv_flag: device word, non-zero = a trial was rejected, everything queued behind it
     // returns at once.  dec_f0 != null: this launch first decides the previous step's first trial -- f1 = dec_kl +
     // dec_lam * dec_logdet against dec_f0 (mvnmf.py:84), the host's expression operation for operation -- and on rejection

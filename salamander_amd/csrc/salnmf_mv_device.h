@@ -155,7 +155,7 @@ __device__ inline void mv_load_W(const double* __restrict__ W, double* Wl, int K
 }
 
 // ---- MvNMF W step, split so that everything that depends on W alone can run on a second stream while the
-// passes over the samples run (salnmf.hip: mv_update_W_impl)
+// passes over the samples run (salnmf_host_mv.h: mv_update_W_impl)
 
 // W-only half of update_W_unconstrained: A = W @ Y_minus, B = W @ |Y| with Y = (W W^T + delta I)^-1
 // (mvnmf.py:48-54, in the K x V layout), and log det(W W^T + delta I) (mvnmf.py:19-24).

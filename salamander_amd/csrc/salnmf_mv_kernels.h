@@ -41,7 +41,7 @@ struct MvRootParams {
     double* f0_out;
     double lam;
     int n_given;
-    // optional (steps queued ahead of the host on a SAMPLE-SHARDED engine: salnmf.hip, mv_steps_queued): the device-side
+    // optional (steps queued ahead of the host on a SAMPLE-SHARDED engine: salnmf_host_mv.h, mv_steps_queued): the device-side
     // line-search decision that tail_kernel takes on an unsharded engine (TailParams::mv_flag, dec_*), here in the kernel
     // that follows the all-reduce of [G | rowsums_H | KL | the previous trial's KL] -- the operands are the all-reduced
     // sums, the same bits on every rank, so every rank takes the same decision.
