@@ -330,8 +330,8 @@ static int launch_fused(salnmf_engine* e, const FusedParams& p, int grid = 0, hi
     const FusedSel sel{e->KS, e->KTM, e->KR, DO_G, DO_U, DO_STATS, wts, false};
     FusedParams pw = p;
     if (wts) CK(weight_arrays(e, pw));
-    if (DO_G && DO_U && !DO_STATS && !wts && pw.hscale != nullptr) {
-        // the plain joint step reads its H tiles by LDS-DMA (fused_kernel: HDMA), i.e. as they are in memory: a pending
+    if (DO_G && DO_U && pw.hscale != nullptr) {
+        // the joint steps read their H tiles by LDS-DMA (fused_kernel: HDMA), i.e. as they are in memory: a pending
         // rescale (an accepted MvNMF trial, salnmf_set_H_scale) is applied as a pass of its own first
         if (pw.hscale != e->cs || pw.H != e->H || !e->h_pending) return fail("internal: the joint step cannot apply a foreign exposure scale on the fly");
         CK(flush_H_scale(e));

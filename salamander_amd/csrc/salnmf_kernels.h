@@ -701,13 +701,14 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
     // (Round 5: K = 50 stages 52 rows, not the 64 of the padded layout: 9 KB of LDS that the second H buffer below needs.)
     constexpr int WROWS = 4 * KS > 16 * KTM + KR ? 4 * KS : 16 * KTM + KR;
     static_assert(WROWS <= G_::WROWS, "never more rows than the padded layout");
-    // HDMA (round 5, the plain joint step only): the NEXT tile's H travels straight from global memory into a second LDS
+    // HDMA (round 5, the joint steps): the NEXT tile's H travels straight from global memory into a second LDS
     // tile by LDS-DMA (global_load_lds_dwordx4) instead of through 32 prefetch registers and a staging pass at the top of
     // the tile -- a row of the tile is KP / 2 pieces of 16 bytes, a row of the LDS image one more (LS = KP + 2), as for W.
     // hipcc tracks LDS-DMA writes against vmcnt itself, so the first read of the new tile waits for exactly these loads.
     // Needs the tile's rows as they are in memory: the host applies a pending rescale of H before launching this variant.
-    constexpr bool HDMA_FITS = (WROWS * WS + WAVES * (2 * G_::HL + G_::RL) + KP) * 8 <= 160 * 1024;
-    constexpr bool HDMA = DO_G && DO_U && !DO_STATS && !WTS && !PERSIST && !BLOCKED && !RGIVEN && !MVJ && HDMA_FITS;
+    // (every joint step -- plain, weighted, with the objective folded in -- where 160 KB have the room)
+    constexpr bool HDMA_FITS = (WROWS * WS + WAVES * (2 * G_::HL + G_::RL) + KP + (DO_STATS ? LOGTAB_DOUBLES : 0) + (WTS ? WAVES * 32 : 0)) * 8 <= 160 * 1024;
+    constexpr bool HDMA = DO_G && DO_U && !PERSIST && !BLOCKED && !RGIVEN && !MVJ && HDMA_FITS;
     constexpr int REGION = (HDMA ? 2 : 1) * G_::HL + G_::RL;  // per wave: [H tile | R tile | (HDMA) second H tile]
     constexpr int LDSD = WROWS * WS + WAVES * REGION;
     __shared__ __attribute__((aligned(16))) double lds[LDSD + KP + (DO_STATS ? LOGTAB_DOUBLES : 0) + (WTS ? WAVES * 32 : 0)];
