@@ -644,8 +644,8 @@ void salnmf_destroy(salnmf_engine* e) {
         }
         if (t[FK_NSEC] > 0) {
             static const char* names[FK_NSEC] = {"prologue", "a.stage_H", "a.P_product", "a.KL_terms", "a.divisions", "a.prefetch+R_transpose", "a.G_phase",
-                                                 "a.U_phase+H_update", "b.stage_H", "b.P_product", "b.KL_terms", "b.divisions", "b.prefetch+R_transpose",
-                                                 "b.G_phase", "b.U_phase+H_update", "epilogue"};
+                                                 "a.U_phase+H_update", "b.stage_H|-", "b.P_product|coop.load+stage", "b.KL_terms|coop.phase_A", "b.divisions|epi.wait_slowest_wave", "b.prefetch+R_tr|coop.phase_B",
+                                                 "b.G_phase|epi.park+barrier", "b.U_phase|epi.sum+slab_stores", "epilogue"};
             unsigned long long tot = 0;
             for (int i = 0; i < FK_NSEC; ++i) tot += t[i];
             fprintf(stderr, "[salnmf dev profile] fused passes of engine N=%lld K=%d: %zu waves, %llu (wave, tile) pairs, %.0f shader-clock cycles per wave in all\n",

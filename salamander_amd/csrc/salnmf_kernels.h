@@ -100,6 +100,21 @@ __device__ __forceinline__ double xor16(double v) {
     return dpp_f64<0xB1>(v);
 }
 
+// Sum over the four lanes l, l ^ 16, l ^ 32, l ^ 48 (the four q groups of an accumulator column), the same bits in all four,
+// by v_permlane16_swap / v_permlane32_swap of the value with itself: VALU moves, no LDS round trip -- as two __shfl_xor steps
+// (two ds_bpermute each on doubles, dependent) a sum costs a few hundred cycles.  The same pairs in the same order as
+// t += shfl_xor(t, 16); t += shfl_xor(t, 32): a + b and b + a are the same bits.
+__device__ __forceinline__ double rows_sum(double v) {
+    unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    v = __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+    lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+
 template <int KS>
 struct Geo {
     static constexpr int KT = (KS + 3) / 4;        // signature tiles of 16
@@ -604,17 +619,22 @@ __device__ __attribute__((noinline)) bool persist_wait_W(unsigned* sync, unsigne
     return ok;
 }
 
-// Epilogue geometry of the fused kernel's numerator reduction, shared with the cooperative tile: ROUNDS feature
-// ranges of VTR tiles; within a round tile t = kt * VTR + h is owned by wave t % 4 (its slot i = t / 4).
+// Epilogue geometry of the fused kernel's numerator reduction, shared with the cooperative tile.  The cross-wave sum runs
+// in ROUNDS feature ranges of VTR tiles: in a round EVERY wave parks ALL NT = KT * VTR accumulator tiles of the range in LDS
+// (area [wave][tile][reg][lane]), one barrier, then wave w sums tiles w, w + 4, ... over the four waves in the order
+// 0 + 1 + 2 + 3 and stores them.  The cooperative leftover tile parks its contribution (one per tile, index kt * VT + vt)
+// and its remainder rows in the idle waves' LDS; the owners take theirs into registers before the rounds reuse that memory.
 template <int KT, int KR, int LDS_DOUBLES>
 struct EpiGeo {
-    static constexpr int REMD = KR > 0 ? WAVES * KR * VMAX : 0;  // parked remainder rows
-    static constexpr int ROUNDS = (3 * KT * VT * 256 + REMD <= LDS_DOUBLES) ? 1 : 2;
+    static constexpr int REMD = KR > 0 ? WAVES * KR * VMAX : 0;  // parked remainder rows of the four waves
+    static constexpr int COOP_REM = KT * VT * 256;               // offset of the remainder rows inside the cooperative park
+    static constexpr int COOP_DOUBLES = COOP_REM + (KR > 0 ? KR * VMAX : 0);
+    static constexpr int need(int rounds) { return WAVES * KT * (VT / rounds) * 256 + REMD; }
+    static constexpr int ROUNDS = need(1) <= LDS_DOUBLES ? 1 : (need(2) <= LDS_DOUBLES ? 2 : (need(3) <= LDS_DOUBLES ? 3 : 6));
+    static_assert(need(ROUNDS) <= LDS_DOUBLES, "the parked accumulator tiles must fit in LDS");
     static constexpr int VTR = VT / ROUNDS, NT = KT * VTR;
     static constexpr int MAXI = (NT + WAVES - 1) / WAVES;        // tiles a wave owns per round, at most
-    static constexpr int REM = ROUNDS * NT * 256;                // offset of the remainder rows in the cooperative park
-    static constexpr int COOP_DOUBLES = REM + (KR > 0 ? KR * VMAX : 0);
-    static constexpr int pos(int kt, int vt) { return (vt / VTR) * NT + kt * VTR + (vt % VTR); }
+    static constexpr int PARK = WAVES * NT * 256;                // the rounds' area; the four waves' remainder rows follow it
 };
 
 // H update with an l-half penalty (_utils_klnmf.py:349-361): I = 4 H (W^T aux) [w_kl^2]; D = w_lh^2 / 4 + I;
@@ -782,7 +802,8 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
     // The joint step with the objective folded in (DO_STATS) does the same: its numerator is summed in the plain step's order.
     constexpr bool COOP = DO_G && DO_U && !RGIVEN && !MVJ;  // (with per-sample weights too: process_tile_coop honours them)
     using CO_ = EpiGeo<KT, KR, LDSD>;
-    static_assert(CO_::COOP_DOUBLES <= (WAVES - 1) * REGION, "the cooperative tile's numerator park must fit the idle waves' LDS");
+    constexpr int CSLAB = WROWS * WS + REGION;  // the cooperative tile's park: the LDS regions of waves 1..3, free meanwhile
+    static_assert(!COOP || CO_::COOP_DOUBLES <= (WAVES - 1) * REGION, "the cooperative tile's numerator park must fit the idle waves' LDS");
     const int64_t nleft = p.ntiles % tstride;
     const bool coop = COOP && nleft > 0 && nleft <= (int64_t)gridDim.x && p.hscale == nullptr;
     const int64_t nfull = coop ? p.ntiles - nleft : p.ntiles;  // tiles of the one-wave-per-tile rounds
@@ -1241,7 +1262,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         asm volatile("" : "+v"(tid));
         const int lane = tid & 63, wave = tid >> 6, c16 = lane & 15, q = lane >> 4;
         double* Hs = lds + WROWS * WS;  // wave 0's H tile and R tile serve as the shared ones
-        double* cslab = lds + WROWS * WS + REGION;  // the LDS regions of waves 1..3 are free meanwhile
+        double* cslab = lds + CSLAB;  // the LDS regions of waves 1..3 are free meanwhile
         double* Rs = Hs + G_::HL;
         const int wv = __builtin_amdgcn_readfirstlane(wave);
         // loads first (they fly while the slower waves of the workgroup arrive): the H tile, 16 bytes per thread and
@@ -1280,6 +1301,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
             }
         }
         __syncthreads();
+        FK_TICK(9);   // loads + first barrier (the slower waves of the workgroup arrive) + staging + second barrier
         // ---- phase A, one feature tile at a time (compile-time tile index: the accumulators are registers)
         auto phase_a = [&](auto vtag, const double (&xv)[4]) __attribute__((always_inline)) {
             constexpr int VTI = decltype(vtag)::value;
@@ -1339,7 +1361,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-                for (int r2 = 0; r2 < 4; ++r2) cslab[((CO_::pos(kt, VTI)) * 4 + r2) * 64 + lane] = gc[kt][r2];
+                for (int r2 = 0; r2 < 4; ++r2) cslab[((kt * VT + VTI) * 4 + r2) * 64 + lane] = gc[kt][r2];
             if (KR > 0) {
 #pragma unroll
                 for (int j = 0; j < KR; ++j) {
@@ -1350,9 +1372,8 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
                         if (WTS && wkl) hv *= wg0[2 * (4 * r + q)];
                         t = __builtin_fma(hv, pp[r], t);
                     }
-                    t += __shfl_xor(t, 16, 64);
-                    t += __shfl_xor(t, 32, 64);
-                    if (q == 0) cslab[CO_::REM + j * VMAX + 16 * VTI + c16] = t;
+                    t = rows_sum(t);
+                    if (q == 0) cslab[CO_::COOP_REM + j * VMAX + 16 * VTI + c16] = t;
                 }
             }
         };
@@ -1364,6 +1385,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
             else phase_a(integral_constant<int, 5>{}, xx[0]);
         }
         __syncthreads();  // the ratio tile is complete
+        FK_TICK(10);  // phase A + its barrier
         // ---- phase B
         if (wv < KT) {
             const int kt = wv;
@@ -1452,10 +1474,13 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
             Hnx = t;
         }
     }
+    FK_TICK(8);  // (non-MVJ kernels: sections 8..12 time the cooperative tile -- 8 is always ~0: the loop's own ticks precede it)
     if (COOP && coop && (int64_t)blockIdx.x < nleft) process_tile_coop(nfull + blockIdx.x);
+    FK_TICK(12);
 
     // ---- workgroup reductions, fixed order (deterministic)
     __syncthreads();  // every wave is done with the LDS copy of W
+    FK_TICK(11);  // (non-MVJ: the wait for the workgroup's slowest wave)
     if (DO_G) {
         // the asm MFMAs are opaque to hipcc: drain the matrix pipe before any VALU read of g
         asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
@@ -1463,38 +1488,34 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
             for (int vt = 0; vt < VT; ++vt) asm volatile("" : "+a"(g[kt][vt]));  // orders the reads below after the drain
-        // Cross-wave sum as a reduce-scatter through LDS (all of it is free now): accumulator tile t = (kt, vt) is
-        // owned by wave t % 4.  Every wave parks the tiles it does not own in the accumulator layout (one
-        // conflict-free ds_write per register, no index arithmetic), ONE barrier, then the owner adds the four
-        // contributions in the fixed order wave 0 + 1 + 2 + 3 and stores its tiles: 128-byte row segments.
-        // ROUNDS = 2 (feature halves) only where the parked tiles do not fit (KT = 4).
-        constexpr int REMD = CO_::REMD, ROUNDS = CO_::ROUNDS, VTR = CO_::VTR, NT = CO_::NT;
-        static_assert(3 * NT * 256 + REMD <= LDSD, "parked accumulator tiles must fit in LDS");
-        auto owned = [](int o) constexpr { return o < NT ? (NT - o + 3) / 4 : 0; };   // tiles owned by wave o
-        auto pbase = [&](int o) constexpr { int b = 0; for (int i = 0; i < o; ++i) b += 3 * owned(i); return b; };
-        double* remL = lds + 3 * NT * 256;  // [WAVES][KR][VMAX]
-        const int wv = __builtin_amdgcn_readfirstlane(wave);  // provably uniform: scalar branches below
+        // Cross-wave sum through LDS (all of it is free now), EpiGeo's scheme.  Round 5: every wave parks ALL tiles of a
+        // round -- compile-time register indices and no branch, where the 3/4-parking form before had a scalar branch per
+        // tile and wave -- and the owners read all four contributions from LDS.  Same sums in the same order (wave
+        // 0 + 1 + 2 + 3, then the cooperative tile's share): same bits.  profiles/r05/epilogue.md.
+        constexpr int ROUNDS = CO_::ROUNDS, VTR = CO_::VTR, NT = CO_::NT, MAXI = CO_::MAXI;
+        double* remL = lds + CO_::PARK;  // [WAVES][KR][VMAX]
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
         // a cooperative leftover tile left its numerator contribution in LDS: the owners take theirs into registers
-        // before the parking below reuses that memory
+        // before the parking below reuses that memory (clamped addresses, no branch per element)
         const bool coopwg = COOP && coop && (int64_t)blockIdx.x < nleft;
-        double cc[ROUNDS][CO_::MAXI][4];
+        double cc[ROUNDS][MAXI][4];
         double crem[2] = {0.0, 0.0};
         if (COOP && coopwg) {
-            const double* cl = lds + WROWS * WS + REGION;
+            const double* cl = lds + CSLAB;
 #pragma unroll
             for (int half = 0; half < ROUNDS; ++half)
 #pragma unroll
-                for (int i = 0; i < CO_::MAXI; ++i)
+                for (int i = 0; i < MAXI; ++i) {
+                    const int t = wv + WAVES * i < NT ? wv + WAVES * i : NT - 1;  // (a slot beyond the wave's last tile is not used)
+                    const int kt = t / VTR, vt = half * VTR + (t - kt * VTR);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int t = wv + WAVES * i;
-                        cc[half][i][r] = t < NT ? cl[((half * NT + t) * 4 + r) * 64 + lane] : 0.0;
-                    }
+                    for (int r = 0; r < 4; ++r) cc[half][i][r] = cl[((kt * VT + vt) * 4 + r) * 64 + lane];
+                }
             if (KR > 0) {
 #pragma unroll
                 for (int it = 0; it < 2; ++it) {
                     const int i = tid + it * BLOCK;
-                    if (i < KR * VMAX) crem[it] = cl[CO_::REM + i];
+                    crem[it] = cl[CO_::COOP_REM + (i < KR * VMAX ? i : 0)];
                 }
             }
             __syncthreads();
@@ -1502,60 +1523,49 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         double* out = p.Gpart + (int64_t)blockIdx.x * K * VMAX;
 #pragma unroll
         for (int half = 0; half < ROUNDS; ++half) {
+            double* mine = lds + (size_t)wv * NT * 256 + lane;
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-                for (int h = 0; h < VTR; ++h) {
-                    const int t = kt * VTR + h, o = t % WAVES, i = t / WAVES;
-                    if (wv != o) {
-                        const int src = wv < o ? wv : wv - 1;
-                        double* dst = lds + ((pbase(o) + src * owned(o) + i) * 4) * 64 + lane;
+                for (int h = 0; h < VTR; ++h)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) dst[r * 64] = g[kt][half * VTR + h][r];
-                    }
-                }
+                    for (int r = 0; r < 4; ++r) mine[((kt * VTR + h) * 4 + r) * 64] = g[kt][half * VTR + h][r];
             if (KR > 0 && half == 0) {
 #pragma unroll
                 for (int j = 0; j < KR; ++j)
 #pragma unroll
                     for (int vt = 0; vt < VT; ++vt) {
-                        double t = grem[j][vt];  // sum the four q groups (lanes l, l^16, l^32, l^48)
-                        t += __shfl_xor(t, 16, 64);
-                        t += __shfl_xor(t, 32, 64);
+                        const double t = rows_sum(grem[j][vt]);  // the four q groups (lanes l, l^16, l^32, l^48)
                         if (q == 0) remL[(wv * KR + j) * VMAX + 16 * vt + c16] = t;
                     }
             }
             __syncthreads();
+            FK_TICK(13);  // (non-MVJ: parking of the accumulator tiles + barrier)
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt)
+            for (int i = 0; i < MAXI; ++i) {
+                const int t = wv + WAVES * i;  // (uniform) the i-th tile this wave owns
+                if (t < NT) {
+                    const int kt = t / VTR, vt = half * VTR + (t - kt * VTR);
+                    const double* from = lds + (size_t)t * 256 + lane;
+                    double acc[4];
 #pragma unroll
-                for (int h = 0; h < VTR; ++h) {
-                    const int t = kt * VTR + h, o = t % WAVES, i = t / WAVES;
-                    if (wv == o) {
-                        const int vt = half * VTR + h;
-                        double acc[4];
+                    for (int r = 0; r < 4; ++r) {
+                        acc[r] = from[r * 64];
 #pragma unroll
-                        for (int w = 0; w < WAVES; ++w) {
-                            const int src = w < o ? w : w - 1;
-                            const double* from = lds + ((pbase(o) + src * owned(o) + i) * 4) * 64 + lane;
+                        for (int w = 1; w < WAVES; ++w) acc[r] += from[(size_t)w * NT * 256 + r * 64];
+                    }
+                    if (COOP && coopwg) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const double v = (w == o) ? g[kt][vt][r] : from[r * 64];
-                                acc[r] = (w == 0) ? v : acc[r] + v;
-                            }
-                        }
-                        if (COOP && coopwg) {
+                        for (int r = 0; r < 4; ++r) acc[r] += cc[half][i][r];
+                    }
+                    const int v = 16 * vt + c16;
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) acc[r] += cc[half][i][r];
-                        }
-                        const int v = 16 * vt + c16;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int k = 16 * kt + q + 4 * r;
-                            if (k < K && v < V) st_shared<PERSIST>(&out[k * VMAX + v], acc[r]);
-                        }
+                    for (int r = 0; r < 4; ++r) {
+                        const int k = 16 * kt + q + 4 * r;
+                        if (k < K && v < V) st_shared<PERSIST>(&out[k * VMAX + v], acc[r]);
                     }
                 }
+            }
             if (KR > 0 && half == 0) {
 #pragma unroll
                 for (int it = 0; it < 2; ++it) {
@@ -1570,6 +1580,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
             }
             if (half + 1 < ROUNDS) __syncthreads();
         }
+        FK_TICK(14);  // (non-MVJ: the owners' sums and the slab stores issued)
     }
     if (PERSIST) {
         if (!persist_publish_and_tail(p.sync, p.abort_host, p.Gpart, p.G, p.Wmut, K, V, p.n_given, lds, step, tid)) return;
