@@ -878,6 +878,24 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         load_tile_X(t);
     };
     bool x_first = false;  // (HDMA) the tile about to be processed was loaded X first (the register-staged prologue only)
+    // (HDMA) a workgroup with a cooperative leftover tile fetches that tile's operands while its LAST ordinary tile runs, in
+    // the slot where the next tile's prefetch would go: wave 0 sends the H tile by DMA into its free H buffer, every wave
+    // loads its own columns of X into the (free) X prefetch registers -- the cooperative tile then starts without a memory
+    // round trip of its own (3.1 k cycles of its 12.6 k at c2, profiles/r05/epilogue.md)
+    const bool coop_here = COOP && HDMA && coop && (int64_t)blockIdx.x < nleft;  // (uniform)
+    bool coop_fetched = false;
+    auto coop_prefetch = [&]() __attribute__((always_inline)) {
+        const int64_t ct = nfull + blockIdx.x;
+        const int wvu = __builtin_amdgcn_readfirstlane(wave);
+        if (wvu == 0) load_tile_H(ct);  // -> buffer (tiles per wave) & 1 of wave 0's region
+        const int vt0 = wvu < 2 ? 2 * wvu : wvu + 2, nvt = wvu < 2 ? 2 : 1;  // the feature tiles of this wave: {0,1} {2,3} {4} {5}
+        const double* xsrc = p.X + (ct * 16 + q) * VMAX + c16;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[i][r] = xsrc[4 * r * VMAX + 16 * (vt0 + (i < nvt ? i : 0))];  // (a wave with one tile loads it twice)
+        coop_fetched = true;
+    };
 
     // HALF 0: the whole tile as the template switches say; (MVJ) HALF 1: the update_H half, HALF 2: the numerator half on
     // the H' that half 1 left in the wave's LDS tile (no staging, no rescale, X still in registers)
@@ -1021,6 +1039,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         // prefetch the next tile: X and the staging registers are free from here on, and the loads
         // get the G and U phases to land
         if (HALF != 1 && tile + tstride < nfull) load_tile(tile + tstride);  // (MVJ: X serves the second half too)
+        else if (HALF != 1 && coop_here) coop_prefetch();
 
         if (TU) {
             // ---- transpose R through LDS: write accumulator layout, read A-operand layout
@@ -1261,22 +1280,30 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
         const int lane = tid & 63, wave = tid >> 6, c16 = lane & 15, q = lane >> 4;
-        double* Hs = lds + WROWS * WS;  // wave 0's H tile and R tile serve as the shared ones
+        // wave 0's H tile and R tile serve as the shared ones; a prefetched H tile (coop_prefetch) lies in the buffer wave 0's
+        // next tile would have gone to: every wave has done the same number of tiles, so every wave knows which one
+        const bool pre = HDMA && coop_fetched;  // (uniform over the workgroup)
+        double* Hs = lds + WROWS * WS + ((pre && ((nfull / tstride) & 1)) ? G_::HL + G_::RL : 0);
         double* cslab = lds + CSLAB;  // the LDS regions of waves 1..3 are free meanwhile
-        double* Rs = Hs + G_::HL;
+        double* Rs = lds + WROWS * WS + G_::HL;
         const int wv = __builtin_amdgcn_readfirstlane(wave);
         // loads first (they fly while the slower waves of the workgroup arrive): the H tile, 16 bytes per thread and
         // round, and this wave's columns of X
         constexpr int HR = (16 * KP + 2 * BLOCK - 1) / (2 * BLOCK);
         d2 hst[HR];
-#pragma unroll
-        for (int j = 0; j < HR; ++j) {
-            const int e = 2 * tid + 2 * BLOCK * j;
-            hst[j] = (e < 16 * KP) ? *reinterpret_cast<const d2*>(p.H + n0 * KP + e) : (d2){0, 0};
-        }
         const int vt0 = wv < 2 ? 2 * wv : wv + 2, nvt = wv < 2 ? 2 : 1;  // {0,1} {2,3} {4} {5}
         double xx[2][4];
-        {
+        if (pre) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xx[i][r] = x[i][r];
+        } else {
+#pragma unroll
+            for (int j = 0; j < HR; ++j) {
+                const int e = 2 * tid + 2 * BLOCK * j;
+                hst[j] = (e < 16 * KP) ? *reinterpret_cast<const d2*>(p.H + n0 * KP + e) : (d2){0, 0};
+            }
             const double* xsrc = p.X + (n0 + q) * VMAX + c16;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -1290,17 +1317,22 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
             wco[0] = p.wkl_eff[n0 + tid];
             wco[1] = p.wlh_eff[n0 + tid];
         }
-        __syncthreads();  // every wave has left its own last tile: wave 0's LDS regions are free
+        // every wave has left its own last tile: wave 0's LDS regions are free.  (The DMA pieces of a prefetched H tile are
+        // invisible to hipcc: wave 0 waits for them by hand before it joins the barrier.)
+        if (pre) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
         if (WTS && tid < 16) *reinterpret_cast<d2*>(wg0 + 2 * tid) = wco;
+        if (!pre) {
 #pragma unroll
-        for (int j = 0; j < HR; ++j) {
-            const int e = 2 * tid + 2 * BLOCK * j;
-            if (e < 16 * KP) {
-                const int row = e / KP, col = e - row * KP;
-                *reinterpret_cast<d2*>(Hs + row * LS + col) = hst[j];
+            for (int j = 0; j < HR; ++j) {
+                const int e = 2 * tid + 2 * BLOCK * j;
+                if (e < 16 * KP) {
+                    const int row = e / KP, col = e - row * KP;
+                    *reinterpret_cast<d2*>(Hs + row * LS + col) = hst[j];
+                }
             }
         }
-        __syncthreads();
+        if (WTS || !pre) __syncthreads();
         FK_TICK(9);   // loads + first barrier (the slower waves of the workgroup arrive) + staging + second barrier
         // ---- phase A, one feature tile at a time (compile-time tile index: the accumulators are registers)
         auto phase_a = [&](auto vtag, const double (&xv)[4]) __attribute__((always_inline)) {
