@@ -731,7 +731,13 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
     constexpr bool HDMA = DO_G && DO_U && !PERSIST && !BLOCKED && !RGIVEN && !MVJ && HDMA_FITS;
     constexpr int REGION = (HDMA ? 2 : 1) * G_::HL + G_::RL;  // per wave: [H tile | R tile | (HDMA) second H tile]
     constexpr int LDSD = WROWS * WS + WAVES * REGION;
-    __shared__ __attribute__((aligned(16))) double lds[LDSD + KP + (DO_STATS ? LOGTAB_DOUBLES : 0) + (WTS ? WAVES * 32 : 0)];
+    // The epilogue's cross-wave sum wants 4 x (all accumulator tiles) in ONE round (EpiGeo): where the tile loop's layout is
+    // smaller than that the array is simply made as large as the round needs (one workgroup per CU either way), up to the
+    // 160 KB a workgroup can have; the small arrays behind it (hscale copy, log table, weights) keep their own space.
+    constexpr int LDS_EXTRA = KP + (DO_STATS ? LOGTAB_DOUBLES : 0) + (WTS ? WAVES * 32 : 0);
+    using CO_ = EpiGeo<KT, KR, 160 * 1024 / 8 - LDS_EXTRA>;
+    constexpr int LDS_MAIN = LDSD > CO_::need(CO_::ROUNDS) ? LDSD : CO_::need(CO_::ROUNDS);
+    __shared__ __attribute__((aligned(16))) double lds[LDS_MAIN + LDS_EXTRA];
 
     // MvNMF update_H pass: the grid's last workgroup may be the one that does the W-only algebra instead of tiles
     constexpr bool MVU = DO_U && DO_STATS && (!DO_G || MVJ);
@@ -772,7 +778,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
     double* const Hdma0 = lds + WROWS * WS + __builtin_amdgcn_readfirstlane(wave) * REGION;
     int hsel = 0;
 
-    double* hsl = lds + LDSD;  // [KP] copy of hscale
+    double* hsl = lds + LDS_MAIN;  // [KP] copy of hscale
     if (p.hscale && tid < KP) hsl[tid] = p.hscale[tid];
     double* ltab = hsl + KP;              // (DO_STATS) table of log_pos
     if (DO_STATS) stage_logtab(ltab, tid);
@@ -801,7 +807,6 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
     // profiles/r03/ab_step_variants.txt.)
     // The joint step with the objective folded in (DO_STATS) does the same: its numerator is summed in the plain step's order.
     constexpr bool COOP = DO_G && DO_U && !RGIVEN && !MVJ;  // (with per-sample weights too: process_tile_coop honours them)
-    using CO_ = EpiGeo<KT, KR, LDSD>;
     constexpr int CSLAB = WROWS * WS + REGION;  // the cooperative tile's park: the LDS regions of waves 1..3, free meanwhile
     static_assert(!COOP || CO_::COOP_DOUBLES <= (WAVES - 1) * REGION, "the cooperative tile's numerator park must fit the idle waves' LDS");
     const int64_t nleft = p.ntiles % tstride;

@@ -176,7 +176,8 @@ def test_peer_exchange_argument_checks():
     assert np.array_equal(e.download_W(), ref.download_W()) and np.array_equal(e.download_H(), ref.download_H())
     assert set(tl) == {"step", "fused_pass", "tail_exchange_launch", "local_slab_reduce", "peer_stores_and_flags", "wait_for_peer_flags",
                        "read_and_sum_peer_rows", "w_row_finish", "longest_flag_wait"}
-    assert 0 < tl["step"] < 1e4 and 0 <= tl["wait_for_peer_flags"] <= tl["longest_flag_wait"] < 1e3 and tl["local_slab_reduce"] > 0
+    # (the mean of equal waits may exceed their maximum by a rounding error)
+    assert 0 < tl["step"] < 1e4 and 0 <= tl["wait_for_peer_flags"] <= tl["longest_flag_wait"] * (1 + 1e-9) < 1e3 and tl["local_slab_reduce"] > 0
     with pytest.raises(RuntimeError, match="peer-to-peer"):
         ref.profile_sharded_steps(2, 0)
     with pytest.raises(RuntimeError, match="cannot be switched off"):
