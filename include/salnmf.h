@@ -75,8 +75,11 @@ int salnmf_device_count(void);
  * CorrNMF (its two passes over X block by block; everything else is K- and dim-sized) and the device-side
  * initialisation incl. the separableNMF selection.  On signature chunks also: MvNMF (round 5: the same plain form, its
  * K x K algebra -- Gram matrix, elimination, log det, A and B -- in global memory; mvnmf.py:116-126 has no limit on
- * n_signatures).  The fp32 fast mode and sample sharding answer with an error in both cases, CorrNMF and the device-side
- * initialisation on more than 64 signatures too. */
+ * n_signatures).  Sample shards (salnmf_comm_init / salnmf_p2p_connect) of either kind run the KLNMF entry points, the
+ * device-side initialisation and -- on feature blocks -- CorrNMF: the numerators of all blocks / chunks cross the ranks in
+ * ONE all-reduce of K * V doubles per W update (through RCCL beyond the peer inbox's 16 384 doubles); MvNMF there answers
+ * with an error.  So does the fp32 fast mode in both cases, and CorrNMF and the device-side initialisation on more than 64
+ * signatures. */
 int salnmf_create(int device, int n_features, int64_t n_samples, int n_signatures,
                   salnmf_engine** out);
 void salnmf_destroy(salnmf_engine* e);

@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("SALNMF_LIB") or os.path.join(_HERE, "lib", "libsalnmf
 
 UNIQUE_ID_BYTES = 128
 P2P_HANDLE_BYTES = 64
+P2P_MAX_COUNT = 16384  # salnmf_p2p_kernels.h: P2P_MAX_WG * P2P_BLOCK doubles per exchange
 PRECISIONS = {"f64": 0, "f32": 1}
 DTYPE_CODES = {"float64": 0, "float32": 1, "int32": 2, "int64": 3, "uint16": 4}  # SALNMF_F64 ...
 CLIP_ALL = 0

@@ -1152,6 +1152,8 @@ static int blocked_numerators(salnmf_engine* e, bool weighted = true) {
         hipLaunchKernelGGL(tail_kernel, dim3(e->K), dim3(TAIL_BLOCK), 0, e->stream, t);
         HIPCK(hipGetLastError());
     }
+    // sample shards: the blocks' compact numerators lie back to back (K * V doubles in all): one exchange for all of them
+    if (sharded(e)) CK(allreduce(e, e->Gblk, (size_t)e->K * e->V));
     return 0;
 }
 static int blocked_finish_W(salnmf_engine* e, int n_given, int clip_mode) {
@@ -1228,6 +1230,7 @@ static int chunk_ratio(salnmf_engine* e) {  // e->PR = X / (H W)
 //   weighted = false: MvNMF's passes (no sample weights: mvnmf.py:56,162-165); g_only: the numerator rows are reduced into
 //   e->red and W is left alone (the MvNMF W step takes its own root from them)
 static int chunk_passes(salnmf_engine* e, bool do_g, bool do_u, int n_given, int clip_mode, bool weighted = true, bool g_only = false) {
+    const bool shard = sharded(e) && do_g && n_given < e->K;
     for (int ci = 0; ci < e->NC; ++ci) {
         const auto& c = e->kc[(size_t)ci];
         const int given = std::max(0, std::min(c.K, n_given - c.k0));  // given rows inside this chunk
@@ -1246,12 +1249,18 @@ static int chunk_passes(salnmf_engine* e, bool do_g, bool do_u, int n_given, int
         if (launch_fused_inst(sel, p, e->grid, e->stream, nullptr, nullptr)) return fail("no kernel instantiation for KS=%d KTM=%d KR=%d", c.KS, c.KTM, c.KR);
         HIPCK(hipGetLastError());
         if (g) {
-            TailParams t = tail_params(e, e->grid, e->red + (size_t)c.k0 * e->V, given, clip_mode, g_only ? 0 : 1, false);
+            TailParams t = tail_params(e, e->grid, e->red + (size_t)c.k0 * e->V, given, clip_mode, (g_only || shard) ? 0 : 1, false);
             t.W = t.Wout = e->W + (size_t)c.k0 * e->V;
             t.K = c.K;
             hipLaunchKernelGGL(tail_kernel, dim3(c.K), dim3(TAIL_BLOCK), 0, e->stream, t);
             HIPCK(hipGetLastError());
         }
+    }
+    if (shard) {
+        // the chunks' numerator rows lie in e->red as one K x V matrix: one exchange, then the W update of every row (the
+        // given rows' numerators were not formed: they are not read either)
+        CK(allreduce(e, e->red, (size_t)e->K * e->V));
+        if (!g_only) CK(launch_tail(e, 0, e->red, n_given, clip_mode, 1));
     }
     return 0;
 }

@@ -16,7 +16,6 @@ int salnmf_comm_unique_id(char* out_id) {
 }
 
 int salnmf_comm_init(salnmf_engine* e, const char* id_bytes, int n_ranks, int rank) {
-    if (e && split(e)) return single_block(e, "a sample-sharded engine");
     if (!e || !id_bytes) return fail("null argument");
     if (e->comm) return fail("communicator already attached");
     if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail("rank %d out of range for %d ranks", rank, n_ranks);
@@ -94,7 +93,6 @@ int salnmf_comm_observed(salnmf_engine* e, int* rccl_nranks, int* rccl_rank, int
 }
 
 int salnmf_p2p_export(salnmf_engine* e, int n_ranks, int64_t max_count, char* handle_out) {
-    if (e && split(e)) return single_block(e, "a sample-sharded engine");
     if (!e || !handle_out) return fail("null argument");
     if (e->p2p.local) return fail("the peer-to-peer inbox is exported already");
     if (n_ranks < 1 || n_ranks > P2P_MAX_RANKS) return fail("peer-to-peer exchange supports 1..%d ranks, not %d", P2P_MAX_RANKS, n_ranks);

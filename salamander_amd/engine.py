@@ -397,9 +397,10 @@ class Engine:
         """Allocate this engine's inbox of the peer-to-peer exchange (``include/salnmf.h``) and return its IPC handle.
 
         ``max_count`` defaults to the largest of the small all-reduces: the numerator with the MvNMF sums
-        (K*V + K + 2) and the Gram matrix of the device-side initialisation (96*96 + 1)."""
+        (K*V + K + 2) and the Gram matrix of the device-side initialisation (96*96 + 1), at most the inbox limit of
+        16 384 doubles -- larger all-reduces (wide or many-signature engines) go through the RCCL communicator."""
         if max_count is None:
-            max_count = max(self.K * self.V + self.K + 2, 96 * 96 + 2)
+            max_count = min(max(self.K * self.V + self.K + 2, 96 * 96 + 2), _lib.P2P_MAX_COUNT)
         buf = ctypes.create_string_buffer(_lib.P2P_HANDLE_BYTES)
         _lib.check(self._lib.salnmf_p2p_export(self._h, int(n_ranks), int(max_count), buf))
         return buf.raw

@@ -278,3 +278,124 @@ def test_sharded_mvnmf_steps_queued_ahead_of_the_host_equal_the_classic_form(tmp
     assert rel_l2(parts[0]["q_one_W"], W.T) < 1e-7
     assert rel_l2(np.concatenate([p["q_one_H"] for p in parts], axis=0), H.T) < 1e-7
     assert np.isclose(float(parts[0]["q_one_obj"]), orc.kl_divergence_penalized(X.T, W, H, c["lam"], c["delta"]), rtol=1e-9)
+
+
+# ---- sample shards of engines with feature blocks (> 96 features) or signature chunks (> 64 signatures): the numerators of
+# all blocks / chunks cross the ranks in ONE exchange per W update (salnmf.hip: blocked_numerators, chunk_passes)
+SPLIT_CASES = {
+    "blocks": dict(V=288, K=20, N=1700, n_given=0),      # three feature blocks
+    "ragged_blocks": dict(V=250, K=12, N=1500, n_given=3),  # last block 58 wide, given signatures
+    "chunks": dict(V=96, K=100, N=1700, n_given=0),      # two signature chunks (64 + 36)
+    "chunks_given": dict(V=96, K=130, N=1300, n_given=70),  # the first chunk all given: its numerators are never formed
+}
+SPLIT_STEPS = 6
+
+
+def _split_problem(case):
+    from oracle import klnmf_oracle as orc
+
+    c = SPLIT_CASES[case]
+    X, W0, H0 = orc.synthetic_problem(c["V"], c["N"], c["K"], seed=11)
+    wkl = np.random.default_rng(3).uniform(0.5, 2.0, c["N"])
+    return c, X, W0, H0, wkl
+
+
+def _corr_state(c):
+    rng = np.random.default_rng(17)
+    return rng.normal(0, 0.3, c["K"]), rng.normal(0, 0.4, (c["K"], 6)), rng.normal(0, 0.4, (c["N"], 6))
+
+
+def _lib_const(name):
+    from salamander_amd import _lib
+
+    return getattr(_lib, name)
+
+
+def _split_worker(rank, world, port, out_dir, case):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+
+    from salamander_amd.distributed import attach_peer_exchange, shard_bounds
+    from salamander_amd.engine import Engine
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        c, X, W0, H0, wkl = _split_problem(case)
+        a, b = shard_bounds(c["N"], world, rank)
+        e = Engine(b - a, c["V"], c["K"])
+        e.upload_X(X[a:b]), e.upload_W(W0), e.upload_H(H0[a:b])
+        attach_peer_exchange(e)
+        assert e.comm_info() == (world, rank, c["N"])
+        e.kl_step(SPLIT_STEPS, c["n_given"])
+        Wk, Hk, obj = e.download_W(), e.download_H(), e.objective()
+        # weighted steps, then the W half alone with the other clip rule (update_W, _utils_klnmf.py:164-217)
+        e.set_weights(wkl[a:b], None)
+        e.kl_step(2, c["n_given"])
+        e.update_W(c["n_given"])
+        Ww, Hw, objw = e.download_W(), e.download_H(), e.objective()
+        extra = {}
+        if c["K"] <= 64:
+            # one CorrNMF update's signature side on the shards (corrnmf_det.py:64-85): aux + numerators of every feature
+            # block, one exchange, the W update; the Poisson log-likelihood and the scalings' sums all-reduced
+            e.set_weights(None, None)
+            e.upload_W(W0)
+            beta, L, U = _corr_state(c)
+            e.corr_configure(U.shape[1])
+            e.corr_upload(_lib_const("CORR_SIGNATURE_SCALINGS"), beta)
+            e.corr_upload(_lib_const("CORR_SIGNATURE_EMBEDDINGS"), L)
+            e.corr_upload(_lib_const("CORR_SAMPLE_EMBEDDINGS"), U[a:b])
+            e.corr_update_sample_scalings(), e.corr_compute_exposures(), e.corr_compute_aux()
+            e.corr_update_signatures(c["n_given"]), e.corr_update_signature_scalings()
+            extra = dict(Wc=e.download_W(), betac=e.corr_download(_lib_const("CORR_SIGNATURE_SCALINGS")), llh=e.corr_poisson_llh())
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), Wk=Wk, Hk=Hk, obj=obj, Ww=Ww, Hw=Hw, objw=objw, **extra)
+        dist.barrier()  # nobody frees its inbox while a peer may still be inside an exchange
+        e.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,case", [(2, "blocks"), (3, "ragged_blocks"), (2, "chunks"), (3, "chunks_given")])
+def test_sharded_steps_of_engines_with_feature_blocks_or_signature_chunks(tmp_path, world, case):
+    from oracle import klnmf_oracle as orc
+
+    mp.spawn(_split_worker, args=(world, _free_port(), str(tmp_path), case), nprocs=world, join=True)
+    parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    c, X, W0, H0, wkl = _split_problem(case)
+    ng = c["n_given"]
+    W, H = W0.T, H0.T
+    for _ in range(SPLIT_STEPS):
+        W, H = orc.update_WH(X.T, W, H, None, None, ng)
+    for p in parts[1:]:
+        assert np.array_equal(parts[0]["Wk"], p["Wk"]) and np.array_equal(parts[0]["Ww"], p["Ww"])  # the same bits on every rank
+        assert p["obj"] == parts[0]["obj"] and p["objw"] == parts[0]["objw"]
+    assert np.array_equal(parts[0]["Wk"][:ng], W0[:ng])
+    assert rel_l2(parts[0]["Wk"], W.T) < 1e-11
+    assert rel_l2(np.concatenate([p["Hk"] for p in parts], axis=0), H.T) < 1e-11
+    assert np.isclose(float(parts[0]["obj"]), orc.kl_divergence(X.T, W, H), rtol=1e-10)
+    for _ in range(2):
+        W, H = orc.update_WH(X.T, W, H, wkl, None, ng)
+    W = orc.update_W(X.T, W, H, wkl, ng)
+    assert rel_l2(parts[0]["Ww"], W.T) < 1e-11
+    assert rel_l2(np.concatenate([p["Hw"] for p in parts], axis=0), H.T) < 1e-11
+    assert np.isclose(float(parts[0]["objw"]), orc.kl_divergence(X.T, W, H, wkl), rtol=1e-10)
+    if c["K"] <= 64:
+        # the CorrNMF signature side: equal to one engine that holds all samples (sums over the samples in another order)
+        from salamander_amd.engine import Engine
+
+        beta, L, U = _corr_state(c)
+        e1 = Engine(c["N"], c["V"], c["K"])
+        e1.upload_X(X), e1.upload_W(W0)
+        e1.corr_configure(U.shape[1])
+        e1.corr_upload(_lib_const("CORR_SIGNATURE_SCALINGS"), beta)
+        e1.corr_upload(_lib_const("CORR_SIGNATURE_EMBEDDINGS"), L)
+        e1.corr_upload(_lib_const("CORR_SAMPLE_EMBEDDINGS"), U)
+        e1.corr_update_sample_scalings(), e1.corr_compute_exposures(), e1.corr_compute_aux()
+        e1.corr_update_signatures(ng), e1.corr_update_signature_scalings()
+        for p in parts[1:]:
+            assert np.array_equal(parts[0]["Wc"], p["Wc"]) and np.array_equal(parts[0]["betac"], p["betac"]) and p["llh"] == parts[0]["llh"]
+        assert rel_l2(parts[0]["Wc"], e1.download_W()) < 1e-12
+        assert rel_l2(parts[0]["betac"], e1.corr_download(_lib_const("CORR_SIGNATURE_SCALINGS"))) < 1e-12
+        assert np.isclose(float(parts[0]["llh"]), e1.corr_poisson_llh(), rtol=1e-12)
+        e1.close()
