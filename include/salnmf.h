@@ -64,7 +64,7 @@ int salnmf_build_flags(void);
 int salnmf_device_count(void);
 
 /* Create an engine for a shard of n_samples rows on HIP device `device`.
- * Limits of this build: n_signatures <= 512; n_features <= 3072; not both n_signatures > 64 and n_features > 96.  Up to
+ * Limits of this build: n_signatures <= 512; n_features <= 3072.  Up to
  * 96 features and 64 signatures (every BASELINE configuration) the whole API is available.  Wider catalogues (SBS-288,
  * SBS-1536, ...) run the KLNMF entry points -- upload / download, salnmf_kl_step (both halves from the old state, as
  * update_WH), salnmf_update_H / _W, the objectives (blocking and queued), salnmf_samplewise_kl, salnmf_reconstruct,
@@ -75,7 +75,9 @@ int salnmf_device_count(void);
  * CorrNMF (its two passes over X block by block; everything else is K- and dim-sized) and the device-side
  * initialisation incl. the separableNMF selection.  On signature chunks also: MvNMF (round 5: the same plain form, its
  * K x K algebra -- Gram matrix, elimination, log det, A and B -- in global memory; mvnmf.py:116-126 has no limit on
- * n_signatures).  Sample shards (salnmf_comm_init / salnmf_p2p_connect) of either kind run the KLNMF entry points, the
+ * n_signatures).  Both together (round 5): per feature block the chain over the chunks forms that block's ratio, every chunk
+ * runs its numerator pass and its share of U = R W^T on it (accumulated over the blocks); the KLNMF entry points and MvNMF.
+ * Sample shards (salnmf_comm_init / salnmf_p2p_connect) of either kind run the KLNMF entry points, the
  * device-side initialisation and -- on feature blocks -- CorrNMF: the numerators of all blocks / chunks cross the ranks in
  * ONE all-reduce of K * V doubles per W update (through RCCL beyond the peer inbox's 16 384 doubles); MvNMF there answers
  * with an error.  So does the fp32 fast mode in both cases, and CorrNMF and the device-side initialisation on more than 64

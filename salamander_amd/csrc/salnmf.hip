@@ -493,7 +493,7 @@ static int sharded_tail(salnmf_engine* e, int n_given, int clip_mode) {
 // whatever hipMalloc had handed back.)
 static int ensure_halt(salnmf_engine* e) {
     if (e->Halt) return 0;
-    const size_t bytes = (size_t)e->Np * e->KP * sizeof(double);
+    const size_t bytes = (size_t)e->NC * e->Np * e->KP * sizeof(double);
     HIPCK(hipMalloc(&e->Halt, bytes));
     HIPCK(hipMemsetAsync(e->Halt, 0, bytes, e->stream));
     return 0;
@@ -703,8 +703,6 @@ int salnmf_create(int device, int n_features, int64_t n_samples, int n_signature
     *out = nullptr;
     if (n_features < 1 || n_features > VMAX * NB_MAX) return fail("n_features must be in [1, %d], got %d", VMAX * NB_MAX, n_features);
     if (n_signatures < 1 || n_signatures > KC * NC_MAX) return fail("n_signatures must be in [1, %d], got %d", KC * NC_MAX, n_signatures);
-    if (n_signatures > KC && n_features > VMAX)
-        return fail("n_signatures > %d together with n_features > %d is not available (got %d, %d)", KC, VMAX, n_signatures, n_features);
     if (n_samples < 1) return fail("n_samples must be positive");
     int ndev = 0;
     HIPCK(hipGetDeviceCount(&ndev));
@@ -782,10 +780,10 @@ int salnmf_create(int device, int n_features, int64_t n_samples, int n_signature
     ALLOC(e->Hsumpart, (size_t)e->grid * K);
     ALLOC(e->KLpart, (size_t)e->grid);
     ALLOC(e->red, K * V + K + 2);
-    ALLOC(e->objpart, (size_t)std::max(e->NB, e->NC) * e->fgrid);
+    ALLOC(e->objpart, (size_t)(e->NB > 1 && e->NC > 1 ? e->NB + e->NC : std::max(e->NB, e->NC)) * e->fgrid);
     if (e->NB > 1) {
         ALLOC(e->Gblk, (size_t)e->NB * K * VMAX);
-        ALLOC(e->Uacc, Np * KP);
+        ALLOC(e->Uacc, (size_t)e->NC * Np * KP);
     }
     ALLOC(e->scal, 16);
     ALLOC(e->Wunc, K * V);
@@ -1185,15 +1183,17 @@ static int blocked_kl_step_once(salnmf_engine* e, int n_given) {
 // the update passes then run on the given ratio, once per chunk, each with the geometry of its chunk's size.
 //   W, hscale (MvNMF line-search trials): the signature matrix instead of e->W, and H read as clip(H * hscale[k]) -- both
 //   compact over all signatures
-static FwdParams chunk_fwd_params(salnmf_engine* e, const salnmf_engine::Chunk& c, int ci, const double* W = nullptr, const double* hscale = nullptr) {
+//   b: the feature block (engines with more than 96 features AND more than 64 signatures run the chain block by block)
+static FwdParams chunk_fwd_params(salnmf_engine* e, const salnmf_engine::Chunk& c, int ci, const double* W = nullptr, const double* hscale = nullptr,
+                                  int b = 0) {
     FwdParams p{};
-    p.X = e->X;
+    p.X = e->X + (size_t)b * e->Np * VMAX;
     p.H = e->H + (size_t)ci * e->Np * e->KP;
-    p.W = (W ? W : e->W) + (size_t)c.k0 * e->V;
+    p.W = (W ? W : e->W) + (size_t)c.k0 * e->V + (size_t)VMAX * b;
     p.hscale = hscale ? hscale + c.k0 : nullptr;
-    p.xlx = e->xlx;
+    p.xlx = e->xlx ? e->xlx + (size_t)b * e->Np * 16 : nullptr;
     p.N = e->N;
-    p.V = e->V;
+    p.V = block_width(e, b);
     p.ldw = e->V;
     p.K = c.K;
     p.ntiles = e->ntiles;
@@ -1201,10 +1201,10 @@ static FwdParams chunk_fwd_params(salnmf_engine* e, const salnmf_engine::Chunk& 
 }
 // the chain: chunks 0 .. NC-2 accumulate into e->PR (mode 2), the last chunk runs `last_mode` with `last` as its template
 // (out, weights) on top of the accumulated product
-static int chunk_chain(salnmf_engine* e, int last_mode, const FwdParams& last, const double* W = nullptr, const double* hscale = nullptr) {
+static int chunk_chain(salnmf_engine* e, int last_mode, const FwdParams& last, const double* W = nullptr, const double* hscale = nullptr, int b = 0) {
     for (int ci = 0; ci < e->NC; ++ci) {
         const auto& c = e->kc[(size_t)ci];
-        FwdParams p = chunk_fwd_params(e, c, ci, W, hscale);
+        FwdParams p = chunk_fwd_params(e, c, ci, W, hscale, b);
         p.pin = ci == 0 ? nullptr : e->PR;
         const bool is_last = ci == e->NC - 1;
         if (is_last) {
@@ -1269,6 +1269,70 @@ static int chunk_passes(salnmf_engine* e, bool do_g, bool do_u, int n_given, int
 static int chunked_kl_step_once(salnmf_engine* e, int n_given) {
     CK(chunk_ratio(e));
     return chunk_passes(e, n_given < e->K, true, n_given, SALNMF_CLIP_ALL);
+}
+
+// ---- n_features > 96 AND n_signatures > 64 (round 5): the two decompositions together.  Per feature block b the chain over
+// the chunks forms that block's ratio R_b = X_b / (H W_b) in e->PR; on it every chunk runs its numerator pass (G of the pair
+// (chunk, block) -> its rows of the block's compact numerator in Gblk) and its share U += R_b W_(chunk, b)^T of the update_H
+// product, accumulated over the blocks through the chunk's part of Uacc; the last block's pass updates the chunk's columns of
+// H.  The chains read the OLD H of all chunks: a joint step writes the new H to the second buffer (Hout), an update_H alone
+// may go in place (the last block's chain is done before its passes).  W afterwards as on feature blocks (blocked_finish_W).
+static inline bool grid_split(const salnmf_engine* e) { return e->NB > 1 && e->NC > 1; }
+static int grid_passes(salnmf_engine* e, bool do_g, bool do_u, int n_given, double* Hout, bool weighted = true) {
+    const size_t hc = (size_t)e->Np * e->KP;
+    bool any_g = false;
+    for (int b = 0; b < e->NB; ++b) {
+        FwdParams last{};
+        last.out = e->PR;
+        CK(chunk_chain(e, 4, last, nullptr, nullptr, b));
+        const int vb = block_width(e, b);
+        for (int ci = 0; ci < e->NC; ++ci) {
+            const auto& c = e->kc[(size_t)ci];
+            const int given = std::max(0, std::min(c.K, n_given - c.k0));
+            FusedParams p = fused_params(e);
+            p.X = e->PR;
+            p.V = vb;
+            p.ldw = e->V;
+            p.W = e->W + (size_t)c.k0 * e->V + (size_t)VMAX * b;
+            p.H = p.Hout = e->H + (size_t)ci * hc;
+            p.K = c.K;
+            p.hscale = nullptr;
+            if (!weighted) p.wkl = p.wlh = nullptr;
+            CK(weight_arrays(e, p));
+            if (do_g && given < c.K) {
+                FusedSel sel{c.KS, c.KTM, c.KR, true, false, false, true, false, false};
+                sel.RGIVEN = true;
+                if (launch_fused_inst(sel, p, e->grid, e->stream, nullptr, nullptr)) return fail("no kernel instantiation for KS=%d KTM=%d KR=%d", c.KS, c.KTM, c.KR);
+                HIPCK(hipGetLastError());
+                TailParams t = tail_params(e, e->grid, e->Gblk + (size_t)b * e->K * VMAX + (size_t)c.k0 * vb, 0, 0, 0, false);
+                t.V = vb;
+                t.K = c.K;
+                hipLaunchKernelGGL(tail_kernel, dim3(c.K), dim3(TAIL_BLOCK), 0, e->stream, t);
+                HIPCK(hipGetLastError());
+                any_g = true;
+            }
+            if (do_u) {
+                p.Hout = Hout + (size_t)ci * hc;
+                p.Uacc = e->Uacc + (size_t)ci * hc;
+                p.ublock = b == 0 ? 1 : (b == e->NB - 1 ? 3 : 2);
+                FusedSel sel{c.KS, c.KTM, c.KR, false, true, false, true, false, true};
+                sel.RGIVEN = true;
+                if (launch_fused_inst(sel, p, e->grid, e->stream, nullptr, nullptr)) return fail("no kernel instantiation for KS=%d KTM=%d KR=%d", c.KS, c.KTM, c.KR);
+                HIPCK(hipGetLastError());
+            }
+        }
+    }
+    if (any_g && sharded(e)) CK(allreduce(e, e->Gblk, (size_t)e->K * e->V));
+    if (do_u) e->h_pending = false;
+    return 0;
+}
+static int grid_kl_step_once(salnmf_engine* e, int n_given) {
+    if (n_given >= e->K) return grid_passes(e, false, true, n_given, e->H);  // W untouched (_utils_klnmf.py:330-331)
+    CK(ensure_halt(e));
+    CK(grid_passes(e, true, true, n_given, e->Halt));
+    CK(blocked_finish_W(e, n_given, SALNMF_CLIP_ALL));
+    std::swap(e->H, e->Halt);
+    return 0;
 }
 
 int salnmf_set_lockstep(salnmf_engine* e, int on) {
@@ -1371,6 +1435,11 @@ int salnmf_kl_step(salnmf_engine* e, int n_steps, int n_given) {
     if (!e) return fail("null engine");
     if (n_given < 0 || n_given > e->K) return fail("n_given out of range");
     CK(enter(e));
+    if (grid_split(e)) {
+        e->keep_valid = false;  // (the joint step uses the second H buffer itself)
+        for (int i = 0; i < n_steps; ++i) CK(grid_kl_step_once(e, n_given));
+        return 0;
+    }
     if (e->NB > 1) {
         e->keep_valid = false;  // (the joint step uses the second H buffer itself)
         for (int i = 0; i < n_steps; ++i) CK(blocked_kl_step_once(e, n_given));
@@ -1464,6 +1533,7 @@ int salnmf_kl_rollback(salnmf_engine* e) {
 int salnmf_update_H(salnmf_engine* e) {
     if (!e) return fail("null engine");
     CK(enter(e));
+    if (grid_split(e)) return grid_passes(e, false, true, 0, e->H);
     if (e->NB > 1) {
         CK(blocked_update_H(e, e->H));
         e->h_pending = false;
@@ -1501,6 +1571,10 @@ int salnmf_update_W(salnmf_engine* e, int n_given, int clip_mode) {
     if (!e) return fail("null engine");
     CK(enter(e));
     if (n_given >= e->K) return 0;  // _utils_klnmf.py:204-205
+    if (grid_split(e)) {
+        CK(grid_passes(e, true, false, n_given, nullptr));
+        return blocked_finish_W(e, n_given, clip_mode);
+    }
     if (e->NB > 1) {
         CK(blocked_numerators(e));
         return blocked_finish_W(e, n_given, clip_mode);
@@ -1550,6 +1624,28 @@ static int objective_partials(salnmf_engine* e, const double* W, const double* h
         p.wlh = nullptr;
     }
     const int fgrid = grid > 0 ? grid : e->fgrid;
+    if (e->NB > 1 && e->NC > 1) {
+        // a sum over the feature blocks of the chunk chain's divergence; the l-half penalty once (the last chunk's share by
+        // block 0's last launch, the other chunks' by the small kernel)
+        int n = 0;
+        for (int b = 0; b < e->NB; ++b) {
+            FwdParams last = p;
+            if (b > 0) last.wlh = nullptr;
+            last.out = e->objpart + n;
+            CK(chunk_chain(e, 0, last, W, hscale, b));
+            n += e->fgrid;
+        }
+        if (p.wlh) {
+            for (int ci = 0; ci + 1 < e->NC; ++ci) {
+                hipLaunchKernelGGL(lhalf_penalty_kernel, dim3(e->fgrid), dim3(256), 0, e->stream, e->H + (size_t)ci * e->Np * e->KP, p.wlh, e->N,
+                                   e->kc[(size_t)ci].K, e->KP, e->objpart + n);
+                HIPCK(hipGetLastError());
+                n += e->fgrid;
+            }
+        }
+        *nparts = n;
+        return 0;
+    }
     if (e->NC > 1) {
         // the chain over the signature chunks; the last launch evaluates the divergence (and its own chunk's share of the
         // l-half penalty, klnmf.py:75-79), the other chunks' shares come from a small kernel each
@@ -1722,10 +1818,19 @@ int salnmf_samplewise_kl(salnmf_engine* e, double* out) {
     CK(fwd_params(e, p));
     HIPCK(hipMalloc(&dev, (size_t)e->NB * e->Np * sizeof(double)));
     if (e->NC > 1) {
-        FwdParams last{};
-        last.out = dev;
-        int rcc = chunk_chain(e, 1, last);
+        int rcc = 0;
+        for (int b = 0; b < e->NB && !rcc; ++b) {  // (feature blocks as well: a sum over the blocks, as below)
+            FwdParams last{};
+            last.out = dev + (size_t)b * e->Np;
+            rcc = chunk_chain(e, 1, last, nullptr, nullptr, b);
+        }
         if (!rcc) rcc = download(e, out, dev, (size_t)e->N);
+        std::vector<double> part(e->NB > 1 ? (size_t)e->N : 0);
+        for (int b = 1; b < e->NB && !rcc; ++b) {
+            rcc = download(e, part.data(), dev + (size_t)b * e->Np, (size_t)e->N);
+            if (!rcc)
+                for (int64_t n = 0; n < e->N; ++n) out[n] += part[(size_t)n];
+        }
         (void)hipFree(dev);
         return rcc;
     }
@@ -1762,7 +1867,19 @@ int salnmf_reconstruct(salnmf_engine* e, double* out) {
     HIPCK(hipMalloc(&dev, (size_t)e->Np * VMAX * sizeof(double)));
     p.out = dev;
     int rc = 0;
-    if (e->NC > 1) {
+    if (e->NC > 1 && e->NB > 1) {
+        std::vector<double> part((size_t)e->N * VMAX);
+        for (int b = 0; b < e->NB && !rc; ++b) {  // the chunk chain of one feature block at a time
+            FwdParams last{};
+            last.out = dev;
+            const int vb = block_width(e, b);
+            rc = chunk_chain(e, 2, last, nullptr, nullptr, b);
+            if (!rc) rc = download_padded(e, part.data(), dev, vb, VMAX);
+            if (!rc)
+                for (int64_t n = 0; n < e->N; ++n)
+                    memcpy(out + (size_t)n * e->V + (size_t)VMAX * b, part.data() + (size_t)n * vb, (size_t)vb * sizeof(double));
+        }
+    } else if (e->NC > 1) {
         FwdParams last{};
         last.out = dev;
         rc = chunk_chain(e, 2, last);

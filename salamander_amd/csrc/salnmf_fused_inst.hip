@@ -58,7 +58,12 @@ static int launch_geometry(const FusedSel& s, const FusedParams& p, int grid, hi
     if (s.RGIVEN) {  // n_signatures > 64: one chunk's passes on the given ratio (weights honoured at run time)
         // (chunks use the geometries whose H layout is 64 columns wide: salnmf.hip, salnmf_create)
         if constexpr (KS >= 13) {
-            if (s.STATS || s.BLOCKED) return 1;
+            if (s.STATS) return 1;
+            if (s.BLOCKED) {  // > 96 features as well: the update_H pass of one (chunk, feature block) pair on that block's ratio
+                if (s.G || !s.U) return 1;
+                launch_one<KS, KTM, KR, false, true, false, true, false, true, true>(p, grid, st, e0, e1);
+                return 0;
+            }
             if (s.G && s.U) launch_one<KS, KTM, KR, true, true, false, true, false, false, true>(p, grid, st, e0, e1);
             else if (s.U) launch_one<KS, KTM, KR, false, true, false, true, false, false, true>(p, grid, st, e0, e1);
             else if (s.G) launch_one<KS, KTM, KR, true, false, false, true, false, false, true>(p, grid, st, e0, e1);

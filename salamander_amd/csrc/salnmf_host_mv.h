@@ -10,14 +10,12 @@ static int mv_logdet_to_slot(salnmf_engine* e, const double* W, double delta, in
     return 0;
 }
 
-// ---- MvNMF on more than 96 features (feature blocks, one signature chunk) or on more than 64 signatures (signature chunks,
-// one feature block; round 5): the step of mvnmf.py:197-210 in its plain form -- update_H over the blocks / chunks, the
+// ---- MvNMF on more than 96 features (feature blocks), on more than 64 signatures (signature chunks; round 5) or both: the step of mvnmf.py:197-210 in its plain form -- update_H over the blocks / chunks, the
 // numerator passes, the W-only algebra, root, and a host-driven line search whose objectives are the KLNMF path's forward
 // passes.  No speculation: such a problem spends its time in the passes over the samples
 // (csrc/salnmf_mv_wide_kernels.h has the kernels).
-static inline bool mv_wide(const salnmf_engine* e) { return (e->NB > 1) != (e->NC > 1); }
+static inline bool mv_wide(const salnmf_engine* e) { return split(e); }
 static int mv_wide_check(const salnmf_engine* e) {
-    if (e->NB > 1 && e->NC > 1) return fail("MvNMF is not available for n_features > %d together with n_signatures > %d", VMAX, KC);
     if (sharded(e)) return fail("MvNMF on more than %d features or more than %d signatures is not available on a sample-sharded engine", VMAX, KC);
     return 0;
 }
@@ -43,6 +41,10 @@ static int mv_wide_logdet(salnmf_engine* e, const double* W, double delta, int s
 }
 // update_H of an MvNMF step (MvNMF._update_H, mvnmf.py:162-165: in place, unweighted) on a split engine
 static int mv_wide_update_H(salnmf_engine* e) {
+    if (grid_split(e)) {
+        CK(flush_H_scale(e));
+        return grid_passes(e, false, true, 0, e->H, false);
+    }
     if (e->NC > 1) {
         CK(flush_H_scale(e));
         CK(chunk_ratio(e));
@@ -58,8 +60,12 @@ static int mv_wide_prepare(salnmf_engine* e, double delta) {
     CK(flush_H_scale(e));  // (the column sums below read H as it is)
     if (e->NC > 1) {
         CK(ensure_mv_scratch(e));
-        CK(chunk_ratio(e));
-        CK(chunk_passes(e, true, false, 0, 0, false, true));  // every row's numerator, W untouched
+        if (grid_split(e)) {
+            CK(grid_passes(e, true, false, 0, nullptr, false));  // every (chunk, block) pair's numerator -> Gblk
+        } else {
+            CK(chunk_ratio(e));
+            CK(chunk_passes(e, true, false, 0, 0, false, true));  // every row's numerator, W untouched
+        }
         for (int ci = 0; ci < e->NC; ++ci) {
             const auto& c = e->kc[(size_t)ci];
             hipLaunchKernelGGL(colsum_kernel, dim3(c.K), dim3(256), 0, e->stream, e->H + (size_t)ci * e->Np * e->KP, e->N, e->KP,
@@ -83,7 +89,7 @@ static int mv_wide_prepare(salnmf_engine* e, double delta) {
 }
 static int mv_wide_root(salnmf_engine* e, double lam, int n_given) {
     hipLaunchKernelGGL(mv_trial_row_wide_kernel<true>, dim3(e->K), dim3(256), 0, e->stream, e->W, e->Wunc, 1.0, 0, e->K, e->V, e->Wtrial, e->cs, e->mvA,
-                       e->mvB, e->NC > 1 ? e->red : e->Gblk, e->red + (size_t)e->K * e->V, lam, n_given);
+                       e->mvB, (e->NC > 1 && e->NB == 1) ? e->red : e->Gblk, e->red + (size_t)e->K * e->V, lam, n_given);
     HIPCK(hipGetLastError());
     return 0;
 }

@@ -708,7 +708,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
 #define FK_TICK(i) do { } while (0)
 #endif
     static_assert(!MVJ || (DO_G && DO_U && DO_STATS && !WTS && !PERSIST && !BLOCKED && !RGIVEN), "MVJ: the unweighted MvNMF pass pair");
-    static_assert(!RGIVEN || (WTS && !DO_STATS && !PERSIST && !BLOCKED), "given ratio: the weighted-capable plain passes only");
+    static_assert(!RGIVEN || (WTS && !DO_STATS && !PERSIST), "given ratio: the weighted-capable plain passes only (with BLOCKED: the update_H pass of one feature block)");
     static_assert(!PERSIST || (DO_G && DO_U && !DO_STATS && !WTS), "the persistent mode is the plain joint step");
     static_assert(!BLOCKED || (DO_U && !DO_G && !DO_STATS && WTS && !PERSIST), "feature blocks: the weighted-capable update_H pass only");
     using G_ = Geo<KS>;

@@ -185,16 +185,17 @@ __global__ void __launch_bounds__(MVM_BLOCK) mv_many_eliminate_kernel(double* __
 // eliminated augmented matrix; one workgroup per signature row, m in order
 __global__ void __launch_bounds__(128) mv_many_AB_kernel(const double* __restrict__ S, const double* __restrict__ W, int K, int V, double* __restrict__ A,
                                                          double* __restrict__ B) {
-    const int k = blockIdx.x, v = threadIdx.x;
-    if (v >= V) return;
-    double a = 0.0, b = 0.0;
-    for (int m = 0; m < K; ++m) {
-        const double y = S[(int64_t)m * 2 * K + K + k], w = W[(int64_t)m * V + v];
-        a = __builtin_fma(fmax(0.0, -y), w, a);
-        b = __builtin_fma(fabs(y), w, b);
+    const int k = blockIdx.x;
+    for (int v = threadIdx.x; v < V; v += blockDim.x) {  // (more than 96 features as well)
+        double a = 0.0, b = 0.0;
+        for (int m = 0; m < K; ++m) {
+            const double y = S[(int64_t)m * 2 * K + K + k], w = W[(int64_t)m * V + v];
+            a = __builtin_fma(fmax(0.0, -y), w, a);
+            b = __builtin_fma(fabs(y), w, b);
+        }
+        A[(int64_t)k * V + v] = a;
+        B[(int64_t)k * V + v] = b;
     }
-    A[(int64_t)k * V + v] = a;
-    B[(int64_t)k * V + v] = b;
 }
 
 }  // namespace salnmf

@@ -287,6 +287,7 @@ SPLIT_CASES = {
     "ragged_blocks": dict(V=250, K=12, N=1500, n_given=3),  # last block 58 wide, given signatures
     "chunks": dict(V=96, K=100, N=1700, n_given=0),      # two signature chunks (64 + 36)
     "chunks_given": dict(V=96, K=130, N=1300, n_given=70),  # the first chunk all given: its numerators are never formed
+    "blocks_and_chunks": dict(V=192, K=70, N=1500, n_given=2),  # two feature blocks x two signature chunks
 }
 SPLIT_STEPS = 6
 
@@ -356,7 +357,7 @@ def _split_worker(rank, world, port, out_dir, case):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,case", [(2, "blocks"), (3, "ragged_blocks"), (2, "chunks"), (3, "chunks_given")])
+@pytest.mark.parametrize("world,case", [(2, "blocks"), (3, "ragged_blocks"), (2, "chunks"), (3, "chunks_given"), (2, "blocks_and_chunks")])
 def test_sharded_steps_of_engines_with_feature_blocks_or_signature_chunks(tmp_path, world, case):
     from oracle import klnmf_oracle as orc
 
