@@ -80,8 +80,8 @@ int salnmf_device_count(void);
  * Sample shards (salnmf_comm_init / salnmf_p2p_connect) of either kind run the KLNMF entry points, the
  * device-side initialisation and -- on feature blocks -- CorrNMF: the numerators of all blocks / chunks cross the ranks in
  * ONE all-reduce of K * V doubles per W update (through RCCL beyond the peer inbox's 16 384 doubles); MvNMF there answers
- * with an error.  So does the fp32 fast mode in both cases, and CorrNMF and the device-side initialisation on more than 64
- * signatures. */
+ * with an error.  So does the fp32 fast mode in both cases, and CorrNMF on more than 64 signatures.  The device-side
+ * initialisation runs everywhere (more than 64 signatures: projection and post-processing chunk by chunk). */
 int salnmf_create(int device, int n_features, int64_t n_samples, int n_signatures,
                   salnmf_engine** out);
 void salnmf_destroy(salnmf_engine* e);

@@ -21,7 +21,6 @@ static int gram_diagonal_block(salnmf_engine* e, const double* Xb, std::vector<d
 }
 
 int salnmf_init_gram(salnmf_engine* e, double* gram_out, double* xsum_out) {
-    if (e && e->NC > 1) return single_block(e, "the device-side initialisation");
     if (!e || !gram_out) return fail("null argument");
     CK(enter(e));
     const int V = e->V;
@@ -83,35 +82,42 @@ int salnmf_init_gram(salnmf_engine* e, double* gram_out, double* xsum_out) {
 }
 
 int salnmf_init_project(salnmf_engine* e, const double* B, double* posneg_out) {
-    if (e && e->NC > 1) return single_block(e, "the device-side initialisation");
     if (!e || !B || !posneg_out) return fail("null argument");
     CK(enter(e));
-    const int K = e->K, V = e->V, KP = e->KP;
+    // (more than 64 signatures: chunk by chunk -- the chunk's rows of B into the chunk's columns of H, its norms behind the
+    // earlier chunks')
+    const int K = e->K, V = e->V, KP = e->KP, NC = e->NC;
     const int pgrid = (int)std::min<int64_t>(1024, e->ntiles);
-    CK(ensure_scratch(e, (size_t)K * V + (size_t)pgrid * 2 * KP + 2 * KP));
+    CK(ensure_scratch(e, (size_t)K * V + (size_t)pgrid * 2 * KP + (size_t)NC * 2 * KP));
     double* dB = e->scratch;
     double* part = dB + (size_t)K * V;
     double* red = part + (size_t)pgrid * 2 * KP;
     CK(upload(e, dB, B, (size_t)K * V));
     e->h_pending = false;  // H is overwritten in full
     const size_t lds = ((size_t)KP * PROJ_LD + 16 * PROJ_LD + 256) * sizeof(double);
-    for (int b = 0; b < e->NB; ++b)  // (feature blocks: the projection is a sum over them, accumulated in H)
-        hipLaunchKernelGGL(init_project_kernel, dim3(pgrid), dim3(256), lds, e->stream, e->X + (size_t)b * e->Np * VMAX, dB + (size_t)VMAX * b, e->H, e->N,
-                           e->ntiles, block_width(e, b), V, K, KP, part, b == 0 ? 1 : 0, b == e->NB - 1 ? 1 : 0);
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(2 * KP), dim3(256), 0, e->stream, part, pgrid, 2 * KP, 2 * KP, red);
-    HIPCK(hipGetLastError());
-    CK(allreduce(e, red, (size_t)2 * KP));
-    std::vector<double> host((size_t)2 * KP);
+    for (int ci = 0; ci < NC; ++ci) {
+        const auto& c = e->kc[(size_t)ci];
+        for (int b = 0; b < e->NB; ++b)  // (feature blocks: the projection is a sum over them, accumulated in H)
+            hipLaunchKernelGGL(init_project_kernel, dim3(pgrid), dim3(256), lds, e->stream, e->X + (size_t)b * e->Np * VMAX,
+                               dB + (size_t)c.k0 * V + (size_t)VMAX * b, e->H + (size_t)ci * e->Np * KP, e->N, e->ntiles, block_width(e, b), V, c.K, KP, part,
+                               b == 0 ? 1 : 0, b == e->NB - 1 ? 1 : 0);
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(2 * KP), dim3(256), 0, e->stream, part, pgrid, 2 * KP, 2 * KP, red + (size_t)ci * 2 * KP);
+        HIPCK(hipGetLastError());
+    }
+    CK(allreduce(e, red, (size_t)NC * 2 * KP));
+    std::vector<double> host((size_t)NC * 2 * KP);
     CK(download(e, host.data(), red, host.size()));
-    for (int j = 0; j < K; ++j) {
-        posneg_out[j] = host[j];
-        posneg_out[K + j] = host[KP + j];
+    for (int ci = 0; ci < NC; ++ci) {
+        const auto& c = e->kc[(size_t)ci];
+        for (int j = 0; j < c.K; ++j) {
+            posneg_out[c.k0 + j] = host[(size_t)ci * 2 * KP + j];
+            posneg_out[K + c.k0 + j] = host[(size_t)ci * 2 * KP + KP + j];
+        }
     }
     return 0;
 }
 
 int salnmf_init_finish(salnmf_engine* e, const double* scale, const int* take_neg, const double* post, double zero_below, double fill) {
-    if (e && e->NC > 1) return single_block(e, "the device-side initialisation");
     if (!e || !scale || !take_neg || !post) return fail("null argument");
     CK(enter(e));
     const int K = e->K;
@@ -123,38 +129,44 @@ int salnmf_init_finish(salnmf_engine* e, const double* scale, const int* take_ne
     CK(upload(e, dpost, post, (size_t)K));
     HIPCK(hipMemcpyAsync(dneg, take_neg, (size_t)K * sizeof(int), hipMemcpyHostToDevice, e->stream));
     HIPCK(hipStreamSynchronize(e->stream));
-    InitFinishParams p;
-    p.H = e->H;
-    p.scale = dscale;
-    p.take_neg = dneg;
-    p.post = dpost;
-    p.zero_below = zero_below;
-    p.fill = fill;
-    p.N = e->N;
-    p.Np = e->Np;
-    p.K = K;
-    p.KP = e->KP;
-    hipLaunchKernelGGL(init_finish_kernel, dim3(2048), dim3(256), 0, e->stream, p);
-    HIPCK(hipGetLastError());
+    for (int ci = 0; ci < e->NC; ++ci) {  // (signature chunks: the chunk's entries of the operands, its columns of H)
+        const auto& c = e->kc[(size_t)ci];
+        InitFinishParams p;
+        p.H = e->H + (size_t)ci * e->Np * e->KP;
+        p.scale = dscale + c.k0;
+        p.take_neg = dneg + c.k0;
+        p.post = dpost + c.k0;
+        p.zero_below = zero_below;
+        p.fill = fill;
+        p.N = e->N;
+        p.Np = e->Np;
+        p.K = c.K;
+        p.KP = e->KP;
+        p.first_component = c.k0 == 0 ? 1 : 0;
+        hipLaunchKernelGGL(init_finish_kernel, dim3(2048), dim3(256), 0, e->stream, p);
+        HIPCK(hipGetLastError());
+    }
     HIPCK(hipStreamSynchronize(e->stream));  // the scratch operands may be reused by the next call
     return 0;
 }
 
 int salnmf_init_flat(salnmf_engine* e, const double* post) {
-    if (e && e->NC > 1) return single_block(e, "the device-side initialisation");
     if (!e || !post) return fail("null argument");
     CK(enter(e));
     e->h_pending = false;
     CK(ensure_scratch(e, (size_t)e->K));
     CK(upload(e, e->scratch, post, (size_t)e->K));
-    hipLaunchKernelGGL(init_flat_kernel, dim3(1024), dim3(256), 0, e->stream, e->X, e->H, e->N, e->Np, e->K, e->KP, e->scratch, e->NB);
-    HIPCK(hipGetLastError());
+    for (int ci = 0; ci < e->NC; ++ci) {
+        const auto& c = e->kc[(size_t)ci];
+        hipLaunchKernelGGL(init_flat_kernel, dim3(1024), dim3(256), 0, e->stream, e->X, e->H + (size_t)ci * e->Np * e->KP, e->N, e->Np, c.K, e->KP,
+                           e->scratch + c.k0, e->NB, e->K);
+        HIPCK(hipGetLastError());
+    }
     HIPCK(hipStreamSynchronize(e->stream));  // the scratch operand may be reused by the next call
     return 0;
 }
 
 int salnmf_init_separable(salnmf_engine* e, int n_select, int64_t* chosen_out, double* norms_out) {
-    if (e && e->NC > 1) return single_block(e, "the device-side initialisation");
     if (!e || !chosen_out) return fail("null argument");
     if (n_select < 1 || (int64_t)n_select > e->N) return fail("n_select must be in [1, n_samples]");
     if (sharded(e)) return fail("the separableNMF selection needs all samples on one engine: not available on a sharded engine");

@@ -170,6 +170,7 @@ struct InitFinishParams {
     double fill;                         // "nndsvda": value of the zeros (X.mean()); 0 = leave them
     int64_t N, Np;
     int K, KP;
+    int first_component;                 // column 0 of this H is the first component of the SVD (signature chunks: chunk 0 only)
 };
 __global__ void init_finish_kernel(InitFinishParams p) {
     const int64_t total = p.Np * p.KP;
@@ -179,7 +180,7 @@ __global__ void init_finish_kernel(InitFinishParams p) {
         if (n >= p.N || j >= p.K) continue;  // pads keep the filler init_project_kernel wrote
         const double x = p.H[i];
         double v;
-        if (j == 0) v = fabs(x) * p.scale[0];
+        if (j == 0 && p.first_component) v = fabs(x) * p.scale[0];
         else v = p.scale[j] * (p.take_neg[j] ? (x < 0.0 ? -x : 0.0) : (x > 0.0 ? x : 0.0));
         if (v < p.zero_below) v = 0.0;
         if (p.fill != 0.0 && v == 0.0) v = p.fill;
@@ -189,8 +190,9 @@ __global__ void init_finish_kernel(InitFinishParams p) {
 
 // init_flat (methods.py:58-66) + post-processing: exposure (n, j) = clip(rowsum(X_n) / K * post[j])
 //   nb feature blocks of X at stride Np * VMAX (pads are zero): the row sum runs over all of them, block after block
+//   K: columns of this H (one chunk of the signatures), Ktot: n_signatures
 __global__ void init_flat_kernel(const double* __restrict__ X, double* __restrict__ H, int64_t N, int64_t Np, int K, int KP,
-                                 const double* __restrict__ post, int nb) {
+                                 const double* __restrict__ post, int nb, int Ktot) {
     const int lane = threadIdx.x & 15;
     const int64_t row0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const int64_t rstride = ((int64_t)gridDim.x * blockDim.x) >> 4;
@@ -200,7 +202,7 @@ __global__ void init_flat_kernel(const double* __restrict__ X, double* __restric
             for (int v = lane; v < VMAX; v += 16) s += X[((int64_t)b * Np + n) * VMAX + v];
 #pragma unroll
         for (int m = 1; m < 16; m <<= 1) s += __shfl_xor(s, m, 64);
-        const double e = s / K;
+        const double e = s / Ktot;
         for (int j = lane; j < KP; j += 16) H[n * KP + j] = (j < K) ? (n < N ? clip_lo(e * post[j], kEps) : 1.0) : 0.0;
     }
 }

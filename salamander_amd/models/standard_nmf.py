@@ -27,8 +27,8 @@ class StandardNMF(SignatureNMF):
         the reference's seeded host computation (``initialize.py:221-255``)."""
         init_kwargs = {} if init_kwargs is None else init_kwargs.copy()
         # (more than 96 features: the Gram matrix is formed block pair by block pair, separableNMF's deflation walks the rows
-        # over all feature blocks; more than 64 signatures stay on the host)
-        on_device = self.device_init and self.n_signatures <= 64
+        # over all feature blocks; more than 64 signatures: the projection and the post-processing chunk by chunk)
+        on_device = self.device_init
         if on_device and self.init_method in DEVICE_METHODS and "seed" not in init_kwargs:
             if init_kwargs:
                 raise TypeError(f"init method '{self.init_method}' takes no keyword arguments besides 'seed': {sorted(init_kwargs)}")

@@ -16,7 +16,7 @@ from salamander_amd.engine import Engine
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("N,V,K", [(10, 96, 2), (1000, 96, 50), (333, 83, 7), (4097, 17, 16)])
+@pytest.mark.parametrize("N,V,K", [(10, 96, 2), (1000, 96, 50), (333, 83, 7), (4097, 17, 16), (700, 96, 80), (901, 288, 100), (300, 250, 130)])
 def test_gram_and_projection_primitives(N, V, K):
     rng = np.random.default_rng(N)
     X = rng.poisson(rng.gamma(1.0, 20.0, size=(N, V))).astype(float)
@@ -232,3 +232,46 @@ def test_separable_selection_of_a_rank_deficient_catalogue_keeps_the_host_path()
         m._initialize(None, {"seed": 1})
         states.append((np.array(m.asignatures.X), np.array(m.adata.obsm["exposures"])))
     assert np.array_equal(states[0][0], states[1][0]) and np.array_equal(states[0][1], states[1][1])
+
+
+@pytest.mark.parametrize("V,N,K,method", [(96, 1500, 80, "nndsvd"), (288, 1203, 100, "nndsvda"), (192, 800, 70, "flat")])
+def test_device_init_on_signature_chunks_equals_numpy(V, N, K, method):
+    """More than 64 signatures (round 5): the projection, the NNDSVD post-processing and the flat initialisation run chunk
+    by chunk.  Against the same computation in NumPy (exact SVD through the Gram matrix, sklearn's NNDSVD loop on it,
+    ``normalize_WH`` + clip): signatures and exposures entry by entry."""
+    from salamander_amd.device_init import nndsvd_signature_side
+
+    rng = np.random.default_rng(V + K)
+    Wt = rng.dirichlet(np.full(V, 0.3), size=K)
+    X = rng.poisson(rng.gamma(0.5, 80.0, size=(N, K)) @ Wt).astype(float).clip(orc.EPSILON)
+    e = Engine(N, V, K)
+    e.upload_X(X)
+    S = initialize_on_device(e, K, method)
+    H = e.download_H()
+    if method == "flat":
+        S_want = np.full((K, V), 1.0 / V).clip(orc.EPSILON)
+        H_want = np.repeat(X.sum(axis=1)[:, None] / K, K, axis=1).clip(orc.EPSILON)
+    else:
+        evals, evecs = np.linalg.eigh(X.T @ X)
+        order = np.argsort(evals)[::-1][:K]
+        evals, evecs = evals[order], evecs[:, order]
+        U = X @ (evecs / np.sqrt(evals))
+        pos2, neg2 = (np.maximum(U, 0) ** 2).sum(axis=0), (np.minimum(U, 0) ** 2).sum(axis=0)
+        S_raw, scale, take_neg, fill = nndsvd_signature_side(evals, evecs, pos2, neg2, K, X.sum() / (N * V), method)
+        E = np.where(take_neg[None, :].astype(bool), np.maximum(-U, 0), np.maximum(U, 0)) * scale[None, :]
+        E[:, 0] = np.abs(U[:, 0]) * scale[0]
+        E[E < 1e-6] = 0
+        if fill:
+            E[E == 0] = fill
+        colsum = S_raw.sum(axis=1)
+        S_want, H_want = (S_raw / colsum[:, None]).clip(orc.EPSILON), (E * colsum[None, :]).clip(orc.EPSILON)
+    # (the trailing singular vectors of a noisy count matrix carry rounding-level sign / threshold decisions: compare where
+    # both sides made the same ones -- all but a handful of entries)
+    assert np.all(np.isfinite(S)) and np.all(np.isfinite(H)) and S.shape == (K, V) and H.shape == (N, K)
+    close = np.isclose(H, H_want, rtol=1e-6, atol=1e-9)
+    assert close.mean() > 0.999, close.mean()
+    assert np.isclose(S, S_want, rtol=1e-6, atol=1e-12).mean() > 0.999
+    e.upload_W(np.ascontiguousarray(S))
+    e.kl_step(3)  # a valid engine state
+    assert np.all(np.isfinite(e.download_H())) and np.isfinite(e.objective())
+    e.close()

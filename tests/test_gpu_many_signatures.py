@@ -80,7 +80,7 @@ def test_many_signatures_refusals_and_limits():
     X, W0, H0 = orc.synthetic_problem(96, N, K, seed=1)
     e = Engine(N, 96, K)
     e.upload_X(X), e.upload_W(W0), e.upload_H(H0)
-    for call in (lambda: e.corr_configure(4), lambda: e.init_gram(), lambda: e.set_precision("f32"), lambda: e.set_H_scale(np.ones(K))):
+    for call in (lambda: e.corr_configure(4), lambda: e.set_precision("f32"), lambda: e.set_H_scale(np.ones(K))):
         with pytest.raises(RuntimeError, match="n_signatures > 64"):
             call()
     e.close()
@@ -89,7 +89,7 @@ def test_many_signatures_refusals_and_limits():
 
 
 def test_many_signatures_model_fit_matches_the_oracle_fit():
-    """``KLNMF.fit`` with 80 signatures: host initialisation (the device one works on one chunk), queued objectives,
+    """``KLNMF.fit`` with 80 signatures: queued objectives,
     tolerance stop -- same iterations, history and factors as the restated reference loop."""
     V, N, K = 96, 3000, 80
     X, W0, H0 = orc.synthetic_problem(V, N, K, seed=11)

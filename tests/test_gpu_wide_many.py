@@ -134,7 +134,7 @@ def test_wide_many_mvnmf_backtracking():
 
 def test_wide_many_refusals():
     e = Engine(300, 192, 80)
-    for call in (lambda: e.corr_configure(4), lambda: e.init_gram(), lambda: e.set_precision("f32")):
+    for call in (lambda: e.corr_configure(4), lambda: e.set_precision("f32")):
         with pytest.raises(RuntimeError, match="n_signatures > 64|n_features > 96"):
             call()
     e.close()
