@@ -78,9 +78,9 @@ int salnmf_device_count(void);
  * n_signatures).  Both together (round 5): per feature block the chain over the chunks forms that block's ratio, every chunk
  * runs its numerator pass and its share of U = R W^T on it (accumulated over the blocks); the KLNMF entry points and MvNMF.
  * Sample shards (salnmf_comm_init / salnmf_p2p_connect) of either kind run the KLNMF entry points, the
- * device-side initialisation and -- on feature blocks -- CorrNMF: the numerators of all blocks / chunks cross the ranks in
- * ONE all-reduce of K * V doubles per W update (through RCCL beyond the peer inbox's 16 384 doubles); MvNMF there answers
- * with an error.  So does the fp32 fast mode in both cases, and CorrNMF on more than 64 signatures.  The device-side
+ * device-side initialisation, MvNMF and -- on feature blocks -- CorrNMF: the numerators of all blocks / chunks cross the
+ * ranks in ONE all-reduce of K * V doubles per W update (through RCCL beyond the peer inbox's 16 384 doubles).  The fp32
+ * fast mode answers with an error in both cases, and so does CorrNMF on more than 64 signatures.  The device-side
  * initialisation runs everywhere (more than 64 signatures: projection and post-processing chunk by chunk). */
 int salnmf_create(int device, int n_features, int64_t n_samples, int n_signatures,
                   salnmf_engine** out);

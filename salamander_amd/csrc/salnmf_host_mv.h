@@ -15,10 +15,7 @@ static int mv_logdet_to_slot(salnmf_engine* e, const double* W, double delta, in
 // passes.  No speculation: such a problem spends its time in the passes over the samples
 // (csrc/salnmf_mv_wide_kernels.h has the kernels).
 static inline bool mv_wide(const salnmf_engine* e) { return split(e); }
-static int mv_wide_check(const salnmf_engine* e) {
-    if (sharded(e)) return fail("MvNMF on more than %d features or more than %d signatures is not available on a sample-sharded engine", VMAX, KC);
-    return 0;
-}
+static int mv_wide_check(const salnmf_engine*) { return 0; }  // (round 5: every split engine runs MvNMF, sample shards included)
 // (signature chunks) the K x 2K scratch of the global-memory elimination
 static int ensure_mv_scratch(salnmf_engine* e) {
     if (e->mvS) return 0;
@@ -72,6 +69,7 @@ static int mv_wide_prepare(salnmf_engine* e, double delta) {
                                e->red + (size_t)e->K * e->V + c.k0);
             HIPCK(hipGetLastError());
         }
+        if (sharded(e)) CK(allreduce(e, e->red + (size_t)e->K * e->V, (size_t)e->K));  // rowsums_H over all shards
         hipLaunchKernelGGL(mv_many_gram_kernel<true>, dim3(e->K), dim3(256), 0, e->stream, e->W, e->K, e->V, delta, e->mvS);
         HIPCK(hipGetLastError());
         hipLaunchKernelGGL(mv_many_eliminate_kernel<true>, dim3(1), dim3(MVM_BLOCK), 0, e->stream, e->mvS, e->K, e->scal + 3);
@@ -83,6 +81,7 @@ static int mv_wide_prepare(salnmf_engine* e, double delta) {
     CK(blocked_numerators(e, false));  // update_W_unconstrained takes no weights (mvnmf.py:37-66): as the narrow path
     hipLaunchKernelGGL(colsum_kernel, dim3(e->K), dim3(256), 0, e->stream, e->H, e->N, e->KP, e->red + (size_t)e->K * e->V);
     HIPCK(hipGetLastError());
+    if (sharded(e)) CK(allreduce(e, e->red + (size_t)e->K * e->V, (size_t)e->K));  // rowsums_H over all shards
     hipLaunchKernelGGL(mv_prepare_W_wide_kernel, dim3(1), dim3(MV_BLOCK), 0, e->stream, e->W, e->K, e->V, delta, e->mvA, e->mvB, e->scal + 3);
     HIPCK(hipGetLastError());
     return 0;

@@ -290,6 +290,7 @@ SPLIT_CASES = {
     "blocks_and_chunks": dict(V=192, K=70, N=1500, n_given=2),  # two feature blocks x two signature chunks
 }
 SPLIT_STEPS = 6
+SPLIT_LAM, SPLIT_DELTA = 0.7, 0.9
 
 
 def _split_problem(case):
@@ -350,6 +351,12 @@ def _split_worker(rank, world, port, out_dir, case):
             e.corr_update_sample_scalings(), e.corr_compute_exposures(), e.corr_compute_aux()
             e.corr_update_signatures(c["n_given"]), e.corr_update_signature_scalings()
             extra = dict(Wc=e.download_W(), betac=e.corr_download(_lib_const("CORR_SIGNATURE_SCALINGS")), llh=e.corr_poisson_llh())
+        # MvNMF steps on the shards (the plain form of the split engines: numerators and rowsums_H all-reduced, the line
+        # search's objectives all-reduced scalars -- every rank takes the same decisions)
+        e.set_weights(None, None)
+        e.upload_W(W0), e.upload_H(H0[a:b])
+        gamma, mv_obj = e.mv_step_objective(3, c["n_given"], SPLIT_LAM, SPLIT_DELTA, 1.0)
+        extra.update(Wm=e.download_W(), Hm=e.download_H(), gamma=gamma, mv_obj=mv_obj)
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), Wk=Wk, Hk=Hk, obj=obj, Ww=Ww, Hw=Hw, objw=objw, **extra)
         dist.barrier()  # nobody frees its inbox while a peer may still be inside an exchange
         e.close()
@@ -400,3 +407,12 @@ def test_sharded_steps_of_engines_with_feature_blocks_or_signature_chunks(tmp_pa
         assert rel_l2(parts[0]["betac"], e1.corr_download(_lib_const("CORR_SIGNATURE_SCALINGS"))) < 1e-12
         assert np.isclose(float(parts[0]["llh"]), e1.corr_poisson_llh(), rtol=1e-12)
         e1.close()
+    W, H, g = W0.T, H0.T, 1.0
+    for _ in range(3):
+        W, H, g = orc.mvnmf_step(X.T, W, H, SPLIT_LAM, SPLIT_DELTA, g, ng)
+    for p in parts[1:]:
+        assert np.array_equal(parts[0]["Wm"], p["Wm"]) and p["gamma"] == parts[0]["gamma"] and p["mv_obj"] == parts[0]["mv_obj"]
+    assert np.isclose(float(parts[0]["gamma"]), g, rtol=1e-12)
+    assert rel_l2(parts[0]["Wm"], W.T) < 1e-7
+    assert rel_l2(np.concatenate([p["Hm"] for p in parts], axis=0), H.T) < 1e-7
+    assert np.isclose(float(parts[0]["mv_obj"]), orc.kl_divergence_penalized(X.T, W, H, SPLIT_LAM, SPLIT_DELTA), rtol=1e-9)
