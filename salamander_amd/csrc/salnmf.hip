@@ -631,7 +631,7 @@ void salnmf_destroy(salnmf_engine* e) {
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
 #ifdef SALNMF_DEV_PROFILE
-    if (e->fk_prof) {  // section clocks of every fused pass this engine launched (salnmf_kernels.h: FK_TICK)
+    if (e->fk_prof) {  // section clocks of every fused pass this engine launched (salnmf_fused_kernel.h: FK_TICK)
         std::vector<unsigned long long> rows(FK_PROF_ROWS * (FK_NSEC + 1));
         unsigned long long t[FK_NSEC + 1] = {};
         size_t nw = 0;

@@ -1,4 +1,4 @@
-// Instantiations of the forward / objective pass (salnmf_kernels.h: forward_kernel) and of the fp32 fast mode's
+// Instantiations of the forward / objective pass (salnmf_forward_kernel.h: forward_kernel) and of the fp32 fast mode's
 // fused pass (salnmf_kernels_f32.h), plus the dispatcher over the geometry sets of salnmf_fused_inst.hip.
 #define SALNMF_TEMPLATES_ONLY 1
 #include "salnmf_launch.h"

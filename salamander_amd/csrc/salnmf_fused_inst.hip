@@ -1,4 +1,4 @@
-// Instantiations of the fused update pass (salnmf_kernels.h: fused_kernel) for one set of geometries.
+// Instantiations of the fused update pass (salnmf_fused_kernel.h: fused_kernel) for one set of geometries.
 // Compiled FUSED_GEOM_SETS times with -DSALNMF_GEOM_SET=0..5 (__graft_entry__.py: build) so that the sets build in
 // parallel; each (geometry, variant) pair is instantiated in exactly one translation unit.
 #define SALNMF_TEMPLATES_ONLY 1

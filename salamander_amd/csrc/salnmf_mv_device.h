@@ -2,7 +2,7 @@
 // Reference arithmetic: src/salamander/models/mvnmf.py:19-24 (volume_logdet), :37-66 (update_W_unconstrained).
 // S = W W^T + delta I is symmetric positive definite (delta > 0), so the reference's LU-based inv/det are replaced by a
 // Gauss-Jordan elimination without pivoting (same values to rounding).  Kernels: salnmf_mv_kernels.h; the spare workgroup of the MvNMF
-// update_H pass (salnmf_kernels.h: fused_kernel) runs mv_prepare_W_body too.
+// update_H pass (salnmf_fused_kernel.h: fused_kernel) runs mv_prepare_W_body too.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -161,7 +161,7 @@ __device__ inline void mv_load_W(const double* __restrict__ W, double* Wl, int K
 // (mvnmf.py:48-54, in the K x V layout), and log det(W W^T + delta I) (mvnmf.py:19-24).
 // One workgroup of NT threads; LDS scratch: Wl [K][MV_WS], S [K][MV_LD], T [K][MV_LD], piv [K + 1].  The body is shared by
 // the stand-alone kernel (1024 threads, side stream) and by the spare workgroup of the MvNMF update_H pass
-// (salnmf_kernels.h: fused_kernel, 256 threads); its results do not depend on NT, so both produce the same bits.
+// (salnmf_fused_kernel.h: fused_kernel, 256 threads); its results do not depend on NT, so both produce the same bits.
 template <int NT>
 __device__ __forceinline__ void mv_prepare_W_body(const double* __restrict__ W, int K, int V, double delta, double* __restrict__ Aout,
                                                   double* __restrict__ Bout, double* __restrict__ logdet_out, double* Wl, double* S, double* T,
