@@ -9,6 +9,7 @@ penalties, given signatures (inside and across chunks) and zeros in X."""
 import numpy as np
 import pytest
 
+import salamander_amd as sal
 from conftest import rel_l2
 from oracle import klnmf_oracle as orc
 from salamander_amd import Engine, _lib
@@ -130,6 +131,31 @@ def test_wide_many_mvnmf_backtracking():
     assert np.allclose(got, gs, rtol=1e-12), (got, gs)
     assert rel_l2(e.download_W(), W.T) < 1e-7 and rel_l2(e.download_H(), H.T) < 1e-7
     e.close()
+
+
+def test_wide_many_model_fits_match_the_oracle_fits():
+    """``KLNMF.fit`` and ``MvNMF.fit`` on an SBS-192-sized catalogue with 70 signatures: queued objectives, tolerance stop -- same
+    iterations, history and factors as the restated reference loops; the default initialisation (NNDSVD) runs on the device,
+    chunk by chunk over the feature blocks, and starts a normal fit."""
+    V, N, K = 192, 1500, 70
+    X, W0, H0 = orc.synthetic_problem(V, N, K, seed=13)
+    kw = dict(min_iterations=30, max_iterations=600, conv_test_freq=10, tol=1e-5)
+    m = sal.models.KLNMF(K, "custom", **kw)
+    m.fit(sal.AnnData(X.copy()), init_kwargs={"signatures_mat": W0.copy(), "exposures_mat": H0.copy()})
+    W, H, it, hist = orc.fit_klnmf(X.T, W0.T, H0.T, **kw)
+    assert m.n_iterations_ == it and np.allclose(m.history["objective_function"], hist, rtol=1e-11)
+    assert rel_l2(m.asignatures.X, W.T) < 1e-8 and rel_l2(m.adata.obsm["exposures"], H.T) < 1e-8
+    kw = dict(min_iterations=20, max_iterations=40, conv_test_freq=10, tol=1e-6)
+    mv = sal.models.MvNMF(K, "custom", lam=0.5, delta=1.0, **kw)
+    mv.fit(sal.AnnData(X.copy()), init_kwargs={"signatures_mat": W0.copy(), "exposures_mat": H0.copy()})
+    Wf, Hf, _, it, hist = orc.fit_mvnmf(X.T, W0.T, H0.T, lam=0.5, delta=1.0, **kw)
+    assert mv.n_iterations_ == it and np.allclose(mv.history["objective_function"], hist, rtol=1e-7)
+    assert rel_l2(mv.asignatures.X, Wf.T) < 1e-6 and rel_l2(mv.adata.obsm["exposures"], Hf.T) < 1e-6
+    d = sal.models.KLNMF(K, min_iterations=20, max_iterations=20)
+    d.fit(sal.AnnData(X.copy()))
+    h = d.history["objective_function"]
+    assert np.all(np.isfinite(d.asignatures.X)) and len(h) >= 2 and h[-1] < h[0]
+    assert np.allclose(np.asarray(d.asignatures.X).sum(axis=1), 1.0, atol=1e-6)
 
 
 def test_wide_many_refusals():
