@@ -399,8 +399,9 @@ int salnmf_profile_kl_steps(salnmf_engine* e, int n_steps, int n_given, int samp
 /* Where a SHARDED joint step's microseconds go, on this rank: n_steps steps with HIP events bound to the two dispatches of
  * every step and s_memrealtime stamps inside the tail's exchange (csrc/salnmf_p2p_kernels.h: tail_p2p_kernel).  out9, in
  * microseconds: [0] step (stream time / n_steps) [1] fused pass [2] tail + exchange launch; per row workgroup of the tail,
- * averaged over rows and steps: [3] local slab reduction [4] stores to the peers + flags [5] wait for the peers' flags
- * [6] read + sum of the peers' rows [7] W row finish; [8] the longest flag wait of any row and step.  Needs the
+ * averaged over rows and steps: [3] local slab reduction [4] stores to the peers [5] wait for the peers' rows (the payload
+ * carries its arrival tag: salnmf_p2p_kernels.h) [6] sum of the rows [7] W row finish; [8] the longest such wait of any row
+ * and step.  Needs the
  * peer-to-peer exchange (a one-rank world included); every rank of the world must call it with the same n_steps. */
 int salnmf_profile_sharded_steps(salnmf_engine* e, int n_steps, int n_given, double* out9);
 int salnmf_profile_objective(salnmf_engine* e, int n_calls, double* avg_ms);

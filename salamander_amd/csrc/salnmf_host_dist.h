@@ -100,7 +100,7 @@ int salnmf_p2p_export(salnmf_engine* e, int n_ranks, int64_t max_count, char* ha
     static_assert(sizeof(hipIpcMemHandle_t) == SALNMF_P2P_HANDLE_BYTES, "handle size");
     CK(enter(e));
     e->p2p.max_count = (size_t)max_count;
-    e->p2p.slot = (size_t)max_count + P2P_MAX_WG;
+    e->p2p.slot = 2 * (size_t)max_count;  // (salnmf_p2p_kernels.h: two tagged words per double)
     e->p2p.n_ranks = n_ranks;
     const size_t bytes = 2 * (size_t)n_ranks * e->p2p.slot * sizeof(double);
     HIPCK(hipExtMallocWithFlags((void**)&e->p2p.local, bytes, hipDeviceMallocUncached));

@@ -4,21 +4,21 @@
 //
 // Why not the RCCL call: the vector is 38 KB at K = 50.  A library all-reduce of that size is pure latency (several
 // kernel-internal ring / tree hops, ~25-40 us on 8 GPUs), which is a third of a c3 step.  Here every rank stores its
-// vector straight into an inbox on each peer (7 links in parallel, < 1 us of wire time), raises one flag per workgroup and
-// peer, waits for the peers' flags in its own inbox and adds the n vectors in rank order (its own term from the register
+// vector straight into an inbox on each peer (7 links in parallel, < 1 us of wire time), waits for the peers' words
+// in its own inbox and adds the n vectors in rank order (its own term from the register
 // it still holds) -- the same order on every rank, so all ranks end up with bit-identical sums and hence bit-identical W.
 //
 // Memory: the inboxes are uncached device allocations (hipDeviceMallocUncached: remote stores are visible to the home
 // GPU without any cache maintenance there), exported / opened with hipIpc*MemHandle.  Layout per engine:
-//   inbox[parity 0..1][source rank 0..n-1] = { double data[max_count]; uint64 flag[P2P_MAX_WG]; }
+//   inbox[parity 0..1][source rank 0..n-1] = { uint64 word[2 * max_count] }: element i as { tag | low half }, { tag | high half }
 // Two parities: a rank can run at most one exchange ahead of a peer (its exchange s+1 cannot finish before the peer has
 // sent s+1, which the peer does only after it has finished reading s), so the slot of exchange s+2 is free by then.
-// Flags hold the exchange's sequence number (monotonic; never reset).
-// Ordering (cdna_hip_programming.md, guideline 16): payload stores are system-scope write-through stores, every storing
-// wave drains them (s_waitcnt vmcnt(0)) and joins a workgroup barrier, then one lane per peer stores the flag; the reader
-// polls the flags with system-scope loads from one lane per source, joins a barrier and reads the payload with system-scope
-// loads (the inbox is uncached memory: no load is served from a cache).  Every wait is bounded (20 s of the 100 MHz
-// clock): on expiry the host-visible abort word is set, and a device word that makes the engine's later exchanges return at once.
+// The tag is derived from the exchange's sequence number (monotonic; never reset; never 0).
+// Ordering: none needed beyond the atomicity of an 8-byte store -- every word says by its tag whether it has arrived
+// (p2p_exchange).  Rounds 2-4 drained the payload stores, raised one flag per workgroup and peer and read the payload after
+// the flags: three trips over the fabric on the critical path where this layout has one.  Every wait is bounded (20 s of the
+// 100 MHz clock): on expiry the host-visible abort word is set, and a device word that makes the engine's later exchanges
+// return at once.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -38,15 +38,15 @@ struct P2PParams {
     int rank, n_ranks;
     int parity;
     unsigned long long seq;
-    size_t slot;            // doubles per (parity, source) slot = max_count + P2P_MAX_WG
+    size_t slot;            // 8-byte words per (parity, source) slot = 2 * max_count
     size_t max_count;
     double* inbox[P2P_MAX_RANKS];  // base of every rank's inbox as mapped here ([rank] = the local allocation)
     unsigned long long timeout_ticks;  // of the 100 MHz clock
     unsigned* abort_host;   // pinned host word: 2 = an exchange gave up
     unsigned* abort_dev;    // device word, set with it: later exchanges of this engine return at once instead of waiting again
     // optional (salnmf_profile_sharded_steps): six s_memrealtime stamps (100 MHz) per workgroup of tail_p2p_kernel --
-    // [0] start [1] local slabs reduced [2] row stored to the peers, flags raised [3] every peer's flag seen
-    // [4] peers' rows read and summed [5] W row finished
+    // [0] start [1] local slabs reduced [2] row stored to the peers [3] every peer's row seen
+    // [4] rows summed [5] W row finished
     unsigned long long* stamps;
 };
 
@@ -67,34 +67,56 @@ __device__ __forceinline__ unsigned p2p_abort_word(const P2PParams& p, int tid) 
 }
 
 //   abort_word: p2p_abort_word(p, tid)
+// Round 5: the payload carries its own arrival tag (the "low-latency" layout of collective libraries): a double travels as
+// two 8-byte words { tag : 32 | half of the value : 32 }, each stored atomically; the reader polls ITS OWN element's words from
+// every source until all carry this exchange's tag.  No drain of the stores (the acknowledgement's trip back), no flag store
+// behind it (a second trip) and no separate read of the payload after the flags (a third): one one-way trip on the critical
+// path.  8-byte stores are single transactions on the fabric; a reader that sees one word of a pair new and the other old
+// simply polls again.
 __device__ __forceinline__ double p2p_exchange(const P2PParams& p, int idx, bool active, int flag_idx, double v, int tid, unsigned abort_word) {
+    typedef __attribute__((address_space(1))) unsigned long long gword_t;
     const size_t mine = ((size_t)p.parity * p.n_ranks + p.rank) * p.slot;
     __shared__ int failed;
     if (tid == 0) failed = abort_word != 0;
     __syncthreads();
     if (failed) return 0.0;  // (one lane's reading, so the whole workgroup takes the same way)
+    const unsigned long long tag = ((p.seq % 0xFFFFFFFFull) + 1ull) << 32;  // never 0 (the inbox starts zeroed), differs between exchanges s and s + 2
     // (this rank's own contribution stays in its register: no round trip through its own uncached inbox)
     if (active) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+        const unsigned long long w0 = tag | (bits & 0xFFFFFFFFull), w1 = tag | (bits >> 32);
         for (int r = 0; r < p.n_ranks; ++r)
-            if (r != p.rank) __hip_atomic_store((gdouble_t*)(p.inbox[r] + mine + idx), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    // every storing wave drains its (write-through, system-scope) stores: they are acknowledged by the destination
-    // before the flag is issued.  No release fence: that would write back this GPU's whole L2 in every workgroup, and
-    // nothing but the uncached inbox is shared with the peers.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid < p.n_ranks && tid != p.rank) {
-        gflag_t* flag = (gflag_t*)(p.inbox[tid] + mine + p.max_count) + flag_idx;
-        __hip_atomic_store(flag, p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (r != p.rank) {
+                gword_t* dst = (gword_t*)(p.inbox[r] + mine) + 2 * (size_t)idx;
+                __hip_atomic_store(dst, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(dst + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
     }
     p2p_stamp(p, flag_idx, 2, tid);
-    // wait for this workgroup's slice from every other source (lane r polls source r)
-    if (tid < p.n_ranks && tid != p.rank) {
-        const gflag_t* flag = (const gflag_t*)(p.inbox[p.rank] + ((size_t)p.parity * p.n_ranks + tid) * p.slot + p.max_count) + flag_idx;
+    // every lane waits for its own element from every other source (the inbox is uncached memory: no load is served from a cache)
+    double t[P2P_MAX_RANKS];
+#pragma unroll
+    for (int r = 0; r < P2P_MAX_RANKS; ++r) t[r] = 0.0;
+    if (active) {
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         for (unsigned spins = 1;; ++spins) {
-            if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == p.seq) break;
-            __builtin_amdgcn_s_sleep(1);
+            unsigned long long w[P2P_MAX_RANKS][2];
+#pragma unroll
+            for (int r = 0; r < P2P_MAX_RANKS; ++r) {
+                const bool peer = r < p.n_ranks && r != p.rank;
+                const gword_t* src = (const gword_t*)(p.inbox[p.rank] + ((size_t)p.parity * p.n_ranks + (peer ? r : p.rank)) * p.slot) + 2 * (size_t)idx;
+                w[r][0] = peer ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : tag;
+                w[r][1] = peer ? __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : tag;
+            }
+            bool all = true;
+#pragma unroll
+            for (int r = 0; r < P2P_MAX_RANKS; ++r) all = all && (w[r][0] >> 32) == (tag >> 32) && (w[r][1] >> 32) == (tag >> 32);
+            if (all) {
+#pragma unroll
+                for (int r = 0; r < P2P_MAX_RANKS; ++r) t[r] = __longlong_as_double((long long)((w[r][0] & 0xFFFFFFFFull) | (w[r][1] << 32)));
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
             if ((spins & 63u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > p.timeout_ticks) {
                 failed = 1;
                 __hip_atomic_store((__attribute__((address_space(1))) unsigned*)p.abort_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -106,14 +128,7 @@ __device__ __forceinline__ double p2p_exchange(const P2PParams& p, int idx, bool
     __syncthreads();
     p2p_stamp(p, flag_idx, 3, tid);
     if (failed || !active) return 0.0;
-    // all peers' values in flight together, then the sum in rank order (this rank's own term from the register)
-    double t[P2P_MAX_RANKS];
-#pragma unroll
-    for (int r = 0; r < P2P_MAX_RANKS; ++r)
-        t[r] = (r < p.n_ranks && r != p.rank)
-                   ? __hip_atomic_load((const gdouble_t*)(p.inbox[p.rank] + ((size_t)p.parity * p.n_ranks + r) * p.slot + idx), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_SYSTEM)
-                   : 0.0;
+    // the sum in rank order (this rank's own term from the register)
     double s = 0.0;
 #pragma unroll
     for (int r = 0; r < P2P_MAX_RANKS; ++r)
