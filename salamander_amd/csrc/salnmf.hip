@@ -439,6 +439,7 @@ static P2PParams next_exchange(salnmf_engine* e, double* buf, size_t count) {
     q.rank = e->rank;
     q.n_ranks = e->n_ranks;
     q.seq = ++e->p2p.seq;
+    q.tag = ((q.seq % 0xFFFFFFFFull) + 1ull) << 32;  // (salnmf_p2p_kernels.h: never 0, differs between exchanges s and s + 2)
     q.parity = (int)(q.seq & 1);
     q.slot = e->p2p.slot;
     q.max_count = e->p2p.max_count;

@@ -38,6 +38,7 @@ struct P2PParams {
     int rank, n_ranks;
     int parity;
     unsigned long long seq;
+    unsigned long long tag;  // this exchange's arrival tag in the high half of a word: ((seq mod (2^32 - 1)) + 1) << 32
     size_t slot;            // 8-byte words per (parity, source) slot = 2 * max_count
     size_t max_count;
     double* inbox[P2P_MAX_RANKS];  // base of every rank's inbox as mapped here ([rank] = the local allocation)
@@ -60,10 +61,11 @@ typedef __attribute__((address_space(1))) unsigned long long gflag_t;
 // One workgroup's part of an exchange: element `idx` of the vector (value v, where `active`), completion flag `flag_idx`
 // of the slot.  Called by every thread of the workgroup; returns the sum over the ranks in rank order (0 where inactive
 // or after a wait gave up, in which case the abort word is set).
-// The engine's "an earlier exchange gave up" word, read by lane 0 (0 elsewhere).  A kernel that has other work before its
-// exchange issues this load first, so that its round trip is not on the exchange's critical path.
-__device__ __forceinline__ unsigned p2p_abort_word(const P2PParams& p, int tid) {
-    return tid == 0 ? __hip_atomic_load((__attribute__((address_space(1))) unsigned*)p.abort_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+// The engine's "an earlier exchange gave up" word.  A kernel that has other work before its exchange issues this load first,
+// so that its round trip is not on the exchange's critical path.
+__device__ __forceinline__ unsigned p2p_abort_word(const P2PParams& p, int) {
+    // (every lane: one request per wave; a lane's own copy lets it skip its wait below, the workgroup's common decision is lane 0's)
+    return __hip_atomic_load((__attribute__((address_space(1))) unsigned*)p.abort_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 //   abort_word: p2p_abort_word(p, tid)
@@ -77,10 +79,8 @@ __device__ __forceinline__ double p2p_exchange(const P2PParams& p, int idx, bool
     typedef __attribute__((address_space(1))) unsigned long long gword_t;
     const size_t mine = ((size_t)p.parity * p.n_ranks + p.rank) * p.slot;
     __shared__ int failed;
-    if (tid == 0) failed = abort_word != 0;
-    __syncthreads();
-    if (failed) return 0.0;  // (one lane's reading, so the whole workgroup takes the same way)
-    const unsigned long long tag = ((p.seq % 0xFFFFFFFFull) + 1ull) << 32;  // never 0 (the inbox starts zeroed), differs between exchanges s and s + 2
+    if (tid == 0) failed = abort_word != 0;  // (read behind the barrier below; a wait that gives up sets it too)
+    const unsigned long long tag = p.tag;    // never 0 (the inbox starts zeroed), differs between exchanges s and s + 2 (host: next_exchange)
     // (this rank's own contribution stays in its register: no round trip through its own uncached inbox)
     if (active) {
         const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
@@ -93,13 +93,15 @@ __device__ __forceinline__ double p2p_exchange(const P2PParams& p, int idx, bool
             }
     }
     p2p_stamp(p, flag_idx, 2, tid);
-    // every lane waits for its own element from every other source (the inbox is uncached memory: no load is served from a cache)
+    // every lane waits for its own element from every other source (the inbox is uncached memory: no load is served from a
+    // cache).  The clock is read only once a poll has come back empty: the common case -- the peers' rows are there -- pays
+    // for neither the read nor the loop.  A lane that knows of an earlier failure does not wait again.
     double t[P2P_MAX_RANKS];
 #pragma unroll
     for (int r = 0; r < P2P_MAX_RANKS; ++r) t[r] = 0.0;
-    if (active) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        for (unsigned spins = 1;; ++spins) {
+    if (active && p.n_ranks > 1 && abort_word == 0) {
+        unsigned long long t0 = 0;
+        for (unsigned spins = 0;; ++spins) {
             unsigned long long w[P2P_MAX_RANKS][2];
 #pragma unroll
             for (int r = 0; r < P2P_MAX_RANKS; ++r) {
@@ -116,8 +118,9 @@ __device__ __forceinline__ double p2p_exchange(const P2PParams& p, int idx, bool
                 for (int r = 0; r < P2P_MAX_RANKS; ++r) t[r] = __longlong_as_double((long long)((w[r][0] & 0xFFFFFFFFull) | (w[r][1] << 32)));
                 break;
             }
+            if (spins == 0) t0 = __builtin_amdgcn_s_memrealtime();
             __builtin_amdgcn_s_sleep(2);
-            if ((spins & 63u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > p.timeout_ticks) {
+            if ((spins & 63u) == 63u && __builtin_amdgcn_s_memrealtime() - t0 > p.timeout_ticks) {
                 failed = 1;
                 __hip_atomic_store((__attribute__((address_space(1))) unsigned*)p.abort_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store((__attribute__((address_space(1))) unsigned*)p.abort_host, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
