@@ -693,14 +693,19 @@ def main():
                 e1 = sal.Engine(n_total, V, K, device=device)
                 e1.upload_X(Xa), e1.upload_W(W0), e1.upload_H(Ha)
                 del Xa, Ha
-                e1.kl_step(5)
+                # the protocol of the timed blocks above: the same warm-up, blocks of the same K steps timed the same way, as
+                # many of them as fill the same busy time (a handful of blocks right after the upload ran 9 % slow at the
+                # 125 000-sample shard: the clocks had not settled, and the comparison flattered the sharded run)
+                e1.kl_step(max(args.warmup, 5))
                 e1.sync()
                 ts = []
-                for _ in range(5):
+                busy = 0.0
+                while len(ts) < 5 or (busy < args.busy_seconds and len(ts) < 1000):
                     t0 = time.perf_counter()
                     e1.kl_step(args.steps)
                     e1.sync()
                     ts.append((time.perf_counter() - t0) / args.steps)
+                    busy += ts[-1] * args.steps
                 e1.close()
                 t1 = statistics.median(ts)
                 one_gpu = {
@@ -709,7 +714,8 @@ def main():
                     "ms_per_step": t1 * 1e3,
                     "steps_per_s": 1.0 / t1,
                     "speedup_of_this_run": (args.steps / median) * t1,
-                    "how": f"rank 0 alone, median of 5 blocks of {args.steps} steps, same {n_total}-sample problem"
+                    "how": f"rank 0 alone, median of {len(ts)} blocks of {args.steps} steps after {max(args.warmup, 5)} warm-up steps (the timed blocks' protocol), "
+                           f"same {n_total}-sample problem"
                     + (" (the other ranks' engines idle on the SAME device: rehearsal)" if args.rehearse_one_device else ""),
                 }
             except Exception as exc:
