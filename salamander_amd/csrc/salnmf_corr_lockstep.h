@@ -45,7 +45,8 @@ struct LockstepParams {
     int* n_evals;                  // [K]
     int* active;                   // [1] signatures that still need an evaluation after this round
     double* part;                  // [K][S][LS_REC] partial sums of one evaluation round
-    double* red;                   // [K][LS_REC]    reduced (and all-reduced) sums
+    double* red;                   // [K][red_ld]    reduced (and all-reduced) sums
+    int red_ld;                    // doubles per record of `red`: 66 + dim^2, the live part of a record -- what a sharded solve all-reduces
     double* log_y;                 // [K][LS_EVAL_MAX][64]
     double* log_f;                 // [K][LS_EVAL_MAX]
     double* log_g;                 // [K][LS_EVAL_MAX][64]
@@ -274,7 +275,7 @@ __global__ void __launch_bounds__(256) ls_begin_mfma_kernel(LockstepParams q, do
 
 // red[k][2 + m] = sum over the workgroups' partial sums of ls_begin_mfma_kernel: sixteen interleaved sub-sums (wave w:
 // partials w, w + 16, ... in order), then the sixteen in order
-__global__ void __launch_bounds__(1024) ls_reduce_sg_kernel(const double* __restrict__ part2, double* __restrict__ red, int nparts, int K, int dim) {
+__global__ void __launch_bounds__(1024) ls_reduce_sg_kernel(const double* __restrict__ part2, double* __restrict__ red, int red_ld, int nparts, int K, int dim) {
     __shared__ double sub[16][64];
     const int k = blockIdx.x, m = threadIdx.x & 63, w = threadIdx.x >> 6;
     double t = 0.0;
@@ -295,7 +296,7 @@ __global__ void __launch_bounds__(1024) ls_reduce_sg_kernel(const double* __rest
     if (w == 0) {
         double tot = sub[0][m];
         for (int i = 1; i < 16; ++i) tot += sub[i][m];
-        red[(int64_t)k * LS_REC + 2 + m] = tot;
+        red[(int64_t)k * red_ld + 2 + m] = tot;
     }
 }
 
@@ -885,7 +886,7 @@ __global__ void __launch_bounds__(SIGT) ls_eval_packed_kernel(LockstepParams q) 
 
 // red[k][e] = sum over the S chunk partials, fixed order; only the first `len` entries of a record are live
 //   dynB > 0: the records were written under the live-group map of a round with dynB workgroups (LsLive)
-__global__ void __launch_bounds__(256) ls_reduce_kernel(const double* __restrict__ part, double* __restrict__ red, const int* __restrict__ state,
+__global__ void __launch_bounds__(256) ls_reduce_kernel(const double* __restrict__ part, double* __restrict__ red, int red_ld, const int* __restrict__ state,
                                                         int S, int first, int len, int all_signatures, int dynB = 0, int K = 0, int64_t N = 0,
                                                         int* active = nullptr) {
     // (the round's count of signatures that still ask for an evaluation starts from zero: ls_advance_kernel adds to it --
@@ -921,13 +922,13 @@ __global__ void __launch_bounds__(256) ls_reduce_kernel(const double* __restrict
             }
             for (; s < S; ++s) t += part[((int64_t)k * S + s) * LS_REC + e];
         }
-        red[(int64_t)k * LS_REC + e] = t;  // zero for signatures that asked for nothing: the all-reduce covers all K
+        red[(int64_t)k * red_ld + e] = t;  // zero for signatures that asked for nothing: the all-reduce covers all K
     }
 }
 
-__global__ void ls_copy_sg_kernel(const double* __restrict__ red, double* __restrict__ sg, int K) {
+__global__ void ls_copy_sg_kernel(const double* __restrict__ red, int red_ld, double* __restrict__ sg, int K) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < K * 64) sg[i] = red[(int64_t)(i / 64) * LS_REC + 2 + (i & 63)];
+    if (i < K * 64) sg[i] = red[(int64_t)(i / 64) * red_ld + 2 + (i & 63)];
 }
 
 // Hl [64][CORR_LD] <- a compact dim x dim Hessian (and, if asked, a copy of it to `copy`): eight loads in flight per lane
@@ -1058,7 +1059,7 @@ __global__ void __launch_bounds__(64) ls_advance_kernel(LockstepParams q) {
     double* lf = q.log_f + (int64_t)k * LS_EVAL_MAX;
     double* lg = q.log_g + (int64_t)k * LS_EVAL_MAX * 64;
     double* lH = q.log_H + (int64_t)k * LS_EVAL_MAX * dim * dim;
-    const double* red = q.red + (int64_t)k * LS_REC;
+    const double* red = q.red + (int64_t)k * q.red_ld;
     // ---- the evaluation at the requested point (same arithmetic as SignatureEmbeddingEval::fun_grad)
     const int i = q.n_evals[k];
     const double y = q.req[k * 64 + lane];

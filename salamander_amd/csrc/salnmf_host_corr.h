@@ -306,6 +306,7 @@ static int lockstep_signature_solves(salnmf_engine* e, const double* U, const do
     q.sg = b; b += (size_t)K * 64;
     q.part = b; b += n_part;
     q.red = b; b += (size_t)K * LS_REC;
+    q.red_ld = 66 + dim * dim;  // (the live part of a record: what a sharded solve sends through the all-reduce -- 130 doubles per signature at dim 8, 1 666 at dim 40, of the 4 162 a record is laid out for)
     q.log_y = b; b += (size_t)K * LS_EVAL_MAX * 64;
     q.log_g = b; b += (size_t)K * LS_EVAL_MAX * 64;
     q.log_f = b; b += (size_t)K * LS_EVAL_MAX;
@@ -333,14 +334,14 @@ static int lockstep_signature_solves(salnmf_engine* e, const double* U, const do
         const int nwg = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)4 * n_cus, (n_rows + 255) / 256, (int64_t)S * LS_REC / 64}));
         const int64_t rows_per_wg = ((n_rows + nwg - 1) / nwg + 255) / 256 * 256;
         hipLaunchKernelGGL(ls_begin_mfma_kernel, dim3(nwg), dim3(256), 0, e->stream, q, q.part, rows_per_wg);
-        hipLaunchKernelGGL(ls_reduce_sg_kernel, dim3(K), dim3(1024), 0, e->stream, q.part, q.red, nwg, K, dim);
+        hipLaunchKernelGGL(ls_reduce_sg_kernel, dim3(K), dim3(1024), 0, e->stream, q.part, q.red, q.red_ld, nwg, K, dim);
     } else {
         hipLaunchKernelGGL(ls_begin_kernel, grid, dim3(SIGT), 0, e->stream, q);
-        hipLaunchKernelGGL(ls_reduce_kernel, dim3(K, 1), dim3(256), 0, e->stream, q.part, q.red, q.state, S, 2, 64, 1);
+        hipLaunchKernelGGL(ls_reduce_kernel, dim3(K, 1), dim3(256), 0, e->stream, q.part, q.red, q.red_ld, q.state, S, 2, 64, 1);
     }
     HIPCK(hipGetLastError());
-    if (shard) CK(allreduce(e, q.red, (size_t)K * LS_REC));
-    hipLaunchKernelGGL(ls_copy_sg_kernel, dim3((K * 64 + 255) / 256), dim3(256), 0, e->stream, q.red, q.sg, K);
+    if (shard) CK(allreduce(e, q.red, (size_t)K * q.red_ld));
+    hipLaunchKernelGGL(ls_copy_sg_kernel, dim3((K * 64 + 255) / 256), dim3(256), 0, e->stream, q.red, q.red_ld, q.sg, K);
     HIPCK(hipGetLastError());
     const int rec = 66 + dim * dim;
     for (hipEvent_t& ev : e->ls_ev)
@@ -361,10 +362,10 @@ static int lockstep_signature_solves(salnmf_engine* e, const double* U, const do
             else hipLaunchKernelGGL((ls_eval_packed_kernel<5, 0, false, false>), grid, dim3(SIGT), 0, e->stream, q);
         } else if (multi) hipLaunchKernelGGL(ls_eval_multi_kernel, grid, dim3(SIGT), 0, e->stream, q);
         else hipLaunchKernelGGL(ls_eval_kernel, grid, dim3(SIGT), 0, e->stream, q);
-        hipLaunchKernelGGL(ls_reduce_kernel, dim3(K, (rec + 255) / 256), dim3(256), 0, e->stream, q.part, q.red, q.state, S, 0, rec, 0, q.dyn ? S * groups : 0, K,
+        hipLaunchKernelGGL(ls_reduce_kernel, dim3(K, (rec + 255) / 256), dim3(256), 0, e->stream, q.part, q.red, q.red_ld, q.state, S, 0, rec, 0, q.dyn ? S * groups : 0, K,
                            (int64_t)n_rows, q.active);
         HIPCK(hipGetLastError());
-        if (shard) CK(allreduce(e, q.red, (size_t)K * LS_REC));
+        if (shard) CK(allreduce(e, q.red, (size_t)K * q.red_ld));
         hipLaunchKernelGGL(ls_advance_kernel, dim3(K), dim3(64), 0, e->stream, q);
         HIPCK(hipGetLastError());
         HIPCK(hipMemcpyAsync(hactive + (r & 1), q.active, sizeof(int), hipMemcpyDeviceToHost, e->stream));
@@ -481,13 +482,13 @@ static int gather_sample_side(salnmf_engine* e) {
 int salnmf_corr_update_signature_embeddings(salnmf_engine* e, double variance, int maxiter, int* status_out) {
     CK(corr_ready(e));
     if (!(variance > 0.0)) return fail("variance must be positive");
-    if (sharded(e) && !e->comm) return fail("the sharded signature-embedding solves gather through the RCCL communicator: call salnmf_comm_init");
-    if (e->comm) {
+    if (sharded(e)) {
         // sample-sharded: with enough samples the solves run in lockstep on the local rows and the sums of every
-        // evaluation are all-reduced (1 + dim + dim^2 per signature); small problems gather the sample side once
-        // and solve on identical inputs
+        // evaluation are all-reduced (66 + dim^2 per signature: through the peer exchange where that fits its inbox, else
+        // through RCCL); small problems gather the sample side once (RCCL) and solve on identical inputs
         if (e->lockstep && e->N_total >= LS_MIN_ROWS * e->n_ranks)
             return lockstep_signature_solves(e, e->Uemb, e->alpha, e->aux, e->N, variance, maxiter, status_out, true);
+        if (!e->comm) return fail("the sharded signature-embedding solves of a small cohort gather through the RCCL communicator: call salnmf_comm_init");
         CK(gather_sample_side(e));
         return launch_signature_solves(e, e->gU, e->galpha, e->gaux, e->N_total, variance, maxiter, status_out);
     }

@@ -396,11 +396,12 @@ class Engine:
     def p2p_export(self, n_ranks: int, max_count: int | None = None) -> bytes:
         """Allocate this engine's inbox of the peer-to-peer exchange (``include/salnmf.h``) and return its IPC handle.
 
-        ``max_count`` defaults to the largest of the small all-reduces: the numerator with the MvNMF sums
-        (K*V + K + 2) and the Gram matrix of the device-side initialisation (96*96 + 1), at most the inbox limit of
-        16 384 doubles -- larger all-reduces (wide or many-signature engines) go through the RCCL communicator."""
+        ``max_count`` defaults to the inbox limit of 16 384 doubles (4 MB of inbox at 8 ranks): the numerator with the MvNMF
+        sums (K*V + K + 2), the Gram matrix of the device-side initialisation (96*96 + 1) and, for small ``dim_embeddings``,
+        the evaluation records of CorrNMF's lockstep signature solves (K * (66 + dim^2)) all fit; larger all-reduces (wide or
+        many-signature engines, dim 40) go through the RCCL communicator."""
         if max_count is None:
-            max_count = min(max(self.K * self.V + self.K + 2, 96 * 96 + 2), _lib.P2P_MAX_COUNT)
+            max_count = _lib.P2P_MAX_COUNT
         buf = ctypes.create_string_buffer(_lib.P2P_HANDLE_BYTES)
         _lib.check(self._lib.salnmf_p2p_export(self._h, int(n_ranks), int(max_count), buf))
         return buf.raw

@@ -192,9 +192,12 @@ class MultimodalCorrNMF:
             self._comm_attached[name] = False
             self._x_resident.discard(name)
         if self.distributed and not self._comm_attached.get(name):
-            from ..distributed import attach_communicator
+            from ..distributed import attach_communicator, attach_peer_exchange
 
             attach_communicator(e)
+            # the small all-reduces (numerators, scalings, at small dim_embeddings the lockstep solves' evaluation records) by
+            # peer stores where the GPUs of the node can map each other's memory; otherwise everything stays on RCCL
+            attach_peer_exchange(e, required=False)
             self._comm_attached[name] = True
         return e
 

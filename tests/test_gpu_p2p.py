@@ -416,3 +416,91 @@ def test_sharded_steps_of_engines_with_feature_blocks_or_signature_chunks(tmp_pa
     assert rel_l2(parts[0]["Wm"], W.T) < 1e-7
     assert rel_l2(np.concatenate([p["Hm"] for p in parts], axis=0), H.T) < 1e-7
     assert np.isclose(float(parts[0]["mv_obj"]), orc.kl_divergence_penalized(X.T, W, H, SPLIT_LAM, SPLIT_DELTA), rtol=1e-9)
+
+
+# ---- a whole CorrNMF update on sample shards, ranks as processes on one GPU (round 5): the first run of the sharded CorrNMF
+# path with more than one rank on a GPU.  No RCCL (two RCCL ranks cannot share a device): every sum over the samples --
+# numerators, scalings, the lockstep signature solves' evaluation records (66 + dim^2 doubles per signature: they fit the
+# peer inbox at this dim), the embedding norms, the Poisson log-likelihood -- goes through the peer exchange.
+CORR_SHARD = dict(V=96, K=12, N=9000, dim=6, variance=0.8)
+
+
+def _corr_shard_problem():
+    from oracle import klnmf_oracle as orc
+
+    c = CORR_SHARD
+    X, W, _ = orc.synthetic_problem(c["V"], c["N"], c["K"], seed=21)
+    rng = np.random.default_rng(23)
+    return c, X, W, rng.normal(0, 0.3, c["K"]), rng.normal(0, 0.4, (c["K"], c["dim"])), rng.normal(0, 0.4, (c["N"], c["dim"]))
+
+
+def _corr_update(e, c, n_updates=2):
+    from salamander_amd import _lib
+
+    status = None
+    for _ in range(n_updates):  # (corrnmf_det.py:64-141: the order of CorrNMFDet._update_parameters)
+        e.corr_update_sample_scalings(), e.corr_compute_exposures(), e.corr_compute_aux()
+        e.corr_update_signatures(0), e.corr_update_signature_scalings()
+        status = e.corr_update_signature_embeddings(c["variance"], 0, return_status=True)
+        e.corr_update_sample_embeddings(c["variance"], 3)
+    sumsq, llh = e.corr_embedding_sumsq(), e.corr_poisson_llh()
+    return dict(W=e.download_W(), beta=e.corr_download(_lib.CORR_SIGNATURE_SCALINGS), L=e.corr_download(_lib.CORR_SIGNATURE_EMBEDDINGS),
+                U=e.corr_download(_lib.CORR_SAMPLE_EMBEDDINGS), alpha=e.corr_download(_lib.CORR_SAMPLE_SCALINGS), status=status,
+                sumsq=np.array(sumsq), llh=llh)
+
+
+def _corr_shard_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+
+    from salamander_amd import _lib
+    from salamander_amd.distributed import attach_peer_exchange, shard_bounds
+    from salamander_amd.engine import Engine
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        c, X, W, beta, L, U = _corr_shard_problem()
+        a, b = shard_bounds(c["N"], world, rank)
+        e = Engine(b - a, c["V"], c["K"])
+        e.upload_X(X[a:b]), e.upload_W(W)
+        attach_peer_exchange(e)
+        e.corr_configure(c["dim"])
+        e.corr_upload(_lib.CORR_SIGNATURE_SCALINGS, beta), e.corr_upload(_lib.CORR_SIGNATURE_EMBEDDINGS, L)
+        e.corr_upload(_lib.CORR_SAMPLE_EMBEDDINGS, U[a:b])
+        out = _corr_update(e, c)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), a=a, b=b, **out)
+        dist.barrier()  # nobody frees its inbox while a peer may still be inside an exchange
+        e.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_corrnmf_update_over_the_peer_exchange_matches_one_engine(tmp_path, world):
+    from salamander_amd import _lib
+    from salamander_amd.engine import Engine
+
+    mp.spawn(_corr_shard_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    c, X, W, beta, L, U = _corr_shard_problem()
+    e1 = Engine(c["N"], c["V"], c["K"])
+    e1.upload_X(X), e1.upload_W(W)
+    e1.corr_configure(c["dim"])
+    e1.corr_upload(_lib.CORR_SIGNATURE_SCALINGS, beta), e1.corr_upload(_lib.CORR_SIGNATURE_EMBEDDINGS, L)
+    e1.corr_upload(_lib.CORR_SAMPLE_EMBEDDINGS, U)
+    want = _corr_update(e1, c)
+    e1.close()
+    for p in parts[1:]:  # the replicated state: the same bits on every rank (sums in rank order)
+        for key in ("W", "beta", "L", "sumsq"):
+            assert np.array_equal(parts[0][key], p[key]), key
+        assert p["llh"] == parts[0]["llh"] and np.array_equal(p["status"], parts[0]["status"])
+    assert np.array_equal(parts[0]["status"], want["status"])
+    # against the engine that holds all samples: the sums over the samples in another order -- rounding level on the dense
+    # pieces, a few digits more through two updates' Newton-CG solves
+    assert rel_l2(parts[0]["W"], want["W"]) < 1e-11 and rel_l2(parts[0]["beta"], want["beta"]) < 1e-9
+    assert rel_l2(parts[0]["L"], want["L"]) < 1e-7
+    assert rel_l2(np.concatenate([p["U"] for p in parts]), want["U"]) < 1e-7
+    assert rel_l2(np.concatenate([p["alpha"] for p in parts]), want["alpha"]) < 1e-9
+    assert np.allclose(parts[0]["sumsq"], want["sumsq"], rtol=1e-7) and np.isclose(float(parts[0]["llh"]), want["llh"], rtol=1e-9)
