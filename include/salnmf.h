@@ -269,7 +269,7 @@ int salnmf_corr_update_signature_embeddings(salnmf_engine* e, double variance, i
 /* From 2 048 samples on, the signature solves run in LOCKSTEP (csrc/salnmf_corr_lockstep.h): one evaluation round
  * per launch over (chunks x signatures) workgroups, the K Newton-CG solvers replayed from their evaluation logs
  * between rounds -- 3x faster than one workgroup per signature at c5, and shardable: a sample-sharded engine
- * all-reduces the 1 + dim + dim^2 sums per signature of every round.  0 forces the single-kernel form; the two agree
+ * all-reduces the 66 + dim^2 sums per signature of every round (through the peer exchange where they fit its inbox).  0 forces the single-kernel form; the two agree
  * to rounding of the sums. */
 int salnmf_set_lockstep(salnmf_engine* e, int on);
 /* The sample solves (both entry points above) run BATCHED where the shape allows (at most 80 signatures over all
