@@ -347,8 +347,16 @@ class MultimodalCorrNMF:
                 e.corr_compute_aux()
                 if "signature_scalings" not in given_mod:
                     e.corr_update_signature_scalings()
-            for name, e in zip(names, engines):
-                if "signature_embeddings" not in given.get(name, {}):
+            todo = [e for name, e in zip(names, engines) if "signature_embeddings" not in given.get(name, {})]
+            if len(todo) > 1 and not self.distributed and getattr(self, "solve_side_by_side", True):
+                # the modalities' signature solves are independent (mmcorrnmf.py:319-334) and each engine has its own stream:
+                # driven from one host thread per modality, one modality's evaluation rounds fill the GPU while the other's
+                # small kernels between the rounds (reduction, solver replay: ~10 % of a round with the device nearly idle)
+                # and its host round trips run.  Same launches per engine, hence the same bits.  (Sharded engines keep the
+                # sequential order: two communicators driven concurrently would have to agree on an order across the ranks.)
+                list(self._solve_pool(len(todo)).map(lambda eng: eng.corr_update_signature_embeddings(self.variance, 0), todo))
+            else:
+                for e in todo:
                     e.corr_update_signature_embeddings(self.variance, 0)
             if "sample_embeddings" not in given:
                 Engine.corr_update_sample_embeddings_multi(engines, self.variance, 3)
@@ -357,6 +365,15 @@ class MultimodalCorrNMF:
             for name, e in zip(names, engines):
                 given_mod = given.get(name, {})
                 e.corr_update_signatures(given_mod["asignatures"].n_obs if "asignatures" in given_mod else 0)
+
+    def _solve_pool(self, n: int):
+        """Host threads that drive the modalities' signature solves side by side (ctypes releases the GIL inside a call)."""
+        pool = getattr(self, "_pool", None)
+        if pool is None or pool._max_workers < n:
+            from concurrent.futures import ThreadPoolExecutor
+
+            pool = self._pool = ThreadPoolExecutor(max_workers=n, thread_name_prefix="salnmf-solve")
+        return pool
 
     def _resident_sumsq(self):
         sig = [self._engines[name].corr_embedding_sumsq() for name in self.mod_names]

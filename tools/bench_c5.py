@@ -39,11 +39,12 @@ for N, dim in CONFIGS:
         for e in engines: e.sync()
         return (time.perf_counter() - t0) * 1e3
     t_sig = timed(lambda: [e.corr_update_signature_embeddings(model.variance, 0) for e in engines])
+    t_sig_par = timed(lambda: list(model._solve_pool(len(engines)).map(lambda e: e.corr_update_signature_embeddings(model.variance, 0), engines)))
     t_smp = timed(lambda: sal.Engine.corr_update_sample_embeddings_multi(engines, model.variance, 3))
     t_aux = timed(lambda: [e.corr_compute_aux() for e in engines])
-    print(f"c5 N={N} dim={dim}: update steps {[round(s*1e3,1) for s in steps]} ms; signature solves {t_sig:.1f} ms, joint sample solves {t_smp:.1f} ms, "
+    print(f"c5 N={N} dim={dim}: update steps {[round(s*1e3,1) for s in steps]} ms; signature solves {t_sig:.1f} ms one modality after the other / {t_sig_par:.1f} ms side by side (one host thread each), joint sample solves {t_smp:.1f} ms, "
           f"aux passes {t_aux:.2f} ms, ELBO {t_obj*1e3:.1f} ms (value {obj:.6e}); host init {t_init:.2f} s, upload {t_up:.2f} s", flush=True)
-    out.append({"N": N, "dim": dim, "ns_signatures": [40, 40], "features": [96, 83], "update_ms": [s * 1e3 for s in steps], "signature_solves_ms": t_sig,
+    out.append({"N": N, "dim": dim, "ns_signatures": [40, 40], "features": [96, 83], "update_ms": [s * 1e3 for s in steps], "signature_solves_ms": t_sig, "signature_solves_side_by_side_ms": t_sig_par,
                 "joint_sample_solves_ms": t_smp, "aux_passes_ms": t_aux, "elbo_ms": t_obj * 1e3, "elbo": obj})
     for e in engines: e.close()
     model._engines = {}
