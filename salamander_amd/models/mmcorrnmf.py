@@ -60,6 +60,10 @@ class MultimodalCorrNMF:
         self.device = device
         self.distributed = distributed
         self.device_init = device_init  # deterministic init methods: the signatures on the GPU (device_init.py)
+        # ours: the modalities' signature-embedding solves driven from one host thread each (same launches per engine, same
+        # bits; `_device_steps`); False: one modality after the other (sharded models always)
+        self.solve_side_by_side = True
+        self._pool = None
         self._comm_attached: dict[str, bool] = {}
         self._x_resident: set[str] = set()  # modalities whose X the device already holds from the initialisation
         names = [f"mod{n}" for n in range(1, len(ns_signatures) + 1)]
@@ -348,7 +352,7 @@ class MultimodalCorrNMF:
                 if "signature_scalings" not in given_mod:
                     e.corr_update_signature_scalings()
             todo = [e for name, e in zip(names, engines) if "signature_embeddings" not in given.get(name, {})]
-            if len(todo) > 1 and not self.distributed and getattr(self, "solve_side_by_side", True):
+            if len(todo) > 1 and not self.distributed and self.solve_side_by_side:
                 # the modalities' signature solves are independent (mmcorrnmf.py:319-334) and each engine has its own stream:
                 # driven from one host thread per modality, one modality's evaluation rounds fill the GPU while the other's
                 # small kernels between the rounds (reduction, solver replay: ~10 % of a round with the device nearly idle)
@@ -368,7 +372,7 @@ class MultimodalCorrNMF:
 
     def _solve_pool(self, n: int):
         """Host threads that drive the modalities' signature solves side by side (ctypes releases the GIL inside a call)."""
-        pool = getattr(self, "_pool", None)
+        pool = self._pool
         if pool is None or pool._max_workers < n:
             from concurrent.futures import ThreadPoolExecutor
 
