@@ -152,25 +152,37 @@ __global__ void __launch_bounds__(256) mv_many_gram_kernel(const double* __restr
 
 // One workgroup.  AUG: Gauss-Jordan on [K][2K] -- afterwards the right half is the inverse; else forward elimination of the
 // trailing block only (the pivots are all a log det needs).  logdet_out = sum_p log(pivot_p), p in order.
+// At pivot p only the columns p .. K + p of the augmented matrix can change: left of the pivot row p is zero already, and right
+// of column K + p the identity part has not been touched (row p is zero there), so the update x - f * 0 leaves those entries
+// as they are -- they are skipped (half the work; the touched entries get the same fused multiply-adds as before).  Threads
+// are laid out (row group, column): a row of the update is read and written in whole 128-byte lines, a thread's rows are
+// independent loads the compiler keeps in flight, and there is no integer division in the loop.
 template <bool AUG>
 __global__ void __launch_bounds__(MVM_BLOCK) mv_many_eliminate_kernel(double* __restrict__ S, int K, double* __restrict__ logdet_out) {
     __shared__ double f[MVM_KMAX];          // column p of the matrix (the row multipliers)
-    __shared__ double prow[2 * MVM_KMAX];   // row p divided by the pivot
+    __shared__ double prow[MVM_KMAX + 1];   // row p divided by the pivot, columns c0 .. c0 + ncol - 1
     __shared__ double lp[MVM_KMAX];         // log of the pivots
     const int tid = threadIdx.x, ld = AUG ? 2 * K : K;
+    constexpr int TX = 128, TY = MVM_BLOCK / TX;  // columns per pass x rows per pass
+    const int tx = tid % TX, ty = tid / TX;
     for (int p = 0; p < K; ++p) {
         const double pivot = S[(int64_t)p * ld + p];
-        const int c0 = AUG ? 0 : p, r0 = AUG ? 0 : p + 1;
-        for (int c = c0 + tid; c < ld; c += MVM_BLOCK) prow[c] = S[(int64_t)p * ld + c] / pivot;
+        const int c0 = p, r0 = AUG ? 0 : p + 1;
+        const int ncol = AUG ? K + 1 : K - p;
+        for (int c = tid; c < ncol; c += MVM_BLOCK) prow[c] = S[(int64_t)p * ld + c0 + c] / pivot;
         for (int r = r0 + tid; r < K; r += MVM_BLOCK) f[r] = S[(int64_t)r * ld + p];
         if (tid == 0) lp[p] = log(pivot);
         __syncthreads();
-        const int ncol = ld - c0, nrow = K - r0;
-        for (int64_t i = tid; i < (int64_t)nrow * ncol; i += MVM_BLOCK) {
-            const int r = r0 + (int)(i / ncol), c = c0 + (int)(i % ncol);
-            double* dst = S + (int64_t)r * ld + c;
-            if (r == p) *dst = prow[c];
-            else *dst = __builtin_fma(-f[r], prow[c], *dst);
+        for (int cb = 0; cb < ncol; cb += TX) {
+            const int c = cb + tx;
+            if (c < ncol) {
+                const double pc = prow[c];
+                for (int r = r0 + ty; r < K; r += TY) {
+                    double* dst = S + (int64_t)r * ld + c0 + c;
+                    if (r == p) *dst = pc;
+                    else *dst = __builtin_fma(-f[r], pc, *dst);
+                }
+            }
         }
         __syncthreads();
     }
