@@ -78,9 +78,10 @@ static int launch_geometry(const FusedSel& s, const FusedParams& p, int grid, hi
         launch_one<KS, KTM, KR, true, true, true, false, false, false, false, true>(p, grid, st, e0, e1);
         return 0;
     }
-    if (s.BLOCKED) {  // n_features > 96: the update_H pass over one feature block (weights honoured at run time)
-        if (!(s.U && !s.G && !s.STATS)) return 1;
-        launch_one<KS, KTM, KR, false, true, false, true, false, true>(p, grid, st, e0, e1);
+    if (s.BLOCKED) {  // n_features > 96: the update_H pass over one feature block, alone or with the block's numerator (weights honoured at run time)
+        if (!(s.U && !s.STATS)) return 1;
+        if (s.G) launch_one<KS, KTM, KR, true, true, false, true, false, true>(p, grid, st, e0, e1);
+        else launch_one<KS, KTM, KR, false, true, false, true, false, true>(p, grid, st, e0, e1);
         return 0;
     }
     // the variants the engine uses: joint step / update_H / update_W, each weighted or not; the two MvNMF passes

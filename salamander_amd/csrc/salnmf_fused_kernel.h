@@ -34,7 +34,8 @@ namespace salnmf {
 // the tail launch and the launch ramp per step by two counter hand-offs, and the first tile of the next step is
 // already in flight while a workgroup waits.
 //
-// BLOCKED (n_features > 96, update_H pass only): this launch covers ONE 96-feature block of X and W; the product
+// BLOCKED (n_features > 96; the update_H pass alone or, round 5, with the block's numerator G in the same pass: every block's
+// numerator is formed from the OLD H, which only the last block's pass rewrites): this launch covers ONE 96-feature block of X and W; the product
 // U = R W^T is accumulated over the blocks' launches through p.Uacc (p.ublock), the last block updates H.
 //
 // RGIVEN (n_signatures > 64, one launch per chunk of <= 64 signatures): p.X holds the ratio R = X / (H W) over ALL
@@ -65,7 +66,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
     static_assert(!MVJ || (DO_G && DO_U && DO_STATS && !WTS && !PERSIST && !BLOCKED && !RGIVEN), "MVJ: the unweighted MvNMF pass pair");
     static_assert(!RGIVEN || (WTS && !DO_STATS && !PERSIST), "given ratio: the weighted-capable plain passes only (with BLOCKED: the update_H pass of one feature block)");
     static_assert(!PERSIST || (DO_G && DO_U && !DO_STATS && !WTS), "the persistent mode is the plain joint step");
-    static_assert(!BLOCKED || (DO_U && !DO_G && !DO_STATS && WTS && !PERSIST), "feature blocks: the weighted-capable update_H pass only");
+    static_assert(!BLOCKED || (DO_U && !DO_STATS && WTS && !PERSIST), "feature blocks: the weighted-capable update_H pass, alone or with the block's numerator");
     using G_ = Geo<KS>;
     constexpr int KT = KTM;  // MFMA tiles on the output side
     constexpr int KP = G_::KP, LS = G_::LS, HV = G_::HV;
@@ -161,7 +162,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
     // loads that nothing hides, stays, and the statistics code in the shared tile costs the main loop registers:
     // profiles/r03/ab_step_variants.txt.)
     // The joint step with the objective folded in (DO_STATS) does the same: its numerator is summed in the plain step's order.
-    constexpr bool COOP = DO_G && DO_U && !RGIVEN && !MVJ;  // (with per-sample weights too: process_tile_coop honours them)
+    constexpr bool COOP = DO_G && DO_U && !RGIVEN && !MVJ && !BLOCKED;  // (with per-sample weights too: process_tile_coop honours them)
     constexpr int CSLAB = WROWS * WS + REGION;  // the cooperative tile's park: the LDS regions of waves 1..3, free meanwhile
     static_assert(!COOP || CO_::COOP_DOUBLES <= (WAVES - 1) * REGION, "the cooperative tile's numerator park must fit the idle waves' LDS");
     const int64_t nleft = p.ntiles % tstride;
@@ -295,6 +296,17 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
             x_first = false;
         }
         __builtin_amdgcn_wave_barrier();
+        // (BLOCKED) the earlier blocks' running sum of U for this tile: requested now, it is the U product's starting value a
+        // whole P / G phase later -- read after the product, as rounds 4 had it, every tile paid a memory round trip that
+        // nothing hid (one wave per SIMD).  U = (U_0 + U_1 + ...) with block b's own products added onto the running sum.
+        d4 uacc0[BLOCKED ? KT : 1];
+        if (BLOCKED && TU) {
+            const double* ua = p.Uacc + (n0 + q) * KP + c16;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) uacc0[kt][r] = p.ublock != 1 ? ua[4 * r * KP + 16 * kt] : 0.0;
+        }
         constexpr int FKB = 1 + 7 * (HALF == 2 ? 1 : 0);
         FK_TICK(FKB + 0);
 
@@ -470,7 +482,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
             // ---- U = R . W^T   (A = R[n=c16][v=4s+q], B = W[k=16kt+c16][v=4s+q])
             d4 u[KT];
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) u[kt] = (d4){0, 0, 0, 0};
+            for (int kt = 0; kt < KT; ++kt) u[kt] = BLOCKED ? uacc0[kt] : (d4){0, 0, 0, 0};
             // H of this tile in the U accumulator layout; read now, consumed by the epilogue
             double hcur[4][KT];
 #pragma unroll
@@ -524,13 +536,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
             if (BLOCKED) {
                 // this block's share of U joins the earlier blocks' (order: block 0 + 1 + ...); all but the last block
                 // leave the running sum in Uacc and do not touch H
-                double* ua = p.Uacc + (n0 + q) * KP + c16;
-                if (p.ublock != 1) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int kt = 0; kt < KT; ++kt) u[kt][r] += ua[4 * r * KP + 16 * kt];
-                }
+                double* ua = p.Uacc + (n0 + q) * KP + c16;  // (the running sum is in u already: uacc0)
                 const int jr = rs_idx >> 2, rr = rs_idx & 3;
                 const bool rem_owner = KR > 0 && jr < KR && (c16 & (NVP == 16 ? 0 : (NVP == 8 ? 1 : 3))) == 0;
                 double* uar = p.Uacc + (n0 + q + 4 * rr) * KP + KB + jr;

@@ -117,8 +117,7 @@ int salnmf_corr_compute_aux(salnmf_engine* e) {
     if (e->NB > 1) {
         // U = R W^T summed over the feature blocks, aux = H * U unclipped by the last block's launch; the numerators of
         // update_signatures block by block into Gblk (applied by salnmf_corr_update_signatures)
-        CK(blocked_update_H(e, e->aux, 0.0, false));
-        return blocked_numerators(e, false);
+        return blocked_joint_passes(e, e->aux, 0.0, false);  // (one pass per block for both)
     }
     FusedParams p = fused_params(e);
     p.wkl = nullptr;  // CorrNMF is unweighted (corrnmf_det.py:80-85)
