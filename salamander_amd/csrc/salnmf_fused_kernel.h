@@ -307,6 +307,12 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) uacc0[kt][r] = p.ublock != 1 ? ua[4 * r * KP + 16 * kt] : 0.0;
         }
+        double uarem0 = 0.0;  // (the same for the remainder column this lane owns after the reduce-scatter of the U phase)
+        if (BLOCKED && TU && KR > 0 && p.ublock != 1) {
+            const int ridx = NVP == 16 ? c16 : (NVP == 8 ? (c16 >> 1) : (c16 >> 2));
+            const int jr0 = ridx >> 2, rr0 = ridx & 3;
+            if (jr0 < KR && (c16 & (NVP == 16 ? 0 : (NVP == 8 ? 1 : 3))) == 0) uarem0 = p.Uacc[(n0 + q + 4 * rr0) * KP + KB + jr0];
+        }
         constexpr int FKB = 1 + 7 * (HALF == 2 ? 1 : 0);
         FK_TICK(FKB + 0);
 
@@ -540,7 +546,7 @@ __global__ void __launch_bounds__(BLOCK, 1) fused_kernel(FusedParams p) {
                 const int jr = rs_idx >> 2, rr = rs_idx & 3;
                 const bool rem_owner = KR > 0 && jr < KR && (c16 & (NVP == 16 ? 0 : (NVP == 8 ? 1 : 3))) == 0;
                 double* uar = p.Uacc + (n0 + q + 4 * rr) * KP + KB + jr;
-                if (KR > 0 && rem_owner && p.ublock != 1) urem[0] += *uar;
+                if (KR > 0 && rem_owner) urem[0] += uarem0;  // (0 for the first block)
                 if (p.ublock != 3) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
