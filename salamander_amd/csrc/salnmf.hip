@@ -1321,9 +1321,23 @@ static int grid_passes(salnmf_engine* e, bool do_g, bool do_u, int n_given, doub
             p.hscale = nullptr;
             if (!weighted) p.wkl = p.wlh = nullptr;
             CK(weight_arrays(e, p));
-            // (the two halves stay separate passes here: the joint instantiation on a given ratio with the U accumulation over the
-            // blocks measured 84.7 us against 35.8 + 35.3 us for the numerator pass and the update_H pass -- 288 x 100: 781 against 752 us)
             const bool g = do_g && given < c.K;
+            if (g && do_u) {  // both halves of the pair in one pass over the block's ratio
+                p.Hout = Hout + (size_t)ci * hc;
+                p.Uacc = e->Uacc + (size_t)ci * hc;
+                p.ublock = b == 0 ? 1 : (b == e->NB - 1 ? 3 : 2);
+                FusedSel sel{c.KS, c.KTM, c.KR, true, true, false, true, false, true};
+                sel.RGIVEN = true;
+                if (launch_fused_inst(sel, p, e->grid, e->stream, nullptr, nullptr)) return fail("no kernel instantiation for KS=%d KTM=%d KR=%d", c.KS, c.KTM, c.KR);
+                HIPCK(hipGetLastError());
+                TailParams t = tail_params(e, e->grid, e->Gblk + (size_t)b * e->K * VMAX + (size_t)c.k0 * vb, 0, 0, 0, false);
+                t.V = vb;
+                t.K = c.K;
+                hipLaunchKernelGGL(tail_kernel, dim3(c.K), dim3(TAIL_BLOCK), 0, e->stream, t);
+                HIPCK(hipGetLastError());
+                any_g = true;
+                continue;
+            }
             if (g) {
                 FusedSel sel{c.KS, c.KTM, c.KR, true, false, false, true, false, false};
                 sel.RGIVEN = true;

@@ -59,9 +59,10 @@ static int launch_geometry(const FusedSel& s, const FusedParams& p, int grid, hi
         // (chunks use the geometries whose H layout is 64 columns wide: salnmf.hip, salnmf_create)
         if constexpr (KS >= 13) {
             if (s.STATS) return 1;
-            if (s.BLOCKED) {  // > 96 features as well: the update_H pass of one (chunk, feature block) pair on that block's ratio
-                if (s.G || !s.U) return 1;
-                launch_one<KS, KTM, KR, false, true, false, true, false, true, true>(p, grid, st, e0, e1);
+            if (s.BLOCKED) {  // > 96 features as well: the passes of one (chunk, feature block) pair on that block's ratio
+                if (!s.U) return 1;
+                if (s.G) launch_one<KS, KTM, KR, true, true, false, true, false, true, true>(p, grid, st, e0, e1);
+                else launch_one<KS, KTM, KR, false, true, false, true, false, true, true>(p, grid, st, e0, e1);
                 return 0;
             }
             if (s.G && s.U) launch_one<KS, KTM, KR, true, true, false, true, false, false, true>(p, grid, st, e0, e1);
