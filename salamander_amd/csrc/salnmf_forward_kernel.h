@@ -90,6 +90,18 @@ __global__ void __launch_bounds__(BLOCK, (fwd_lds_doubles<KS>() * 8 <= 80 * 1024
         d2 hv[HV];
 #pragma unroll
         for (int j = 0; j < HV; ++j) hv[j] = hsrc[64 * j];
+        // (PIN) the product of the chunks before this one: requested with the tile's other loads -- behind the staging of H it was
+        // a second memory round trip per tile
+        d4 pr[VT];
+#pragma unroll
+        for (int vt = 0; vt < VT; ++vt) pr[vt] = (d4){0, 0, 0, 0};
+        if (PIN && p.pin) {
+            const double* psrc = p.pin + (n0 + q) * VMAX + c16;
+#pragma unroll
+            for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pr[vt][r] = psrc[4 * r * VMAX + 16 * vt];
+        }
         double x[VT][4];
         if (MODE != 2) {
             const double* xsrc = p.X + (n0 + q) * VMAX + c16;
@@ -125,16 +137,6 @@ __global__ void __launch_bounds__(BLOCK, (fwd_lds_doubles<KS>() * 8 <= 80 * 1024
         }
         __builtin_amdgcn_wave_barrier();
 
-        d4 pr[VT];
-#pragma unroll
-        for (int vt = 0; vt < VT; ++vt) pr[vt] = (d4){0, 0, 0, 0};
-        if (PIN && p.pin) {
-            const double* psrc = p.pin + (n0 + q) * VMAX + c16;
-#pragma unroll
-            for (int vt = 0; vt < VT; ++vt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) pr[vt][r] = psrc[4 * r * VMAX + 16 * vt];
-        }
         const double* ha = Hl + c16 * LS + q;
         const double* wb = Wl + q * WS + c16;
 #pragma unroll
