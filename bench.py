@@ -338,6 +338,32 @@ def extra_weighted_step(sal, device):
     return {"workload": f"c2 with per-sample weights: {V}x{N_C2}, k={K}, 7 blocks of 200 steps (median)", "us_per_step": res}
 
 
+def extra_wide_catalogue(sal, device):
+    """A wide catalogue (SBS-288 contexts) and more than 64 signatures at c2's number of samples: the joint step of engines with
+    feature blocks (one pass per 96-feature block) and signature chunks (the reference has no limit on either size)."""
+    from salamander_amd.synthetic import synthetic_problem
+
+    res = {}
+    for name, (Vw, Kw) in (("288x50", (288, 50)), ("96x100", (96, 100)), ("288x100", (288, 100))):
+        X, W0, H0 = synthetic_problem(Vw, N_C2, Kw, seed=0)
+        e = sal.Engine(N_C2, Vw, Kw, device=device)
+        e.upload_X(X), e.upload_W(W0), e.upload_H(H0)
+        del X, H0
+        e.kl_step(20)
+        e.sync()
+        blocks = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            e.kl_step(50)
+            e.sync()
+            blocks.append((time.perf_counter() - t0) / 50)
+        e.close()
+        t = statistics.median(blocks)
+        res[name] = {"us_per_step": t * 1e6, "frac_of_fp64_mfma_peak_on_6VKN": 6.0 * Vw * Kw * N_C2 / t / 1e12 / FP64_MFMA_PEAK_TFLOPS}
+    return {"workload": f"KLNMF joint steps at {N_C2} samples, n_features x n_signatures beyond one 96-feature block / one 64-signature chunk, 5 blocks of 50 steps (median)",
+            "engines": res}
+
+
 def problem_rows(start, stop):
     """Rows [start, stop) of the 10^6-sample problem: 125 000-row blocks, block b drawn with seed b
     (per-shard seeds, no 8 GB host temporary).  W0 is block 0's."""
@@ -893,7 +919,7 @@ def main():
             # last: a utilisation trace of this process shows the device at work for the first part of the run, then nothing
             if not args.no_extra:
                 extra = {}
-                for name, fn in (("c4_mvnmf", extra_c4), ("c2_default_init_fit", extra_default_init_fit), ("c2_fp32_fast_mode", extra_fast_mode), ("c2_weighted_step", extra_weighted_step), ("c5_mmcorrnmf", extra_c5)):
+                for name, fn in (("c4_mvnmf", extra_c4), ("c2_default_init_fit", extra_default_init_fit), ("c2_fp32_fast_mode", extra_fast_mode), ("c2_weighted_step", extra_weighted_step), ("c5_mmcorrnmf", extra_c5), ("wide_catalogues", extra_wide_catalogue)):
                     t_sec = time.perf_counter()
                     try:
                         extra[name] = fn(sal, local_rank)
